@@ -1,0 +1,173 @@
+"""Oracle: DinoInterface / StegoInterface pre- and post-processing.  TEST INFRASTRUCTURE ONLY.
+
+Follows wild_visual_navigation/feature_extractor/dino_interface.py:52-59,70-92 and
+stego_interface.py:51-58,73-111.  torchvision is absent here, so ``T.Resize(NEAREST)``,
+``T.CenterCrop`` and ``T.Normalize`` are restated from their documented tensor semantics.
+"""
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import vit
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def resize_nearest_center_crop(img: torch.Tensor, size: int) -> torch.Tensor:
+    """T.Resize(size, NEAREST) (smaller edge -> size, aspect kept) then T.CenterCrop(size).
+
+    dino_interface.py:54-57.  Identity when the input is already size x size.
+    """
+    H, W = img.shape[-2:]
+    if (H, W) != (size, size):
+        if H <= W:
+            nh, nw = size, int(size * W / H)
+        else:
+            nh, nw = int(size * H / W), size
+        if (nh, nw) != (H, W):
+            img = F.interpolate(img, size=(nh, nw), mode="nearest")
+        top = int(round((nh - size) / 2.0))
+        left = int(round((nw - size) / 2.0))
+        img = img[..., top : top + size, left : left + size]
+    return img
+
+
+def normalize(img: torch.Tensor) -> torch.Tensor:
+    """T.Normalize(IMAGENET mean/std) -- dino_interface.py:52."""
+    mean = torch.tensor(IMAGENET_MEAN, dtype=img.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=img.dtype).view(1, 3, 1, 1)
+    return (img - mean) / std
+
+
+def dino_transform(img: torch.Tensor, input_size: int) -> torch.Tensor:
+    return normalize(resize_nearest_center_crop(img, input_size))
+
+
+def upsample_bilinear_ac(feat: torch.Tensor, out: int) -> torch.Tensor:
+    """F.interpolate(features, (H, H), mode='bilinear', align_corners=True) -- dino_interface.py:87-90.
+    Note the reference uses H (the image height) for BOTH output dims."""
+    return F.interpolate(feat, (out, out), mode="bilinear", align_corners=True)
+
+
+def dino_inference(sd, img: torch.Tensor, input_size: int, patch: int, heads: int) -> torch.Tensor:
+    """DinoInterface.inference: [B,3,H,W] in [0,1] -> dense [B,D,H,H] fp32."""
+    x = dino_transform(img, input_size)
+    feat = vit.vit_features(sd, x, patch, heads)
+    return upsample_bilinear_ac(feat, img.shape[2])
+
+
+# ----------------------------------------------------------------------------------------------
+# STEGO head + per-image clustering.  The arithmetic lives in the absent third-party ``stego``
+# package (stego_interface.py:14,43,91,94-100) -> PARITY UNPINNED; the definition below is the one
+# this build documents (DESIGN.md "STEGO definition"): published STEGO segmentation head
+# (1x1 conv D->C linear branch + 1x1 conv D->D, ReLU, 1x1 conv D->C non-linear branch, summed),
+# single pass (no flip TTA), and, for run_clustering=True, a deterministic per-image cosine
+# k-means on the patch-resolution code (n_image_clusters centroids, fixed iteration count,
+# lowest-index tie-break) whose labels are then nearest-upsampled by stego_interface.py:108.
+# ----------------------------------------------------------------------------------------------
+STEGO_CODE_DIM = 90
+KMEANS_ITERS = 10
+
+
+def make_stego_head_state_dict(D: int = 384, C: int = STEGO_CODE_DIM, seed: int = 0) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def rn(*shape, std):
+        return torch.randn(*shape, generator=g) * std
+
+    return {
+        "cluster1.0.weight": rn(C, D, std=0.08),
+        "cluster1.0.bias": rn(C, std=0.02),
+        "cluster2.0.weight": rn(D, D, std=0.06),
+        "cluster2.0.bias": rn(D, std=0.02),
+        "cluster2.2.weight": rn(C, D, std=0.08),
+        "cluster2.2.bias": rn(C, std=0.02),
+    }
+
+
+def stego_code_tokens(head: Dict[str, torch.Tensor], tok: torch.Tensor) -> torch.Tensor:
+    """Patch tokens [B, G*G, D] -> code [B, G*G, C] (1x1 convs == per-token linears)."""
+    lin = F.linear(tok, head["cluster1.0.weight"], head["cluster1.0.bias"])
+    hid = F.relu(F.linear(tok, head["cluster2.0.weight"], head["cluster2.0.bias"]))
+    return lin + F.linear(hid, head["cluster2.2.weight"], head["cluster2.2.bias"])
+
+
+def _seq_dot_f32(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """sum_d a[..., d] * b[..., d] accumulated strictly in index order, one fp32 rounding per
+    multiply and per add (no FMA) -- the exact order the HIP k-means kernel uses, so integer
+    outputs can be compared bit-for-bit."""
+    acc = np.zeros(np.broadcast_shapes(a.shape[:-1], b.shape[:-1]), dtype=np.float32)
+    for d in range(a.shape[-1]):
+        acc = (acc + (a[..., d] * b[..., d]).astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def _normalize_rows_f32(x: np.ndarray) -> np.ndarray:
+    n2 = _seq_dot_f32(x, x)
+    n = np.sqrt(n2).astype(np.float32)
+    n = np.maximum(n, np.float32(1e-12))
+    return (x / n[..., None]).astype(np.float32)
+
+
+def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) -> np.ndarray:
+    """Deterministic cosine k-means over one image's code vectors.
+
+    code: [P, C] fp32.  Returns int32 labels [P] in 0..K-1 (not yet compacted).
+      x_p   = code_p / max(||code_p||, 1e-12)
+      c_k^0 = x at index floor((2k+1) P / (2K))
+      repeat ``iters`` times: label_p = argmax_k <x_p, c_k> (lowest k wins ties);
+                              c_k = normalise(sum of its x_p in ascending p); empty cluster keeps c_k.
+      final labels = one more assignment against the last centroids.
+    All arithmetic fp32, accumulation strictly sequential (see _seq_dot_f32).
+    """
+    code = np.ascontiguousarray(code, dtype=np.float32)
+    P, C = code.shape
+    x = _normalize_rows_f32(code)
+    init = [((2 * k + 1) * P) // (2 * K) for k in range(K)]
+    cent = x[init].copy()
+
+    def assign(cent):
+        sim = _seq_dot_f32(x[:, None, :], cent[None, :, :])  # [P, K]
+        return np.argmax(sim, axis=1).astype(np.int32)  # first maximum == lowest index
+
+    for _ in range(iters):
+        lab = assign(cent)
+        sums = np.zeros((K, C), dtype=np.float32)
+        np.add.at(sums, lab, x)  # unbuffered, processes p = 0..P-1 in order
+        cnt = np.bincount(lab, minlength=K)
+        new = _normalize_rows_f32(sums)
+        cent = np.where((cnt > 0)[:, None], new, cent).astype(np.float32)
+    return assign(cent)
+
+
+def relabel_ascending(seg: np.ndarray) -> np.ndarray:
+    """feature_extractor.py:245-246: replace the sorted unique ids by 0..K'-1."""
+    uniq = np.unique(seg)
+    lut = np.zeros(int(uniq.max()) + 1, dtype=np.int64)
+    lut[uniq] = np.arange(len(uniq))
+    return lut[seg]
+
+
+def upsample_nearest(lab: torch.Tensor, out: int) -> torch.Tensor:
+    """F.interpolate(pred[None].float(), (H,H), mode='nearest').int() -- stego_interface.py:108-109."""
+    return F.interpolate(lab[None].float(), (out, out), mode="nearest").int()
+
+
+def stego_inference(
+    sd, head, img: torch.Tensor, input_size: int, patch: int, heads: int, n_image_clusters: int
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """StegoInterface.inference as used by FeatureExtractor (run_clustering=True, run_crf=False).
+    Returns (code [B,C,H,H] fp32, cluster_pred [1,B,H,H] int32)."""
+    x = dino_transform(img, input_size)
+    tok = vit.vit_tokens(sd, x, patch, heads)[:, 1:]
+    B, P, D = tok.shape
+    G = input_size // patch
+    code = stego_code_tokens(head, tok)  # [B, P, C]
+    labels = np.stack([kmeans_cosine_labels(code[b].numpy(), n_image_clusters) for b in range(B)])
+    labels = torch.from_numpy(labels).reshape(B, G, G)
+    code_map = code.reshape(B, G, G, -1).permute(0, 3, 1, 2)
+    H = img.shape[2]
+    return upsample_bilinear_ac(code_map, H), upsample_nearest(labels, H)
