@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of the WVN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic frames PER GPU (weak scaling):
+  BASELINE.json configs[2]: 64 frames 448x448 -> ImageNet-normalise + patchify -> DINO ViT-S/8 (12
+  blocks, bf16 MFMA, fp32 accumulate/residual) -> STEGO head (90-d code) -> per-image cosine k-means
+  (20 clusters) segment maps -> fused bilinear-upsample + per-segment mean pooling -> ONE optimisation
+  step of the traversability MLP (forward, loss, backward, Adam) on the batch's segment rows, with the
+  gradient / statistic all-reduce over RCCL when N > 1.
+Inputs are resident in HBM before the timed region; weights are seeded synthetic (no network).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+fused attention, HIP-event timed on the launch stream inside the timed region) and `cpu_baseline`
+(the CPU oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def vit_flops_per_frame(S=448, P=8, D=384, depth=12):
+    G = S // P
+    N = G * G + 1
+    per_block = 24 * N * D * D + 4 * N * N * D
+    return depth * per_block + 2 * G * G * 3 * P * P * D, 4 * N * N * D  # (total, attention per block)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE configs[2]: 64)")
+    ap.add_argument("--size", type=int, default=448)
+    ap.add_argument("--chunk", type=int, default=16, help="frames pushed through the backbone at a time")
+    ap.add_argument("--segmentation", default="stego", choices=["stego", "grid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    return ap.parse_args()
+
+
+def make_pipeline(args, dev):
+    from wild_visual_navigation_amd.feature_extractor import FeatureExtractor
+    from wild_visual_navigation_amd.model import SimpleMLP
+    from wild_visual_navigation_amd.traversability_estimator import MlpTrainer
+
+    ftype = "stego" if args.segmentation == "stego" else "dino"
+    fe = FeatureExtractor(dev, segmentation_type=args.segmentation, feature_type=ftype, input_size=args.size,
+                          backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
+                          max_chunk=args.chunk)
+    torch.manual_seed(42)
+    model = SimpleMLP(fe.feature_dim, [256, 32, 1], True).to(dev)
+    return fe, model, MlpTrainer(model)
+
+
+def hot_path_step(fe, trainer, img, labels_u, args):
+    """One pass: frames -> features/segments -> pooled rows -> one MLP optimisation step."""
+    feat, seg, nseg = fe.extract_batch(img)
+    B, S, D = feat.shape
+    if args.segmentation == "stego":
+        keep = (torch.arange(S, device=feat.device)[None] < nseg[:, None]).reshape(-1)  # ids that exist per image
+        x = feat.reshape(B * S, D)[keep]
+        u = labels_u.reshape(B * S, 2)[keep]
+    else:
+        x = feat.reshape(B * S, D)
+        u = labels_u.reshape(B * S, 2)
+    y_valid = u[:, 0] < 0.16  # 16 % labelled segments, like assets/graph/graph.pt (16 / 100)
+    y = y_valid.float() * (0.5 + 0.5 * u[:, 1])
+    return trainer.train_step(x, y, y_valid), x.shape[0]
+
+
+def cpu_baseline(args):
+    """CPU oracle (a PORT: PyTorch/numpy restatement of the reference algorithm) on a bounded sample of
+    the same workload: `cpu_frames` frames through backbone + STEGO head + k-means + pooling, then one
+    MLP step on their rows.  Timed on this box's host cores."""
+    import numpy as np
+
+    from oracle import interfaces as OI, mlp as OM, segments as OS, vit as OV
+
+    n = args.cpu_frames
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0)
+    head = OI.make_stego_head_state_dict(384, 90, seed=0)
+    img = torch.rand(n, 3, args.size, args.size, generator=torch.Generator().manual_seed(1))
+    G = args.size // 8
+    t0 = time.perf_counter()
+    rows = []
+    with torch.no_grad():
+        for b in range(n):
+            tok = OV.vit_tokens(sd, OI.normalize(img[b:b + 1]), 8, 6)[:, 1:]
+            if args.segmentation == "stego":
+                code = OI.stego_code_tokens(head, tok)
+                lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), 20))
+                seg = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), args.size)[0, 0].long()
+                fmap = code.reshape(1, G, G, -1).permute(0, 3, 1, 2)
+            else:
+                seg = OS.segment_grid(args.size, args.size, 32)[0, 0]
+                fmap = tok.reshape(1, G, G, -1).permute(0, 3, 1, 2)
+            dense = OI.upsample_bilinear_ac(fmap, args.size)
+            rows.append(OS.sparsify_features(dense, seg))
+        x = torch.cat(rows)
+        gsel = torch.Generator().manual_seed(2)
+        yv = torch.rand(x.shape[0], generator=gsel) < 0.16
+        yv[0] = yv[1] = True
+        y = yv.float() * (0.5 + 0.5 * torch.rand(x.shape[0], generator=gsel))
+        st = OM.TrainState(OM.make_mlp_state_dict(x.shape[1]))
+        OM.train_step(st, x, y, yv)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frames {args.size}x{args.size} through the CPU oracle (ViT-S/8 12 blocks fp32 + "
+                      f"{args.segmentation} segmentation + pooling + 1 MLP step), {dt:.1f} s wall"}
+
+
+def main():
+    args = parse()
+    from wild_visual_navigation_amd import distributed as D, ops
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    fe, model, trainer = make_pipeline(args, dev)
+    B = args.batch
+    gen = torch.Generator().manual_seed(1000 + rank)
+    img = torch.rand(B, 3, args.size, args.size, generator=gen).to(dev)  # resident in HBM before timing
+    n_lab = 20 if args.segmentation == "stego" else (args.size // 32) ** 2
+    labels_u = torch.rand(B, n_lab, 2, generator=gen).to(dev)
+
+    for _ in range(args.warmup):
+        hot_path_step(fe, trainer, img, labels_u, args)
+    torch.cuda.synchronize()
+    D.barrier()
+    ops.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows = 0
+    for _ in range(args.steps):
+        losses, rows = hot_path_step(fe, trainer, img, labels_u, args)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(False)
+    prof = ops.prof_collect()
+    dt = D.max_over_ranks(dt, dev)
+    loss_val = float(losses[0].item())
+
+    if rank == 0:
+        frames = world * B * args.steps
+        total_flops, attn_flops_block = vit_flops_per_frame(args.size)
+        att_ms, att_n = prof["attention"]
+        chunk = min(args.chunk, B)
+        # every attention launch processes `chunk` frames (the last chunk of a batch may be smaller)
+        frames_per_launch = (B * args.steps * 12) / max(att_n, 1) / 12
+        att_avg_ms = att_ms / max(att_n, 1)
+        att_tflops = attn_flops_block * frames_per_launch / (att_avg_ms * 1e-3) / 1e12 if att_n else 0.0
+        kern = {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in prof.items()}
+        out = {
+            "metric": "frames/sec (448x448 DINO-ViT-S/8 + seg + MLP train-step)",
+            "value": round(frames / dt, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU + STEGO head + "
+                                   f"{args.segmentation} segmentation + fused segment pooling + 1 traversability-MLP "
+                                   f"Adam step on {rows} rows/GPU", "frames_per_gpu_per_step": B,
+                       "backbone_chunk": chunk, "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP grads)"},
+            "backbone_tflops": round(total_flops * frames / dt / 1e12 / world, 1),
+            "final_loss": loss_val,
+            "roofline": {"bound": "mfma", "kernel": "attention_bf16_kernel", "achieved": round(att_tflops, 1),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tflops / PEAK_BF16_TFLOPS, 4),
+                         "traffic": None, "avg_launch_ms": round(att_avg_ms, 4),
+                         "algorithmic_flops_per_launch": attn_flops_block * frames_per_launch},
+            "kernel_ms": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

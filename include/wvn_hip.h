@@ -1,0 +1,181 @@
+/*
+ * wvn_hip.h -- C-ABI of libwvn_hip.so: the MI355X (gfx950) native implementation of Wild Visual
+ * Navigation's  feature_extractor -> traversability_estimator  hot path.
+ *
+ * The reference (leggedrobotics/wild_visual_navigation) has no FFI layer: the path sits behind plain
+ * Python classes that issue stock PyTorch ops.  Each entry point below replaces the arithmetic of
+ * one reference function (cited as file:line, relative to the reference root) and is what a
+ * maintainer binds with ctypes.  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; no allocation happens inside
+ *     the library (callers own memory -- torch.empty in the Python host layer);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work
+ *     is stream-ordered and asynchronous;
+ *   - return value: 0 = ok, 1001 = bad argument, 1002 = workspace too small, otherwise a hipError_t;
+ *   - tensors are dense row-major; "tokens" are [B, G*G, D] (patch-major == NHWC feature map).
+ */
+#ifndef WVN_HIP_H
+#define WVN_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WVN_MAX_DEPTH 32
+#define WVN_PREC_F32 0  /* exact mode: fp32 storage + fp32 FMA everywhere (parity gate, <= 1e-3) */
+#define WVN_PREC_BF16 1 /* fast mode: bf16 operands on MFMA, fp32 accumulate / statistics / residual */
+
+int wvn_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * DINO ViT backbone  (replaces stego.backbones.backbone.get_backbone(cfg)(img), called from
+ * wild_visual_navigation/feature_extractor/dino_interface.py:45,84, plus the T.Normalize of :52).
+ * Weights: matrices in torch.nn.Linear layout [out][in]; bf16 bits (uint16) when precision ==
+ * WVN_PREC_BF16, float otherwise.  Biases, LayerNorm affine and the position table are always fp32.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct wvn_vit_layer {
+  const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
+  const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
+  const void* fc1_w;  /* [F][D]    blocks.i.mlp.fc1.weight   */
+  const void* fc2_w;  /* [D][F]    blocks.i.mlp.fc2.weight   */
+  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} wvn_vit_layer;
+
+typedef struct wvn_vit_model {
+  int img_size; /* network input side S (448)            */
+  int patch;    /* P (8 or 16)                           */
+  int dim;      /* D (384); heads * 64                   */
+  int depth;    /* number of blocks (12)                 */
+  int heads;    /* h (6); head dim is fixed at 64        */
+  int mlp_dim;  /* F (1536)                              */
+  int precision;
+  int reserved;
+  const void* patch_w;  /* [D][3*P*P] conv weight flattened (c, py, px)            */
+  const float* patch_b; /* [D]                                                      */
+  const float* cls_pos; /* [D]  = cls_token + pos_embed[0]                          */
+  const float* pos;     /* [1+G*G][D] position table already resampled to the grid  */
+  const float *norm_g, *norm_b;
+  wvn_vit_layer layers[WVN_MAX_DEPTH];
+} wvn_vit_model;
+
+size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch);
+
+/* img [B,3,S,S] fp32 in [0,1] (already resized/cropped, dino_interface.py:54-57) ->
+ *   tokens_f32  [B, G*G, D]  final-LayerNorm'ed patch tokens (class token dropped), may be NULL
+ *   tokens_lowp [B*G*G rows, ld_lowp] same values in the model precision (bf16/f32), may be NULL
+ * The workspace must be zero-filled once after allocation (padding rows are never written). */
+int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
+                    int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-kernel-category HIP-event timing of wvn_vit_forward (bench.py roofline leg).  Categories:
+ * 0 patchify 1 patch_gemm 2 layernorm 3 qkv_gemm 4 attention 5 proj_gemm 6 fc1_gemm 7 fc2_gemm */
+#define WVN_PROF_NCAT 8
+int wvn_prof_enable(int on);
+int wvn_prof_collect(double* ms_by_cat_host, long long* launches_by_cat_host); /* syncs recorded events, resets */
+
+/* ---------------------------------------------------------------------------------------------
+ * Building blocks, exported so tests/ can check each kernel against the oracle.
+ * ------------------------------------------------------------------------------------------- */
+/* C = epilogue(A[M,K] * W[N,K]^T + bias).  epi: 0 bf16 out, 1 gelu->bf16, 2 relu->bf16, 3 f32 out,
+ * 4 f32 out += (residual), 5 same as 4.  A/W bf16, K % 64 == 0. */
+int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                  int K, int epi, void* stream);
+/* fp32 GEMM C = epilogue(op(A) op(B) + bias); transA: A stored [K,M]; transB: B stored [N,K].
+ * epi: 0 none, 1 relu, 2 gelu, 3 C +=, 4 sigmoid on column 0, 5 relu-mask (mask > 0 ? acc : 0). */
+int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, int transB, const float* bias, float* C,
+                 int ldc, int M, int N, int K, int epi, const float* mask, int ldmask, void* stream);
+int wvn_layernorm(const float* x, const float* gamma, const float* beta, void* y, int y_is_bf16, int rows, int D,
+                  float eps, void* stream);
+/* q,k [B,h,npad,64]; v: bf16 path takes V^T [B,h,64,npad], f32 path takes V [B,h,npad,64];
+ * out [B*ntok, h*64].  npad % 128 == 0, pad rows must be finite. */
+int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad,
+                       float scale, void* stream);
+int wvn_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok, int npad,
+                      float scale, void* stream);
+int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream);
+int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
+
+/* F.interpolate(features, (H,H), mode="bilinear", align_corners=True) of dino_interface.py:87-90 /
+ * stego_interface.py:107: tokens [B,G*G,D] -> dense [B,D,H,H] fp32. */
+int wvn_upsample_bilinear(const float* tokens, float* dense, int B, int G, int D, int H, void* stream);
+/* F.interpolate(pred[None].float(), (H,H), mode="nearest").int()  (stego_interface.py:108-109) */
+int wvn_upsample_nearest_i32(const int* labels, int* out, int B, int G, int H, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Segments
+ * ------------------------------------------------------------------------------------------- */
+/* FeatureExtractor.sparsify_features (feature_extractor.py:390-396) fused with the bilinear
+ * up-sampling that precedes it: feat[b][s][:] = mean over {seg[b]==s} of upsample(tokens[b]).
+ * seg [B,H,W] int32 (-1 = ignore), tokens [B,G*G,ld] fp32, feat [B,S,D].
+ * scratch_w: B*S*G*G floats, scratch_cnt: B*S ints (receives the pixel count per segment). */
+int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float* feat, float* scratch_w,
+                              int* scratch_cnt, int B, int H, int W, int G, int S, int D, void* stream);
+/* FeatureExtractor.sparsify_features on an explicit pixel-resolution map (no resampling):
+ * tokens [B,P,D] pixel-major, seg [B,P] -> feat [B,S,D] = per-segment mean (0/0 = NaN). S <= 236. */
+int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, int B, int P, int S, int D,
+                       void* stream);
+/* MissionNode.update_supervision_signal (traversability_estimator/nodes.py:400-440).
+ * mask [C,H,W] fp32 (NaN = unlabeled), seg [H,W] int32 -> signal [S] fp32, valid [S] uint8.
+ * scratch_sum: S floats, scratch_cnt: S ints. */
+int wvn_label_pool(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* scratch_sum,
+                   int* scratch_cnt, int H, int W, int S, void* stream);
+/* SegmentExtractor.centers (segment_extractor.py:70-92): centers [S,2] fp32 (x,y). scratch: 3*S u64. */
+int wvn_seg_centers(const int* seg, float* centers, void* scratch, int H, int W, int S, void* stream);
+/* SegmentExtractor.adjacency_list (segment_extractor.py:39-67): edges [max_edges,2] int64 sorted by
+ * key = left + right*S, *count = E (device int).  scratch_bitmap: S*S bytes. */
+int wvn_seg_adjacency(const int* seg, long long* edges, int* count, unsigned char* scratch_bitmap, int H, int W, int S,
+                      int max_edges, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * STEGO head + clustering  (stego.stego.Stego.get_code / postprocess, stego_interface.py:91-100)
+ * ------------------------------------------------------------------------------------------- */
+/* rows of code [rows, ldc] -> xn [rows, C] = code / max(||code||, 1e-12), sequential fp32 */
+int wvn_normalize_rows(const float* code, int ldc, float* xn, int rows, int C, void* stream);
+/* deterministic cosine k-means per image on xn [B,P,C]; labels [B,P] int32; nseg [B] distinct ids;
+ * relabel != 0 compacts ids to 0..K'-1 ascending (feature_extractor.py:245-246). C in {16,64,90}. */
+int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, int B, int P, int C, int K, int iters, int relabel,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Traversability MLP  (model/simple_mlp.py:10-39, utils/loss.py:93-160,
+ * utils/confidence_generator.py:78-82,182-193, traversability_estimator.py:100,464-477)
+ * Parameters live in ONE flat fp32 buffer [W1 | b1 | W2 | b2 | W3 | b3], Wi in Linear layout;
+ * gradients / Adam moments use the same layout (so the data-parallel exchange is one all-reduce).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct wvn_mlp_desc {
+  int D;  /* input features (384 dino / 90 stego) */
+  int H1; /* 256 */
+  int H2; /* 32  */
+  int reserved;
+} wvn_mlp_desc;
+size_t wvn_mlp_param_count(const wvn_mlp_desc* d);
+size_t wvn_mlp_workspace_bytes(const wvn_mlp_desc* d, int rows);
+
+/* SimpleMLP.forward: x [R,D] -> out [R,1+D] (sigmoid on column 0).  h1/h2 (post-ReLU) may be NULL
+ * for inference, in which case they are carved from the workspace. */
+int wvn_mlp_forward(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, int R, float* out, float* h1,
+                    float* h2, void* workspace, size_t workspace_bytes, void* stream);
+/* One optimisation step, split at the two points where data-parallel ranks exchange:
+ *  A: forward + per-row reconstruction loss + local statistic  stats[4] (double) =
+ *     { n_labelled, sum loss_reco, sum loss_reco^2, R }                    -> all-reduce(sum) stats
+ *  B: loss gradient + backward: grads[param_count + 2] (last two = sum weighted trav loss, sum raw
+ *     trav loss)                                                            -> all-reduce(sum) grads
+ *  C: Adam (lr, betas (0.9,0.999), eps 1e-8) + losses[5] = {total, trav, reco, conf mean, conf std} */
+int wvn_mlp_train_phase_a(const wvn_mlp_desc* d, const float* params, const float* x, int ldx,
+                          const unsigned char* y_valid, int R, double* stats, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int wvn_mlp_train_phase_b(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
+                          const unsigned char* y_valid, int R, const double* stats, float std_factor, float w_trav,
+                          float w_reco, float* grads, float* confidence_out, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* grads, float* adam_m, float* adam_v,
+                          int step, float lr, const double* stats, float w_trav, float w_reco, float* losses,
+                          void* stream);
+/* quick_start.py:194-210 / loss.py:162-164: trav[r] = out[r][0], conf[r] = confidence(mse(out[r][1:], x[r])) */
+int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,
+                       float* trav, float* conf, int R, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WVN_HIP_H */

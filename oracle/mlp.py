@@ -134,3 +134,69 @@ def train_step(st: TrainState, x, y, y_valid, lr=1e-3, std_factor=0.5, w_trav=0.
         "mean": st.mean,
         "std": st.std,
     }
+
+
+# --------------------------------------------------------------------------------------------------
+# Data-parallel decomposition of train_step (what wvn_mlp_train_phase_{a,b,c} compute per rank).
+# Summing `stats` and `flat grads` over ranks and then calling phase_c on every rank must reproduce
+# train_step on the concatenated batch (tests/test_distributed_gloo.py, tests/test_gpu_mlp.py).
+# --------------------------------------------------------------------------------------------------
+def flat_of(d: Dict[str, torch.Tensor]) -> torch.Tensor:
+    return torch.cat([d[k].reshape(-1) for k in KEYS])
+
+
+def phase_a_local(sd, x, y_valid):
+    out, h1, h2 = mlp_forward(sd, x, keep=True)
+    lr = ((out[:, 1:] - x) ** 2).mean(dim=1)
+    pos = lr[y_valid].double()
+    stats = torch.tensor([float(pos.numel()), float(pos.sum()), float((pos * pos).sum()), float(x.shape[0])],
+                         dtype=torch.float64)
+    return stats, (out, h1, h2, lr)
+
+
+def stats_mean_std(stats) -> Tuple[float, float]:
+    n, s1, s2 = float(stats[0]), float(stats[1]), float(stats[2])
+    mean = s1 / n if n > 0 else float("nan")
+    var = (s2 - s1 * s1 / n) / (n - 1.0) if n > 1 else float("nan")
+    std = math.sqrt(var) if var == var and var > 0 else (0.0 if var == var else float("nan"))
+    return float(torch.tensor(mean, dtype=torch.float32)), float(torch.tensor(std, dtype=torch.float32))
+
+
+def phase_b_local(sd, x, y, y_valid, cache, stats, std_factor=0.5, w_trav=0.03, w_reco=0.5) -> torch.Tensor:
+    out, h1, h2, lr = cache
+    R_tot, n_valid = float(stats[3]), float(stats[0])
+    D = x.shape[1]
+    mean, std = stats_mean_std(stats)
+    conf = confidence_from_stats(lr, mean, std, std_factor)
+    s = out[:, 0]
+    diff = s - y
+    raw = diff * diff
+    wrow = torch.where(y_valid, torch.ones_like(raw), 1 - conf)
+    g_out = torch.zeros_like(out)
+    g_out[:, 0] = (w_trav / R_tot) * wrow * 2 * diff * s * (1 - s)
+    g_out[:, 1:] = (w_reco / (n_valid * D)) * 2 * (out[:, 1:] - x) * y_valid[:, None].float()
+    grads = {}
+    grads["layers.4.weight"] = g_out.T @ h2
+    grads["layers.4.bias"] = g_out.sum(0)
+    g_h2 = (g_out @ sd["layers.4.weight"]) * (h2 > 0)
+    grads["layers.2.weight"] = g_h2.T @ h1
+    grads["layers.2.bias"] = g_h2.sum(0)
+    g_h1 = (g_h2 @ sd["layers.2.weight"]) * (h1 > 0)
+    grads["layers.0.weight"] = g_h1.T @ x
+    grads["layers.0.bias"] = g_h1.sum(0)
+    extra = torch.stack([(raw * wrow).sum(), raw.sum()])
+    return torch.cat([flat_of(grads), extra])
+
+
+def phase_c(st: TrainState, flat_grads: torch.Tensor, stats, lr=1e-3, w_trav=0.03, w_reco=0.5) -> Dict[str, float]:
+    st.step += 1
+    off = 0
+    for k in KEYS:
+        n = st.sd[k].numel()
+        adam_update(st.sd[k], flat_grads[off:off + n].view_as(st.sd[k]), st.m[k], st.v[k], st.step, lr=lr)
+        off += n
+    R_tot = float(stats[3])
+    reco = float(stats[1]) / float(stats[0])
+    st.mean, st.std = stats_mean_std(stats)
+    return {"loss_total": w_trav * float(flat_grads[off]) / R_tot + w_reco * reco,
+            "loss_trav": float(flat_grads[off + 1]) / R_tot, "loss_reco": reco, "mean": st.mean, "std": st.std}

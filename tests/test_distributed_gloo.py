@@ -1,0 +1,74 @@
+"""world_size-2 gloo run of the data-parallel training protocol (no GPU): each rank owns a ragged
+shard of the rows, computes its LOCAL phase-A statistic and phase-B gradient (oracle restatement of
+wvn_mlp_train_phase_{a,b}), exchanges them with the product's collectives
+(wild_visual_navigation_amd.distributed) in the product's order (stats before backward, grads before
+Adam), and must end up with the single-process trajectory and bit-identical replicas."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import mlp as OM
+    from wild_visual_navigation_amd import distributed as D
+
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.is_parallel()
+    c = torch.load(os.path.join(ROOT, "tests", "golden", "mlp_train.pt"), weights_only=False)["graph_pt_D90"]
+    x, y, yv = c["x"], c["y"], c["y_valid"]
+    # ragged frame sharding: 5 "frames" of 20 rows over 2 ranks -> 3 + 2 frames
+    f0, f1 = D.shard_range(5, rank, world)
+    lo, hi = f0 * 20, f1 * 20
+    st = OM.TrainState(c["sd0"])
+    traj = []
+    for _ in range(10):
+        stats, cache = OM.phase_a_local(st.sd, x[lo:hi], yv[lo:hi])
+        D.allreduce_sum_(stats)                                # exchange 1: 4 doubles
+        g = OM.phase_b_local(st.sd, x[lo:hi], y[lo:hi], yv[lo:hi], cache, stats)
+        D.allreduce_sum_(g)                                    # exchange 2: flat grads (+2 loss sums)
+        o = OM.phase_c(st, g, stats)
+        traj.append([o["loss_total"], o["loss_trav"], o["loss_reco"], o["mean"], o["std"]])
+    D.barrier()
+    assert D.max_over_ranks(float(rank)) == float(world - 1)
+    q.put((rank, traj, {k: v.clone() for k, v in st.sd.items()}))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_training_matches_single_process_and_reference():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, t0, sd0), (_, t1, sd1) = res
+    assert t0 == t1, "ranks disagree on the losses"
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged on {k}"
+    c = torch.load(os.path.join(ROOT, "tests", "golden", "mlp_train.pt"), weights_only=False)["graph_pt_D90"]
+    ref = c["traj"]  # produced by the REFERENCE's SimpleMLP + TraversabilityLoss + torch.optim.Adam
+    assert torch.allclose(torch.tensor(t0), ref.double().float(), rtol=3e-4, atol=2e-6)
+    for k in sd0:
+        assert torch.allclose(sd0[k], c["sd10"][k], atol=3e-5), k

@@ -1,0 +1,185 @@
+"""End-to-end parity of the HIP backbone / interfaces / FeatureExtractor against the CPU oracle on the
+same seeded inputs and weights, plus size-independent properties at BASELINE.json's full size.
+
+Tolerances: exact mode (fp32 storage + fp32 FMA) <= 1e-3 absolute on un-normalised final features
+(north_star); bf16 MFMA mode is compared at the tolerance bf16 operand rounding allows (stated per
+test) -- it is the speed path, the fp32 mode is the parity gate.  Segment-index maps: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import interfaces as OI, segments as OS, vit as OV
+from wild_visual_navigation_amd import ops
+from wild_visual_navigation_amd.backbone import VitBackbone
+from wild_visual_navigation_amd.feature_extractor import DinoInterface, FeatureExtractor, StegoInterface
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel_l2(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("S,depth,B", [(64, 2, 3), (224, 12, 2), (448, 12, 1)])
+def test_vit_exact_mode_within_1e3(dev, S, depth, B):
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=depth)
+    img = torch.rand(B, 3, S, S, generator=g(1))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    bb = VitBackbone(sd, S, 8, 6, device=dev, precision="fp32", max_chunk=2)
+    got = bb.forward_tokens(img.to(dev)).cpu()
+    err = (got - want).abs().max().item()
+    assert err < 1e-3, f"exact-mode tokens differ by {err}"
+    feat = bb.forward(img.to(dev)).cpu()
+    assert torch.equal(feat, got.reshape(B, S // 8, S // 8, 384).permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("S,depth,B", [(64, 2, 3), (224, 12, 2), (448, 12, 1)])
+def test_vit_bf16_mode(dev, S, depth, B):
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=depth)
+    img = torch.rand(B, 3, S, S, generator=g(1))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    bb = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16", max_chunk=2)
+    got = bb.forward_tokens(img.to(dev)).cpu()
+    # bf16 operands (2^-9 relative rounding per GEMM input) through `depth` residual blocks; outputs are
+    # LayerNorm'ed (O(1) magnitudes).  Measured error is reported by bench.py / DESIGN.md.
+    assert rel_l2(got, want) < 2.5e-2 and (got - want).abs().max().item() < 0.25
+    cos = torch.nn.functional.cosine_similarity(got.reshape(-1, 384), want.reshape(-1, 384), dim=1)
+    assert cos.min().item() > 0.995
+
+
+def test_batch_invariance_and_chunking(dev):
+    """A frame's features must not depend on its batch neighbours or on the chunking (bit-exact)."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=3)
+    img = torch.rand(5, 3, 64, 64, generator=g(2)).to(dev)
+    for prec in ("bf16", "fp32"):
+        a = VitBackbone(sd, 64, 8, 6, device=dev, precision=prec, max_chunk=5).forward_tokens(img)
+        b = VitBackbone(sd, 64, 8, 6, device=dev, precision=prec, max_chunk=2).forward_tokens(img)
+        c = VitBackbone(sd, 64, 8, 6, device=dev, precision=prec, max_chunk=1).forward_tokens(img[3:4])
+        assert torch.equal(a, b) and torch.equal(a[3:4], c), prec
+
+
+def test_dino_interface_inference_matches_oracle(dev):
+    """Non-square frame like assets/demo_data (299x224): resize(NEAREST)+center-crop, normalise, backbone,
+    bilinear(align_corners) to (H, H)."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=3, depth=2)
+    img = torch.rand(1, 3, 224, 299, generator=g(4))
+    want = OI.dino_inference(sd, img, 224, 8, 6)
+    di = DinoInterface(dev, input_size=224, backbone_type="vit_small", patch_size=8, pretrained_weights=sd,
+                       precision="fp32")
+    got = di.inference(img.to(dev)).cpu()
+    assert got.shape == (1, 384, 224, 224) and (got - want).abs().max().item() < 1e-3
+    assert di.input_size == 224 and di.vit_patch_size == 8 and di.backbone == "dino" and di.backbone_type == "vit_small"
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 0.2)])
+def test_feature_extractor_grid_and_random(dev, prec, tol):
+    S = 224
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=5, depth=2)
+    img = torch.rand(1, 3, S, S, generator=g(6))
+    dense = OI.dino_inference(sd, img, S, 8, 6)
+    fe = FeatureExtractor(dev, segmentation_type="grid", feature_type="dino", input_size=S, backbone_type="vit_small",
+                          patch_size=8, pretrained_weights=sd, precision=prec)
+    edges, feat, seg, center, dfeat = fe.extract(img.to(dev), return_dense_features=True)
+    oseg = OS.segment_grid(S, S, 32)
+    assert torch.equal(seg.cpu(), oseg[0, 0])  # segment-index map: bit-exact
+    assert torch.equal(edges.cpu(), OS.adjacency_list(oseg).T)
+    assert torch.allclose(center.cpu(), OS.centers(oseg), atol=1e-4)
+    assert (feat.cpu() - OS.sparsify_features(dense, oseg[0, 0])).abs().max().item() < tol
+    assert (dfeat.cpu() - dense).abs().max().item() < tol
+    assert fe.feature_dim == 384 and fe.feature_type == "dino" and fe.segmentation_type == "grid"
+    # public sparsify_features on an explicit dense map == reference semantics
+    sp = fe.sparsify_features(dfeat, seg)
+    assert (sp.cpu() - OS.sparsify_features(dfeat.cpu(), seg.cpu())).abs().max().item() < 1e-4
+    # random-pixel mode (feature_extractor.py:96-111)
+    fr = FeatureExtractor(dev, segmentation_type="random", feature_type="dino", input_size=S,
+                          backbone_type="vit_small", patch_size=8, pretrained_weights=sd, precision=prec)
+    e2, f2, s2, c2, d2 = fr.extract(img.to(dev), n_random_pixels=100)
+    assert e2 is None and c2 is None and d2 is None and f2.shape == (100, 384)
+    s2 = s2.cpu()
+    idx = torch.stack([(s2.reshape(-1) == j).nonzero()[0, 0] for j in range(100)])
+    assert (s2 >= 0).sum() == 100
+    assert (f2.cpu() - dense[0].reshape(384, -1)[:, idx].T).abs().max().item() < tol
+
+
+def test_feature_extractor_stego_pipeline(dev):
+    """feature_type = segmentation_type = 'stego' (the reference's ROS default): code, k-means
+    segment map (bit-exact given the GPU's own fp32 code), relabel, pooled 90-d features."""
+    S, K = 224, 20
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=7, depth=2)
+    head = OI.make_stego_head_state_dict(384, 90, seed=0)
+    img = torch.rand(1, 3, S, S, generator=g(8))
+    tok = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    code_ref = OI.stego_code_tokens(head, tok)  # [1, P, 90]
+    for prec, tol in (("fp32", 1e-3), ("bf16", 0.25)):
+        fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=S,
+                              backbone_type="vit_small", patch_size=8, pretrained_weights=sd, head_weights=head,
+                              n_image_clusters=K, precision=prec)
+        edges, feat, seg, center, dense = fe.extract(img.to(dev), return_dense_features=True)
+        code = fe._extractor.feature_tokens.cpu()
+        assert (code - code_ref).abs().max().item() < tol, prec
+        # integer outputs: oracle clustering of the SAME fp32 code must agree bit-for-bit
+        lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), K))
+        G = S // 8
+        want_seg = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), S)[0, 0].long()
+        assert torch.equal(seg.cpu(), want_seg), prec
+        n_seg = int(want_seg.max()) + 1
+        assert feat.shape == (n_seg, 90) and center.shape == (n_seg, 2)
+        dense_ref = OI.upsample_bilinear_ac(code.reshape(1, G, G, 90).permute(0, 3, 1, 2), S)
+        assert (dense.cpu() - dense_ref).abs().max().item() < 1e-4
+        assert (feat.cpu() - OS.sparsify_features(dense_ref, want_seg)).abs().max().item() < 1e-4
+        assert torch.equal(edges.cpu(), OS.adjacency_list(want_seg[None, None]).T)
+        assert fe.feature_dim == 90
+
+
+def test_stego_interface_contract(dev):
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=9, depth=1)
+    si = StegoInterface(dev, input_size=64, n_image_clusters=6, run_crf=False, run_clustering=True,
+                        backbone_weights=sd, precision="fp32")
+    lin, clu = si.inference(torch.rand(2, 3, 64, 64, generator=g(1)).to(dev))
+    assert lin.shape == clu.shape == (1, 2, 64, 64) and clu.dtype == torch.int32
+    assert si.features.shape == (2, 90, 64, 64) and si.cluster_segments is clu and si.linear_segments is lin
+    assert int(clu.min()) == 0 and int(clu.max()) < 6
+
+
+def test_extract_batch_equals_per_frame(dev):
+    """Batched hot path (BASELINE config 3 shape, scaled down) == per-frame extract()."""
+    S = 64
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=11, depth=2)
+    img = torch.rand(4, 3, S, S, generator=g(12)).to(dev)
+    fe = FeatureExtractor(dev, segmentation_type="grid", feature_type="dino", input_size=S, backbone_type="vit_small",
+                          patch_size=8, pretrained_weights=sd, precision="bf16")
+    feat, seg, nseg = fe.extract_batch(img, cell_size=16)
+    assert feat.shape == (4, 16, 384) and seg.shape == (4, S, S) and nseg.tolist() == [16] * 4
+    for b in range(4):
+        _, f1, s1, _, _ = fe.extract(img[b:b + 1], cell_size=16)
+        assert torch.equal(f1, feat[b]) and torch.equal(s1.int(), seg[b])
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_448(dev):
+    """448x448 ViT-S/8 (N = 3137 tokens), 12 blocks, bf16: properties that do not need a full-size oracle."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0)
+    bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=2)
+    img = torch.rand(3, 3, 448, 448, generator=g(1)).to(dev)
+    img[2] = img[0]
+    tok = bb.forward_tokens(img)
+    assert tok.shape == (3, 3136, 384) and torch.isfinite(tok).all()
+    assert torch.equal(tok[0], tok[2])  # identical frames -> identical features, whatever the batch slot
+    assert not torch.equal(tok[0], tok[1])
+    # final LayerNorm: every token has the affine-LN statistics of norm.weight / norm.bias
+    gm, bt = sd["norm.weight"].to(dev), sd["norm.bias"].to(dev)
+    z = (tok - bt) / gm
+    assert z.mean(-1).abs().max().item() < 2e-3 and (z.var(-1, unbiased=False) - 1).abs().max().item() < 2e-2
+    # fused pooling: a grid cell's pooled feature == mean over its pixels of the explicitly up-sampled map
+    seg = OS.segment_grid(448, 448, 32)[0, 0].to(dev)
+    pooled = ops.segpool_bilinear_mean(seg[None].int(), tok[:1], 56, 196)[0]
+    dense = ops.upsample_bilinear(tok[:1], 56, 448)
+    want = dense[0].reshape(384, 14, 32, 14, 32).mean(dim=(2, 4)).reshape(384, 196).T
+    assert (pooled - want).abs().max().item() < 1e-4
+    # weights of every segment sum to one: pooling a constant map returns the constant
+    ones = torch.ones(1, 3136, 8, device=dev)
+    assert (ops.segpool_bilinear_mean(seg[None].int(), ones, 56, 196) - 1).abs().max().item() < 1e-5

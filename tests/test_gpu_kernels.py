@@ -1,0 +1,257 @@
+"""Per-kernel parity on the GPU, called through the C-ABI (ops.py -> libwvn_hip.so), against the CPU
+oracle / fp32 torch restatement of the same op on the same seeded inputs.  Tolerances are written
+next to each check: bit-exact for integer outputs, fp32 round-off for fp32 kernels, bf16 input
+quantisation for the MFMA kernels (compared against fp32 math ON THE bf16-ROUNDED INPUTS, so only
+accumulation order and the output rounding differ)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import interfaces as OI, segments as OS
+from wild_visual_navigation_amd import _lib, ops
+from wild_visual_navigation_amd._lib import check, lib, ptr, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (257, 1152, 384), (1000, 90, 768), (64, 384, 1536)])
+def test_gemm_bf16_epilogues(dev, M, N, K):
+    a = bf(torch.randn(M, K, generator=g(1)))
+    w = bf(torch.randn(N, K, generator=g(2)) * 0.1)
+    bias = torch.randn(N, generator=g(3))
+    ref = a.float() @ w.float().T + bias
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    scale = ref.abs().max().item()
+    out = ops.gemm_bf16(ad, wd, bd, _lib.EPI_F32).cpu()
+    assert (out - ref).abs().max().item() < 2e-5 * scale * math.sqrt(K), "fp32-out epilogue"
+    out = ops.gemm_bf16(ad, wd, bd, _lib.EPI_BF16).float().cpu()
+    assert (out - ref).abs().max().item() < 8e-3 * scale, "bf16-out epilogue (1 bf16 ulp of the result)"
+    out = ops.gemm_bf16(ad, wd, bd, _lib.EPI_GELU_BF16).float().cpu()
+    assert (out - F.gelu(ref)).abs().max().item() < 8e-3 * scale
+    out = ops.gemm_bf16(ad, wd, bd, _lib.EPI_RELU_BF16).float().cpu()
+    assert (out - F.relu(ref)).abs().max().item() < 8e-3 * scale
+    c0 = torch.randn(M, N, generator=g(4))
+    cd = c0.clone().to(dev)
+    ops.gemm_bf16(ad, wd, bd, _lib.EPI_RESID_F32, out=cd)
+    assert (cd.cpu() - (c0 + ref)).abs().max().item() < 2e-5 * scale * math.sqrt(K)
+
+
+def test_gemm_bf16_transpose_detecting_and_strided(dev):
+    # asymmetric, structured operands: C[m][n] = m*3 + n (exactly representable) catches row/col swaps
+    M, N, K = 160, 200, 64
+    a = torch.zeros(M, K)
+    a[:, 0] = torch.arange(M).float() * 3
+    a[:, 1] = 1.0
+    w = torch.zeros(N, K)
+    w[:, 0] = 1.0
+    w[:, 1] = torch.arange(N).float()
+    big = torch.zeros(M, 2 * K, dtype=torch.bfloat16, device=dev)  # A is a strided view (lda = 2K)
+    big[:, K:] = bf(a).to(dev)
+    out = ops.gemm_bf16(big[:, K:], bf(w).to(dev), None, _lib.EPI_F32).cpu()
+    want = torch.arange(M).float()[:, None] * 3 + torch.arange(N).float()[None]
+    assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_f32_layouts_and_epilogues(dev, ta, tb):
+    M, N, K = 150, 97, 203
+    A = torch.randn(M, K, generator=g(1))
+    B = torch.randn(K, N, generator=g(2))
+    bias = torch.randn(N, generator=g(3))
+    ref = A.double() @ B.double() + bias.double()
+    a_st = (A.T.contiguous() if ta else A).to(dev)
+    b_st = (B.T.contiguous() if tb else B).to(dev)
+    out = ops.gemm_f32(a_st, b_st, bias.to(dev), _lib.F32_NONE, trans_a=ta, trans_b=tb).cpu()
+    assert (out.double() - ref).abs().max().item() < 2e-4
+    out = ops.gemm_f32(a_st, b_st, bias.to(dev), _lib.F32_RELU, trans_a=ta, trans_b=tb).cpu()
+    assert (out.double() - ref.clamp(min=0)).abs().max().item() < 2e-4
+    out = ops.gemm_f32(a_st, b_st, bias.to(dev), _lib.F32_GELU, trans_a=ta, trans_b=tb).cpu()
+    assert (out.double() - F.gelu(ref)).abs().max().item() < 2e-4
+    out = ops.gemm_f32(a_st, b_st, bias.to(dev), _lib.F32_SIGMOID0, trans_a=ta, trans_b=tb).cpu()
+    want = ref.clone()
+    want[:, 0] = torch.sigmoid(want[:, 0])
+    assert (out.double() - want).abs().max().item() < 2e-4
+    mask = torch.randn(M, N, generator=g(5))
+    out = ops.gemm_f32(a_st, b_st, None, _lib.F32_RELUMASK, trans_a=ta, trans_b=tb, mask=mask.to(dev)).cpu()
+    want = torch.where(mask > 0, ref - bias.double(), torch.zeros_like(ref))
+    assert (out.double() - want).abs().max().item() < 2e-4
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("D", [384, 768, 64])
+def test_layernorm(dev, D):
+    rows = 301
+    x = torch.randn(rows, D, generator=g(1)) * 3 + 1
+    gm, bt = 1 + 0.1 * torch.randn(D, generator=g(2)), 0.1 * torch.randn(D, generator=g(3))
+    ref = F.layer_norm(x, (D,), gm, bt, eps=1e-6)
+    y = torch.empty(rows, D, device=dev)
+    check(lib().wvn_layernorm(ptr(x.to(dev)), ptr(gm.to(dev)), ptr(bt.to(dev)), ptr(y), 0, rows, D, 1e-6, stream()))
+    assert (y.cpu() - ref).abs().max().item() < 1e-5
+    yb = torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
+    check(lib().wvn_layernorm(ptr(x.to(dev)), ptr(gm.to(dev)), ptr(bt.to(dev)), ptr(yb), 1, rows, D, 1e-6, stream()))
+    assert (yb.float().cpu() - ref).abs().max().item() < 8e-3 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale):
+    att = torch.softmax((q.double() @ k.double().transpose(-1, -2)) * scale, dim=-1)
+    return att @ v.double()  # [B,h,N,64]
+
+
+def _pad(t, npad):
+    B, h, N, d = t.shape
+    out = torch.zeros(B, h, npad, d, dtype=t.dtype)
+    out[:, :, :N] = t
+    return out
+
+
+@pytest.mark.parametrize("ntok", [65, 197, 785, 130])
+def test_attention_f32(dev, ntok):
+    B, h, scale = 2, 3, 0.125
+    q, k, v = (torch.randn(B, h, ntok, 64, generator=g(s)) for s in (1, 2, 3))
+    k[0, 1, ntok // 2] *= 6.0  # a spiky key forces a late running-max jump (rescale branch)
+    npad = (ntok + 127) // 128 * 128
+    out = torch.empty(B * ntok, h * 64, device=dev)
+    check(lib().wvn_attention_f32(ptr(_pad(q, npad).to(dev)), ptr(_pad(k, npad).to(dev)), ptr(_pad(v, npad).to(dev)),
+                                  ptr(out), B, h, ntok, npad, scale, stream()))
+    ref = _attn_ref(q, k, v, scale).permute(0, 2, 1, 3).reshape(B * ntok, h * 64)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("ntok", [65, 197, 785, 130, 3137])
+def test_attention_bf16(dev, ntok):
+    B, h, scale = (1, 2, 0.125) if ntok > 1000 else (2, 3, 0.125)
+    q, k, v = (bf(torch.randn(B, h, ntok, 64, generator=g(s))) for s in (1, 2, 3))
+    k[0, 1, ntok // 2] = bf(k[0, 1, ntok // 2].float() * 6.0)
+    k[0, 0, ntok - 1] = bf(k[0, 0, ntok - 1].float() * 5.0)  # spike in the (masked-tail) last tile
+    npad = (ntok + 127) // 128 * 128
+    vt = _pad(v, npad).transpose(-1, -2).contiguous()  # [B,h,64,npad]
+    out = torch.empty(B * ntok, h * 64, dtype=torch.bfloat16, device=dev)
+    check(lib().wvn_attention_bf16(ptr(_pad(q, npad).to(dev)), ptr(_pad(k, npad).to(dev)), ptr(vt.to(dev)), ptr(out),
+                                   B, h, ntok, npad, scale, stream()))
+    ref = _attn_ref(q.float(), k.float(), v.float(), scale).permute(0, 2, 1, 3).reshape(B * ntok, h * 64)
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    # P is rounded to bf16 before PV (rel 2^-9 per term, averaging down) and O to bf16 on store
+    assert err < 2e-2, err
+    # uniform V => output must be exactly that constant row (softmax weights sum to 1 within rounding)
+    v1 = torch.ones(B, h, npad, 64, dtype=torch.bfloat16)
+    v1[:, :, ntok:] = 0
+    check(lib().wvn_attention_bf16(ptr(_pad(q, npad).to(dev)), ptr(_pad(k, npad).to(dev)),
+                                   ptr(v1.transpose(-1, -2).contiguous().to(dev)), ptr(out), B, h, ntok, npad, scale,
+                                   stream()))
+    assert (out.float().cpu() - 1.0).abs().max().item() < 1e-2
+
+
+# ---------------------------------------------------------------------------- patchify / up-sampling
+@pytest.mark.parametrize("S,P", [(64, 8), (224, 8), (64, 16)])
+def test_patchify(dev, S, P):
+    img = torch.rand(2, 3, S, S, generator=g(1))
+    G = S // P
+    want = F.unfold(OI.normalize(img), kernel_size=P, stride=P).transpose(1, 2).reshape(2 * G * G, 3 * P * P)
+    out = torch.empty(2 * G * G, 3 * P * P, device=dev)
+    check(lib().wvn_patchify(ptr(img.to(dev)), ptr(out), 0, 2, S, P, stream()))
+    assert (out.cpu() - want).abs().max().item() < 1e-6
+    outb = torch.empty(2 * G * G, 3 * P * P, dtype=torch.bfloat16, device=dev)
+    check(lib().wvn_patchify(ptr(img.to(dev)), ptr(outb), 1, 2, S, P, stream()))
+    assert torch.equal(outb.cpu(), bf(out.cpu()))
+
+
+@pytest.mark.parametrize("G,H,D", [(8, 64, 40), (28, 224, 90), (56, 448, 384), (14, 100, 33)])
+def test_upsample_bilinear_and_nearest(dev, G, H, D):
+    tok = torch.randn(2, G * G, D, generator=g(1))
+    ref = OI.upsample_bilinear_ac(tok.reshape(2, G, G, D).permute(0, 3, 1, 2), H)
+    out = ops.upsample_bilinear(tok.to(dev), G, H).cpu()
+    assert out.shape == ref.shape and (out - ref).abs().max().item() < 2e-5
+    lab = torch.randint(0, 20, (2, G, G), generator=g(2), dtype=torch.int32)
+    want = torch.stack([OI.upsample_nearest(lab[b], H)[0] for b in range(2)])
+    assert torch.equal(ops.upsample_nearest_labels(lab.to(dev), H).cpu(), want)  # integer map: bit-exact
+
+
+# ------------------------------------------------------------------------------------------- segments
+def _blobs(H, W, S, seed):
+    gg = g(seed)
+    cy, cx = torch.rand(S, generator=gg) * H, torch.rand(S, generator=gg) * W
+    ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    return ((ys[..., None] - cy) ** 2 + (xs[..., None] - cx) ** 2).argmin(-1)
+
+
+@pytest.mark.parametrize("G,H,S,D", [(8, 64, 7, 24), (28, 224, 50, 90), (56, 448, 100, 384)])
+def test_segpool_fused_matches_dense_reference(dev, G, H, S, D):
+    B = 2
+    tok = torch.randn(B, G * G, D, generator=g(1))
+    seg = torch.stack([_blobs(H, H, S, 10 + b) for b in range(B)])
+    seg[1][seg[1] == 3] = 0  # an id without pixels -> NaN row, like the reference's empty mean
+    dense = OI.upsample_bilinear_ac(tok.reshape(B, G, G, D).permute(0, 3, 1, 2), H)
+    def pooled(b):
+        sp = OS.sparsify_features(dense[b:b + 1], seg[b])  # [max id + 1, D]
+        return torch.cat([sp, torch.full((S - sp.shape[0], D), float("nan"))])
+
+    want = torch.stack([pooled(b) for b in range(B)])
+    got, cnt = ops.segpool_bilinear_mean(seg.to(dev), tok.to(dev), G, S, return_counts=True)
+    got = got.cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.allclose(got, want, atol=2e-5, equal_nan=True), (got - want).nan_to_num().abs().max()
+    want_cnt = torch.stack([torch.bincount(seg[b].reshape(-1), minlength=S) for b in range(B)])
+    assert torch.equal(cnt.cpu().long(), want_cnt)  # exact integer pixel counts
+    # random-pixel segmentation (seg = -1 elsewhere): pooled feature == interpolated feature at that pixel
+    idx = torch.randperm(H * H, generator=g(5))[:S]
+    sr = OS.segment_random(H, H, idx)
+    got = ops.segpool_bilinear_mean(sr[None].to(dev), tok[:1].to(dev), G, S)[0].cpu()
+    want = dense[0].reshape(D, H * H)[:, idx].T
+    assert torch.allclose(got, want, atol=2e-5)
+
+
+def test_segmean_dense_golden(dev, golden):
+    for name, c in golden("segments.pt").items():
+        seg = c["seg"].long()
+        H, W = seg.shape
+        if H != W:
+            continue
+        dense = torch.randn(1, c["dense_D"], H, W, generator=g(c["dense_seed"]))
+        tokens = dense[0].permute(1, 2, 0).reshape(1, H * W, -1)
+        got = ops.segmean_tokens(seg[None].to(dev), tokens.to(dev), int(seg.max()) + 1)[0].cpu()
+        assert torch.allclose(got, c["sparsified"], atol=1e-5, equal_nan=True), name
+
+
+def test_adjacency_and_centers_golden(dev, golden):
+    for name, c in golden("segments.pt").items():
+        seg = c["seg"].long().to(dev)
+        S = int(seg.max()) + 1
+        assert torch.equal(ops.seg_adjacency(seg, S).cpu(), c["adjacency"]), name  # bit-exact
+        assert torch.allclose(ops.seg_centers(seg, S).cpu(), c["centers"], atol=1e-4, equal_nan=True), name
+
+
+def test_label_pool_golden(dev, golden):
+    for name, c in golden("label_pool.pt").items():
+        S = c["signal"].shape[0]
+        sig, valid = ops.label_pool(c["mask"].to(dev), c["seg"].to(dev), S)
+        assert torch.allclose(sig.cpu(), c["signal"], atol=1e-6), name
+        assert torch.equal(valid.cpu(), c["valid"]), name
+
+
+# -------------------------------------------------------------------------------------------- k-means
+@pytest.mark.parametrize("P,C,K", [(64, 90, 5), (784, 90, 20), (3136, 90, 20), (196, 16, 7)])
+def test_kmeans_bit_exact(dev, P, C, K):
+    code = torch.randn(2, P, C, generator=g(1))
+    code[1, :, : C // 2] += 2.0  # second image has structure
+    lab, nseg = ops.kmeans_cosine(code.to(dev), K, iters=10, relabel=False)
+    for b in range(2):
+        want = OI.kmeans_cosine_labels(code[b].numpy(), K, iters=10)
+        assert np.array_equal(lab[b].cpu().numpy(), want), f"image {b}: {(lab[b].cpu().numpy() != want).sum()} labels differ"
+        assert int(nseg[b]) == len(np.unique(want))
+    lab2, _ = ops.kmeans_cosine(code.to(dev), K, iters=10, relabel=True)
+    for b in range(2):
+        want = OI.relabel_ascending(OI.kmeans_cosine_labels(code[b].numpy(), K, iters=10))
+        assert np.array_equal(lab2[b].cpu().numpy(), want)

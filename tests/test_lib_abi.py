@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/wvn_hip.h declares (no compute calls:
+this runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from wild_visual_navigation_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "wvn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wvn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built():
+    assert os.path.exists(_lib.LIB_PATH), "run python -c 'import __graft_entry__ as g; g.build()'"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    h = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(h, name), f"{name} declared in wvn_hip.h but not exported"
+    assert set(declared) == set(_lib.EXPORTED_SYMBOLS), set(declared) ^ set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.VitLayer) == 12 * 8
+    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 12 * 8
+    assert C.sizeof(_lib.MlpDesc) == 16
+
+
+def test_host_only_queries():
+    h = _lib.lib()
+    assert h.wvn_version() >= 100
+    assert h.wvn_mlp_param_count(C.byref(_lib.MlpDesc(384, 256, 32, 0))) == 119489
+    assert h.wvn_mlp_param_count(C.byref(_lib.MlpDesc(90, 256, 32, 0))) == 34523
+    m = _lib.VitModel()
+    m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim, m.precision = 448, 8, 384, 12, 6, 1536, _lib.PREC_BF16
+    one = h.wvn_vit_workspace_bytes(C.byref(m), 1)
+    two = h.wvn_vit_workspace_bytes(C.byref(m), 2)
+    # x fp32 + xn bf16 + q/k/v^T bf16 (3200-padded) + hidden bf16 + patches bf16, per frame
+    expect = 3137 * 384 * 4 + 3137 * 384 * 2 + 3 * 6 * 3200 * 64 * 2 + 3137 * 1536 * 2 + 3136 * 192 * 2
+    assert expect <= one <= expect + 8 * 256 and two > one
+
+
+def test_argument_validation_without_gpu():
+    h = _lib.lib()
+    assert h.wvn_gemm_bf16(None, 0, None, 0, None, None, 0, 1, 1, 64, 0, None) == 1001
+    assert h.wvn_vit_forward(None, None, 1, None, None, 0, None, 0, None) == 1001
+    with pytest.raises(_lib.WvnError):
+        _lib.check(1002, "x")
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    from wild_visual_navigation_amd import ops
+    from wild_visual_navigation_amd.backbone import VitBackbone, synthetic_vit_state_dict
+
+    with pytest.raises(_lib.WvnError):
+        ops.upsample_bilinear(torch.zeros(1, 4, 8), 2, 4)  # CPU tensor: must refuse, not fall back
+    with pytest.raises(_lib.WvnError):
+        VitBackbone(synthetic_vit_state_dict(depth=1, pretrain_grid=2), 16, 8, 6, device="cpu")

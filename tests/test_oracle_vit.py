@@ -1,0 +1,79 @@
+"""Architecture guard for the (un-pinned) backbone restatement: copy the synthetic weights into
+HuggingFace's ViTModel and require agreement to fp32 round-off."""
+import pytest
+import torch
+
+from oracle import interfaces as OI, vit as OV
+
+
+def _hf_model(sd, patch, heads, img):
+    transformers = pytest.importorskip("transformers")
+    D = sd["cls_token"].shape[-1]
+    depth = OV.vit_depth(sd)
+    cfg = transformers.ViTConfig(hidden_size=D, num_hidden_layers=depth, num_attention_heads=heads,
+                                 intermediate_size=4 * D, hidden_act="gelu", layer_norm_eps=1e-6, image_size=img,
+                                 patch_size=patch, qkv_bias=True, hidden_dropout_prob=0.0,
+                                 attention_probs_dropout_prob=0.0)
+    m = transformers.ViTModel(cfg, add_pooling_layer=False).eval()
+    hs = {}
+    hs["embeddings.cls_token"] = sd["cls_token"]
+    hs["embeddings.position_embeddings"] = sd["pos_embed"]
+    hs["embeddings.patch_embeddings.projection.weight"] = sd["patch_embed.proj.weight"]
+    hs["embeddings.patch_embeddings.projection.bias"] = sd["patch_embed.proj.bias"]
+    hs["layernorm.weight"], hs["layernorm.bias"] = sd["norm.weight"], sd["norm.bias"]
+    new_layout = any(k.startswith("layers.0.") for k in m.state_dict())  # transformers >= 5 renamed the encoder keys
+    for i in range(depth):
+        p = f"blocks.{i}."
+        w, b = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
+        if new_layout:
+            q = f"layers.{i}."
+            names = dict(q="attention.q_proj", k="attention.k_proj", v="attention.v_proj", o="attention.o_proj",
+                         fc1="mlp.fc1", fc2="mlp.fc2")
+        else:
+            q = f"encoder.layer.{i}."
+            names = dict(q="attention.attention.query", k="attention.attention.key", v="attention.attention.value",
+                         o="attention.output.dense", fc1="intermediate.dense", fc2="output.dense")
+        for j, n in enumerate(("q", "k", "v")):
+            hs[q + names[n] + ".weight"] = w[j * D:(j + 1) * D]
+            hs[q + names[n] + ".bias"] = b[j * D:(j + 1) * D]
+        hs[q + names["o"] + ".weight"], hs[q + names["o"] + ".bias"] = sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]
+        hs[q + "layernorm_before.weight"], hs[q + "layernorm_before.bias"] = sd[p + "norm1.weight"], sd[p + "norm1.bias"]
+        hs[q + "layernorm_after.weight"], hs[q + "layernorm_after.bias"] = sd[p + "norm2.weight"], sd[p + "norm2.bias"]
+        hs[q + names["fc1"] + ".weight"], hs[q + names["fc1"] + ".bias"] = sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]
+        hs[q + names["fc2"] + ".weight"], hs[q + names["fc2"] + ".bias"] = sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]
+    missing, unexpected = m.load_state_dict(hs, strict=False)
+    assert not unexpected and not [k for k in missing if "pooler" not in k], (missing, unexpected)
+    return m
+
+
+@pytest.mark.parametrize("arch,heads,img,depth", [("vit_small", 6, 64, 3), ("vit_base", 12, 32, 2)])
+def test_vit_matches_huggingface(arch, heads, img, depth):
+    patch = 8
+    sd = OV.make_vit_state_dict(arch, patch, pretrain_grid=img // patch, seed=1, depth=depth)
+    x = OI.normalize(torch.rand(2, 3, img, img, generator=torch.Generator().manual_seed(2)))
+    with torch.no_grad():
+        ours = OV.vit_tokens(sd, x, patch, heads)
+        hf = _hf_model(sd, patch, heads, img)(pixel_values=x).last_hidden_state
+    assert ours.shape == hf.shape
+    assert (ours - hf).abs().max().item() < 2e-4
+
+
+def test_param_count_matches_survey():
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28)
+    assert sum(v.numel() for v in sd.values()) == 21_670_272  # ViT-S/8 = 21.67 M params
+
+
+def test_pos_embed_resampling():
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, depth=1)
+    same = OV.interpolate_pos_embed(sd["pos_embed"], 28)
+    assert torch.equal(same, sd["pos_embed"])
+    up = OV.interpolate_pos_embed(sd["pos_embed"], 56)
+    assert up.shape == (1, 1 + 56 * 56, 384) and torch.equal(up[:, 0], sd["pos_embed"][:, 0])
+
+
+def test_transform_identity_and_crop():
+    img = torch.rand(1, 3, 224, 299)  # the demo frames are 299x224
+    out = OI.resize_nearest_center_crop(img, 224)
+    assert out.shape[-2:] == (224, 224) and torch.equal(out, img[..., :, 38:262])
+    sq = torch.rand(1, 3, 224, 224)
+    assert OI.resize_nearest_center_crop(sq, 224) is sq

@@ -1,0 +1,173 @@
+"""DINO ViT backbone on MI355X: host-side owner of the device weights / workspace around
+``wvn_vit_forward`` (include/wvn_hip.h).
+
+Replaces the module returned by ``stego.backbones.backbone.get_backbone(cfg)`` that the reference
+calls at wild_visual_navigation/feature_extractor/dino_interface.py:45,84.  Weights come in the
+upstream DINO state-dict layout, so released DINO checkpoints load unchanged; without a checkpoint
+(this build has no network) seeded synthetic weights of the same architecture are used.
+"""
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+ARCH = {"vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}
+
+
+def synthetic_vit_state_dict(arch="vit_small", patch=8, pretrain_grid=28, seed=0, depth=None) -> Dict[str, torch.Tensor]:
+    """Seeded random weights with realistic scales in the upstream DINO layout (no network here to
+    fetch dl.fbaipublicfiles.com/dino checkpoints).  LayerNorm affine and biases are non-trivial."""
+    D, dd, _ = ARCH[arch]
+    depth = dd if depth is None else depth
+    g = torch.Generator().manual_seed(seed)
+
+    def tn(*s, std=0.02):
+        return torch.nn.init.trunc_normal_(torch.empty(*s), std=std, a=-2 * std, b=2 * std, generator=g)
+
+    def rn(*s, std):
+        return torch.randn(*s, generator=g) * std
+
+    sd = {
+        "patch_embed.proj.weight": tn(D, 3, patch, patch, std=0.05), "patch_embed.proj.bias": rn(D, std=0.02),
+        "cls_token": tn(1, 1, D), "pos_embed": tn(1, 1 + pretrain_grid * pretrain_grid, D, std=0.1),
+        "norm.weight": 1.0 + rn(D, std=0.1), "norm.bias": rn(D, std=0.1),
+    }
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = 1.0 + rn(D, std=0.1)
+        sd[p + "norm1.bias"] = rn(D, std=0.05)
+        sd[p + "attn.qkv.weight"] = tn(3 * D, D, std=0.06)
+        sd[p + "attn.qkv.bias"] = rn(3 * D, std=0.02)
+        sd[p + "attn.proj.weight"] = tn(D, D, std=0.04)
+        sd[p + "attn.proj.bias"] = rn(D, std=0.02)
+        sd[p + "norm2.weight"] = 1.0 + rn(D, std=0.1)
+        sd[p + "norm2.bias"] = rn(D, std=0.05)
+        sd[p + "mlp.fc1.weight"] = tn(4 * D, D, std=0.04)
+        sd[p + "mlp.fc1.bias"] = rn(4 * D, std=0.02)
+        sd[p + "mlp.fc2.weight"] = tn(D, 4 * D, std=0.03)
+        sd[p + "mlp.fc2.bias"] = rn(D, std=0.02)
+    return sd
+
+
+def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
+    """DINO's position-table resampling (bicubic, scale (grid+0.1)/g), done ONCE when the model is
+    built -- it depends only on the input size, so it is weight preparation, not per-frame work."""
+    n_pre = pos_embed.shape[1] - 1
+    g = int(round(math.sqrt(n_pre)))
+    if g == grid:
+        return pos_embed.clone()
+    D = pos_embed.shape[-1]
+    tab = pos_embed[:, 1:].reshape(1, g, g, D).permute(0, 3, 1, 2).float()
+    sf = (grid + 0.1) / g
+    tab = F.interpolate(tab, scale_factor=(sf, sf), mode="bicubic")
+    if tab.shape[-1] != grid or tab.shape[-2] != grid:
+        raise _lib.WvnError(f"position table resampling produced {tuple(tab.shape)}, expected grid {grid}")
+    tab = tab.permute(0, 2, 3, 1).reshape(1, grid * grid, D)
+    return torch.cat([pos_embed[:, :1].float(), tab], dim=1)
+
+
+class VitBackbone:
+    """Device-resident DINO ViT.  ``precision``: "bf16" (MFMA fast path) or "fp32" (exact mode)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
+                 device="cuda", precision: str = "bf16", max_chunk: int = 16):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
+        self.lib = _lib.lib()
+        self.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_F32}[precision]
+        self.img_size, self.patch, self.heads = img_size, patch, heads
+        self.grid = img_size // patch
+        self.dim = state_dict["cls_token"].shape[-1]
+        self.depth = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
+        self.mlp_dim = state_dict["blocks.0.mlp.fc1.weight"].shape[0]
+        self.max_chunk = max_chunk
+        self._keep = []  # device tensors referenced by raw pointers in the C struct
+        wdt = torch.bfloat16 if self.precision == _lib.PREC_BF16 else torch.float32
+
+        def mat(t):
+            t = t.detach().to(self.device, dtype=wdt).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        def vec(t):
+            t = t.detach().to(self.device, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        sd = state_dict
+        m = _lib.VitModel()
+        m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim = img_size, patch, self.dim, self.depth, heads, self.mlp_dim
+        m.precision = self.precision
+        m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1))
+        m.patch_b = vec(sd["patch_embed.proj.bias"])
+        pos = resample_pos_embed(sd["pos_embed"].float().cpu(), self.grid)[0]  # [1+G*G, D]
+        m.cls_pos = vec(sd["cls_token"].reshape(-1).float().cpu() + pos[0])
+        m.pos = vec(pos)
+        m.norm_g, m.norm_b = vec(sd["norm.weight"]), vec(sd["norm.bias"])
+        for i in range(self.depth):
+            p = f"blocks.{i}."
+            L = m.layers[i]
+            L.qkv_w, L.qkv_b = mat(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
+            L.proj_w, L.proj_b = mat(sd[p + "attn.proj.weight"]), vec(sd[p + "attn.proj.bias"])
+            L.fc1_w, L.fc1_b = mat(sd[p + "mlp.fc1.weight"]), vec(sd[p + "mlp.fc1.bias"])
+            L.fc2_w, L.fc2_b = mat(sd[p + "mlp.fc2.weight"]), vec(sd[p + "mlp.fc2.bias"])
+            L.ln1_g, L.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
+            L.ln2_g, L.ln2_b = vec(sd[p + "norm2.weight"]), vec(sd[p + "norm2.bias"])
+        self.model = m
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+
+    # ---- workspace (zero-filled once: pad rows of q/k/v^T are never written by the kernels) -------------
+    def _workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or self._ws_batch < batch:
+            n = self.lib.wvn_vit_workspace_bytes(C.byref(self.model), batch)
+            self._ws = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+        return self._ws
+
+    @property
+    def lowp_dtype(self):
+        return torch.bfloat16 if self.precision == _lib.PREC_BF16 else torch.float32
+
+    def forward_tokens(self, img: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       lowp_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """img [B,3,S,S] fp32 in [0,1] -> final-LN patch tokens [B, G*G, D] fp32 (fresh tensor unless
+        ``out`` is given).  ``lowp_out`` (optional, [B*G*G, ld] in the model precision) receives the same
+        values for a following MFMA GEMM (STEGO head).  Frames are pushed through in chunks of
+        ``max_chunk`` so a chunk's activations stay resident in the 256 MB Infinity Cache."""
+        _lib.require_cuda(img, "img")
+        B, Cc, S, S2 = img.shape
+        if Cc != 3 or S != self.img_size or S2 != self.img_size:
+            raise _lib.WvnError(f"expected [B,3,{self.img_size},{self.img_size}], got {tuple(img.shape)}")
+        img = img.contiguous().float()
+        P = self.grid * self.grid
+        if out is None:
+            out = torch.empty(B, P, self.dim, dtype=torch.float32, device=self.device)
+        chunk = min(self.max_chunk, B)
+        ws = self._workspace(chunk)
+        st = _lib.stream()
+        esz = 2 if self.precision == _lib.PREC_BF16 else 4
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            lp, ld = 0, 0
+            if lowp_out is not None:
+                ld = lowp_out.stride(0)
+                lp = lowp_out.data_ptr() + b0 * P * ld * esz
+            rc = self.lib.wvn_vit_forward(C.byref(self.model), img[b0:].data_ptr(), nb, out[b0:].data_ptr(), lp, ld,
+                                          ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "wvn_vit_forward")
+        return out
+
+    def forward(self, img: torch.Tensor) -> torch.Tensor:
+        """What get_backbone's module returns: per-patch features [B, D, G, G] (a permuted view of the
+        token tensor; no copy)."""
+        tok = self.forward_tokens(img)
+        B = tok.shape[0]
+        return tok.reshape(B, self.grid, self.grid, self.dim).permute(0, 3, 1, 2)
+
+    __call__ = forward

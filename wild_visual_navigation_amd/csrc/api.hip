@@ -1,0 +1,422 @@
+// C-ABI of libwvn_hip.so (see include/wvn_hip.h) and the host-side launch sequences:
+// the ViT forward chain and the three phases of the traversability-MLP optimisation step.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/wvn_hip.h"
+#include "common.h"
+#include "wvn_internal.h"
+
+#define RET_IF(x)            \
+  do {                       \
+    int rc__ = (x);          \
+    if (rc__ != WVN_OK) return rc__; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// profiling: HIP events around each launch category of wvn_vit_forward, on the launch stream
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ProfSpan { hipEvent_t a, b; int cat; };
+bool g_prof_on = false;
+std::vector<ProfSpan> g_spans;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t get_event() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct Span {
+  hipStream_t st; hipEvent_t a{}, b{}; int cat; bool on;
+  Span(int cat_, hipStream_t st_) : st(st_), cat(cat_), on(g_prof_on) {
+    if (on) { a = get_event(); b = get_event(); (void)hipEventRecord(a, st); }
+  }
+  ~Span() {
+    if (on) { (void)hipEventRecord(b, st); g_spans.push_back({a, b, cat}); }
+  }
+};
+
+struct VitDims {
+  int B, S, P, G, D, H, F, KP, ntok, npad, npatch;
+  size_t esz;
+  long long M, Mp;
+};
+VitDims vit_dims(const wvn_vit_model* m, int batch) {
+  VitDims d;
+  d.B = batch; d.S = m->img_size; d.P = m->patch; d.G = d.S / d.P; d.D = m->dim; d.H = m->heads; d.F = m->mlp_dim;
+  d.KP = 3 * d.P * d.P; d.npatch = d.G * d.G; d.ntok = d.npatch + 1;
+  d.npad = (d.ntok + 127) / 128 * 128;
+  d.esz = m->precision == WVN_PREC_BF16 ? 2 : 4;
+  d.M = (long long)batch * d.ntok; d.Mp = (long long)batch * d.npatch;
+  return d;
+}
+struct VitWs { float* x; void* xn; void* q; void* k; void* v; void* hid; void* patches; size_t total; };
+VitWs vit_carve(const VitDims& d, void* base) {
+  VitWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return (void*)((char*)base + o); };
+  w.x = (float*)take((size_t)d.M * d.D * 4);
+  w.xn = take((size_t)d.M * d.D * d.esz);
+  size_t qkv = (size_t)d.B * d.H * d.npad * 64 * d.esz;
+  w.q = take(qkv); w.k = take(qkv); w.v = take(qkv);
+  w.hid = take((size_t)d.M * d.F * d.esz);
+  w.patches = take((size_t)d.Mp * d.KP * d.esz);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" {
+
+int wvn_version(void) { return 100; }
+
+int wvn_prof_enable(int on) { g_prof_on = on != 0; return WVN_OK; }
+
+int wvn_prof_collect(double* ms, long long* launches) {
+  for (int i = 0; i < WVN_PROF_NCAT; ++i) { ms[i] = 0.0; launches[i] = 0; }
+  for (auto& s : g_spans) {
+    hipError_t e = hipEventSynchronize(s.b);
+    if (e != hipSuccess) return (int)e;
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, s.a, s.b);
+    if (e != hipSuccess) return (int)e;
+    if (s.cat >= 0 && s.cat < WVN_PROF_NCAT) { ms[s.cat] += t; launches[s.cat] += 1; }
+    g_event_pool.push_back(s.a);
+    g_event_pool.push_back(s.b);
+  }
+  g_spans.clear();
+  return WVN_OK;
+}
+
+size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch) {
+  if (!m || batch <= 0) return 0;
+  VitDims d = vit_dims(m, batch);
+  return vit_carve(d, nullptr).total;
+}
+
+int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
+                    int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !img || !workspace || batch <= 0) return WVN_ERR_ARG;
+  if (m->dim != m->heads * 64 || m->depth <= 0 || m->depth > WVN_MAX_DEPTH || m->img_size % m->patch) return WVN_ERR_ARG;
+  if (m->dim % 128 || m->mlp_dim % 128) return WVN_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const VitDims d = vit_dims(m, batch);
+  if (d.KP % 64) return WVN_ERR_ARG;
+  const VitWs w = vit_carve(d, workspace);
+  if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
+  const bool bf = m->precision == WVN_PREC_BF16;
+  const float scale = 1.0f / sqrtf(64.f);
+  const int M = (int)d.M, Mp = (int)d.Mp;
+
+  { Span s(0, st); RET_IF(wvn_patchify_launch(img, w.patches, bf, d.B, d.S, d.P, st)); }
+  RET_IF(wvn_cls_rows_launch(m->cls_pos, w.x, d.B, d.ntok, d.D, st));
+  {
+    Span s(1, st);
+    if (bf) {
+      GemmBf16Params p{};
+      p.A = (const bf16_t*)w.patches; p.lda = d.KP; p.W = (const bf16_t*)m->patch_w; p.ldw = d.KP; p.bias = m->patch_b;
+      p.C = w.x; p.ldc = d.D; p.M = Mp; p.N = d.D; p.K = d.KP; p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok;
+      RET_IF(wvn_gemm_bf16_launch(p, EPI_PATCH, st));
+    } else {
+      GemmF32Params p{};
+      p.A = (const float*)w.patches; p.lda = d.KP; p.B = (const float*)m->patch_w; p.ldb = d.KP; p.transB = 1;
+      p.bias = m->patch_b; p.C = w.x; p.ldc = d.D; p.M = Mp; p.N = d.D; p.K = d.KP; p.batch = 1; p.splitk = 1;
+      p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok;
+      RET_IF(wvn_gemm_f32_launch(p, F32_EPI_PATCH, st));
+    }
+  }
+  for (int l = 0; l < m->depth; ++l) {
+    const wvn_vit_layer& L = m->layers[l];
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, st)); }
+    {
+      Span s(3, st);
+      if (bf) {
+        GemmBf16Params p{};
+        p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.qkv_w; p.ldw = d.D; p.bias = L.qkv_b;
+        p.M = M; p.N = 3 * d.D; p.K = d.D; p.q = (bf16_t*)w.q; p.k = (bf16_t*)w.k; p.vt = (bf16_t*)w.v;
+        p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok;
+        RET_IF(wvn_gemm_bf16_launch(p, EPI_QKV, st));
+      } else {
+        GemmF32Params p{};
+        p.A = (const float*)w.xn; p.lda = d.D; p.B = (const float*)L.qkv_w; p.ldb = d.D; p.transB = 1; p.bias = L.qkv_b;
+        p.C = (float*)w.q; p.M = M; p.N = 3 * d.D; p.K = d.D; p.batch = 1; p.splitk = 1;
+        p.q = (float*)w.q; p.k = (float*)w.k; p.v = (float*)w.v; p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok;
+        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_QKV, st));
+      }
+    }
+    {
+      Span s(4, st);
+      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.npad, scale, st));
+      else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.npad, scale, st));
+    }
+    {
+      Span s(5, st);
+      if (bf) {
+        GemmBf16Params p{};
+        p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.proj_w; p.ldw = d.D; p.bias = L.proj_b;
+        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.D;
+        RET_IF(wvn_gemm_bf16_launch(p, EPI_RESID_F32, st));
+      } else {
+        GemmF32Params p{};
+        p.A = (const float*)w.xn; p.lda = d.D; p.B = (const float*)L.proj_w; p.ldb = d.D; p.transB = 1; p.bias = L.proj_b;
+        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.D; p.batch = 1; p.splitk = 1;
+        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RESID, st));
+      }
+    }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, st)); }
+    {
+      Span s(6, st);
+      if (bf) {
+        GemmBf16Params p{};
+        p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.fc1_w; p.ldw = d.D; p.bias = L.fc1_b;
+        p.C = w.hid; p.ldc = d.F; p.M = M; p.N = d.F; p.K = d.D;
+        RET_IF(wvn_gemm_bf16_launch(p, EPI_GELU_BF16, st));
+      } else {
+        GemmF32Params p{};
+        p.A = (const float*)w.xn; p.lda = d.D; p.B = (const float*)L.fc1_w; p.ldb = d.D; p.transB = 1; p.bias = L.fc1_b;
+        p.C = (float*)w.hid; p.ldc = d.F; p.M = M; p.N = d.F; p.K = d.D; p.batch = 1; p.splitk = 1;
+        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_GELU, st));
+      }
+    }
+    {
+      Span s(7, st);
+      if (bf) {
+        GemmBf16Params p{};
+        p.A = (const bf16_t*)w.hid; p.lda = d.F; p.W = (const bf16_t*)L.fc2_w; p.ldw = d.F; p.bias = L.fc2_b;
+        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.F;
+        RET_IF(wvn_gemm_bf16_launch(p, EPI_RESID_F32, st));
+      } else {
+        GemmF32Params p{};
+        p.A = (const float*)w.hid; p.lda = d.F; p.B = (const float*)L.fc2_w; p.ldb = d.F; p.transB = 1; p.bias = L.fc2_b;
+        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.F; p.batch = 1; p.splitk = 1;
+        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RESID, st));
+      }
+    }
+  }
+  {
+    Span s(2, st);
+    RET_IF(wvn_layernorm_launch(w.x, m->norm_g, m->norm_b, tokens_lowp, bf, ld_lowp, tokens_f32, d.D, Mp, d.D, 1e-6f, 1, d.ntok, st));
+  }
+  return WVN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// building blocks
+// ---------------------------------------------------------------------------------------------
+int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                  int K, int epi, void* stream) {
+  if (epi < 0 || epi > EPI_ACCUM_F32 || !C) return WVN_ERR_ARG;
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
+}
+
+int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, int transB, const float* bias, float* C,
+                 int ldc, int M, int N, int K, int epi, const float* mask, int ldmask, void* stream) {
+  if (epi < 0 || epi > F32_EPI_RELUMASK) return WVN_ERR_ARG;
+  GemmF32Params p{};
+  p.A = A; p.lda = lda; p.transA = transA; p.B = B; p.ldb = ldb; p.transB = transB; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.batch = 1; p.splitk = 1; p.mask = mask; p.ldmask = ldmask;
+  return wvn_gemm_f32_launch(p, epi, (hipStream_t)stream);
+}
+
+int wvn_layernorm(const float* x, const float* gamma, const float* beta, void* y, int y_is_bf16, int rows, int D,
+                  float eps, void* stream) {
+  if (!y) return WVN_ERR_ARG;
+  return wvn_layernorm_launch(x, gamma, beta, y, y_is_bf16, D, nullptr, 0, rows, D, eps, 0, 0, (hipStream_t)stream);
+}
+
+int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad,
+                       float scale, void* stream) {
+  return wvn_attention_bf16_launch((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, heads, ntok,
+                                   npad, scale, (hipStream_t)stream);
+}
+int wvn_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok, int npad,
+                      float scale, void* stream) {
+  return wvn_attention_f32_launch(q, k, v, out, B, heads, ntok, npad, scale, (hipStream_t)stream);
+}
+int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream) {
+  return wvn_patchify_launch(img, patches, out_is_bf16, B, S, P, (hipStream_t)stream);
+}
+int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
+  if (!src || !dst || n <= 0 || n > 0x7fffffffll) return WVN_ERR_ARG;
+  return wvn_cast_f32_bf16_launch(src, (int)n, (bf16_t*)dst, (int)n, 1, (int)n, (hipStream_t)stream);
+}
+int wvn_upsample_bilinear(const float* tokens, float* dense, int B, int G, int D, int H, void* stream) {
+  return wvn_upsample_bilinear_launch(tokens, dense, B, G, D, H, (hipStream_t)stream);
+}
+int wvn_upsample_nearest_i32(const int* labels, int* out, int B, int G, int H, void* stream) {
+  if (!labels || !out) return WVN_ERR_ARG;
+  return wvn_upsample_nearest_i32_launch(labels, out, B, G, H, (hipStream_t)stream);
+}
+int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float* feat, float* scratch_w,
+                              int* scratch_cnt, int B, int H, int W, int G, int S, int D, void* stream) {
+  return wvn_segpool_launch(seg, tokens, ld, feat, scratch_w, scratch_cnt, B, H, W, G, S, D, (hipStream_t)stream);
+}
+int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, int B, int P, int S, int D,
+                       void* stream) {
+  return wvn_segmean_tokens_launch(seg, tokens, feat, scratch_cnt, B, P, S, D, (hipStream_t)stream);
+}
+int wvn_label_pool(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* scratch_sum,
+                   int* scratch_cnt, int H, int W, int S, void* stream) {
+  return wvn_label_pool_launch(mask, C, seg, signal, valid, scratch_sum, scratch_cnt, H, W, S, (hipStream_t)stream);
+}
+int wvn_seg_centers(const int* seg, float* centers, void* scratch, int H, int W, int S, void* stream) {
+  return wvn_centers_launch(seg, centers, (unsigned long long*)scratch, H, W, S, (hipStream_t)stream);
+}
+int wvn_seg_adjacency(const int* seg, long long* edges, int* count, unsigned char* scratch_bitmap, int H, int W, int S,
+                      int max_edges, void* stream) {
+  return wvn_adjacency_launch(seg, edges, count, scratch_bitmap, H, W, S, max_edges, (hipStream_t)stream);
+}
+int wvn_normalize_rows(const float* code, int ldc, float* xn, int rows, int C, void* stream) {
+  return wvn_normalize_rows_launch(code, ldc, xn, rows, C, (hipStream_t)stream);
+}
+int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, int B, int P, int C, int K, int iters, int relabel,
+                      void* stream) {
+  return wvn_kmeans_launch(xn, labels, nseg, B, P, C, K, iters, relabel, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// traversability MLP
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct MlpOff { size_t W1, b1, W2, b2, W3, b3, total; int O; };
+MlpOff mlp_off(const wvn_mlp_desc* d) {
+  MlpOff o;
+  o.O = 1 + d->D;
+  o.W1 = 0; o.b1 = o.W1 + (size_t)d->H1 * d->D; o.W2 = o.b1 + d->H1; o.b2 = o.W2 + (size_t)d->H2 * d->H1;
+  o.W3 = o.b2 + d->H2; o.b3 = o.W3 + (size_t)o.O * d->H2; o.total = o.b3 + o.O;
+  return o;
+}
+int mlp_splitk(int R) { int s = (R + 511) / 512; return s < 1 ? 1 : (s > 32 ? 32 : s); }
+struct MlpWs { float *h1, *h2, *out, *lr, *g_out, *g_h2, *g_h1, *trav_w, *trav_raw, *part; size_t total; };
+MlpWs mlp_carve(const wvn_mlp_desc* d, int R, void* base) {
+  MlpWs w;
+  size_t off = 0;
+  const int O = 1 + d->D;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n * sizeof(float), 256); return (float*)((char*)base + o); };
+  w.h1 = take((size_t)R * d->H1); w.h2 = take((size_t)R * d->H2); w.out = take((size_t)R * O); w.lr = take(R);
+  w.g_out = take((size_t)R * O); w.g_h2 = take((size_t)R * d->H2); w.g_h1 = take((size_t)R * d->H1);
+  w.trav_w = take(R); w.trav_raw = take(R);
+  size_t mx = (size_t)d->H1 * d->D;
+  if ((size_t)d->H2 * d->H1 > mx) mx = (size_t)d->H2 * d->H1;
+  if ((size_t)O * d->H2 > mx) mx = (size_t)O * d->H2;
+  w.part = take(mx * mlp_splitk(R));
+  w.total = off;
+  return w;
+}
+int mlp_fwd(const wvn_mlp_desc* d, const float* P, const float* x, int ldx, int R, float* out, float* h1, float* h2,
+            hipStream_t st) {
+  const MlpOff o = mlp_off(d);
+  GemmF32Params p{};
+  p.batch = 1; p.splitk = 1; p.transB = 1;
+  p.A = x; p.lda = ldx; p.B = P + o.W1; p.ldb = d->D; p.bias = P + o.b1; p.C = h1; p.ldc = d->H1; p.M = R; p.N = d->H1; p.K = d->D;
+  RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RELU, st));
+  p.A = h1; p.lda = d->H1; p.B = P + o.W2; p.ldb = d->H1; p.bias = P + o.b2; p.C = h2; p.ldc = d->H2; p.N = d->H2; p.K = d->H1;
+  RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RELU, st));
+  p.A = h2; p.lda = d->H2; p.B = P + o.W3; p.ldb = d->H2; p.bias = P + o.b3; p.C = out; p.ldc = o.O; p.N = o.O; p.K = d->H2;
+  RET_IF(wvn_gemm_f32_launch(p, F32_EPI_SIGMOID0, st));
+  return WVN_OK;
+}
+// dW[M,N] = G^T[M,R] * Hm[R,N] via deterministic split-K
+int mlp_wgrad(const float* G, int ldg, const float* Hm, int ldh, int M, int N, int R, float* part, float* dst,
+              hipStream_t st) {
+  const int sk = mlp_splitk(R);
+  GemmF32Params p{};
+  p.batch = 1; p.splitk = sk; p.A = G; p.lda = ldg; p.transA = 1; p.B = Hm; p.ldb = ldh; p.transB = 0;
+  p.C = sk > 1 ? part : dst; p.ldc = N; p.M = M; p.N = N; p.K = R;
+  RET_IF(wvn_gemm_f32_launch(p, F32_EPI_NONE, st));
+  if (sk > 1) RET_IF(wvn_splitk_reduce_launch(part, sk, (size_t)M * N, nullptr, N, dst, st));
+  return WVN_OK;
+}
+}  // namespace
+
+size_t wvn_mlp_param_count(const wvn_mlp_desc* d) { return d ? mlp_off(d).total : 0; }
+size_t wvn_mlp_workspace_bytes(const wvn_mlp_desc* d, int rows) {
+  if (!d || rows <= 0) return 0;
+  return mlp_carve(d, rows, nullptr).total;
+}
+
+int wvn_mlp_forward(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, int R, float* out, float* h1,
+                    float* h2, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !params || !x || !out || R <= 0) return WVN_ERR_ARG;
+  if (!h1 || !h2) {
+    if (!workspace) return WVN_ERR_ARG;
+    MlpWs w = mlp_carve(d, R, workspace);
+    if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
+    if (!h1) h1 = w.h1;
+    if (!h2) h2 = w.h2;
+  }
+  return mlp_fwd(d, params, x, ldx, R, out, h1, h2, (hipStream_t)stream);
+}
+
+int wvn_mlp_train_phase_a(const wvn_mlp_desc* d, const float* params, const float* x, int ldx,
+                          const unsigned char* y_valid, int R, double* stats, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!d || !params || !x || !y_valid || !stats || !workspace || R <= 0) return WVN_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MlpWs w = mlp_carve(d, R, workspace);
+  if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
+  RET_IF(mlp_fwd(d, params, x, ldx, R, w.out, w.h1, w.h2, st));
+  return wvn_mlp_rowloss_stats_launch(w.out, 1 + d->D, x, ldx, y_valid, w.lr, stats, R, d->D, st);
+}
+
+int wvn_mlp_train_phase_b(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
+                          const unsigned char* y_valid, int R, const double* stats, float std_factor, float w_trav,
+                          float w_reco, float* grads, float* confidence_out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!d || !params || !x || !y || !y_valid || !stats || !grads || !workspace || R <= 0) return WVN_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MlpWs w = mlp_carve(d, R, workspace);
+  if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
+  const MlpOff o = mlp_off(d);
+  const int O = o.O;
+  RET_IF(wvn_mlp_gradout_launch(w.out, O, x, ldx, y, y_valid, w.lr, stats, std_factor, w_trav, w_reco, w.g_out, O,
+                                w.trav_w, w.trav_raw, confidence_out, grads + o.total, R, d->D, st));
+  // layer 3
+  RET_IF(mlp_wgrad(w.g_out, O, w.h2, d->H2, O, d->H2, R, w.part, grads + o.W3, st));
+  RET_IF(wvn_colsum_launch(w.g_out, O, R, O, grads + o.b3, st));
+  {
+    GemmF32Params p{};
+    p.batch = 1; p.splitk = 1; p.A = w.g_out; p.lda = O; p.B = params + o.W3; p.ldb = d->H2; p.transB = 0;
+    p.C = w.g_h2; p.ldc = d->H2; p.M = R; p.N = d->H2; p.K = O; p.mask = w.h2; p.ldmask = d->H2;
+    RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RELUMASK, st));
+  }
+  // layer 2
+  RET_IF(mlp_wgrad(w.g_h2, d->H2, w.h1, d->H1, d->H2, d->H1, R, w.part, grads + o.W2, st));
+  RET_IF(wvn_colsum_launch(w.g_h2, d->H2, R, d->H2, grads + o.b2, st));
+  {
+    GemmF32Params p{};
+    p.batch = 1; p.splitk = 1; p.A = w.g_h2; p.lda = d->H2; p.B = params + o.W2; p.ldb = d->H1; p.transB = 0;
+    p.C = w.g_h1; p.ldc = d->H1; p.M = R; p.N = d->H1; p.K = d->H2; p.mask = w.h1; p.ldmask = d->H1;
+    RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RELUMASK, st));
+  }
+  // layer 1
+  RET_IF(mlp_wgrad(w.g_h1, d->H1, x, ldx, d->H1, d->D, R, w.part, grads + o.W1, st));
+  RET_IF(wvn_colsum_launch(w.g_h1, d->H1, R, d->H1, grads + o.b1, st));
+  return WVN_OK;
+}
+
+int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* grads, float* adam_m, float* adam_v,
+                          int step, float lr, const double* stats, float w_trav, float w_reco, float* losses,
+                          void* stream) {
+  if (!d || !params || !grads || !adam_m || !adam_v || !stats || step <= 0) return WVN_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const MlpOff o = mlp_off(d);
+  RET_IF(wvn_adam_launch(params, grads, adam_m, adam_v, (int)o.total, step, lr, 0.9f, 0.999f, 1e-8f, st));
+  if (losses) RET_IF(wvn_mlp_losses_launch(stats, grads + o.total, w_trav, w_reco, losses, st));
+  return WVN_OK;
+}
+
+int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,
+                       float* trav, float* conf, int R, int D, void* stream) {
+  if (!out || !x) return WVN_ERR_ARG;
+  return wvn_mlp_confidence_launch(out, ldo, x, ldx, mean, std, std_factor, trav, conf, R, D, (hipStream_t)stream);
+}
+
+}  // extern "C"

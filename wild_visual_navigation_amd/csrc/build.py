@@ -1,0 +1,81 @@
+"""Build libwvn_hip.so (gfx950 only) in-tree with hipcc.
+
+    python -m wild_visual_navigation_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to csrc/_build/, the library to
+wild_visual_navigation_amd/lib/libwvn_hip.so (git-ignored, shipped to the GPU box by gpurun).
+Code-object v5 so that the HIP 7.0 runtime bundled with the PyTorch wheel loads what the ROCm 7.2
+compiler emits; the library links libamdhip64.so.7 by soname, which resolves to the runtime torch
+already loaded (one HIP runtime per process, so torch's stream handles are valid inside the library).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(PKG, "lib", "libwvn_hip.so")
+SOURCES = [
+    "api.hip", "gemm_bf16.hip", "gemm_f32.hip", "elementwise.hip", "attention_bf16.hip", "attention_f32.hip",
+    "segments.hip", "stego.hip", "mlp.hip",
+]
+HEADERS = ["common.h", "wvn_internal.h", os.path.join("..", "..", "include", "wvn_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall",
+         "-Wno-unused-function"]
+# bit-exact integer outputs need un-fused multiply/add in the k-means kernels (see stego.hip)
+EXTRA = {"stego.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(HERE, h)) for h in HEADERS] + [os.path.abspath(__file__)]
+    hipcc = _hipcc()
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((s, [hipcc] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj]))
+
+    def run(job):
+        name, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return name, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for name, rc, log in ex.map(run, jobs):
+                if verbose and log.strip():
+                    print(f"[hipcc {name}]\n{log}", file=sys.stderr)
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {name}:\n{log}")
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB, {len(jobs)} objects recompiled)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,222 @@
+// HBM-bound elementwise / normalisation kernels of the backbone (gfx950).
+//   patchify  : ImageNet-normalise + im2col of PxP patches (fused; one pass over the frame)
+//   cls rows  : token 0 of every frame = cls_token + pos[0]
+//   layernorm : one 64-lane wave per token row, two-pass statistics in registers, fp32 math
+//   upsample  : bilinear align_corners=True  token-major [B,G*G,D] -> NCHW [B,D,H,H]
+#include "common.h"
+#include "wvn_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// patchify: img [B,3,S,S] fp32 in [0,1] -> patches [B*G*G, 3*P*P], k = c*P*P + py*P + px
+// (the flattening order of the conv weight [D,3,P,P]).  dino_interface.py:52 normalisation fused.
+// One thread per (patch, c, py): reads P contiguous floats, writes P contiguous outputs.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int P>
+__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int S) {
+  const int G = S / P;
+  const long long total = (long long)B * G * G * 3 * P;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  // order threads so that consecutive threads walk gx fastest -> contiguous image reads per row
+  int gx = (int)(i % G);
+  long long r = i / G;
+  int py = (int)(r % P); r /= P;
+  int gy = (int)(r % G); r /= G;
+  int c = (int)(r % 3);
+  int b = (int)(r / 3);
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const float* src = img + (((size_t)b * 3 + c) * S + (gy * P + py)) * S + gx * P;
+  T* dst = out + ((size_t)b * G * G + gy * G + gx) * (3 * P * P) + c * P * P + py * P;
+#pragma unroll
+  for (int px = 0; px < P; ++px) ElemIO<T>::store(dst + px, (src[px] - mean[c]) / stdv[c]);
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls_pos, float* __restrict__ x, int B, int ntok, int D) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  int b = i / D, d = i - b * D;
+  x[(size_t)b * ntok * D + d] = cls_pos[d];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per output row.  D <= 64*VPT_MAX.  Statistics exactly as torch (biased
+// variance, eps inside the sqrt), all in fp32.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VPT>  // VPT = D / 64 values per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, int ldy,
+                                                        float* __restrict__ y2, int ldy2, int rows_out, int D,
+                                                        float eps, int drop_cls, int ntok) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows_out) return;
+  size_t in_row = row;
+  if (drop_cls) {
+    int np = ntok - 1;
+    int b = row / np, pp = row - b * np;
+    in_row = (size_t)b * ntok + 1 + pp;
+  }
+  const float* xr = x + in_row * D;
+  float v[VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    v[i] = xr[lane + 64 * i];
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    float d = v[i] - mean;
+    q += d * d;
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    int c = lane + 64 * i;
+    float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    if (y) ElemIO<T>::store(y + (size_t)row * ldy + c, o);
+    if (y2) y2[(size_t)row * ldy2 + c] = o;
+  }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd,
+                                     int rows, int cols) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * cols) return;
+  int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+  dst[(size_t)r * ldd + c] = f32_to_bf16(src[(size_t)r * lds_ + c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear (align_corners=True) upsample of a token-major feature map to NCHW, the tensor
+// DinoInterface.inference returns (dino_interface.py:87-90).  HBM-write bound (308 MB/frame at
+// 448^2 x 384): one block per (b, output row y, 32-channel slab) stages the two source rows it
+// needs (2 x G x 32 floats) in LDS and emits full 448-float rows with coalesced stores.
+// ATen semantics: src = dst * (G-1)/(H-1) (fp32), i0 = (int)src, i1 = i0 + (i0 < G-1), w1 = src - i0.
+// ---------------------------------------------------------------------------------------------
+constexpr int UP_CH = 32;
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ tok, float* __restrict__ out, int B,
+                                                       int G, int D, int H) {
+  extern __shared__ float rows[];  // [2][G][UP_CH+1]
+  const int y = blockIdx.x, cs = blockIdx.y * UP_CH, b = blockIdx.z;
+  const float scale = (H > 1) ? (float)(G - 1) / (float)(H - 1) : 0.f;
+  const float sy = scale * (float)y;
+  const int y0 = (int)sy;
+  const int y1 = y0 + (y0 < G - 1 ? 1 : 0);
+  const float wy1 = sy - (float)y0, wy0 = 1.f - wy1;
+  const int tid = threadIdx.x;
+  const int nload = 2 * G * UP_CH;
+  for (int i = tid; i < nload; i += blockDim.x) {
+    int c = i % UP_CH;
+    int gx = (i / UP_CH) % G;
+    int r = i / (UP_CH * G);
+    int gy = r ? y1 : y0;
+    int ch = cs + c;
+    rows[(r * G + gx) * (UP_CH + 1) + c] = (ch < D) ? tok[((size_t)b * G * G + gy * G + gx) * D + ch] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < UP_CH * H; i += blockDim.x) {
+    int xo = i % H, c = i / H;
+    if (cs + c >= D) continue;
+    float sx = scale * (float)xo;
+    int x0 = (int)sx;
+    int x1 = x0 + (x0 < G - 1 ? 1 : 0);
+    float wx1 = sx - (float)x0, wx0 = 1.f - wx1;
+    float t0 = wx0 * rows[(0 * G + x0) * (UP_CH + 1) + c] + wx1 * rows[(0 * G + x1) * (UP_CH + 1) + c];
+    float t1 = wx0 * rows[(1 * G + x0) * (UP_CH + 1) + c] + wx1 * rows[(1 * G + x1) * (UP_CH + 1) + c];
+    out[(((size_t)b * D + cs + c) * H + y) * H + xo] = wy0 * t0 + wy1 * t1;
+  }
+}
+
+// nearest upsample of an integer label grid [B,G,G] -> [B,H,H]  (stego_interface.py:108-109;
+// ATen nearest: src = min((int)floorf(dst * (float)G / H), G-1))
+__global__ void upsample_nearest_i32_kernel(const int* __restrict__ lab, int* __restrict__ out, int B, int G, int H) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H * H) return;
+  int x = (int)(i % H);
+  int y = (int)((i / H) % H);
+  int b = (int)(i / ((long long)H * H));
+  const float sc = (float)G / (float)H;
+  int sy = min((int)floorf((float)y * sc), G - 1);
+  int sx = min((int)floorf((float)x * sc), G - 1);
+  out[i] = lab[((size_t)b * G + sy) * G + sx];
+}
+
+}  // namespace
+
+int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, int S, int P, hipStream_t st) {
+  if (!img || !patches || S % P != 0) return WVN_ERR_ARG;
+  const int G = S / P;
+  long long total = (long long)B * G * G * 3 * P;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (P == 8) {
+    if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 8>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
+    else hipLaunchKernelGGL((patchify_kernel<float, 8>), grid, dim3(256), 0, st, img, (float*)patches, B, S);
+  } else if (P == 16) {
+    if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 16>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
+    else hipLaunchKernelGGL((patchify_kernel<float, 16>), grid, dim3(256), 0, st, img, (float*)patches, B, S);
+  } else {
+    return WVN_ERR_ARG;
+  }
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, hipStream_t st) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(ceil_div(B * D, 256)), dim3(256), 0, st, cls_pos, x, B, ntok, D);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+template <typename T>
+static int ln_dispatch(const float* x, const float* g, const float* b, T* y, int ldy, float* y2, int ldy2, int rows_out,
+                       int D, float eps, int drop_cls, int ntok, hipStream_t st) {
+  dim3 grid(ceil_div(rows_out, 4)), block(256);
+  switch (D / 64) {
+    case 6: hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
+    case 12: hipLaunchKernelGGL((layernorm_kernel<T, 12>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
+    case 16: hipLaunchKernelGGL((layernorm_kernel<T, 16>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
+    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
+    default: return WVN_ERR_ARG;
+  }
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
+                         float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
+                         hipStream_t st) {
+  if (!x || !gamma || !beta || (D % 64) != 0 || rows_out <= 0) return WVN_ERR_ARG;
+  if (y_bf16) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, st);
+  return ln_dispatch<float>(x, gamma, beta, (float*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, st);
+}
+
+int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st) {
+  long long n = (long long)rows * cols;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds_, dst, ldd,
+                     rows, cols);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_upsample_bilinear_launch(const float* tok, float* out, int B, int G, int D, int H, hipStream_t st) {
+  if (!tok || !out) return WVN_ERR_ARG;
+  size_t shm = (size_t)2 * G * (UP_CH + 1) * sizeof(float);
+  hipLaunchKernelGGL(upsample_kernel, dim3(H, ceil_div(D, UP_CH), B), dim3(256), shm, st, tok, out, B, G, D, H);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_upsample_nearest_i32_launch(const int* lab, int* out, int B, int G, int H, hipStream_t st) {
+  long long n = (long long)B * H * H;
+  hipLaunchKernelGGL(upsample_nearest_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lab, out, B, G, H);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}

@@ -1,0 +1,295 @@
+// Segment kernels (HBM-bound integer / scatter work; wave-level reductions, no GEMM reshaping):
+//   segpool_weights + segpool_reduce : FeatureExtractor.sparsify_features fused with the bilinear
+//        up-sampling of DinoInterface.inference -- the [B,D,H,H] dense map (308 MB/frame) is never
+//        materialised.  mean_{pixels in s} bilinear(F)(pixel) = sum_p W[s,p] F[p] / |s| with
+//        W[s,p] = sum of the bilinear tap weights that pixels of s put on patch p.
+//   label_pool      : MissionNode.update_supervision_signal (nodes.py:400-440)
+//   centers         : SegmentExtractor.centers (segment_extractor.py:70-92), exact integer sums
+//   adjacency       : SegmentExtractor.adjacency_list (segment_extractor.py:39-67), bit-exact
+#include "common.h"
+#include "wvn_internal.h"
+
+namespace {
+
+__device__ inline float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// One lane per pixel, a wave covers 64 consecutive pixels of the flattened frame.  Runs of lanes
+// with the same (segment, row, left tap) are reduced in-wave (prefix-sum differences) so that one
+// lane per run issues the 4 weight atomics + 1 count atomic (~8x fewer L2 atomics at P=8).
+__global__ __launch_bounds__(256) void segpool_weights_kernel(const int* __restrict__ seg, float* __restrict__ W,
+                                                              int* __restrict__ cnt, int H, int Wd, int G, int S) {
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int npix = H * Wd;
+  const bool inb = pix < npix;
+  int s = -1, y = 0, x = 0;
+  if (inb) {
+    s = seg[(size_t)b * npix + pix];
+    y = pix / Wd;
+    x = pix - y * Wd;
+  }
+  if (s >= S) s = -1;
+  // align_corners=True taps; the reference resizes to (H, H) using H for both dims (dino_interface.py:88)
+  const float scale = (H > 1) ? (float)(G - 1) / (float)(H - 1) : 0.f;
+  const float sx = scale * (float)x, sy = scale * (float)y;
+  const int x0 = (int)sx, y0 = (int)sy;
+  const int x1 = x0 + (x0 < G - 1 ? 1 : 0), y1 = y0 + (y0 < G - 1 ? 1 : 0);
+  const float wx1 = sx - (float)x0, wx0 = 1.f - wx1;
+  const float wy1 = sy - (float)y0, wy0 = 1.f - wy1;
+
+  const long long key = (s < 0) ? -1ll : (((long long)s * H + y) * G + x0);
+  const long long prev = __shfl_up(key, 1, 64);
+  const bool head = (lane == 0) || (key != prev);
+  const unsigned long long heads = __ballot(head);
+  const float p0 = wave_incl_scan(s < 0 ? 0.f : wx0, lane);
+  const float p1 = wave_incl_scan(s < 0 ? 0.f : wx1, lane);
+  // end of my run = lane before the next head (or 63)
+  const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+  const int last = above ? (lane + __builtin_ctzll(above)) : 63;
+  const float e0 = __shfl(p0, last, 64), e1 = __shfl(p1, last, 64);
+  const float b0 = __shfl_up(p0, 1, 64), b1 = __shfl_up(p1, 1, 64);
+  if (head && s >= 0) {
+    const float r0 = e0 - (lane ? b0 : 0.f), r1 = e1 - (lane ? b1 : 0.f);
+    float* Wr = W + ((size_t)b * S + s) * (size_t)(G * G);
+    atomicAdd(Wr + y0 * G + x0, wy0 * r0);
+    if (r1 != 0.f) atomicAdd(Wr + y0 * G + x1, wy0 * r1);
+    if (wy1 != 0.f) {
+      atomicAdd(Wr + y1 * G + x0, wy1 * r0);
+      if (r1 != 0.f) atomicAdd(Wr + y1 * G + x1, wy1 * r1);
+    }
+    atomicAdd(cnt + (size_t)b * S + s, last - lane + 1);
+  }
+}
+
+// feat[b][s][:] = (sum_p W[b][s][p] * F[b][p][:]) / cnt[b][s]   (0/0 -> NaN like the reference's empty mean)
+// One workgroup per (s, b); thread = channel.  W rows are sparse: chunks are staged in LDS and
+// zero entries skipped (wave-uniform branch).  Accumulation order is ascending p: deterministic.
+__global__ void segpool_reduce_kernel(const float* __restrict__ W, const int* __restrict__ cnt,
+                                      const float* __restrict__ F, int ldf, float* __restrict__ feat, int P, int S,
+                                      int D) {
+  __shared__ float wch[256];
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int d = threadIdx.x;
+  const float* Wr = W + ((size_t)b * S + s) * P;
+  const float* Fb = F + (size_t)b * P * ldf;
+  float acc = 0.f;
+  for (int p0 = 0; p0 < P; p0 += 256) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) wch[i] = (p0 + i < P) ? Wr[p0 + i] : 0.f;
+    __syncthreads();
+    const int n = min(256, P - p0);
+    for (int i = 0; i < n; ++i) {
+      const float w = wch[i];
+      if (w != 0.f && d < D) acc = fmaf(w, Fb[(size_t)(p0 + i) * ldf + d], acc);
+    }
+  }
+  if (d < D) feat[((size_t)b * S + s) * D + d] = acc / (float)cnt[(size_t)b * S + s];
+}
+
+// ---- label pooling --------------------------------------------------------------------------
+__global__ void label_pool_accum_kernel(const float* __restrict__ mask, int C, const int* __restrict__ seg,
+                                        float* __restrict__ sum, int* __restrict__ cnt, int npix, int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  float t = 0.f;
+  int c = 0;
+  for (int ch = 0; ch < C; ++ch) {
+    float v = mask[(size_t)ch * npix + i];
+    if (!isnan(v)) { t += v; ++c; }
+  }
+  int s = seg[i];
+  if (c == 0 || s < 0 || s >= S) return;
+  atomicAdd(sum + s, t / (float)c);
+  atomicAdd(cnt + s, 1);
+}
+__global__ void label_pool_final_kernel(const float* __restrict__ sum, const int* __restrict__ cnt,
+                                        float* __restrict__ signal, unsigned char* __restrict__ valid, int S) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  float m = (cnt[s] > 0) ? sum[s] / (float)cnt[s] : 0.f;  // nan_to_num(0/0) = 0
+  if (isnan(m)) m = 0.f;
+  signal[s] = m;
+  valid[s] = m > 0.f;
+}
+
+// ---- centers ----------------------------------------------------------------------------------
+__global__ void centers_accum_kernel(const int* __restrict__ seg, unsigned long long* __restrict__ acc, int H, int Wd,
+                                     int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * Wd) return;
+  int s = seg[i];
+  if (s < 0 || s >= S) return;
+  int y = i / Wd, x = i - y * Wd;
+  atomicAdd(acc + 3 * s + 0, (unsigned long long)x);
+  atomicAdd(acc + 3 * s + 1, (unsigned long long)y);
+  atomicAdd(acc + 3 * s + 2, 1ull);
+}
+__global__ void centers_final_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ out, int S) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  double n = (double)acc[3 * s + 2];
+  out[2 * s + 0] = (float)((double)acc[3 * s + 0] / n);  // (x, y): the reference transposes before nonzero()
+  out[2 * s + 1] = (float)((double)acc[3 * s + 1] / n);
+}
+
+// ---- adjacency --------------------------------------------------------------------------------
+// pair (left=s[y,x], right=s[y,x+1]) and (s[y,x], s[y+1,x]) wherever they differ; key = left + right*S
+__global__ void adjacency_mark_kernel(const int* __restrict__ seg, unsigned char* __restrict__ bitmap, int H, int Wd,
+                                      int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * Wd) return;
+  int y = i / Wd, x = i - y * Wd;
+  int s = seg[i];
+  if (x + 1 < Wd) {
+    int r = seg[i + 1];
+    if (r != s && r >= 0 && s >= 0 && r < S && s < S) bitmap[(size_t)r * S + s] = 1;
+  }
+  if (y + 1 < H) {
+    int d = seg[i + Wd];
+    if (d != s && d >= 0 && s >= 0 && d < S && s < S) bitmap[(size_t)d * S + s] = 1;
+  }
+}
+// single workgroup: ordered compaction of the S*S bitmap (ascending key) -> edges[E][2] (int64), *count = E
+__global__ __launch_bounds__(1024) void adjacency_compact_kernel(const unsigned char* __restrict__ bitmap,
+                                                                 long long* __restrict__ edges, int* __restrict__ count,
+                                                                 int S, int max_edges) {
+  __shared__ int part[1024];
+  const int n = S * S;
+  const int per = (n + 1023) / 1024;
+  const int beg = threadIdx.x * per, end = min(n, beg + per);
+  int c = 0;
+  for (int i = beg; i < end; ++i) c += bitmap[i];
+  part[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 1024; ++i) { int t = part[i]; part[i] = run; run += t; }
+    *count = run;
+  }
+  __syncthreads();
+  int o = part[threadIdx.x];
+  for (int i = beg; i < end; ++i)
+    if (bitmap[i]) {
+      if (o < max_edges) { edges[2 * o + 0] = i % S; edges[2 * o + 1] = i / S; }
+      ++o;
+    }
+}
+
+
+// ---- plain per-segment mean of an explicit pixel-resolution map (sparsify_features on a dense tensor) ----
+// tokens [B,P,D] (pixel-major), seg [B,P]; workgroup = (pixel chunk, 64-channel slab, b): LDS partial sums,
+// then one global atomic per touched (segment, channel).  sums must be zero-filled, S*64*4 B <= 60 KB.
+constexpr int SM_PIX = 4096;
+__global__ __launch_bounds__(256) void segmean_accum_kernel(const int* __restrict__ seg, const float* __restrict__ tok,
+                                                            float* __restrict__ sums, int* __restrict__ cnt, int P,
+                                                            int S, int D) {
+  extern __shared__ float part[];  // [S][64] + int cnt[S]
+  int* pc = (int*)(part + (size_t)S * 64);
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * SM_PIX;
+  const int ch = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < S * 64; i += 256) part[i] = 0.f;
+  for (int i = threadIdx.x; i < S; i += 256) pc[i] = 0;
+  __syncthreads();
+  const int pend = min(P, p0 + SM_PIX);
+  for (int p = p0 + pl; p < pend; p += 4) {
+    const int s = seg[(size_t)b * P + p];
+    if (s < 0 || s >= S) continue;
+    if (c0 + ch < D) atomicAdd(&part[s * 64 + ch], tok[((size_t)b * P + p) * D + c0 + ch]);
+    if (ch == 0 && blockIdx.y == 0) atomicAdd(&pc[s], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S * 64; i += 256) {
+    const int s = i >> 6, c = i & 63;
+    if (part[i] != 0.f && c0 + c < D) atomicAdd(&sums[((size_t)b * S + s) * D + c0 + c], part[i]);
+  }
+  if (blockIdx.y == 0)
+    for (int i = threadIdx.x; i < S; i += 256)
+      if (pc[i]) atomicAdd(&cnt[(size_t)b * S + i], pc[i]);
+}
+__global__ void segmean_final_kernel(float* __restrict__ sums, const int* __restrict__ cnt, long long n, int D) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sums[i] = sums[i] / (float)cnt[i / D];
+}
+
+}  // namespace
+
+int wvn_segpool_launch(const int* seg, const float* tok, int ldf, float* feat, float* W, int* cnt, int B, int H,
+                       int Wd, int G, int S, int D, hipStream_t st) {
+  if (!seg || !tok || !feat || !W || !cnt || S <= 0 || D <= 0 || D > 1024) return WVN_ERR_ARG;
+  const int P = G * G;
+  hipError_t e = hipMemsetAsync(W, 0, (size_t)B * S * P * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(cnt, 0, (size_t)B * S * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(segpool_weights_kernel, dim3(ceil_div(H * Wd, 256), B), dim3(256), 0, st, seg, W, cnt, H, Wd, G, S);
+  WVN_LAUNCH_CHECK();
+  int threads = ((D + 63) / 64) * 64;
+  hipLaunchKernelGGL(segpool_reduce_kernel, dim3(S, B), dim3(threads), 0, st, W, cnt, tok, ldf, feat, P, S, D);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_label_pool_launch(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* sum,
+                          int* cnt, int H, int Wd, int S, hipStream_t st) {
+  if (!mask || !seg || !signal || !valid || !sum || !cnt) return WVN_ERR_ARG;
+  hipError_t e = hipMemsetAsync(sum, 0, S * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(cnt, 0, S * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(label_pool_accum_kernel, dim3(ceil_div(H * Wd, 256)), dim3(256), 0, st, mask, C, seg, sum, cnt,
+                     H * Wd, S);
+  WVN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(label_pool_final_kernel, dim3(ceil_div(S, 256)), dim3(256), 0, st, sum, cnt, signal, valid, S);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_centers_launch(const int* seg, float* centers, unsigned long long* scratch, int H, int Wd, int S,
+                       hipStream_t st) {
+  if (!seg || !centers || !scratch) return WVN_ERR_ARG;
+  hipError_t e = hipMemsetAsync(scratch, 0, (size_t)3 * S * sizeof(unsigned long long), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(centers_accum_kernel, dim3(ceil_div(H * Wd, 256)), dim3(256), 0, st, seg, scratch, H, Wd, S);
+  WVN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(centers_final_kernel, dim3(ceil_div(S, 256)), dim3(256), 0, st, scratch, centers, S);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_adjacency_launch(const int* seg, long long* edges, int* count, unsigned char* bitmap, int H, int Wd, int S,
+                         int max_edges, hipStream_t st) {
+  if (!seg || !edges || !count || !bitmap) return WVN_ERR_ARG;
+  hipError_t e = hipMemsetAsync(bitmap, 0, (size_t)S * S, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(adjacency_mark_kernel, dim3(ceil_div(H * Wd, 256)), dim3(256), 0, st, seg, bitmap, H, Wd, S);
+  WVN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adjacency_compact_kernel, dim3(1), dim3(1024), 0, st, bitmap, edges, count, S, max_edges);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, int B, int P, int S, int D,
+                              hipStream_t st) {
+  if (!seg || !tok || !out || !cnt || S <= 0 || (size_t)S * 65 * 4 > 60 * 1024) return WVN_ERR_ARG;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * S * D * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(cnt, 0, (size_t)B * S * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  size_t shm = (size_t)S * 65 * 4;
+  hipLaunchKernelGGL(segmean_accum_kernel, dim3(ceil_div(P, SM_PIX), ceil_div(D, 64), B), dim3(256), shm, st, seg, tok,
+                     out, cnt, P, S, D);
+  WVN_LAUNCH_CHECK();
+  long long n = (long long)B * S * D;
+  hipLaunchKernelGGL(segmean_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, cnt, n, D);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}

@@ -1,0 +1,102 @@
+// Internal (C++) launcher interfaces shared between the .hip translation units and api.hip.
+// The public, C-ABI surface is include/wvn_hip.h.
+#pragma once
+#include "common.h"
+
+// ---- bf16 MFMA GEMM (gemm_bf16.hip) -------------------------------------------------------------
+enum GemmEpilogue {
+  EPI_BF16 = 0,       // C(bf16)  = acc + bias
+  EPI_GELU_BF16 = 1,  // C(bf16)  = gelu(acc + bias)            (exact erf GELU)
+  EPI_RELU_BF16 = 2,  // C(bf16)  = relu(acc + bias)
+  EPI_F32 = 3,        // C(f32)   = acc + bias
+  EPI_RESID_F32 = 4,  // C(f32)  += acc + bias                  (residual stream update, in place)
+  EPI_ACCUM_F32 = 5,  // C(f32)  += acc + bias                  (same arithmetic; second GEMM of a sum)
+  EPI_PATCH = 6,      // patch-embed: row remap (b,p) -> b*ntok+1+p, + pos[1+p]
+  EPI_QKV = 7,        // scatter to q/k [b,h,npad,64] and v^T [b,h,64,npad]
+};
+
+struct GemmBf16Params {
+  const bf16_t* A; int lda;   // [M,K]
+  const bf16_t* W; int ldw;   // [N,K]
+  const float* bias;          // [N] or nullptr
+  void* C; int ldc;
+  int M, N, K;
+  // EPI_PATCH
+  const float* pos; int npatch; int ntok;
+  // EPI_QKV
+  bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad;
+};
+int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st);
+
+// ---- fp32 GEMM (gemm_f32.hip): exact-mode linears + the traversability MLP ---------------------
+enum GemmF32Epilogue {
+  F32_EPI_NONE = 0,       // C = acc + bias
+  F32_EPI_RELU = 1,
+  F32_EPI_GELU = 2,
+  F32_EPI_RESID = 3,      // C += acc + bias
+  F32_EPI_SIGMOID0 = 4,   // C = acc + bias, sigmoid applied to column 0 (SimpleMLP output)
+  F32_EPI_RELUMASK = 5,   // C = (mask > 0) ? acc : 0    (backward through ReLU; mask = forward activation)
+  F32_EPI_PATCH = 6,
+  F32_EPI_QKV = 7,        // scatter to q/k [b,h,npad,64] and v [b,h,npad,64] (fp32, not transposed)
+};
+struct GemmF32Params {
+  const float* A; int lda; int transA;  // transA=0: A[M,K] row-major ; 1: A stored [K,M]
+  const float* B; int ldb; int transB;  // transB=0: B[K,N] row-major ; 1: B stored [N,K] (torch Linear)
+  const float* bias;
+  float* C; int ldc;
+  int M, N, K;
+  int batch; long long strideA, strideB, strideC;  // batched over blockIdx.z (0 => shared)
+  int splitk;                                      // >1: C must hold splitk partial [M,N] slabs (stride M*ldc)
+  const float* mask; int ldmask;                   // F32_EPI_RELUMASK
+  const float* pos; int npatch; int ntok;          // F32_EPI_PATCH
+  float* q; float* k; float* v; int heads; int npad;  // F32_EPI_QKV
+};
+int wvn_gemm_f32_launch(const GemmF32Params& p, int epi, hipStream_t st);
+
+// ---- elementwise / normalisation (elementwise.hip) --------------------------------------------
+int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, int S, int P, hipStream_t st);
+int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, hipStream_t st);
+// LayerNorm over rows of x[rows, D] (fp32) -> y (bf16 or f32, leading dim ldy); optional second fp32 output.
+// row_map: 0 = identity; 1 = drop the class token (input row b*ntok+1+p -> output row b*(ntok-1)+p)
+int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
+                         float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
+                         hipStream_t st);
+int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st);
+
+// ---- attention (attention_bf16.hip / attention_f32.hip) ---------------------------------------
+int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
+                              int ntok, int npad, float scale, hipStream_t st);
+int wvn_attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok,
+                             int npad, float scale, hipStream_t st);
+
+// ---- misc launchers defined across the translation units ---------------------------------------
+int wvn_splitk_reduce_launch(const float* part, int splitk, size_t n, const float* bias, int ncols, float* out,
+                             hipStream_t st);
+int wvn_upsample_bilinear_launch(const float* tok, float* out, int B, int G, int D, int H, hipStream_t st);
+int wvn_upsample_nearest_i32_launch(const int* lab, int* out, int B, int G, int H, hipStream_t st);
+int wvn_segpool_launch(const int* seg, const float* tok, int ldf, float* feat, float* W, int* cnt, int B, int H,
+                       int Wd, int G, int S, int D, hipStream_t st);
+int wvn_label_pool_launch(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* sum,
+                          int* cnt, int H, int Wd, int S, hipStream_t st);
+int wvn_centers_launch(const int* seg, float* centers, unsigned long long* scratch, int H, int Wd, int S,
+                       hipStream_t st);
+int wvn_adjacency_launch(const int* seg, long long* edges, int* count, unsigned char* bitmap, int H, int Wd, int S,
+                         int max_edges, hipStream_t st);
+int wvn_normalize_rows_launch(const float* code, int ldc, float* xn, int rows, int C, hipStream_t st);
+int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, int B, int P, int C, int K, int iters, int relabel,
+                      hipStream_t st);
+int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int ldx, const unsigned char* valid,
+                                 float* lr, double* stats, int R, int D, hipStream_t st);
+int wvn_mlp_gradout_launch(const float* out, int ldo, const float* x, int ldx, const float* y,
+                           const unsigned char* valid, const float* lr, const double* stats, float std_factor,
+                           float w_trav, float w_reco, float* g, int ldg, float* trav_w, float* trav_raw,
+                           float* conf_out, float* extra, int R, int D, hipStream_t st);
+int wvn_colsum_launch(const float* A, int lda, int R, int N, float* outv, hipStream_t st);
+int wvn_adam_launch(float* p, const float* g, float* m, float* v, int n, int step, float lr, float b1, float b2,
+                    float eps, hipStream_t st);
+int wvn_mlp_losses_launch(const double* stats, const float* extra, float w_trav, float w_reco, float* losses,
+                          hipStream_t st);
+int wvn_mlp_confidence_launch(const float* out, int ldo, const float* x, int ldx, float mean, float std,
+                              float std_factor, float* trav, float* conf, int R, int D, hipStream_t st);
+int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, int B, int P, int S, int D,
+                              hipStream_t st);

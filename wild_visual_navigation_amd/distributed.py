@@ -1,0 +1,59 @@
+"""Multi-GPU plumbing: one process per GPU, frames sharded by rank, RCCL (torch.distributed backend
+"nccl" on ROCm) for the only exchange the path has -- the two tiny all-reduces of the MLP step
+(traversability_estimator/trainer.py).  Feature extraction / segmentation / pooling need no
+communication (frames are independent)."""
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def is_parallel() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) slice of n_items for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over ranks (no-op for a single process).  Summation order inside RCCL/gloo is
+    fixed for a given world size, so every rank receives bit-identical results."""
+    if is_parallel():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def barrier():
+    if is_parallel():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not is_parallel():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

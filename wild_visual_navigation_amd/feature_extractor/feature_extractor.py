@@ -1,0 +1,234 @@
+"""FeatureExtractor -- same public surface as
+wild_visual_navigation/feature_extractor/feature_extractor.py:19-398 (constructor, ``extract`` 5-tuple,
+``compute_segments`` / ``compute_features`` / ``sparsify_features``, properties), re-designed for
+MI355X: the ViT runs on MFMA kernels, and the per-segment features come from ONE fused
+up-sample + segment-mean kernel pair that reads the 4.8 MB patch map instead of writing and
+re-reading the 308 MB dense map (dino_interface.py:87-90 -> feature_extractor.py:390-396).
+``extract_batch`` is the batched (B > 1) entry point with per-image semantics identical to B = 1.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib, ops
+from .dino_interface import DinoInterface
+from .segment_extractor import SegmentExtractor
+from .stego_interface import StegoInterface
+
+
+class FeatureExtractor:
+    def __init__(self, device: str, segmentation_type: str = "slic", feature_type: str = "dino",
+                 input_size: int = 448, **kwargs):
+        self._device = torch.device(device)
+        self._segmentation_type = segmentation_type
+        self._feature_type = feature_type
+        self._input_size = input_size
+        self._stego_features_already_computed_in_segmentation = False
+        self._tokens = None  # patch-resolution features of the frame(s) being processed
+        self.segment_extractor = SegmentExtractor().to(self._device)
+        precision = kwargs.get("precision", "bf16")
+
+        if self._feature_type == "stego":
+            self._feature_dim = 90
+            self._extractor = StegoInterface(
+                device=device, input_size=input_size,
+                n_image_clusters=kwargs.get("n_image_clusters", 20),
+                run_clustering=kwargs.get("run_clustering", True),
+                run_crf=kwargs.get("run_crf", False),
+                backbone_type=kwargs.get("backbone_type", "vit_small"),
+                patch_size=kwargs.get("patch_size", 8), precision=precision,
+                backbone_weights=kwargs.get("pretrained_weights"), head_weights=kwargs.get("head_weights"),
+                max_chunk=kwargs.get("max_chunk", 16),
+            )
+        elif "dino" in self._feature_type:
+            self._feature_dim = 384  # the reference hard-codes 384 for any dino type (feature_extractor.py:56)
+            self._extractor = DinoInterface(
+                device=device, input_size=input_size, patch_size=kwargs.get("patch_size", 8),
+                backbone=kwargs.get("backbone", self._feature_type),
+                backbone_type=kwargs.get("backbone_type", "vit_small"),
+                pretrained_weights=kwargs.get("pretrained_weights"), precision=precision,
+                max_chunk=kwargs.get("max_chunk", 16),
+            )
+            self._feature_dim = self._extractor.feature_dim
+        elif self._feature_type == "none":
+            self._extractor = None
+        else:
+            # sift / torchvision / histogram ablation extractors are outside the MI355X hot path
+            raise TypeError(f"Extractor[{self._feature_type}] not supported!")
+
+        if self.segmentation_type == "slic":
+            try:
+                from fast_slic import Slic  # CPU SLIC, external; identical to the reference's dependency
+            except ImportError as e:
+                raise _lib.WvnError("segmentation_type='slic' needs the external CPU package fast_slic") from e
+            self.slic = Slic(num_components=kwargs.get("slic_num_components", 100),
+                             compactness=kwargs.get("slic_compactness", 10))
+        elif self.segmentation_type == "stego" and self._feature_type != "stego":
+            raise TypeError("segmentation_type 'stego' requires feature_type 'stego' (as in the reference)")
+
+    # ------------------------------------------------------------------------------------------ props
+    @property
+    def feature_type(self):
+        return self._feature_type
+
+    @property
+    def feature_dim(self):
+        return self._feature_dim
+
+    @property
+    def segmentation_type(self):
+        return self._segmentation_type
+
+    def change_device(self, device):
+        self._device = torch.device(device)
+        self._extractor.change_device(device)
+
+    # ------------------------------------------------------------------------------------------ extract
+    @torch.no_grad()
+    def extract(self, img: torch.Tensor, **kwargs):
+        """feature_extractor.py:95-128.  img [1,3,H,W] fp32 in [0,1].
+        Returns (edges [2,E] i64, feat [S,D] f32, seg [H,W] i64, center [S,2] f32, dense [1,D,H,H] | None)."""
+        img = img.to(self._device)
+        want_dense = kwargs.get("return_dense_features", False)
+        if self._segmentation_type == "random":
+            tokens = self._feature_tokens(img)
+            H, W = img.shape[2:]
+            nr = kwargs.get("n_random_pixels", 100)
+            seg = torch.full((H * W,), -1, dtype=torch.long, device=self._device)
+            indices = torch.randperm(H * W, device=self._device)[:nr]
+            seg[indices] = torch.arange(0, nr, device=self._device)
+            seg = seg.reshape(H, W)
+            # a one-pixel segment's "mean" is the interpolated feature at that pixel
+            feat = ops.segpool_bilinear_mean(seg[None], tokens, self._grid(), nr)[0]
+            dense = ops.upsample_bilinear(tokens, self._grid(), H) if want_dense else None
+            return None, feat, seg, None, dense
+
+        edges, seg, center = self.compute_segments(img, **kwargs)
+        tokens = self._feature_tokens(img)
+        n_seg = center.shape[0]
+        feat = ops.segpool_bilinear_mean(seg[None], tokens, self._grid(), n_seg)[0]
+        dense = ops.upsample_bilinear(tokens, self._grid(), img.shape[2]) if want_dense else None
+        return edges, feat, seg, center, dense
+
+    @torch.no_grad()
+    def extract_batch(self, img: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Batched hot path (no graph structure): img [B,3,H,H] -> (feat [B,S,D], seg [B,H,H] int32,
+        n_segments [B] int32).  Rows of ids that do not occur in an image are NaN (the reference's empty
+        mean).  Supported segmentations: grid, stego."""
+        img = img.to(self._device)
+        B, _, H, W = img.shape
+        if self._segmentation_type == "grid":
+            seg = self.segment_grid(img, **kwargs)[0, 0].to(torch.int32)[None].expand(B, H, W).contiguous()
+            n_seg = (H // kwargs.get("cell_size", 32)) * (W // kwargs.get("cell_size", 32))
+            nseg = torch.full((B,), n_seg, dtype=torch.int32, device=self._device)
+            tokens = self._feature_tokens(img)
+        elif self._segmentation_type == "stego":
+            self._extractor.inference(img)
+            seg = self._extractor.cluster_segments[0]
+            nseg = self._extractor._n_segments
+            n_seg = self._extractor._cfg.n_image_clusters
+            tokens = self._extractor.feature_tokens
+        else:
+            raise TypeError(f"extract_batch: segmentation_type [{self._segmentation_type}] not supported")
+        feat = ops.segpool_bilinear_mean(seg, tokens, self._grid(), n_seg)
+        return feat, seg, nseg
+
+    # ------------------------------------------------------------------------------------------ pieces
+    def _grid(self) -> int:
+        return self._extractor.grid
+
+    def _feature_tokens(self, img: torch.Tensor) -> torch.Tensor:
+        """Patch-resolution features [B, G*G, D] of the configured feature type."""
+        if self._feature_type == "stego":
+            if self._stego_features_already_computed_in_segmentation:
+                self._stego_features_already_computed_in_segmentation = False
+                return self._extractor.feature_tokens
+            self._extractor.inference(img.clone())
+            return self._extractor.feature_tokens
+        return self._extractor.inference_tokens(img)
+
+    def compute_segments(self, img: torch.Tensor, **kwargs):
+        """feature_extractor.py:151-177 -> (edges [2,E], seg [H,W] i64, centers [S,2])."""
+        if self._segmentation_type == "none" or self._segmentation_type is None:
+            edges, seg, centers = self.segment_pixelwise(img, **kwargs)
+            return edges.T, seg[0, 0], centers
+        if self._segmentation_type == "grid":
+            seg = self.segment_grid(img, **kwargs)
+        elif self._segmentation_type == "slic":
+            seg = self.segment_slic(img, **kwargs)
+        elif self._segmentation_type == "stego":
+            seg = self.segment_stego(img, **kwargs)
+        elif self._segmentation_type == "random":
+            seg = self.segment_random(img, **kwargs)
+        else:
+            raise TypeError(f"segmentation_type [{self._segmentation_type}] not supported")
+        edges = self.segment_extractor.adjacency_list(seg)
+        centers = self.segment_extractor.centers(seg)
+        return edges.T, seg[0, 0], centers
+
+    def segment_pixelwise(self, img, **kwargs):
+        B, C, H, W = img.shape
+        seg = torch.arange(0, H * W, 1, device=self._device).reshape(H, W)
+        ys, xs = torch.meshgrid(torch.arange(H, device=self._device), torch.arange(W, device=self._device),
+                                indexing="ij")
+        centers = torch.stack([ys.reshape(-1), xs.reshape(-1)], dim=1)
+        hor = torch.stack([seg[:, :-1].reshape(-1), seg[:, 1:].reshape(-1)], dim=1)
+        ver = torch.stack([seg[:-1, :].reshape(-1), seg[1:, :].reshape(-1)], dim=1)
+        return torch.cat([hor, ver], dim=0), seg[None, None], centers
+
+    def segment_grid(self, img, **kwargs):
+        """feature_extractor.py:198-219: id = row-major index of the cell_size cell (index arithmetic only)."""
+        cell = kwargs.get("cell_size", 32)
+        H, W = img.shape[2:]
+        gy = torch.arange(H, device=self._device) // cell
+        gx = torch.arange(W, device=self._device) // cell
+        return (gy[:, None] * (W // cell) + gx[None, :])[None, None].to(torch.int64)
+
+    def segment_slic(self, img, **kwargs):
+        import numpy as np
+
+        img_np = img[0].permute(1, 2, 0).cpu().numpy()
+        seg = self.slic.iterate(np.uint8(np.ascontiguousarray(img_np) * 255))[None, None]
+        return torch.from_numpy(seg).to(self._device).type(torch.long)
+
+    def segment_random(self, img, **kwargs):
+        H, W = img.shape[2:]
+        nr = kwargs.get("n_random_pixels", 100)
+        seg = torch.full((H * W,), -1, dtype=torch.long, device=self._device)
+        indices = torch.randperm(H * W, device=self._device)[:nr]
+        seg[indices] = torch.arange(0, nr, device=self._device)
+        return seg.reshape(H, W)[None, None]
+
+    def segment_stego(self, img, **kwargs):
+        """feature_extractor.py:237-249; the ascending relabel is done inside the k-means kernel."""
+        self._extractor.inference(img.clone())
+        seg = self._extractor.cluster_segments.to(torch.long)  # [1,1,H,H]
+        self._stego_features_already_computed_in_segmentation = True
+        return seg
+
+    @torch.no_grad()
+    def compute_features(self, img: torch.Tensor, seg: torch.Tensor, center: torch.Tensor, **kwargs):
+        """feature_extractor.py:251-274: dense per-pixel features [B,D,H,H] (materialised on request only)."""
+        if self._feature_type == "none":
+            return None
+        if self._feature_type == "stego":
+            if self._stego_features_already_computed_in_segmentation:
+                self._stego_features_already_computed_in_segmentation = False
+                return self._extractor.features
+            self._extractor.inference(img.clone())
+            return self._extractor.features
+        return self._extractor.inference(img.clone())
+
+    @torch.no_grad()
+    def sparsify_features(self, dense_features: torch.Tensor, seg: torch.Tensor, cumsum_trick=False):
+        """feature_extractor.py:310-398 (default branch) on an explicit dense map: identity resampling
+        through the same segment-mean kernels (grid == image size)."""
+        if self._feature_type in ["histogram"] or self._segmentation_type in ["none"]:
+            return dense_features
+        _lib.require_cuda(dense_features, "dense_features")
+        _, D, H, W = dense_features.shape
+        if H != W:
+            raise _lib.WvnError("sparsify_features expects the square [1,D,H,H] map DinoInterface produces")
+        n_seg = int(seg.max().item()) + 1
+        tokens = dense_features[0].permute(1, 2, 0).reshape(1, H * W, D).contiguous()
+        return ops.segmean_tokens(seg[None], tokens, n_seg)[0]

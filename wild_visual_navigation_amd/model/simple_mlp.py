@@ -1,0 +1,84 @@
+"""SimpleMLP -- wild_visual_navigation/model/simple_mlp.py:10-39 on HIP kernels.
+
+Same constructor, same ``state_dict`` keys (``layers.{0,2,4}.{weight,bias}``), same ``forward(Data)``
+contract ([R, 1+D] with the sigmoid applied to column 0).  All six parameter tensors are views into
+ONE flat fp32 buffer [W1|b1|W2|b2|W3|b3] -- the layout libwvn_hip's MLP entry points, the Adam kernel
+and the data-parallel gradient all-reduce operate on.
+"""
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from .. import _lib
+from ..utils.data import Data
+
+
+class SimpleMLP(torch.nn.Module):
+    def __init__(self, input_size: int = 64, hidden_sizes: List[int] = [255], reconstruction: bool = False):
+        super().__init__()
+        hidden_sizes = list(hidden_sizes)  # the reference mutates its argument (simple_mlp.py:21-22); we do not
+        self.nr_sigmoid_layers = hidden_sizes[-1]
+        if reconstruction:
+            hidden_sizes[-1] = hidden_sizes[-1] + input_size
+        if len(hidden_sizes) != 3 or self.nr_sigmoid_layers != 1 or not reconstruction:
+            raise ValueError("the MI355X path implements the default SimpleMLP(D, [h1, h2, 1], reconstruction=True)")
+        self.input_size = input_size
+        layers, i = [], input_size
+        for hs in hidden_sizes[:-1]:
+            layers += [torch.nn.Linear(i, hs), torch.nn.ReLU()]
+            i = hs
+        layers.append(torch.nn.Linear(i, hidden_sizes[-1]))
+        self.layers = torch.nn.Sequential(*layers)
+        self.output_features = hidden_sizes[-1]
+        self.desc = _lib.MlpDesc(input_size, hidden_sizes[0], hidden_sizes[1], 0)
+        self._flat: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- flat parameter storage --------------------------------------------------------------------
+    def _params_in_order(self):
+        return [self.layers[0].weight, self.layers[0].bias, self.layers[2].weight, self.layers[2].bias,
+                self.layers[4].weight, self.layers[4].bias]
+
+    def flat_params(self) -> torch.Tensor:
+        """The flat buffer the six parameters alias (re-packed if .to()/load broke the aliasing)."""
+        ps = self._params_in_order()
+        ok = self._flat is not None and self._flat.device == ps[0].device
+        if ok:
+            off = 0
+            for p in ps:
+                if p.data_ptr() != self._flat.data_ptr() + 4 * off or not p.is_contiguous():
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
+            off = 0
+            for p in ps:
+                p.data = flat[off: off + p.numel()].view_as(p)
+                off += p.numel()
+            self._flat = flat
+        return self._flat
+
+    def _workspace(self, rows: int) -> torch.Tensor:
+        need = _lib.lib().wvn_mlp_workspace_bytes(C.byref(self.desc), rows)
+        dev = self.layers[0].weight.device
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def forward(self, data: Data) -> torch.Tensor:
+        x = data.x
+        _lib.require_cuda(x, "data.x")
+        x = x.float()
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        R = x.shape[0]
+        flat = self.flat_params()
+        out = torch.empty(R, self.output_features, dtype=torch.float32, device=x.device)
+        ws = self._workspace(R)
+        rc = _lib.lib().wvn_mlp_forward(C.byref(self.desc), flat.data_ptr(), x.data_ptr(), x.stride(0), R,
+                                        out.data_ptr(), 0, 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        _lib.check(rc, "wvn_mlp_forward")
+        return out

@@ -1,0 +1,167 @@
+"""Functional wrappers (torch tensors in / out) around the C-ABI kernels of libwvn_hip.so.
+Allocation and stream selection happen here; arithmetic happens in HIP.  No fallbacks."""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, require_cuda, stream
+
+
+def _i32(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+def upsample_bilinear(tokens: torch.Tensor, grid: int, out_size: int) -> torch.Tensor:
+    """tokens [B,G*G,D] fp32 -> dense [B,D,H,H] (align_corners=True; dino_interface.py:87-90)."""
+    require_cuda(tokens, "tokens")
+    tokens = tokens.contiguous()
+    B, P, D = tokens.shape
+    out = torch.empty(B, D, out_size, out_size, dtype=torch.float32, device=tokens.device)
+    check(lib().wvn_upsample_bilinear(ptr(tokens), ptr(out), B, grid, D, out_size, stream()), "wvn_upsample_bilinear")
+    return out
+
+
+def upsample_nearest_labels(labels: torch.Tensor, out_size: int) -> torch.Tensor:
+    """labels [B,G,G] int32 -> [B,H,H] int32 (stego_interface.py:108-109)."""
+    require_cuda(labels, "labels")
+    labels = _i32(labels).contiguous()
+    B, G, _ = labels.shape
+    out = torch.empty(B, out_size, out_size, dtype=torch.int32, device=labels.device)
+    check(lib().wvn_upsample_nearest_i32(ptr(labels), ptr(out), B, G, out_size, stream()), "wvn_upsample_nearest_i32")
+    return out
+
+
+def segpool_bilinear_mean(seg: torch.Tensor, tokens: torch.Tensor, grid: int, n_seg: int,
+                          return_counts: bool = False):
+    """Fused up-sample + per-segment mean (feature_extractor.py:390-396 on dino_interface.py:87-90).
+    seg [B,H,W] int (-1 ignored), tokens [B,G*G,D] fp32 -> feat [B,S,D] fp32 (NaN row for an empty id)."""
+    require_cuda(tokens, "tokens")
+    seg = _i32(seg).contiguous()
+    B, H, W = seg.shape
+    tokens = tokens.contiguous()
+    D = tokens.shape[-1]
+    dev = tokens.device
+    feat = torch.empty(B, n_seg, D, dtype=torch.float32, device=dev)
+    wbuf = torch.empty(B * n_seg * grid * grid, dtype=torch.float32, device=dev)
+    cnt = torch.empty(B * n_seg, dtype=torch.int32, device=dev)
+    check(lib().wvn_segpool_bilinear_mean(ptr(seg), ptr(tokens), D, ptr(feat), ptr(wbuf), ptr(cnt), B, H, W, grid,
+                                          n_seg, D, stream()), "wvn_segpool_bilinear_mean")
+    return (feat, cnt.reshape(B, n_seg)) if return_counts else feat
+
+
+def segmean_tokens(seg: torch.Tensor, tokens: torch.Tensor, n_seg: int) -> torch.Tensor:
+    """Plain per-segment mean of a pixel-resolution map: seg [B,H,W] / [B,P], tokens [B,P,D] -> [B,S,D]."""
+    require_cuda(tokens, "tokens")
+    tokens = tokens.contiguous().float()
+    B, P, D = tokens.shape
+    seg = _i32(seg).reshape(B, P).contiguous()
+    out = torch.empty(B, n_seg, D, dtype=torch.float32, device=tokens.device)
+    cnt = torch.empty(B * n_seg, dtype=torch.int32, device=tokens.device)
+    check(lib().wvn_segmean_tokens(ptr(seg), ptr(tokens), ptr(out), ptr(cnt), B, P, n_seg, D, stream()),
+          "wvn_segmean_tokens")
+    return out
+
+
+def label_pool(mask: torch.Tensor, seg: torch.Tensor, n_seg: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """MissionNode.update_supervision_signal (nodes.py:400-440). mask [C,H,W] fp32 w/ NaN, seg [H,W]."""
+    require_cuda(mask, "mask")
+    mask = mask.contiguous().float()
+    if mask.dim() == 2:
+        mask = mask[None]
+    seg = _i32(seg).contiguous()
+    Cc, H, W = mask.shape
+    dev = mask.device
+    signal = torch.empty(n_seg, dtype=torch.float32, device=dev)
+    valid = torch.empty(n_seg, dtype=torch.uint8, device=dev)
+    ssum = torch.empty(n_seg, dtype=torch.float32, device=dev)
+    scnt = torch.empty(n_seg, dtype=torch.int32, device=dev)
+    check(lib().wvn_label_pool(ptr(mask), Cc, ptr(seg), ptr(signal), ptr(valid), ptr(ssum), ptr(scnt), H, W, n_seg,
+                               stream()), "wvn_label_pool")
+    return signal, valid.bool()
+
+
+def seg_centers(seg: torch.Tensor, n_seg: int) -> torch.Tensor:
+    require_cuda(seg, "seg")
+    seg = _i32(seg).contiguous()
+    H, W = seg.shape[-2:]
+    out = torch.empty(n_seg, 2, dtype=torch.float32, device=seg.device)
+    scratch = torch.empty(3 * n_seg, dtype=torch.int64, device=seg.device)
+    check(lib().wvn_seg_centers(ptr(seg), ptr(out), ptr(scratch), H, W, n_seg, stream()), "wvn_seg_centers")
+    return out
+
+
+def seg_adjacency(seg: torch.Tensor, n_seg: int) -> torch.Tensor:
+    require_cuda(seg, "seg")
+    seg = _i32(seg).contiguous()
+    H, W = seg.shape[-2:]
+    dev = seg.device
+    max_edges = n_seg * n_seg
+    edges = torch.empty(max_edges, 2, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    bitmap = torch.empty(n_seg * n_seg, dtype=torch.uint8, device=dev)
+    check(lib().wvn_seg_adjacency(ptr(seg), ptr(edges), ptr(count), ptr(bitmap), H, W, n_seg, max_edges, stream()),
+          "wvn_seg_adjacency")
+    return edges[: int(count.item())]  # the edge count fixes the output shape: one host sync, as in the reference
+
+
+def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = True):
+    """code [B,P,C] fp32 (any row stride) -> (labels [B,P] int32, n_segments [B] int32)."""
+    require_cuda(code, "code")
+    B, P, Cc = code.shape
+    if code.stride(2) != 1 or code.stride(0) != P * code.stride(1):
+        code = code.contiguous()
+    dev = code.device
+    xn = torch.empty(B, P, Cc, dtype=torch.float32, device=dev)
+    check(lib().wvn_normalize_rows(ptr(code), code.stride(1), ptr(xn), B * P, Cc, stream()), "wvn_normalize_rows")
+    labels = torch.empty(B, P, dtype=torch.int32, device=dev)
+    nseg = torch.empty(B, dtype=torch.int32, device=dev)
+    check(lib().wvn_kmeans_cosine(ptr(xn), ptr(labels), ptr(nseg), B, P, Cc, K, iters, int(relabel), stream()),
+          "wvn_kmeans_cosine")
+    return labels, nseg
+
+
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epi: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue(a[M,K] @ w[N,K]^T + bias); a, w bf16 (row strides allowed)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        dt = torch.bfloat16 if epi in (_lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_RELU_BF16) else torch.float32
+        out = torch.empty(M, N, dtype=dt, device=a.device)
+    check(lib().wvn_gemm_bf16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
+                              epi, stream()), "wvn_gemm_bf16")
+    return out
+
+
+def gemm_f32(a, b, bias=None, epi=_lib.F32_NONE, trans_a=False, trans_b=True, out=None, mask=None):
+    """fp32 GEMM; trans_b=True means b is stored [N,K] (Linear layout)."""
+    M = a.shape[1] if trans_a else a.shape[0]
+    K = a.shape[0] if trans_a else a.shape[1]
+    N = b.shape[0] if trans_b else b.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    check(lib().wvn_gemm_f32(ptr(a), a.stride(0), int(trans_a), ptr(b), b.stride(0), int(trans_b), ptr(bias), ptr(out),
+                             out.stride(0), M, N, K, epi, ptr(mask), 0 if mask is None else mask.stride(0), stream()),
+          "wvn_gemm_f32")
+    return out
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous().float()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().wvn_cast_f32_to_bf16(ptr(x), ptr(out), x.numel(), stream()), "wvn_cast_f32_to_bf16")
+    return out
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().wvn_prof_enable(int(on)), "wvn_prof_enable")
+
+
+def prof_collect():
+    n = len(_lib.PROF_CATS)
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    check(lib().wvn_prof_collect(ms, cnt), "wvn_prof_collect")
+    return {c: (ms[i], cnt[i]) for i, c in enumerate(_lib.PROF_CATS)}

@@ -1,0 +1,159 @@
+"""TraversabilityEstimator -- the online learner of
+wild_visual_navigation/traversability_estimator/traversability_estimator.py:33-505, hot-path slice:
+constructor (10 reference arguments), ``train() -> dict``, ``make_batch``, ``add_mission_node``,
+``update_supervision``, ``save_checkpoint`` / ``load_checkpoint`` (same dict keys), and the private
+attributes the learning node reads (``_model``, ``_traversability_loss._confidence_generator``,
+``_mission_graph``, ``_step``).  Forward, loss, backward and Adam run in the fused HIP phases
+(trainer.py); with torch.distributed initialised every rank trains on its own frames and the two
+small all-reduces keep the replicas identical.
+"""
+import os
+from threading import Lock
+
+import torch
+
+from ..model import get_model
+from ..utils import Batch, TraversabilityLoss
+from .graphs import MissionGraph
+from .nodes import MissionNode
+from .trainer import MlpTrainer
+
+
+def _get(cfg, key):
+    return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+
+class TraversabilityEstimator:
+    def __init__(self, params, device: str = "cuda", max_distance: float = 3, image_distance_thr: float = None,
+                 supervision_distance_thr: float = None, min_samples_for_training: int = 10,
+                 vis_node_index: int = 10, mode=False, extraction_store_folder=None,
+                 anomaly_detection: bool = False):
+        if anomaly_detection:
+            raise ValueError("anomaly_detection (LinearRnvp / AnomalyLoss) is outside the MI355X hot path")
+        self._device = torch.device(device)
+        self._mode = mode
+        self._extraction_store_folder = extraction_store_folder
+        self._min_samples_for_training = min_samples_for_training
+        self._vis_node_index = vis_node_index
+        self._params = params
+        self._anomaly_detection = anomaly_detection
+        self._mission_graph = MissionGraph()
+        self._learning_lock = Lock()
+        self._pause_training = False
+
+        torch.manual_seed(42)  # seed_everything(42), traversability_estimator.py:78
+        self._model = get_model(_get(params, "model")).to(self._device)
+        self._model.train()
+        loss_cfg, gen = _get(params, "loss"), _get(params, "general")
+        self._traversability_loss = TraversabilityLoss(
+            w_trav=_get(loss_cfg, "w_trav"), w_reco=_get(loss_cfg, "w_reco"), w_temp=_get(loss_cfg, "w_temp"),
+            anomaly_balanced=_get(loss_cfg, "anomaly_balanced"), model=self._model, method=_get(loss_cfg, "method"),
+            confidence_std_factor=_get(loss_cfg, "confidence_std_factor"),
+            trav_cross_entropy=_get(loss_cfg, "trav_cross_entropy"), log_enabled=_get(gen, "log_confidence"),
+            log_folder=_get(gen, "model_path") or "/tmp").to(self._device)
+        self._optimizer = MlpTrainer(self._model, lr=_get(_get(params, "optimizer"), "lr"),
+                                     std_factor=_get(loss_cfg, "confidence_std_factor"),
+                                     w_trav=_get(loss_cfg, "w_trav"), w_reco=_get(loss_cfg, "w_reco"))
+        self._loss = torch.tensor([torch.inf])
+        self._step = 0
+
+    # ------------------------------------------------------------------------------------------------
+    @property
+    def loss(self):
+        return float(self._loss.detach().reshape(-1)[0].item())
+
+    @property
+    def step(self):
+        return self._step
+
+    @property
+    def pause_learning(self):
+        return self._pause_training
+
+    @pause_learning.setter
+    def pause_learning(self, pause: bool):
+        self._pause_training = pause
+
+    def add_mission_node(self, node: MissionNode, verbose: bool = False, update_features: bool = True) -> bool:
+        """traversability_estimator.py:166-196 (graph insertion + first label pooling)."""
+        if self._pause_training:
+            return False
+        ok = self._mission_graph.add_node(node)
+        if ok and node.use_for_training and node.supervision_mask is None and node.feature_segments is not None:
+            H, W = node.feature_segments.shape[-2:]
+            node.supervision_mask = torch.full((3, H, W), float("nan"), device=self._device)
+        node.update_supervision_signal()
+        return ok
+
+    def update_supervision(self, node: MissionNode, mask: torch.Tensor) -> None:
+        """Merge a freshly rendered footprint mask into a node (torch.fmin, traversability_estimator.py:
+        281-286) and re-pool the labels (:287-289).  Rendering the footprint is out of scope."""
+        if node.supervision_mask is None:
+            node.supervision_mask = mask.clone()
+        else:
+            node.supervision_mask = torch.fmin(node.supervision_mask, mask)
+        node.update_supervision_signal()
+
+    def make_batch(self, batch_size: int = 8):
+        nodes = self._mission_graph.get_n_random_valid_nodes(n=batch_size)
+        return Batch.from_data_list([n.as_pyg_data() for n in nodes])
+
+    def train(self):
+        """traversability_estimator.py:449-497: one optimisation step; returns the reference's dict."""
+        if self._pause_training:
+            return {}
+        num_valid_nodes = self._mission_graph.get_num_valid_nodes()
+        return_dict = {"mission_graph_num_valid_node": num_valid_nodes}
+        if num_valid_nodes > self._min_samples_for_training:
+            graph = self.make_batch(_get(_get(self._params, "ablation_data_module"), "batch_size"))
+            if graph is not None:
+                with self._learning_lock:
+                    losses = self.train_on_batch(graph.x, graph.y, graph.y_valid)
+                log_step = (self._step % 20) == 0
+                vals = losses.tolist()  # the one host sync per step (the reference does three .item() calls)
+                if log_step:
+                    print(f"step: {self._step} | loss: {vals[0]:5f} | loss_trav: {vals[1]:5f} | loss_reco: {vals[2]:5f}")
+                self._step += 1
+                return_dict["loss_total"], return_dict["loss_trav"], return_dict["loss_reco"] = vals[0], vals[1], vals[2]
+                return return_dict
+        return_dict["loss_total"] = -1
+        return return_dict
+
+    def train_on_batch(self, x: torch.Tensor, y: torch.Tensor, y_valid: torch.Tensor) -> torch.Tensor:
+        """Fused forward + loss + backward + Adam on this rank's rows; updates the confidence statistic.
+        Returns the device tensor {total, trav, reco, conf_mean, conf_std} without synchronising."""
+        losses = self._optimizer.train_step(x.to(self._device), y.to(self._device), y_valid.to(self._device))
+        cg = self._traversability_loss._confidence_generator
+        with torch.no_grad():
+            cg.mean.copy_(losses[3:4])
+            cg.std.copy_(losses[4:5])
+        self._loss = losses[0:1]
+        return losses
+
+    # ------------------------------------------------------------------------------------------------
+    def save_checkpoint(self, mission_path: str, checkpoint_name: str = "last_checkpoint.pt"):
+        with self._learning_lock:
+            self._pause_training = True
+            os.makedirs(mission_path, exist_ok=True)
+            checkpoint_file = os.path.join(mission_path, checkpoint_name)
+            torch.save({
+                "step": self._step,
+                "model_state_dict": self._model.state_dict(),
+                "optimizer_state_dict": self._optimizer.optimizer_state_dict(),
+                "traversability_loss_state_dict": self._traversability_loss.state_dict(),
+                "loss": self.loss,
+            }, checkpoint_file)
+            self._pause_training = False
+        return checkpoint_file
+
+    def load_checkpoint(self, checkpoint_path: str):
+        with self._learning_lock:
+            self._pause_training = True
+            ck = torch.load(checkpoint_path, map_location=self._device, weights_only=False)
+            self._model.load_state_dict(ck["model_state_dict"])
+            self._optimizer.load_optimizer_state_dict(ck["optimizer_state_dict"])
+            self._traversability_loss.load_state_dict(ck["traversability_loss_state_dict"])
+            self._step = ck["step"]
+            self._loss = torch.tensor([ck["loss"]])
+            self._model.train()
+            self._pause_training = False
