@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--segmentation", default="stego", choices=["stego", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     return ap.parse_args()
 
@@ -89,7 +90,9 @@ def cpu_baseline(args):
     from oracle import interfaces as OI, mlp as OM, segments as OS, vit as OV
 
     n = args.cpu_frames
-    torch.set_num_threads(os.cpu_count() or 1)
+    # PyTorch's intra-op pool does not scale to the GPU box's 256 hardware threads for these matrix
+    # sizes (256 threads ran ~20x slower than the 8-core survey probe); the thread count used is reported.
+    torch.set_num_threads(min(os.cpu_count() or 1, args.cpu_threads))
     sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0)
     head = OI.make_stego_head_state_dict(384, 90, seed=0)
     img = torch.rand(n, 3, args.size, args.size, generator=torch.Generator().manual_seed(1))
@@ -163,7 +166,7 @@ def main():
         att_ms, att_n = prof["attention"]
         chunk = min(args.chunk, B)
         # every attention launch processes `chunk` frames (the last chunk of a batch may be smaller)
-        frames_per_launch = (B * args.steps * 12) / max(att_n, 1) / 12
+        frames_per_launch = (B * args.steps * 12) / max(att_n, 1)  # 12 attention launches per frame-chunk
         att_avg_ms = att_ms / max(att_n, 1)
         att_tflops = attn_flops_block * frames_per_launch / (att_avg_ms * 1e-3) / 1e12 if att_n else 0.0
         kern = {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in prof.items()}

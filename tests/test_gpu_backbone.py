@@ -156,7 +156,9 @@ def test_extract_batch_equals_per_frame(dev):
     assert feat.shape == (4, 16, 384) and seg.shape == (4, S, S) and nseg.tolist() == [16] * 4
     for b in range(4):
         _, f1, s1, _, _ = fe.extract(img[b:b + 1], cell_size=16)
-        assert torch.equal(f1, feat[b]) and torch.equal(s1.int(), seg[b])
+        # tokens are bit-identical (batch invariance); the pooling weights are accumulated with fp32
+        # atomics whose order is not fixed, hence round-off-level differences only
+        assert torch.allclose(f1, feat[b], atol=1e-5, rtol=0) and torch.equal(s1.int(), seg[b])
 
 
 # ------------------------------------------------------------------------------ full-size properties

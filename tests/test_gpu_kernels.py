@@ -49,19 +49,23 @@ def test_gemm_bf16_epilogues(dev, M, N, K):
 
 
 def test_gemm_bf16_transpose_detecting_and_strided(dev):
-    # asymmetric, structured operands: C[m][n] = m*3 + n (exactly representable) catches row/col swaps
+    # asymmetric, structured operands: C[m][n] = m - n (integers < 256 are exact in bf16) catches row/col swaps
     M, N, K = 160, 200, 64
     a = torch.zeros(M, K)
-    a[:, 0] = torch.arange(M).float() * 3
-    a[:, 1] = 1.0
+    a[:, 0] = torch.arange(M).float()
+    a[:, 37] = 1.0
     w = torch.zeros(N, K)
     w[:, 0] = 1.0
-    w[:, 1] = torch.arange(N).float()
+    w[:, 37] = -torch.arange(N).float()
     big = torch.zeros(M, 2 * K, dtype=torch.bfloat16, device=dev)  # A is a strided view (lda = 2K)
     big[:, K:] = bf(a).to(dev)
-    out = ops.gemm_bf16(big[:, K:], bf(w).to(dev), None, _lib.EPI_F32).cpu()
-    want = torch.arange(M).float()[:, None] * 3 + torch.arange(N).float()[None]
-    assert torch.equal(out, want)
+    wd = bf(w).to(dev)
+    want = torch.arange(M).float()[:, None] - torch.arange(N).float()[None]
+    assert torch.equal(ops.gemm_bf16(big[:, K:], wd, None, _lib.EPI_F32).cpu(), want)
+    assert torch.equal(ops.gemm_bf16(big[:, K:], wd, None, _lib.EPI_BF16).float().cpu(), want)
+    out = torch.zeros(M, N + 8, dtype=torch.bfloat16, device=dev)  # strided output view (ldc = N + 8)
+    ops.gemm_bf16(big[:, K:], wd, None, _lib.EPI_RELU_BF16, out=out[:, :N])
+    assert torch.equal(out[:, :N].float().cpu(), want.clamp(min=0)) and float(out[:, N:].abs().sum()) == 0.0
 
 
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
@@ -96,11 +100,12 @@ def test_layernorm(dev, D):
     x = torch.randn(rows, D, generator=g(1)) * 3 + 1
     gm, bt = 1 + 0.1 * torch.randn(D, generator=g(2)), 0.1 * torch.randn(D, generator=g(3))
     ref = F.layer_norm(x, (D,), gm, bt, eps=1e-6)
+    xd, gd, bd = x.to(dev), gm.to(dev), bt.to(dev)  # keep the device tensors alive while raw pointers are in use
     y = torch.empty(rows, D, device=dev)
-    check(lib().wvn_layernorm(ptr(x.to(dev)), ptr(gm.to(dev)), ptr(bt.to(dev)), ptr(y), 0, rows, D, 1e-6, stream()))
+    check(lib().wvn_layernorm(ptr(xd), ptr(gd), ptr(bd), ptr(y), 0, rows, D, 1e-6, stream()))
     assert (y.cpu() - ref).abs().max().item() < 1e-5
     yb = torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
-    check(lib().wvn_layernorm(ptr(x.to(dev)), ptr(gm.to(dev)), ptr(bt.to(dev)), ptr(yb), 1, rows, D, 1e-6, stream()))
+    check(lib().wvn_layernorm(ptr(xd), ptr(gd), ptr(bd), ptr(yb), 1, rows, D, 1e-6, stream()))
     assert (yb.float().cpu() - ref).abs().max().item() < 8e-3 * ref.abs().max().item()
 
 
@@ -124,8 +129,8 @@ def test_attention_f32(dev, ntok):
     k[0, 1, ntok // 2] *= 6.0  # a spiky key forces a late running-max jump (rescale branch)
     npad = (ntok + 127) // 128 * 128
     out = torch.empty(B * ntok, h * 64, device=dev)
-    check(lib().wvn_attention_f32(ptr(_pad(q, npad).to(dev)), ptr(_pad(k, npad).to(dev)), ptr(_pad(v, npad).to(dev)),
-                                  ptr(out), B, h, ntok, npad, scale, stream()))
+    qd, kd, vd = _pad(q, npad).to(dev), _pad(k, npad).to(dev), _pad(v, npad).to(dev)
+    check(lib().wvn_attention_f32(ptr(qd), ptr(kd), ptr(vd), ptr(out), B, h, ntok, npad, scale, stream()))
     ref = _attn_ref(q, k, v, scale).permute(0, 2, 1, 3).reshape(B * ntok, h * 64)
     assert (out.cpu().double() - ref).abs().max().item() < 2e-5
 
@@ -137,10 +142,10 @@ def test_attention_bf16(dev, ntok):
     k[0, 1, ntok // 2] = bf(k[0, 1, ntok // 2].float() * 6.0)
     k[0, 0, ntok - 1] = bf(k[0, 0, ntok - 1].float() * 5.0)  # spike in the (masked-tail) last tile
     npad = (ntok + 127) // 128 * 128
-    vt = _pad(v, npad).transpose(-1, -2).contiguous()  # [B,h,64,npad]
+    vt = _pad(v, npad).transpose(-1, -2).contiguous().to(dev)  # [B,h,64,npad]
     out = torch.empty(B * ntok, h * 64, dtype=torch.bfloat16, device=dev)
-    check(lib().wvn_attention_bf16(ptr(_pad(q, npad).to(dev)), ptr(_pad(k, npad).to(dev)), ptr(vt.to(dev)), ptr(out),
-                                   B, h, ntok, npad, scale, stream()))
+    qd, kd = _pad(q, npad).to(dev), _pad(k, npad).to(dev)
+    check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(vt), ptr(out), B, h, ntok, npad, scale, stream()))
     ref = _attn_ref(q.float(), k.float(), v.float(), scale).permute(0, 2, 1, 3).reshape(B * ntok, h * 64)
     err = (out.float().cpu().double() - ref).abs().max().item()
     # P is rounded to bf16 before PV (rel 2^-9 per term, averaging down) and O to bf16 on store
@@ -148,9 +153,8 @@ def test_attention_bf16(dev, ntok):
     # uniform V => output must be exactly that constant row (softmax weights sum to 1 within rounding)
     v1 = torch.ones(B, h, npad, 64, dtype=torch.bfloat16)
     v1[:, :, ntok:] = 0
-    check(lib().wvn_attention_bf16(ptr(_pad(q, npad).to(dev)), ptr(_pad(k, npad).to(dev)),
-                                   ptr(v1.transpose(-1, -2).contiguous().to(dev)), ptr(out), B, h, ntok, npad, scale,
-                                   stream()))
+    v1t = v1.transpose(-1, -2).contiguous().to(dev)
+    check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(v1t), ptr(out), B, h, ntok, npad, scale, stream()))
     assert (out.float().cpu() - 1.0).abs().max().item() < 1e-2
 
 
@@ -161,10 +165,11 @@ def test_patchify(dev, S, P):
     G = S // P
     want = F.unfold(OI.normalize(img), kernel_size=P, stride=P).transpose(1, 2).reshape(2 * G * G, 3 * P * P)
     out = torch.empty(2 * G * G, 3 * P * P, device=dev)
-    check(lib().wvn_patchify(ptr(img.to(dev)), ptr(out), 0, 2, S, P, stream()))
+    imgd = img.to(dev)
+    check(lib().wvn_patchify(ptr(imgd), ptr(out), 0, 2, S, P, stream()))
     assert (out.cpu() - want).abs().max().item() < 1e-6
     outb = torch.empty(2 * G * G, 3 * P * P, dtype=torch.bfloat16, device=dev)
-    check(lib().wvn_patchify(ptr(img.to(dev)), ptr(outb), 1, 2, S, P, stream()))
+    check(lib().wvn_patchify(ptr(imgd), ptr(outb), 1, 2, S, P, stream()))
     assert torch.equal(outb.cpu(), bf(out.cpu()))
 
 
@@ -175,7 +180,7 @@ def test_upsample_bilinear_and_nearest(dev, G, H, D):
     out = ops.upsample_bilinear(tok.to(dev), G, H).cpu()
     assert out.shape == ref.shape and (out - ref).abs().max().item() < 2e-5
     lab = torch.randint(0, 20, (2, G, G), generator=g(2), dtype=torch.int32)
-    want = torch.stack([OI.upsample_nearest(lab[b], H)[0] for b in range(2)])
+    want = OI.upsample_nearest(lab, H)[0]  # [1,B,H,H] -> [B,H,H]
     assert torch.equal(ops.upsample_nearest_labels(lab.to(dev), H).cpu(), want)  # integer map: bit-exact
 
 

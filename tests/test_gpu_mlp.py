@@ -89,8 +89,9 @@ def test_confidence_kernel_and_per_pixel_inference(dev, golden):
     m = _model(c["sd10"], 90, dev).eval()
     H = 24
     dense = torch.randn(1, 90, H, H, generator=torch.Generator().manual_seed(4))
-    xx = dense[0].permute(1, 2, 0).reshape(-1, 90)
-    pred = m.forward(Data(x=xx.to(dev)))
+    xx = dense[0].permute(1, 2, 0).reshape(-1, 90).contiguous()
+    xd = xx.to(dev)
+    pred = m.forward(Data(x=xd))
     want = OM.mlp_forward(c["sd10"], xx)
     assert (pred.cpu() - want).abs().max().item() < 1e-5
     cg = ConfidenceGenerator(0.5)
@@ -99,7 +100,7 @@ def test_confidence_kernel_and_per_pixel_inference(dev, golden):
     want_conf = cg.inference_without_update(lr)
     trav = torch.empty(H * H, device=dev)
     conf = torch.empty(H * H, device=dev)
-    _lib.check(_lib.lib().wvn_mlp_confidence(pred.data_ptr(), 91, xx.to(dev).data_ptr(), 90, 1.1, 0.3, 0.5,
+    _lib.check(_lib.lib().wvn_mlp_confidence(pred.data_ptr(), 91, xd.data_ptr(), 90, 1.1, 0.3, 0.5,
                                              trav.data_ptr(), conf.data_ptr(), H * H, 90, _lib.stream()))
     assert torch.allclose(conf.cpu(), want_conf, atol=1e-5) and torch.allclose(trav.cpu(), want[:, 0], atol=1e-5)
 

@@ -41,7 +41,7 @@ struct Span {
 };
 
 struct VitDims {
-  int B, S, P, G, D, H, F, KP, ntok, npad, npatch;
+  int B, S, P, G, D, H, F, KP, ntok, ntok_s, npad, npatch;
   size_t esz;
   long long M, Mp;
 };
@@ -49,9 +49,10 @@ VitDims vit_dims(const wvn_vit_model* m, int batch) {
   VitDims d;
   d.B = batch; d.S = m->img_size; d.P = m->patch; d.G = d.S / d.P; d.D = m->dim; d.H = m->heads; d.F = m->mlp_dim;
   d.KP = 3 * d.P * d.P; d.npatch = d.G * d.G; d.ntok = d.npatch + 1;
+  d.ntok_s = (d.ntok + 7) / 8 * 8;  // rows per frame: keeps every 8-token group 16-B aligned and inside one frame
   d.npad = (d.ntok + 127) / 128 * 128;
   d.esz = m->precision == WVN_PREC_BF16 ? 2 : 4;
-  d.M = (long long)batch * d.ntok; d.Mp = (long long)batch * d.npatch;
+  d.M = (long long)batch * d.ntok_s; d.Mp = (long long)batch * d.npatch;
   return d;
 }
 struct VitWs { float* x; void* xn; void* q; void* k; void* v; void* hid; void* patches; size_t total; };
@@ -113,45 +114,45 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
   const int M = (int)d.M, Mp = (int)d.Mp;
 
   { Span s(0, st); RET_IF(wvn_patchify_launch(img, w.patches, bf, d.B, d.S, d.P, st)); }
-  RET_IF(wvn_cls_rows_launch(m->cls_pos, w.x, d.B, d.ntok, d.D, st));
+  RET_IF(wvn_cls_rows_launch(m->cls_pos, w.x, d.B, d.ntok_s, d.D, st));
   {
     Span s(1, st);
     if (bf) {
       GemmBf16Params p{};
       p.A = (const bf16_t*)w.patches; p.lda = d.KP; p.W = (const bf16_t*)m->patch_w; p.ldw = d.KP; p.bias = m->patch_b;
-      p.C = w.x; p.ldc = d.D; p.M = Mp; p.N = d.D; p.K = d.KP; p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok;
+      p.C = w.x; p.ldc = d.D; p.M = Mp; p.N = d.D; p.K = d.KP; p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
       RET_IF(wvn_gemm_bf16_launch(p, EPI_PATCH, st));
     } else {
       GemmF32Params p{};
       p.A = (const float*)w.patches; p.lda = d.KP; p.B = (const float*)m->patch_w; p.ldb = d.KP; p.transB = 1;
       p.bias = m->patch_b; p.C = w.x; p.ldc = d.D; p.M = Mp; p.N = d.D; p.K = d.KP; p.batch = 1; p.splitk = 1;
-      p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok;
+      p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
       RET_IF(wvn_gemm_f32_launch(p, F32_EPI_PATCH, st));
     }
   }
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
-    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, st)); }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st)); }
     {
       Span s(3, st);
       if (bf) {
         GemmBf16Params p{};
         p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.qkv_w; p.ldw = d.D; p.bias = L.qkv_b;
         p.M = M; p.N = 3 * d.D; p.K = d.D; p.q = (bf16_t*)w.q; p.k = (bf16_t*)w.k; p.vt = (bf16_t*)w.v;
-        p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok;
+        p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
         RET_IF(wvn_gemm_bf16_launch(p, EPI_QKV, st));
       } else {
         GemmF32Params p{};
         p.A = (const float*)w.xn; p.lda = d.D; p.B = (const float*)L.qkv_w; p.ldb = d.D; p.transB = 1; p.bias = L.qkv_b;
         p.C = (float*)w.q; p.M = M; p.N = 3 * d.D; p.K = d.D; p.batch = 1; p.splitk = 1;
-        p.q = (float*)w.q; p.k = (float*)w.k; p.v = (float*)w.v; p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok;
+        p.q = (float*)w.q; p.k = (float*)w.k; p.v = (float*)w.v; p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
         RET_IF(wvn_gemm_f32_launch(p, F32_EPI_QKV, st));
       }
     }
     {
       Span s(4, st);
-      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.npad, scale, st));
-      else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.npad, scale, st));
+      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
+      else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
     {
       Span s(5, st);
@@ -167,7 +168,7 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
         RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RESID, st));
       }
     }
-    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, st)); }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st)); }
     {
       Span s(6, st);
       if (bf) {
@@ -199,7 +200,7 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
   }
   {
     Span s(2, st);
-    RET_IF(wvn_layernorm_launch(w.x, m->norm_g, m->norm_b, tokens_lowp, bf, ld_lowp, tokens_f32, d.D, Mp, d.D, 1e-6f, 1, d.ntok, st));
+    RET_IF(wvn_layernorm_launch(w.x, m->norm_g, m->norm_b, tokens_lowp, bf, ld_lowp, tokens_f32, d.D, Mp, d.D, 1e-6f, 1, d.ntok, d.ntok_s, st));
   }
   return WVN_OK;
 }
@@ -228,17 +229,17 @@ int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, i
 int wvn_layernorm(const float* x, const float* gamma, const float* beta, void* y, int y_is_bf16, int rows, int D,
                   float eps, void* stream) {
   if (!y) return WVN_ERR_ARG;
-  return wvn_layernorm_launch(x, gamma, beta, y, y_is_bf16, D, nullptr, 0, rows, D, eps, 0, 0, (hipStream_t)stream);
+  return wvn_layernorm_launch(x, gamma, beta, y, y_is_bf16, D, nullptr, 0, rows, D, eps, 0, 0, 0, (hipStream_t)stream);
 }
 
 int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad,
                        float scale, void* stream) {
   return wvn_attention_bf16_launch((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, heads, ntok,
-                                   npad, scale, (hipStream_t)stream);
+                                   ntok, npad, scale, (hipStream_t)stream);
 }
 int wvn_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok, int npad,
                       float scale, void* stream) {
-  return wvn_attention_f32_launch(q, k, v, out, B, heads, ntok, npad, scale, (hipStream_t)stream);
+  return wvn_attention_f32_launch(q, k, v, out, B, heads, ntok, ntok, npad, scale, (hipStream_t)stream);
 }
 int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream) {
   return wvn_patchify_launch(img, patches, out_is_bf16, B, S, P, (hipStream_t)stream);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ k,
                                                                 const bf16_t* __restrict__ vt,
                                                                 bf16_t* __restrict__ out, int heads, int ntok,
-                                                                int npad, float c_exp) {
+                                                                int ntok_s, int npad, float c_exp) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * TILE_ELEMS];  // [stage][K | Vt][64][72]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
   const float inv = 1.0f / l_tot;
   const int qi = q0 + l31;
   if (qi < ntok) {
-    bf16_t* og = out + ((size_t)b * ntok + qi) * (heads * DH) + head * DH;
+    bf16_t* og = out + ((size_t)b * ntok_s + qi) * (heads * DH) + head * DH;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -186,11 +186,11 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 }  // namespace
 
 int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
-                              int ntok, int npad, float scale, hipStream_t st) {
+                              int ntok, int ntok_s, int npad, float scale, hipStream_t st) {
   if (!q || !k || !vt || !out || npad % QB != 0 || npad < ntok) return WVN_ERR_ARG;
   const float c_exp = scale * 1.44269504088896340736f;
   dim3 grid(ceil_div(ntok, QB), B * heads);
-  hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, q, k, vt, out, heads, ntok, npad, c_exp);
+  hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, q, k, vt, out, heads, ntok, ntok_s, npad, c_exp);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

@@ -13,7 +13,7 @@ constexpr int FQ = 64, FKV = 64, FD = 64, FSTR = 68;
 
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, float* __restrict__ out,
-                                                            int heads, int ntok, int npad, float scale) {
+                                                            int heads, int ntok, int ntok_s, int npad, float scale) {
   __shared__ __attribute__((aligned(16))) float Ks[FKV * FSTR];
   __shared__ __attribute__((aligned(16))) float Vs[FKV * FSTR];
   __shared__ __attribute__((aligned(16))) float Ps[FQ * FSTR];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   }
   if (qrow < ntok) {
     const float inv = 1.0f / l_run;
-    float* og = out + ((size_t)b * ntok + qrow) * (heads * FD) + head * FD + part * 16;
+    float* og = out + ((size_t)b * ntok_s + qrow) * (heads * FD) + head * FD + part * 16;
 #pragma unroll
     for (int d = 0; d < 16; d += 4) {
       f32x4_t t = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
@@ -111,10 +111,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 }  // namespace
 
 int wvn_attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok,
-                             int npad, float scale, hipStream_t st) {
+                             int ntok_s, int npad, float scale, hipStream_t st) {
   if (!q || !k || !v || !out || npad % FQ != 0 || npad < ntok) return WVN_ERR_ARG;
   dim3 grid(ceil_div(ntok, FQ), B * heads);
-  hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, st, q, k, v, out, heads, ntok, npad, scale);
+  hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, st, q, k, v, out, heads, ntok, ntok_s, npad, scale);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

@@ -49,7 +49,7 @@ template <typename T, int VPT>  // VPT = D / 64 values per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, int ldy,
                                                         float* __restrict__ y2, int ldy2, int rows_out, int D,
-                                                        float eps, int drop_cls, int ntok) {
+                                                        float eps, int drop_cls, int ntok, int ntok_s) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows_out) return;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   if (drop_cls) {
     int np = ntok - 1;
     int b = row / np, pp = row - b * np;
-    in_row = (size_t)b * ntok + 1 + pp;
+    in_row = (size_t)b * ntok_s + 1 + pp;
   }
   const float* xr = x + in_row * D;
   float v[VPT];
@@ -168,7 +168,7 @@ int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, in
   return WVN_OK;
 }
 
-int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, hipStream_t st) {
+int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, hipStream_t st) {  // ntok = rows per frame
   hipLaunchKernelGGL(cls_rows_kernel, dim3(ceil_div(B * D, 256)), dim3(256), 0, st, cls_pos, x, B, ntok, D);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
@@ -176,14 +176,14 @@ int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, 
 
 template <typename T>
 static int ln_dispatch(const float* x, const float* g, const float* b, T* y, int ldy, float* y2, int ldy2, int rows_out,
-                       int D, float eps, int drop_cls, int ntok, hipStream_t st) {
+                       int D, float eps, int drop_cls, int ntok, int ntok_s, hipStream_t st) {
   dim3 grid(ceil_div(rows_out, 4)), block(256);
   switch (D / 64) {
-    case 6: hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
-    case 12: hipLaunchKernelGGL((layernorm_kernel<T, 12>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
-    case 16: hipLaunchKernelGGL((layernorm_kernel<T, 16>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
-    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
-    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok); break;
+    case 6: hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
+    case 12: hipLaunchKernelGGL((layernorm_kernel<T, 12>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
+    case 16: hipLaunchKernelGGL((layernorm_kernel<T, 16>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
+    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
     default: return WVN_ERR_ARG;
   }
   WVN_LAUNCH_CHECK();
@@ -192,10 +192,10 @@ static int ln_dispatch(const float* x, const float* g, const float* b, T* y, int
 
 int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
                          float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
-                         hipStream_t st) {
+                         int ntok_s, hipStream_t st) {
   if (!x || !gamma || !beta || (D % 64) != 0 || rows_out <= 0) return WVN_ERR_ARG;
-  if (y_bf16) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, st);
-  return ln_dispatch<float>(x, gamma, beta, (float*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, st);
+  if (y_bf16) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, st);
+  return ln_dispatch<float>(x, gamma, beta, (float*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, st);
 }
 
 int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st) {

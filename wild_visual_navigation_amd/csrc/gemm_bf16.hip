@@ -11,10 +11,16 @@
 //   K-tile); tiles are walked N-fastest with an XCD-aware block remap so the A row-panel and the
 //   (small, shared) W stay in the XCD's L2.
 //
+// Epilogue (the ViT GEMMs have K = 384: six K-tiles, so the epilogue IS the kernel): the
+// accumulators are produced TRANSPOSED (mfma(Wfrag, Afrag): lane <-> output row m, registers <-> 4
+// consecutive output columns n), bias / GELU / ReLU are applied in registers, the tile is staged
+// through the (now idle) operand LDS as a row-major image and leaves the CU as 16-byte, fully
+// coalesced stores (256 contiguous bytes per 16 lanes).  The V third of the QKV projection uses the
+// un-transposed orientation instead, so its LDS image is [d][token] and V^T ([b,h,d,token], what the
+// attention kernel's PV MFMA wants) is written with the same wide stores.
+//
 // Fragment maps (v_mfma_f32_32x32x16_bf16): A: lane l holds row l&31, k-slots (l>>5)*8+j;
 // B: lane l holds col l&31, same k-slots; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
-// SWAP mode issues mfma(Wfrag, Afrag) so the accumulator holds C^T (lane <-> m): used for the V third
-// of the QKV projection, which the attention kernel wants transposed ([b,h,d,token], token-contiguous).
 #include "common.h"
 #include "wvn_internal.h"
 
@@ -24,44 +30,39 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDS_STRIDE = BK + 8;                       // bf16 elements per LDS row (144 B)
 constexpr int STAGE_ELEMS = (BM + BN) * LDS_STRIDE;      // per stage
 constexpr int GEMM_LDS_BYTES = 2 * STAGE_ELEMS * 2;      // 73,728 B
+constexpr int CT_BF16_STRIDE = 128 + 8;                  // output-tile image, bf16 elements per row (272 B)
+constexpr int CT_F32_STRIDE = 128 + 4;                   // output-tile image, floats per row (528 B)
+static_assert(128 * CT_F32_STRIDE * 4 <= GEMM_LDS_BYTES, "fp32 tile image must fit in the operand LDS");
 
-template <int EPI>
-__device__ inline void epilogue_store(const GemmBf16Params& p, int m, int n, float v) {
-  if (m >= p.M || n >= p.N) return;
-  if (p.bias) v += p.bias[n];
-  if constexpr (EPI == EPI_BF16) {
-    ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(v);
-  } else if constexpr (EPI == EPI_GELU_BF16) {
-    ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(gelu_exact(v));
-  } else if constexpr (EPI == EPI_RELU_BF16) {
-    ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(fmaxf(v, 0.f));
-  } else if constexpr (EPI == EPI_F32) {
-    ((float*)p.C)[(size_t)m * p.ldc + n] = v;
-  } else if constexpr (EPI == EPI_RESID_F32) {
-    float* c = (float*)p.C + (size_t)m * p.ldc + n;
-    *c = *c + v;  // in-place residual update: every element is owned by exactly one lane
-  } else if constexpr (EPI == EPI_ACCUM_F32) {
-    float* c = (float*)p.C + (size_t)m * p.ldc + n;
-    *c = *c + v;
-  } else if constexpr (EPI == EPI_PATCH) {
-    // m indexes patches (b, p); token row = b*ntok + 1 + p ; add the position table row 1+p
-    int b = m / p.npatch, pp = m - b * p.npatch;
-    ((float*)p.C)[((size_t)b * p.ntok + 1 + pp) * p.ldc + n] = v + p.pos[(size_t)(1 + pp) * p.ldc + n];
-  } else if constexpr (EPI == EPI_QKV) {
-    // n in [0, 3*D): which = n / D ; head = (n % D) / 64 ; d = n % 64.   m = b*ntok + t
-    int D = p.N / 3;
-    int which = n / D, c = n - which * D, head = c >> 6, d = c & 63;
-    int b = m / p.ntok, t = m - b * p.ntok;
-    size_t bh = (size_t)b * p.heads + head;
-    bf16_t o = f32_to_bf16(v);
-    if (which == 0) p.q[(bh * p.npad + t) * 64 + d] = o;
-    else if (which == 1) p.k[(bh * p.npad + t) * 64 + d] = o;
-    else p.vt[(bh * 64 + d) * p.npad + t] = o;
-  }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below bf16 resolution of the output)
+__device__ inline float gelu_bf16path(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-template <int EPI, bool SWAP>
-__device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, bf16_t* lds) {
+template <int EPI>
+__device__ inline float activate(float v) {
+  if constexpr (EPI == EPI_GELU_BF16) return gelu_bf16path(v);
+  if constexpr (EPI == EPI_RELU_BF16) return fmaxf(v, 0.f);
+  return v;
+}
+
+template <int EPI>
+constexpr bool out_is_bf16() {
+  return EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_QKV;
+}
+
+// TR = true : accumulators hold C^T (lane = row m, regs = cols n)  -> LDS image [m][n]
+// TR = false: accumulators hold C   (lane = col n, regs = rows m)  -> LDS image [n][m]   (V^T tiles)
+template <int EPI, bool TR>
+__device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsigned char* smem) {
+  bf16_t* lds = (bf16_t*)smem;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -69,10 +70,8 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, bf16_t
   const int m0 = tm * BM, n0 = tn * BN;
 
   // staging assignment: 4 A chunks + 4 W chunks of 16 B per thread per K-tile
-  // chunk c = tid + 256*i : row = c >> 3 (0..127), kc = c & 7 (8 bf16 each)
   u32x4_t ra[4], rb[4];
   const int srow = tid >> 3, skc = tid & 7;
-
   auto load_regs = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -125,51 +124,139 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, bf16_t
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if constexpr (SWAP)
+          if constexpr (TR)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
     if (more) store_regs((kt + 1) & 1);
-    __syncthreads();
+    __syncthreads();  // also: after the last K-tile every wave is done with the operand LDS
   }
 
+  // ---------------- epilogue, part 1: registers -> LDS tile image (bias + activation applied) ----------
+  // image row = "lane" dimension, image col = "register" dimension (4 consecutive per register group)
+  constexpr bool OB = out_is_bf16<EPI>();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        int m, n;
-        if constexpr (SWAP) {
-          n = n0 + wn * 64 + j * 32 + rr;
-          m = m0 + wm * 64 + i * 32 + l31;
-        } else {
-          m = m0 + wm * 64 + i * 32 + rr;
-          n = n0 + wn * 64 + j * 32 + l31;
-        }
-        epilogue_store<EPI>(p, m, n, acc[i][j][r]);
+    for (int j = 0; j < 2; ++j) {
+      const int lane_dim = TR ? (wm * 64 + i * 32 + l31) : (wn * 64 + j * 32 + l31);
+      const int reg_base = TR ? (wn * 64 + j * 32) : (wm * 64 + i * 32);
+      float bl = 0.f;
+      if constexpr (!TR) {
+        if (p.bias && n0 + lane_dim < p.N) bl = p.bias[n0 + lane_dim];
       }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c = reg_base + 8 * g4 + 4 * hi;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float b = bl;
+          if constexpr (TR) b = (p.bias && n0 + c + e < p.N) ? p.bias[n0 + c + e] : 0.f;
+          v[e] = activate<EPI>(acc[i][j][4 * g4 + e] + b);
+        }
+        if constexpr (OB) {
+          u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *(u32x2_t*)((bf16_t*)smem + lane_dim * CT_BF16_STRIDE + c) = o;
+        } else {
+          f32x4_t o = {v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)((float*)smem + lane_dim * CT_F32_STRIDE + c) = o;
+        }
+      }
+    }
+  __syncthreads();
+
+  // ---------------- epilogue, part 2: LDS image -> global, 16-byte coalesced --------------------------
+  if constexpr (EPI == EPI_QKV) {
+    const int D = p.N / 3;
+    const int which = n0 / D;  // tile-uniform (D % 128 == 0)
+    const int cbase = n0 - which * D;
+    if constexpr (TR) {  // q / k : image [m][n]; dst[(b*h + head)*npad + t][d]
+      bf16_t* dst = which == 0 ? p.q : p.k;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int ch = tid + 256 * it, row = ch >> 4, c8 = (ch & 15) * 8;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int b = m / p.ntok_s, t = m - b * p.ntok_s;
+        const int cc = cbase + c8, head = cc >> 6, d = cc & 63;
+        const u32x4_t val = *(const u32x4_t*)((const bf16_t*)smem + row * CT_BF16_STRIDE + c8);
+        *(u32x4_t*)(dst + (((size_t)b * p.heads + head) * p.npad + t) * 64 + d) = val;
+      }
+    } else {  // v : image [n = (head, d)][m]; vt[(b*h + head)*64 + d][t], 8 tokens per store
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int ch = tid + 256 * it, row = ch >> 4, c8 = (ch & 15) * 8;
+        const int m = m0 + c8;
+        if (m >= p.M) continue;  // M % 8 == 0 (ntok_s % 8 == 0): a chunk is entirely in or out
+        const int b = m / p.ntok_s, t = m - b * p.ntok_s;
+        const int cc = cbase + row, head = cc >> 6, d = cc & 63;
+        const u32x4_t val = *(const u32x4_t*)((const bf16_t*)smem + row * CT_BF16_STRIDE + c8);
+        *(u32x4_t*)(p.vt + (((size_t)b * p.heads + head) * 64 + d) * p.npad + t) = val;
+      }
+    }
+  } else if constexpr (OB) {
+    bf16_t* C = (bf16_t*)p.C;
+    const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)C & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int ch = tid + 256 * it, row = ch >> 4, c8 = (ch & 15) * 8;
+      const int m = m0 + row, n = n0 + c8;
+      if (m >= p.M || n >= p.N) continue;
+      const bf16_t* src = (const bf16_t*)smem + row * CT_BF16_STRIDE + c8;
+      if (vec_ok && n + 8 <= p.N) {
+        *(u32x4_t*)(C + (size_t)m * p.ldc + n) = *(const u32x4_t*)src;
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) C[(size_t)m * p.ldc + n + e] = src[e];
+      }
+    }
+  } else {
+    float* C = (float*)p.C;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (((uintptr_t)C & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int ch = tid + 256 * it, row = ch >> 5, c4 = (ch & 31) * 4;
+      const int m = m0 + row, n = n0 + c4;
+      if (m >= p.M || n >= p.N) continue;
+      f32x4_t v = *(const f32x4_t*)((const float*)smem + row * CT_F32_STRIDE + c4);
+      size_t orow = (size_t)m;
+      if constexpr (EPI == EPI_PATCH) {
+        const int b = m / p.npatch, pp = m - b * p.npatch;
+        orow = (size_t)b * p.ntok_s + 1 + pp;
+        const f32x4_t pe = *(const f32x4_t*)(p.pos + (size_t)(1 + pp) * p.ldc + n);  // ldc == D, n % 4 == 0
+        v += pe;
+      }
+      float* dst = C + orow * p.ldc + n;
+      if (vec_ok && n + 4 <= p.N) {
+        if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_ACCUM_F32) v += *(const f32x4_t*)dst;
+        *(f32x4_t*)dst = v;
+      } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+          float o = v[e];
+          if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_ACCUM_F32) o += dst[e];
+          dst[e] = o;
+        }
+      }
+    }
+  }
 }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* lds = (bf16_t*)smem;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   if constexpr (EPI == EPI_QKV) {
-    // block-uniform: the V third (n >= 2D) is produced transposed
-    if (tn * BN >= 2 * (p.N / 3)) {
-      gemm_tile<EPI, true>(p, tm, tn, lds);
+    if (tn * BN >= 2 * (p.N / 3)) {  // block-uniform: the V third is produced as V^T
+      gemm_tile<EPI, false>(p, tm, tn, smem);
       return;
     }
   }
-  gemm_tile<EPI, false>(p, tm, tn, lds);
+  gemm_tile<EPI, true>(p, tm, tn, smem);
 }
 
 template <int EPI>
@@ -200,9 +287,13 @@ int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
     case EPI_F32: return launch<EPI_F32>(p, st);
     case EPI_RESID_F32: return launch<EPI_RESID_F32>(p, st);
     case EPI_ACCUM_F32: return launch<EPI_ACCUM_F32>(p, st);
-    case EPI_PATCH: return launch<EPI_PATCH>(p, st);
+    case EPI_PATCH:
+      if ((p.ldc & 3) || !p.pos || p.N % 4) return WVN_ERR_ARG;
+      return launch<EPI_PATCH>(p, st);
     case EPI_QKV:
-      if ((p.N % 3) != 0 || ((p.N / 3) % BN) != 0 || !p.q || !p.k || !p.vt) return WVN_ERR_ARG;
+      if ((p.N % 3) != 0 || ((p.N / 3) % BN) != 0 || !p.q || !p.k || !p.vt || (p.ntok_s % 8) || (p.M % 8) ||
+          (p.npad % 8))
+        return WVN_ERR_ARG;
       return launch<EPI_QKV>(p, st);
     default: return WVN_ERR_ARG;
   }

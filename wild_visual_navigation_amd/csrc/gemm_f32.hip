@@ -31,11 +31,11 @@ __device__ inline void f32_store(const GemmF32Params& p, float* C, int m, int n,
     C[(size_t)m * p.ldc + n] = (p.mask[(size_t)m * p.ldmask + n] > 0.f) ? v : 0.f;
   } else if constexpr (EPI == F32_EPI_PATCH) {
     int b = m / p.npatch, pp = m - b * p.npatch;
-    C[((size_t)b * p.ntok + 1 + pp) * p.ldc + n] = v + p.pos[(size_t)(1 + pp) * p.ldc + n];
+    C[((size_t)b * p.ntok_s + 1 + pp) * p.ldc + n] = v + p.pos[(size_t)(1 + pp) * p.ldc + n];
   } else if constexpr (EPI == F32_EPI_QKV) {
     int D = p.N / 3;
     int which = n / D, c = n - which * D, head = c >> 6, d = c & 63;
-    int b = m / p.ntok, t = m - b * p.ntok;
+    int b = m / p.ntok_s, t = m - b * p.ntok_s;
     size_t o = (((size_t)b * p.heads + head) * p.npad + t) * 64 + d;
     (which == 0 ? p.q : which == 1 ? p.k : p.v)[o] = v;
   }

@@ -23,6 +23,7 @@ struct GemmBf16Params {
   int M, N, K;
   // EPI_PATCH
   const float* pos; int npatch; int ntok;
+  int ntok_s;  // rows per frame in the token matrices (ntok rounded up to 8); row of (b,t) = b*ntok_s + t
   // EPI_QKV
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad;
 };
@@ -48,26 +49,26 @@ struct GemmF32Params {
   int batch; long long strideA, strideB, strideC;  // batched over blockIdx.z (0 => shared)
   int splitk;                                      // >1: C must hold splitk partial [M,N] slabs (stride M*ldc)
   const float* mask; int ldmask;                   // F32_EPI_RELUMASK
-  const float* pos; int npatch; int ntok;          // F32_EPI_PATCH
+  const float* pos; int npatch; int ntok; int ntok_s;  // F32_EPI_PATCH (ntok_s: rows per frame)
   float* q; float* k; float* v; int heads; int npad;  // F32_EPI_QKV
 };
 int wvn_gemm_f32_launch(const GemmF32Params& p, int epi, hipStream_t st);
 
 // ---- elementwise / normalisation (elementwise.hip) --------------------------------------------
 int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, int S, int P, hipStream_t st);
-int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, hipStream_t st);
+int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok_s, int D, hipStream_t st);
 // LayerNorm over rows of x[rows, D] (fp32) -> y (bf16 or f32, leading dim ldy); optional second fp32 output.
 // row_map: 0 = identity; 1 = drop the class token (input row b*ntok+1+p -> output row b*(ntok-1)+p)
 int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
                          float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
-                         hipStream_t st);
+                         int ntok_s, hipStream_t st);
 int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st);
 
 // ---- attention (attention_bf16.hip / attention_f32.hip) ---------------------------------------
 int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
-                              int ntok, int npad, float scale, hipStream_t st);
+                              int ntok, int ntok_s, int npad, float scale, hipStream_t st);
 int wvn_attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok,
-                             int npad, float scale, hipStream_t st);
+                             int ntok_s, int npad, float scale, hipStream_t st);
 
 // ---- misc launchers defined across the translation units ---------------------------------------
 int wvn_splitk_reduce_launch(const float* part, int splitk, size_t n, const float* bias, int ncols, float* out,
