@@ -110,6 +110,13 @@ int wvn_upsample_nearest_i32(const int* labels, int* out, int B, int G, int H, v
  * scratch_w: B*S*G*G floats, scratch_cnt: B*S ints (receives the pixel count per segment). */
 int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float* feat, float* scratch_w,
                               int* scratch_cnt, int B, int H, int W, int G, int S, int D, void* stream);
+/* Same result as wvn_segpool_bilinear_mean for PATCH-ALIGNED segment maps (a [B,G,G] label grid that
+ * the caller would nearest-upsample by exactly the patch size: k-means clusters, grid cells that are a
+ * multiple of the patch): mean over a segment's patches of a separable 3x3 stencil of the patch map.
+ * wy, wx: [G][3] fp32 stencil weights for offsets -1,0,+1 (per-patch-row sums of the align_corners
+ * tap weights / P).  Deterministic, no atomics.  labels [B,G*G] int32, feat [B,S,D]. */
+int wvn_segpool_patch_labels(const int* labels, const float* tokens, int ld, const float* wy, const float* wx,
+                             float* feat, int B, int G, int S, int D, void* stream);
 /* FeatureExtractor.sparsify_features on an explicit pixel-resolution map (no resampling):
  * tokens [B,P,D] pixel-major, seg [B,P] -> feat [B,S,D] = per-segment mean (0/0 = NaN). S <= 236. */
 int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, int B, int P, int S, int D,
@@ -132,9 +139,11 @@ int wvn_seg_adjacency(const int* seg, long long* edges, int* count, unsigned cha
 /* rows of code [rows, ldc] -> xn [rows, C] = code / max(||code||, 1e-12), sequential fp32 */
 int wvn_normalize_rows(const float* code, int ldc, float* xn, int rows, int C, void* stream);
 /* deterministic cosine k-means per image on xn [B,P,C]; labels [B,P] int32; nseg [B] distinct ids;
- * relabel != 0 compacts ids to 0..K'-1 ascending (feature_extractor.py:245-246). C in {16,64,90}. */
-int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, int B, int P, int C, int K, int iters, int relabel,
-                      void* stream);
+ * relabel != 0 compacts ids to 0..K'-1 ascending (feature_extractor.py:245-246). C in {16,64,90}.
+ * scratch: wvn_kmeans_scratch_bytes(B,P,C,K) bytes (centroids + per-chunk partial sums). */
+size_t wvn_kmeans_scratch_bytes(int B, int P, int C, int K);
+int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, void* scratch, int B, int P, int C, int K, int iters,
+                      int relabel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Traversability MLP  (model/simple_mlp.py:10-39, utils/loss.py:93-160,

@@ -70,6 +70,7 @@ def dino_inference(sd, img: torch.Tensor, input_size: int, patch: int, heads: in
 # ----------------------------------------------------------------------------------------------
 STEGO_CODE_DIM = 90
 KMEANS_ITERS = 10
+KMEANS_CHUNK = 64
 
 
 def make_stego_head_state_dict(D: int = 384, C: int = STEGO_CODE_DIM, seed: int = 0) -> Dict[str, torch.Tensor]:
@@ -135,8 +136,14 @@ def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) ->
 
     for _ in range(iters):
         lab = assign(cent)
+        # centroid sums in the kernel's fixed order: chunks of KMEANS_CHUNK consecutive points, members of a
+        # cluster added in ascending point order inside a chunk (from 0), chunk partials added in ascending
+        # chunk order (from 0) -- one fp32 rounding per addition
         sums = np.zeros((K, C), dtype=np.float32)
-        np.add.at(sums, lab, x)  # unbuffered, processes p = 0..P-1 in order
+        for p0 in range(0, P, KMEANS_CHUNK):
+            part = np.zeros((K, C), dtype=np.float32)
+            np.add.at(part, lab[p0:p0 + KMEANS_CHUNK], x[p0:p0 + KMEANS_CHUNK])  # unbuffered: ascending order
+            sums = (sums + part).astype(np.float32)
         cnt = np.bincount(lab, minlength=K)
         new = _normalize_rows_f32(sums)
         cent = np.where((cnt > 0)[:, None], new, cent).astype(np.float32)

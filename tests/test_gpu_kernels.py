@@ -115,9 +115,10 @@ def _attn_ref(q, k, v, scale):
     return att @ v.double()  # [B,h,N,64]
 
 
-def _pad(t, npad):
+def _pad(t, npad, fill=float("nan")):
+    """Pad the token axis to npad.  The padding is NaN-poisoned: the kernels must not let it leak."""
     B, h, N, d = t.shape
-    out = torch.zeros(B, h, npad, d, dtype=t.dtype)
+    out = torch.full((B, h, npad, d), fill, dtype=t.dtype)
     out[:, :, :N] = t
     return out
 

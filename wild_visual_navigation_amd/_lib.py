@@ -65,12 +65,14 @@ _SIGNATURES = {
     "wvn_upsample_bilinear": ([_p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_upsample_nearest_i32": ([_p, _p, _i, _i, _i, _p], _i),
     "wvn_segpool_bilinear_mean": ([_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_segpool_patch_labels": ([_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_segmean_tokens": ([_p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_label_pool": ([_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_seg_centers": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_seg_adjacency": ([_p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_normalize_rows": ([_p, _i, _p, _i, _i, _p], _i),
-    "wvn_kmeans_cosine": ([_p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_kmeans_scratch_bytes": ([_i, _i, _i, _i], _sz),
+    "wvn_kmeans_cosine": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "wvn_mlp_param_count": ([_p], _sz),
     "wvn_mlp_workspace_bytes": ([_p, _i], _sz),
     "wvn_mlp_forward": ([_p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, _p], _i),

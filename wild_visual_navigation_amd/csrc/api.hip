@@ -259,6 +259,10 @@ int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float
                               int* scratch_cnt, int B, int H, int W, int G, int S, int D, void* stream) {
   return wvn_segpool_launch(seg, tokens, ld, feat, scratch_w, scratch_cnt, B, H, W, G, S, D, (hipStream_t)stream);
 }
+int wvn_segpool_patch_labels(const int* labels, const float* tokens, int ld, const float* wy, const float* wx,
+                             float* feat, int B, int G, int S, int D, void* stream) {
+  return wvn_segpool_patch_launch(labels, tokens, ld, wy, wx, feat, B, G, S, D, (hipStream_t)stream);
+}
 int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, int B, int P, int S, int D,
                        void* stream) {
   return wvn_segmean_tokens_launch(seg, tokens, feat, scratch_cnt, B, P, S, D, (hipStream_t)stream);
@@ -277,9 +281,12 @@ int wvn_seg_adjacency(const int* seg, long long* edges, int* count, unsigned cha
 int wvn_normalize_rows(const float* code, int ldc, float* xn, int rows, int C, void* stream) {
   return wvn_normalize_rows_launch(code, ldc, xn, rows, C, (hipStream_t)stream);
 }
-int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, int B, int P, int C, int K, int iters, int relabel,
-                      void* stream) {
-  return wvn_kmeans_launch(xn, labels, nseg, B, P, C, K, iters, relabel, (hipStream_t)stream);
+size_t wvn_kmeans_scratch_bytes(int B, int P, int C, int K) {
+  return (B > 0 && P > 0 && C > 0 && K > 0) ? wvn_kmeans_scratch_floats(B, P, C, K) * sizeof(float) : 0;
+}
+int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, void* scratch, int B, int P, int C, int K, int iters,
+                      int relabel, void* stream) {
+  return wvn_kmeans_launch(xn, labels, nseg, (float*)scratch, B, P, C, K, iters, relabel, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
       rk[i] = *(const u32x4_t*)(kg + (size_t)(kv0 + 32 * i) * DH);
       rv[i] = *(const u32x4_t*)(vg + (size_t)(32 * i) * npad + kv0);
     }
+    // Tail tile: keys >= ntok are padding whose content is not ours (0 * NaN = NaN in the PV MFMA):
+    // scores of those keys are replaced by select below, their V^T columns are zeroed here.
+    if (kv0 + KVB > ntok) {
+      const int kbase = kv0 + skc * 8;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t keep = (kbase + 2 * w < ntok ? 0x0000ffffu : 0u) | (kbase + 2 * w + 1 < ntok ? 0xffff0000u : 0u);
+          rv[i][w] &= keep;
+        }
+    }
   };
   auto store_regs = [&](int stage) {
     bf16_t* Ks = lds + stage * 2 * TILE_ELEMS;

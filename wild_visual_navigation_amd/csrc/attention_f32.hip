@@ -43,7 +43,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     for (int c = tid; c < FKV * FD / 4; c += 256) {
       int row = c >> 4, col = (c & 15) * 4;
       *(f32x4_t*)(Ks + row * FSTR + col) = *(const f32x4_t*)(k + ((size_t)bh * npad + kv0 + row) * FD + col);
-      *(f32x4_t*)(Vs + row * FSTR + col) = *(const f32x4_t*)(v + ((size_t)bh * npad + kv0 + row) * FD + col);
+      // rows >= ntok are padding (content not ours): zero them so that 0 * garbage cannot become NaN
+      const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+      *(f32x4_t*)(Vs + row * FSTR + col) =
+          (kv0 + row < ntok) ? *(const f32x4_t*)(v + ((size_t)bh * npad + kv0 + row) * FD + col) : zero;
     }
     __syncthreads();
     float s[16];

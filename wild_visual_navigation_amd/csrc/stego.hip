@@ -3,17 +3,27 @@
 //
 // Integer outputs (segment-index maps) must be bit-exact against the oracle given the same fp32
 // code, so every floating-point reduction here has a FIXED, documented order and uses the
-// correctly-rounded non-fused intrinsics (__fmul_rn/__fadd_rn/__fsqrt_rn/__fdiv_rn):
-//   * dot products / norms: strictly sequential over the channel index
-//   * centroid sums       : strictly sequential over the point index (ascending)
-//   * argmax              : first maximum (lowest cluster id wins ties)
+// correctly-rounded non-fused intrinsics (__fmul_rn/__fadd_rn/__fsqrt_rn/__fdiv_rn; this file is
+// compiled with -ffp-contract=off):
+//   * dot products / norms : strictly sequential over the channel index
+//   * centroid sums        : points are cut into chunks of KM_CHUNK (64) consecutive indices; inside a
+//                            chunk the members of a cluster are added in ascending point order starting
+//                            from 0, and the chunk partials are then added in ascending chunk order
+//   * argmax               : first maximum (lowest cluster id wins ties)
 // oracle/interfaces.py::kmeans_cosine_labels mirrors this operation for operation.
+//
+// The whole GPU works on every Lloyd iteration (3 small launches per iteration, all images at once):
+//   assign  : one lane per point, centroids of the image in LDS
+//   partial : one workgroup per (chunk, image), lane = channel: LDS table part[K][C] indexed by label
+//             (each lane owns its column, so no atomics and a fixed order)
+//   update  : one workgroup per image: ordered sum over chunks, sequential norm, divide
 #include "common.h"
 #include "wvn_internal.h"
 
 namespace {
 
 constexpr int KM_MAXK = 64;
+constexpr int KM_CHUNK = 64;
 
 // xn[p][:] = code[p][:] / max(||code[p]||, 1e-12)
 __global__ void normalize_rows_kernel(const float* __restrict__ code, int ldc, float* __restrict__ xn, int rows, int C) {
@@ -26,84 +36,141 @@ __global__ void normalize_rows_kernel(const float* __restrict__ code, int ldc, f
   for (int d = 0; d < C; ++d) xn[(size_t)p * C + d] = __fdiv_rn(r[d], n);
 }
 
+// cent[b][k][:] = xn[b][floor((2k+1) P / 2K)][:]
+__global__ void km_init_kernel(const float* __restrict__ xn, float* __restrict__ cent, int P, int C, int K) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+    int k = i / C, d = i - k * C;
+    int p0 = (int)(((long long)(2 * k + 1) * P) / (2 * K));
+    cent[(size_t)b * K * C + i] = xn[((size_t)b * P + p0) * C + d];
+  }
+}
+
 template <int C>
-__device__ inline int assign_point(const float* __restrict__ xp, const float* cent, int K) {
+__global__ __launch_bounds__(256) void km_assign_kernel(const float* __restrict__ xn, const float* __restrict__ cent,
+                                                        int* __restrict__ labels, int P, int K) {
+  extern __shared__ float cs[];  // [K][C]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) cs[i] = cent[(size_t)b * K * C + i];
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float* xp = xn + ((size_t)b * P + p) * C;
   float x[C];
 #pragma unroll
   for (int d = 0; d < C; ++d) x[d] = xp[d];
   int best = 0;
   float bv = -INFINITY;
   for (int k = 0; k < K; ++k) {
-    const float* c = cent + k * C;
+    const float* c = cs + k * C;
     float acc = 0.f;
 #pragma unroll
     for (int d = 0; d < C; ++d) acc = __fadd_rn(acc, __fmul_rn(x[d], c[d]));
     if (acc > bv) { bv = acc; best = k; }
   }
-  return best;
+  labels[(size_t)b * P + p] = best;
 }
 
-// one workgroup per image
-template <int C>
-__global__ __launch_bounds__(1024) void kmeans_kernel(const float* __restrict__ xn, int* __restrict__ labels,
-                                                      int* __restrict__ nseg, int P, int K, int iters, int relabel) {
-  extern __shared__ unsigned char smem_raw[];
-  float* cent = (float*)smem_raw;            // [K][C]
-  float* sums = cent + K * C;                // [K][C]
-  float* nrm = sums + K * C;                 // [K]
-  int* cnt = (int*)(nrm + K);                // [K]
-  int* lut = cnt + K;                        // [K]
-  unsigned char* lab = (unsigned char*)(lut + K);  // [P]
+// part[b][chunk][k][d] = ordered sum of the chunk's members of cluster k ; pcnt[b][chunk][k] = member count
+__global__ void km_partial_kernel(const float* __restrict__ xn, const int* __restrict__ labels,
+                                  float* __restrict__ part, int* __restrict__ pcnt, int P, int C, int K, int nchunk) {
+  extern __shared__ float tab[];  // [K][C] floats + [K] ints
+  int* cn = (int*)(tab + K * C);
+  const int chunk = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) tab[i] = 0.f;
+  for (int i = threadIdx.x; i < K; i += blockDim.x) cn[i] = 0;
+  __syncthreads();
+  const int p0 = chunk * KM_CHUNK, p1 = min(P, p0 + KM_CHUNK);
+  if (d < C) {
+    for (int p = p0; p < p1; ++p) {
+      const int k = labels[(size_t)b * P + p];
+      tab[k * C + d] = __fadd_rn(tab[k * C + d], xn[((size_t)b * P + p) * C + d]);
+    }
+  }
+  if (d == 0)
+    for (int p = p0; p < p1; ++p) cn[labels[(size_t)b * P + p]] += 1;
+  __syncthreads();
+  float* dst = part + ((size_t)b * nchunk + chunk) * K * C;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) dst[i] = tab[i];
+  for (int i = threadIdx.x; i < K; i += blockDim.x) pcnt[((size_t)b * nchunk + chunk) * K + i] = cn[i];
+}
+
+// cent[b][k][:] = normalise(sum over chunks, ascending) if the cluster is non-empty
+__global__ __launch_bounds__(1024) void km_update_kernel(const float* __restrict__ part, const int* __restrict__ pcnt,
+                                                         float* __restrict__ cent, int C, int K, int nchunk) {
+  extern __shared__ float sums[];  // [K][C] + nrm[K] + cnt[K]
+  float* nrm = sums + K * C;
+  int* cnt = (int*)(nrm + K);
   const int b = blockIdx.x;
-  const float* X = xn + (size_t)b * P * C;
-  const int tid = threadIdx.x, nth = blockDim.x;
-
-  for (int i = tid; i < K * C; i += nth) {
-    int k = i / C, d = i - k * C;
-    int p0 = (int)(((long long)(2 * k + 1) * P) / (2 * K));
-    cent[i] = X[(size_t)p0 * C + d];
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s = __fadd_rn(s, part[((size_t)b * nchunk + c) * K * C + i]);
+    sums[i] = s;
+  }
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    int n = 0;
+    for (int c = 0; c < nchunk; ++c) n += pcnt[((size_t)b * nchunk + c) * K + k];
+    cnt[k] = n;
   }
   __syncthreads();
-
-  for (int it = 0; it <= iters; ++it) {
-    for (int p = tid; p < P; p += nth) lab[p] = (unsigned char)assign_point<C>(X + (size_t)p * C, cent, K);
-    __syncthreads();
-    if (it == iters) break;
-    // centroid sums: thread (k,d) walks the points in ascending order
-    for (int i = tid; i < K * C; i += nth) {
-      const int k = i / C, d = i - k * C;
-      float s = 0.f;
-      int n = 0;
-      for (int p = 0; p < P; ++p)
-        if (lab[p] == k) { s = __fadd_rn(s, X[(size_t)p * C + d]); ++n; }
-      sums[i] = s;
-      if (d == 0) cnt[k] = n;
-    }
-    __syncthreads();
-    if (tid < K) {
-      float n2 = 0.f;
-      for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(sums[tid * C + d], sums[tid * C + d]));
-      nrm[tid] = fmaxf(__fsqrt_rn(n2), 1e-12f);
-    }
-    __syncthreads();
-    for (int i = tid; i < K * C; i += nth) {
-      const int k = i / C;
-      if (cnt[k] > 0) cent[i] = __fdiv_rn(sums[i], nrm[k]);
-    }
-    __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float n2 = 0.f;
+    for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(sums[k * C + d], sums[k * C + d]));
+    nrm[k] = fmaxf(__fsqrt_rn(n2), 1e-12f);
   }
-  // optional compaction of the used ids to 0..K'-1 in ascending order (feature_extractor.py:245-246)
-  if (tid < K) cnt[tid] = 0;
   __syncthreads();
-  for (int p = tid; p < P; p += nth) cnt[lab[p]] = 1;  // benign race: all writers store 1
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+    const int k = i / C;
+    if (cnt[k] > 0) cent[(size_t)b * K * C + i] = __fdiv_rn(sums[i], nrm[k]);
+  }
+}
+
+// compaction of the used ids to 0..K'-1 in ascending order (feature_extractor.py:245-246) + distinct count
+__global__ __launch_bounds__(1024) void km_relabel_kernel(int* __restrict__ labels, int* __restrict__ nseg, int P, int K,
+                                                          int relabel) {
+  __shared__ int used[KM_MAXK];
+  __shared__ int lut[KM_MAXK];
+  const int b = blockIdx.x;
+  int* lab = labels + (size_t)b * P;
+  if (threadIdx.x < K) used[threadIdx.x] = 0;
   __syncthreads();
-  if (tid == 0) {
+  for (int p = threadIdx.x; p < P; p += blockDim.x) used[lab[p]] = 1;  // benign race: all writers store 1
+  __syncthreads();
+  if (threadIdx.x == 0) {
     int run = 0;
-    for (int k = 0; k < K; ++k) { lut[k] = run; run += cnt[k]; }
+    for (int k = 0; k < K; ++k) { lut[k] = run; run += used[k]; }
     nseg[b] = run;
   }
   __syncthreads();
-  for (int p = tid; p < P; p += nth) labels[(size_t)b * P + p] = relabel ? lut[lab[p]] : (int)lab[p];
+  if (relabel)
+    for (int p = threadIdx.x; p < P; p += blockDim.x) lab[p] = lut[lab[p]];
+}
+
+template <int C>
+int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, int P, int K, int iters, int relabel,
+               hipStream_t st) {
+  const int nchunk = ceil_div(P, KM_CHUNK);
+  float* cent = scratch;                                   // [B][K][C]
+  float* part = cent + (size_t)B * K * C;                  // [B][nchunk][K][C]
+  int* pcnt = (int*)(part + (size_t)B * nchunk * K * C);   // [B][nchunk][K]
+  const size_t shm_kc = (size_t)K * C * sizeof(float);
+  hipLaunchKernelGGL(km_init_kernel, dim3(B), dim3(256), 0, st, xn, cent, P, C, K);
+  WVN_LAUNCH_CHECK();
+  const int threads_c = ((C + 63) / 64) * 64;
+  for (int it = 0; it <= iters; ++it) {
+    hipLaunchKernelGGL((km_assign_kernel<C>), dim3(ceil_div(P, 256), B), dim3(256), shm_kc, st, xn, cent, labels, P, K);
+    WVN_LAUNCH_CHECK();
+    if (it == iters) break;
+    hipLaunchKernelGGL(km_partial_kernel, dim3(nchunk, B), dim3(threads_c), shm_kc + K * sizeof(int), st, xn, labels,
+                       part, pcnt, P, C, K, nchunk);
+    WVN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(km_update_kernel, dim3(B), dim3(1024), shm_kc + 2 * K * sizeof(float), st, part, pcnt, cent, C, K,
+                       nchunk);
+    WVN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(km_relabel_kernel, dim3(B), dim3(1024), 0, st, labels, nseg, P, K, relabel);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
 }
 
 }  // namespace
@@ -115,16 +182,17 @@ int wvn_normalize_rows_launch(const float* code, int ldc, float* xn, int rows, i
   return WVN_OK;
 }
 
-int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, int B, int P, int C, int K, int iters, int relabel,
-                      hipStream_t st) {
-  if (!xn || !labels || !nseg || K <= 0 || K > KM_MAXK || P <= 0 || P > 60000) return WVN_ERR_ARG;
-  size_t shm = (size_t)(2 * K * C + K) * sizeof(float) + 2 * K * sizeof(int) + (size_t)P;
-  shm = align_up(shm, 16);
-  if (shm > 64 * 1024) return WVN_ERR_ARG;
-  if (C == 90) hipLaunchKernelGGL((kmeans_kernel<90>), dim3(B), dim3(1024), shm, st, xn, labels, nseg, P, K, iters, relabel);
-  else if (C == 64) hipLaunchKernelGGL((kmeans_kernel<64>), dim3(B), dim3(1024), shm, st, xn, labels, nseg, P, K, iters, relabel);
-  else if (C == 16) hipLaunchKernelGGL((kmeans_kernel<16>), dim3(B), dim3(1024), shm, st, xn, labels, nseg, P, K, iters, relabel);
-  else return WVN_ERR_ARG;
-  WVN_LAUNCH_CHECK();
-  return WVN_OK;
+size_t wvn_kmeans_scratch_floats(int B, int P, int C, int K) {
+  const size_t nchunk = (size_t)ceil_div(P, KM_CHUNK);
+  return (size_t)B * K * C + (size_t)B * nchunk * K * C + (size_t)B * nchunk * K;
+}
+
+int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, float* scratch, int B, int P, int C, int K, int iters,
+                      int relabel, hipStream_t st) {
+  if (!xn || !labels || !nseg || !scratch || K <= 0 || K > KM_MAXK || P <= 0) return WVN_ERR_ARG;
+  if ((size_t)K * C * sizeof(float) + 2 * K * sizeof(float) > 60 * 1024) return WVN_ERR_ARG;
+  if (C == 90) return run_kmeans<90>(xn, labels, nseg, scratch, B, P, K, iters, relabel, st);
+  if (C == 64) return run_kmeans<64>(xn, labels, nseg, scratch, B, P, K, iters, relabel, st);
+  if (C == 16) return run_kmeans<16>(xn, labels, nseg, scratch, B, P, K, iters, relabel, st);
+  return WVN_ERR_ARG;
 }

@@ -84,8 +84,9 @@ int wvn_centers_launch(const int* seg, float* centers, unsigned long long* scrat
 int wvn_adjacency_launch(const int* seg, long long* edges, int* count, unsigned char* bitmap, int H, int Wd, int S,
                          int max_edges, hipStream_t st);
 int wvn_normalize_rows_launch(const float* code, int ldc, float* xn, int rows, int C, hipStream_t st);
-int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, int B, int P, int C, int K, int iters, int relabel,
-                      hipStream_t st);
+size_t wvn_kmeans_scratch_floats(int B, int P, int C, int K);
+int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, float* scratch, int B, int P, int C, int K, int iters,
+                      int relabel, hipStream_t st);
 int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int ldx, const unsigned char* valid,
                                  float* lr, double* stats, int R, int D, hipStream_t st);
 int wvn_mlp_gradout_launch(const float* out, int ldo, const float* x, int ldx, const float* y,
@@ -99,5 +100,7 @@ int wvn_mlp_losses_launch(const double* stats, const float* extra, float w_trav,
                           hipStream_t st);
 int wvn_mlp_confidence_launch(const float* out, int ldo, const float* x, int ldx, float mean, float std,
                               float std_factor, float* trav, float* conf, int R, int D, hipStream_t st);
+int wvn_segpool_patch_launch(const int* labels, const float* tok, int ldf, const float* wy, const float* wx,
+                             float* feat, int B, int G, int S, int D, hipStream_t st);
 int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, int B, int P, int S, int D,
                               hipStream_t st);

@@ -117,20 +117,31 @@ class FeatureExtractor:
         mean).  Supported segmentations: grid, stego."""
         img = img.to(self._device)
         B, _, H, W = img.shape
+        G = self._grid()
+        labels_patch = None  # [B,G,G] ids when the segment map is constant on every ViT patch
         if self._segmentation_type == "grid":
+            cell = kwargs.get("cell_size", 32)
             seg = self.segment_grid(img, **kwargs)[0, 0].to(torch.int32)[None].expand(B, H, W).contiguous()
-            n_seg = (H // kwargs.get("cell_size", 32)) * (W // kwargs.get("cell_size", 32))
+            n_seg = (H // cell) * (W // cell)
             nseg = torch.full((B,), n_seg, dtype=torch.int32, device=self._device)
             tokens = self._feature_tokens(img)
+            P = H // G
+            if H == W and G * P == H and cell % P == 0:
+                labels_patch = seg[:, ::P, ::P]
         elif self._segmentation_type == "stego":
             self._extractor.inference(img)
             seg = self._extractor.cluster_segments[0]
             nseg = self._extractor._n_segments
             n_seg = self._extractor._cfg.n_image_clusters
             tokens = self._extractor.feature_tokens
+            labels_patch = self._extractor._labels_patch
         else:
             raise TypeError(f"extract_batch: segmentation_type [{self._segmentation_type}] not supported")
-        feat = ops.segpool_bilinear_mean(seg, tokens, self._grid(), n_seg)
+        feat = None
+        if labels_patch is not None and kwargs.get("patch_aligned_pooling", True):
+            feat = ops.segpool_patch_labels(labels_patch, tokens, G, H, n_seg)  # None if geometry does not allow
+        if feat is None:
+            feat = ops.segpool_bilinear_mean(seg, tokens, G, n_seg)
         return feat, seg, nseg
 
     # ------------------------------------------------------------------------------------------ pieces

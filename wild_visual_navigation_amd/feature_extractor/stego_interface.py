@@ -128,7 +128,8 @@ class StegoInterface:
             # cluster probe: cosine similarity against learned centroids -- not part of the hot path; use
             # k-means semantics with the probe as fixed centroids is not defined upstream here.
             raise _lib.WvnError("run_clustering=False (learned cluster probe) needs the STEGO checkpoint's probe")
-        self._cluster_pred = ops.upsample_nearest_labels(labels.reshape(B, G, G), H)[None]
+        self._labels_patch = labels.reshape(B, G, G)  # patch-resolution cluster ids (before the nearest up-sampling)
+        self._cluster_pred = ops.upsample_nearest_labels(self._labels_patch, H)[None]
         logits = ops.gemm_f32(code.reshape(B * G * G, -1), self._w_probe)
         lin = logits.argmax(dim=1).to(torch.int32).reshape(B, G, G)
         self._linear_pred = ops.upsample_nearest_labels(lin, H)[None]

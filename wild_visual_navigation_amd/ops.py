@@ -51,6 +51,57 @@ def segpool_bilinear_mean(seg: torch.Tensor, tokens: torch.Tensor, grid: int, n_
     return (feat, cnt.reshape(B, n_seg)) if return_counts else feat
 
 
+_STENCILS = {}
+
+
+def patch_stencil_tables(grid: int, out_size: int, device):
+    """[G][3] stencil weights (offsets -1, 0, +1) of the block-averaged align_corners=True bilinear
+    up-sampling grid -> out_size for patch size P = out_size // grid; None when the geometry is not
+    patch-aligned (out_size != grid * P) or a tap falls outside the 3-wide stencil."""
+    key = (grid, out_size, str(device))
+    if key not in _STENCILS:
+        import numpy as np
+
+        P = out_size // grid
+        tab = None
+        if P * grid == out_size and P >= 1:
+            scale = np.float32(grid - 1) / np.float32(out_size - 1) if out_size > 1 else np.float32(0)
+            tab = np.zeros((grid, 3), dtype=np.float32)
+            for y in range(out_size):
+                g = y // P
+                src = np.float32(scale * np.float32(y))
+                y0 = int(src)
+                y1 = y0 + (1 if y0 < grid - 1 else 0)
+                w1 = np.float32(src - np.float32(y0))
+                for yy, ww in ((y0, np.float32(1) - w1), (y1, w1)):
+                    if not -1 <= yy - g <= 1:
+                        tab = None
+                        break
+                    tab[g, yy - g + 1] += ww
+                if tab is None:
+                    break
+            if tab is not None:
+                tab = torch.from_numpy(tab / np.float32(P)).to(device)
+        _STENCILS[key] = tab
+    return _STENCILS[key]
+
+
+def segpool_patch_labels(labels: torch.Tensor, tokens: torch.Tensor, grid: int, out_size: int, n_seg: int):
+    """Patch-aligned fast path of segpool_bilinear_mean: labels [B,G,G] (or [B,G*G]) int32 at patch
+    resolution, tokens [B,G*G,D] -> feat [B,S,D].  Returns None if the geometry is not patch-aligned."""
+    require_cuda(tokens, "tokens")
+    tab = patch_stencil_tables(grid, out_size, tokens.device)
+    if tab is None or n_seg * 65 * 4 > 60 * 1024:
+        return None
+    tokens = tokens.contiguous()
+    B, P, D = tokens.shape
+    labels = _i32(labels).reshape(B, P).contiguous()
+    feat = torch.empty(B, n_seg, D, dtype=torch.float32, device=tokens.device)
+    check(lib().wvn_segpool_patch_labels(ptr(labels), ptr(tokens), D, ptr(tab), ptr(tab), ptr(feat), B, grid, n_seg, D,
+                                         stream()), "wvn_segpool_patch_labels")
+    return feat
+
+
 def segmean_tokens(seg: torch.Tensor, tokens: torch.Tensor, n_seg: int) -> torch.Tensor:
     """Plain per-segment mean of a pixel-resolution map: seg [B,H,W] / [B,P], tokens [B,P,D] -> [B,S,D]."""
     require_cuda(tokens, "tokens")
@@ -117,8 +168,9 @@ def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = T
     check(lib().wvn_normalize_rows(ptr(code), code.stride(1), ptr(xn), B * P, Cc, stream()), "wvn_normalize_rows")
     labels = torch.empty(B, P, dtype=torch.int32, device=dev)
     nseg = torch.empty(B, dtype=torch.int32, device=dev)
-    check(lib().wvn_kmeans_cosine(ptr(xn), ptr(labels), ptr(nseg), B, P, Cc, K, iters, int(relabel), stream()),
-          "wvn_kmeans_cosine")
+    scratch = torch.empty(lib().wvn_kmeans_scratch_bytes(B, P, Cc, K), dtype=torch.uint8, device=dev)
+    check(lib().wvn_kmeans_cosine(ptr(xn), ptr(labels), ptr(nseg), ptr(scratch), B, P, Cc, K, iters, int(relabel),
+                                  stream()), "wvn_kmeans_cosine")
     return labels, nseg
 
 
