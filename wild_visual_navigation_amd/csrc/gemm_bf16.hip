@@ -23,6 +23,7 @@
 // B: lane l holds col l&31, same k-slots; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
 #include "common.h"
 #include "wvn_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,7 +61,7 @@ constexpr bool out_is_bf16() {
 
 // TR = true : accumulators hold C^T (lane = row m, regs = cols n)  -> LDS image [m][n]
 // TR = false: accumulators hold C   (lane = col n, regs = rows m)  -> LDS image [n][m]   (V^T tiles)
-template <int EPI, bool TR>
+template <int EPI, bool TR, int PD>
 __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsigned char* smem) {
   bf16_t* lds = (bf16_t*)smem;
   const int tid = threadIdx.x;
@@ -69,27 +70,32 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
   const int l31 = lane & 31, hi = lane >> 5;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // staging assignment: 4 A chunks + 4 W chunks of 16 B per thread per K-tile
-  u32x4_t ra[4], rb[4];
+  // Staging: 4 A chunks + 4 W chunks of 16 B per thread per K-tile, held in one of PD register sets.
+  // The memory system needs ~2-3k cycles to return a K-tile while its MFMAs take ~0.5k, so PD K-tiles are
+  // kept in flight per workgroup (register prefetch depth PD; slot of tile t = t % PD).  LDS stays
+  // double-buffered: tile t+1 moves registers -> LDS right after the MFMAs of tile t, and the freed
+  // register slot is immediately re-issued for tile t+1+PD.  All slot indices are compile-time (the K
+  // loop is unrolled by PD) so nothing spills to scratch.
+  u32x4_t ra[PD][4], rb[PD][4];
   const int srow = tid >> 3, skc = tid & 7;
-  auto load_regs = [&](int kt) {
+  auto load_regs = [&](int kt, u32x4_t (&a)[4], u32x4_t (&b)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int row = srow + 32 * i;
       int gm = m0 + row, gn = n0 + row;
       u32x4_t z = {0u, 0u, 0u, 0u};
-      ra[i] = (gm < p.M) ? *(const u32x4_t*)(p.A + (size_t)gm * p.lda + kt * BK + skc * 8) : z;
-      rb[i] = (gn < p.N) ? *(const u32x4_t*)(p.W + (size_t)gn * p.ldw + kt * BK + skc * 8) : z;
+      a[i] = (gm < p.M) ? *(const u32x4_t*)(p.A + (size_t)gm * p.lda + kt * BK + skc * 8) : z;
+      b[i] = (gn < p.N) ? *(const u32x4_t*)(p.W + (size_t)gn * p.ldw + kt * BK + skc * 8) : z;
     }
   };
-  auto store_regs = [&](int stage) {
+  auto store_regs = [&](int stage, const u32x4_t (&a)[4], const u32x4_t (&b)[4]) {
     bf16_t* As = lds + stage * STAGE_ELEMS;
     bf16_t* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int row = srow + 32 * i;
-      *(u32x4_t*)(As + row * LDS_STRIDE + skc * 8) = ra[i];
-      *(u32x4_t*)(Bs + row * LDS_STRIDE + skc * 8) = rb[i];
+      *(u32x4_t*)(As + row * LDS_STRIDE + skc * 8) = a[i];
+      *(u32x4_t*)(Bs + row * LDS_STRIDE + skc * 8) = b[i];
     }
   };
 
@@ -102,13 +108,19 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  load_regs(0);
-  store_regs(0);
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (u < nk) load_regs(u, ra[u], rb[u]);
+  store_regs(0, ra[0], rb[0]);
+  if (PD < nk) load_regs(PD, ra[0], rb[0]);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+#pragma unroll
+   for (int u = 0; u < PD; ++u) {
+    const int kt = kt0 + u;
+    if (kt >= nk) break;
     const bool more = (kt + 1 < nk);
-    if (more) load_regs(kt + 1);
     const bf16_t* As = lds + (kt & 1) * STAGE_ELEMS;
     const bf16_t* Bs = As + BM * LDS_STRIDE;
     const bf16_t* a_base = As + (wm * 64 + l31) * LDS_STRIDE + hi * 8;
@@ -130,8 +142,12 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (more) store_regs((kt + 1) & 1);
+    if (more) {
+      store_regs((kt + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);  // tile kt+1: issued PD iterations ago
+      if (kt + 1 + PD < nk) load_regs(kt + 1 + PD, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+    }
     __syncthreads();  // also: after the last K-tile every wave is done with the operand LDS
+   }
   }
 
   // ---------------- epilogue, part 1: registers -> LDS tile image (bias + activation applied) ----------
@@ -243,7 +259,7 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
   }
 }
 
-template <int EPI>
+template <int EPI, int PD>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -252,26 +268,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   if constexpr (EPI == EPI_QKV) {
     if (tn * BN >= 2 * (p.N / 3)) {  // block-uniform: the V third is produced as V^T
-      gemm_tile<EPI, false>(p, tm, tn, smem);
+      gemm_tile<EPI, false, PD>(p, tm, tn, smem);
       return;
     }
   }
-  gemm_tile<EPI, true>(p, tm, tn, smem);
+  gemm_tile<EPI, true, PD>(p, tm, tn, smem);
 }
 
-template <int EPI>
-int launch(const GemmBf16Params& p, hipStream_t st) {
+template <int EPI, int PD>
+int launch_pd(const GemmBf16Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GEMM_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, PD>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, PD>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
+}
+
+// register prefetch depth: WVN_GEMM_PD = 1 | 2 | 3 (default) -- kept selectable for A/B measurements
+int prefetch_depth() {
+  static int pd = 0;
+  if (!pd) {
+    const char* e = getenv("WVN_GEMM_PD");
+    pd = e ? atoi(e) : 3;
+    if (pd < 1 || pd > 3) pd = 3;
+  }
+  return pd;
+}
+
+template <int EPI>
+int launch(const GemmBf16Params& p, hipStream_t st) {
+  switch (prefetch_depth()) {
+    case 1: return launch_pd<EPI, 1>(p, st);
+    case 2: return launch_pd<EPI, 2>(p, st);
+    default: return launch_pd<EPI, 3>(p, st);
+  }
 }
 
 }  // namespace
