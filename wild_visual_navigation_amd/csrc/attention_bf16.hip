@@ -31,6 +31,8 @@
 // neutralised: their scores by select, their V^T columns by zeroing on the way into LDS.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "wvn_internal.h"
 
@@ -42,7 +44,7 @@ constexpr int DH = 64;        // head dim
 constexpr int LSTR = DH + 8;  // LDS row stride in bf16 (144 B)
 constexpr int TILE_ELEMS = KVB * LSTR;
 
-template <int PD, bool XCDMAP, bool PRIO>
+template <int PD, bool XCDMAP, bool PRIO, bool RESCALE_ALWAYS = false>
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ q,
                                                                 const bf16_t* __restrict__ k,
                                                                 const bf16_t* __restrict__ vt,
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
       c[i] = *(const u32x4_t*)(vg + (size_t)(32 * i) * npad + kv0);
     }
   };
-  auto store_regs = [&](int stage, int kv0, const u32x4_t (&a)[2], const u32x4_t (&c)[2]) {
+  auto store_regs = [&](int stage, int kv0, const u32x4_t (&a)[2], const u32x4_t (&c)[2], bool may_be_tail) {
     bf16_t* Ks = lds + stage * 2 * TILE_ELEMS;
     bf16_t* Vs = Ks + TILE_ELEMS;
-    const bool tail = kv0 + KVB > ntok;  // workgroup-uniform
+    const bool tail = may_be_tail && kv0 + KVB > ntok;  // workgroup-uniform
     const int kbase = kv0 + skc * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -109,18 +111,18 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 #pragma unroll
   for (int u = 0; u < PD; ++u)
     if (u < nt) load_regs(u * KVB, rk[u], rv[u]);
-  store_regs(0, 0, rk[0], rv[0]);
+  store_regs(0, 0, rk[0], rv[0], true);
   if (PD < nt) load_regs(PD * KVB, rk[0], rv[0]);
   __syncthreads();
-
-  for (int it0 = 0; it0 < nt; it0 += PD) {
+  // Make the Q fragments "used" here: otherwise hipcc places their vmcnt wait at the first use INSIDE the
+  // tile loop, and on every trip that s_waitcnt vmcnt(0) drains the K/V prefetches as well.
 #pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      const int it = it0 + u;
-      if (it >= nt) break;
-      const int kv0 = it * KVB;
-      const bool more = (it + 1 < nt);
-      const bf16_t* Ks = lds + (it & 1) * 2 * TILE_ELEMS;
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+
+  // one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T  (operands from LDS stage `stage`)
+  auto compute_tile = [&](int kv0, int stage, auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;  // steady-state tiles are never the tail tile
+      const bf16_t* Ks = lds + stage * 2 * TILE_ELEMS;
       const bf16_t* Vs = Ks + TILE_ELEMS;
 
       // ---- S^T = K Q^T : two 32-key sub-tiles ----
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
       }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
       // ---- mask the tail of the last tile ----
-      if (kv0 + KVB > ntok) {
+      if (!STEADY && kv0 + KVB > ntok) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[t][r]);
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      if (__any(mt > m_run)) {
+      if (RESCALE_ALWAYS ? true : __any(mt > m_run)) {
         const float m_new = fmaxf(m_run, mt);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
         m_run = m_new;
@@ -197,9 +199,31 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
         }
       }
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-      if (more) {
-        store_regs((it + 1) & 1, kv0 + KVB, rk[(u + 1) % PD], rv[(u + 1) % PD]);  // tile it+1, issued PD tiles ago
-        if (it + 1 + PD < nt) load_regs((it + 1 + PD) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD]);
+  };
+
+  int it = 0;
+  // steady state: straight-line per PD tiles, no conditions around the loads -> hipcc counts vmcnt exactly
+  // (waits only for the tile being moved to LDS; the younger PD-1 tiles stay in flight across the barrier)
+  for (; it + 2 * PD < nt; it += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int t = it + u;
+      compute_tile(t * KVB, t & 1, std::true_type{});
+      store_regs((t + 1) & 1, (t + 1) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD], false);
+      load_regs((t + 1 + PD) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD]);
+      __syncthreads();
+    }
+  }
+  // drain: the last < 2*PD + PD tiles, same slot pattern with the end-of-sequence conditions
+  for (; it < nt; it += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int t = it + u;
+      if (t >= nt) break;
+      compute_tile(t * KVB, t & 1, std::false_type{});
+      if (t + 1 < nt) {
+        store_regs((t + 1) & 1, (t + 1) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD], true);
+        if (t + 1 + PD < nt) load_regs((t + 1 + PD) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD]);
       }
       __syncthreads();
     }

@@ -61,7 +61,7 @@ constexpr bool out_is_bf16() {
 
 // TR = true : accumulators hold C^T (lane = row m, regs = cols n)  -> LDS image [m][n]
 // TR = false: accumulators hold C   (lane = col n, regs = rows m)  -> LDS image [n][m]   (V^T tiles)
-template <int EPI, bool TR, int PD>
+template <int EPI, bool TR, int PD, int NK>
 __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsigned char* smem) {
   bf16_t* lds = (bf16_t*)smem;
   const int tid = threadIdx.x;
@@ -76,16 +76,24 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
   // double-buffered: tile t+1 moves registers -> LDS right after the MFMAs of tile t, and the freed
   // register slot is immediately re-issued for tile t+1+PD.  All slot indices are compile-time (the K
   // loop is unrolled by PD) so nothing spills to scratch.
+  // Loads are branch-free: rows past M / N are clamped to the last valid row (their results are never
+  // stored; an output element depends only on its own A row and its own W row).  With no control flow
+  // around the loads and a fully unrolled K loop (NK > 0) hipcc counts its vmcnt waits exactly, i.e. it
+  // waits only for the tile it is about to move to LDS while PD-1 younger tiles stay in flight.
   u32x4_t ra[PD][4], rb[PD][4];
   const int srow = tid >> 3, skc = tid & 7;
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pa[i] = p.A + (size_t)min(m0 + srow + 32 * i, p.M - 1) * p.lda + skc * 8;
+    pb[i] = p.W + (size_t)min(n0 + srow + 32 * i, p.N - 1) * p.ldw + skc * 8;
+  }
   auto load_regs = [&](int kt, u32x4_t (&a)[4], u32x4_t (&b)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int row = srow + 32 * i;
-      int gm = m0 + row, gn = n0 + row;
-      u32x4_t z = {0u, 0u, 0u, 0u};
-      a[i] = (gm < p.M) ? *(const u32x4_t*)(p.A + (size_t)gm * p.lda + kt * BK + skc * 8) : z;
-      b[i] = (gn < p.N) ? *(const u32x4_t*)(p.W + (size_t)gn * p.ldw + kt * BK + skc * 8) : z;
+      a[i] = *(const u32x4_t*)(pa[i] + kt * BK);
+      b[i] = *(const u32x4_t*)(pb[i] + kt * BK);
     }
   };
   auto store_regs = [&](int stage, const u32x4_t (&a)[4], const u32x4_t (&b)[4]) {
@@ -107,21 +115,8 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
-#pragma unroll
-  for (int u = 0; u < PD; ++u)
-    if (u < nk) load_regs(u, ra[u], rb[u]);
-  store_regs(0, ra[0], rb[0]);
-  if (PD < nk) load_regs(PD, ra[0], rb[0]);
-  __syncthreads();
-
-  for (int kt0 = 0; kt0 < nk; kt0 += PD) {
-#pragma unroll
-   for (int u = 0; u < PD; ++u) {
-    const int kt = kt0 + u;
-    if (kt >= nk) break;
-    const bool more = (kt + 1 < nk);
-    const bf16_t* As = lds + (kt & 1) * STAGE_ELEMS;
+  auto compute = [&](int stage) {
+    const bf16_t* As = lds + stage * STAGE_ELEMS;
     const bf16_t* Bs = As + BM * LDS_STRIDE;
     const bf16_t* a_base = As + (wm * 64 + l31) * LDS_STRIDE + hi * 8;
     const bf16_t* b_base = Bs + (wn * 64 + l31) * LDS_STRIDE + hi * 8;
@@ -142,12 +137,38 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (more) {
-      store_regs((kt + 1) & 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);  // tile kt+1: issued PD iterations ago
-      if (kt + 1 + PD < nk) load_regs(kt + 1 + PD, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+  };
+
+  if constexpr (NK > 0) {
+    // straight-line software pipeline: every index and every condition below folds at compile time
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+      if (u < NK) load_regs(u, ra[u], rb[u]);
+    store_regs(0, ra[0], rb[0]);
+    if (PD < NK) load_regs(PD, ra[0], rb[0]);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      compute(kt & 1);
+      if (kt + 1 < NK) {
+        store_regs((kt + 1) & 1, ra[(kt + 1) % PD], rb[(kt + 1) % PD]);  // tile kt+1: issued PD tiles ago
+        if (kt + 1 + PD < NK) load_regs(kt + 1 + PD, ra[(kt + 1) % PD], rb[(kt + 1) % PD]);
+      }
+      __syncthreads();  // also: after the last K-tile every wave is done with the operand LDS
     }
-    __syncthreads();  // also: after the last K-tile every wave is done with the operand LDS
-   }
+  } else {
+    // generic K (any multiple of 64): runtime loop, one tile in flight
+    const int nk = p.K / BK;
+    load_regs(0, ra[0], rb[0]);
+    store_regs(0, ra[0], rb[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 1 < nk);
+      if (more) load_regs(kt + 1, ra[0], rb[0]);
+      compute(kt & 1);
+      if (more) store_regs((kt + 1) & 1, ra[0], rb[0]);
+      __syncthreads();
+    }
   }
 
   // ---------------- epilogue, part 1: registers -> LDS tile image (bias + activation applied) ----------
@@ -259,7 +280,7 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
   }
 }
 
-template <int EPI, int PD>
+template <int EPI, int PD, int NK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -268,46 +289,66 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   if constexpr (EPI == EPI_QKV) {
     if (tn * BN >= 2 * (p.N / 3)) {  // block-uniform: the V third is produced as V^T
-      gemm_tile<EPI, false, PD>(p, tm, tn, smem);
+      gemm_tile<EPI, false, PD, NK>(p, tm, tn, smem);
       return;
     }
   }
-  gemm_tile<EPI, true, PD>(p, tm, tn, smem);
+  gemm_tile<EPI, true, PD, NK>(p, tm, tn, smem);
 }
 
-template <int EPI, int PD>
-int launch_pd(const GemmBf16Params& p, hipStream_t st) {
+template <int EPI, int PD, int NK>
+int launch_v(const GemmBf16Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, PD>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, PD, NK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, PD>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, PD, NK>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
 
-// register prefetch depth: WVN_GEMM_PD = 1 | 2 | 3 (default) -- kept selectable for A/B measurements
+// WVN_GEMM_PD (A/B switch): register prefetch depth of the unrolled K pipelines, 1 | 2 | 3 (default);
+// 0 selects the generic runtime-K loop everywhere.
 int prefetch_depth() {
-  static int pd = 0;
-  if (!pd) {
+  static int pd = -1;
+  if (pd < 0) {
     const char* e = getenv("WVN_GEMM_PD");
     pd = e ? atoi(e) : 3;
-    if (pd < 1 || pd > 3) pd = 3;
+    if (pd < 0 || pd > 3) pd = 3;
   }
   return pd;
 }
 
+template <int EPI, int NK>
+int launch_nk(const GemmBf16Params& p, hipStream_t st) {
+  switch (prefetch_depth()) {
+    case 0: return launch_v<EPI, 1, 0>(p, st);
+    case 1: return launch_v<EPI, 1, NK>(p, st);
+    case 2: return launch_v<EPI, 2, NK>(p, st);
+    default: return launch_v<EPI, 3, NK>(p, st);
+  }
+}
+
+// K of the hot-path GEMMs is known: 384 (qkv / proj / fc1 / STEGO hidden), 1536 (fc2), 192 (patch embed),
+// 768 (STEGO code).  Those get the unrolled pipelines; anything else the generic loop.
 template <int EPI>
 int launch(const GemmBf16Params& p, hipStream_t st) {
-  switch (prefetch_depth()) {
-    case 1: return launch_pd<EPI, 1>(p, st);
-    case 2: return launch_pd<EPI, 2>(p, st);
-    default: return launch_pd<EPI, 3>(p, st);
+  const int nk = p.K / BK;
+  if (nk == 6) return launch_nk<EPI, 6>(p, st);
+  if constexpr (EPI == EPI_RESID_F32) {
+    if (nk == 24) return launch_nk<EPI, 24>(p, st);
   }
+  if constexpr (EPI == EPI_PATCH) {
+    if (nk == 3) return launch_nk<EPI, 3>(p, st);
+  }
+  if constexpr (EPI == EPI_F32) {
+    if (nk == 12) return launch_nk<EPI, 12>(p, st);
+  }
+  return launch_v<EPI, 1, 0>(p, st);
 }
 
 }  // namespace
