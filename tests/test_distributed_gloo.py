@@ -47,7 +47,8 @@ def _worker(rank, world, port, q):
         traj.append([o["loss_total"], o["loss_trav"], o["loss_reco"], o["mean"], o["std"]])
     D.barrier()
     assert D.max_over_ranks(float(rank)) == float(world - 1)
-    q.put((rank, traj, {k: v.clone() for k, v in st.sd.items()}))
+    # numpy payloads are pickled inline (torch tensors travel as shared-memory fds that die with the worker)
+    q.put((rank, traj, {k: v.detach().cpu().numpy().copy() for k, v in st.sd.items()}))
     torch.distributed.destroy_process_group()
 
 
@@ -64,6 +65,8 @@ def test_two_rank_training_matches_single_process_and_reference():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, t0, sd0), (_, t1, sd1) = res
+    sd0 = {k: torch.from_numpy(v) for k, v in sd0.items()}
+    sd1 = {k: torch.from_numpy(v) for k, v in sd1.items()}
     assert t0 == t1, "ranks disagree on the losses"
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), f"replicas diverged on {k}"
