@@ -228,57 +228,66 @@ __global__ void segmean_final_kernel(float* __restrict__ sums, const int* __rest
 // (wy/wx = per-patch-row sums of the align_corners tap weights / P, built by the host once per geometry).
 // No atomics, deterministic: lane = channel, each wave walks its quarter of the patches in ascending
 // order into a private LDS table sums[label][channel]; the tables are combined in wave order.
-__global__ void segpool_patch_kernel(const int* __restrict__ labels, const float* __restrict__ tok, int ldf,
-                                     const float* __restrict__ wy, const float* __restrict__ wx,
-                                     float* __restrict__ feat, int G, int S, int D) {
-  extern __shared__ float tabs[];  // [NW][S][64] floats, then [NW][S] ints
-  const int NW = blockDim.x >> 6;
-  int* cnts = (int*)(tabs + (size_t)NW * S * 64);
-  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+__global__ __launch_bounds__(256) void segpool_patch_kernel(const int* __restrict__ labels, const float* __restrict__ tok,
+                                                            int ldf, const float* __restrict__ wy,
+                                                            const float* __restrict__ wx, float* __restrict__ feat,
+                                                            int G, int S, int D) {
+  // One workgroup per (64-channel slab, segment id, frame).  Each of the 4 waves owns a contiguous quarter of
+  // the frame's patches and walks it in ascending order: 64 labels per coalesced load, a ballot picks the
+  // patches of this segment, and every lane (= channel) adds their 3x3 stencil values to its running sum.
+  // The four partial sums are combined in wave order, so the result does not depend on scheduling.
+  __shared__ float part[4][64];
+  __shared__ int cnts[4];
+  const int b = blockIdx.z, s = blockIdx.y, c0 = blockIdx.x * 64;
   const int ch = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* mine = tabs + (size_t)w * S * 64;
-  int* mycnt = cnts + w * S;
-  for (int i = ch; i < S * 64; i += 64) mine[i] = 0.f;
-  for (int i = ch; i < S; i += 64) mycnt[i] = 0;
-  __syncthreads();
   const int P = G * G;
-  const int per = (P + NW - 1) / NW;
+  const int per = (P + 3) / 4;
   const int q0 = w * per, q1 = min(P, q0 + per);
   const bool live = (c0 + ch) < D;
   const float* F = tok + (size_t)b * P * ldf + c0 + ch;
-  for (int q = q0; q < q1; ++q) {
-    const int s = labels[(size_t)b * P + q];
-    if (s < 0 || s >= S) continue;
-    const int gy = q / G, gx = q - gy * G;
-    float acc = 0.f;
-    if (live) {
+  const int* lab = labels + (size_t)b * P;
+  float sum = 0.f;
+  int n = 0;
+  for (int base = q0; base < q1; base += 64) {
+    const int q = base + ch;
+    const int l = q < q1 ? lab[q] : -1;
+    unsigned long long m = __ballot(l == s);
+    n += __popcll(m);
+    while (m) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int qq = base + j;
+      const int gy = qq / G, gx = qq - gy * G;
+      float acc = 0.f;
+      if (live) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int yy = gy + a - 1;
-        const float wa = wy[gy * 3 + a];
-        if (wa == 0.f || yy < 0 || yy >= G) continue;
-        float row = 0.f;
+        for (int a = 0; a < 3; ++a) {
+          const int yy = gy + a - 1;
+          const float wa = wy[gy * 3 + a];
+          if (wa == 0.f || yy < 0 || yy >= G) continue;
+          float row = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const int xx = gx + c - 1;
-          const float wc = wx[gx * 3 + c];
-          if (wc == 0.f || xx < 0 || xx >= G) continue;
-          row = fmaf(wc, F[(size_t)(yy * G + xx) * ldf], row);
+          for (int c = 0; c < 3; ++c) {
+            const int xx = gx + c - 1;
+            const float wc = wx[gx * 3 + c];
+            if (wc == 0.f || xx < 0 || xx >= G) continue;
+            row = fmaf(wc, F[(size_t)(yy * G + xx) * ldf], row);
+          }
+          acc = fmaf(wa, row, acc);
         }
-        acc = fmaf(wa, row, acc);
+        sum += acc;
       }
-      mine[s * 64 + ch] += acc;
     }
-    if (ch == 0) mycnt[s] += 1;
   }
+  part[w][ch] = sum;
+  if (ch == 0) cnts[w] = n;
   __syncthreads();
-  for (int i = threadIdx.x; i < S * 64; i += blockDim.x) {
-    const int s = i >> 6, c = i & 63;
-    if (c0 + c >= D) continue;
-    float t = tabs[i];
-    int n = cnts[s];
-    for (int k = 1; k < NW; ++k) { t += tabs[(size_t)k * S * 64 + i]; n += cnts[k * S + s]; }
-    feat[((size_t)b * S + s) * D + c0 + c] = t / (float)n;  // 0/0 = NaN for an id without patches
+  if (w == 0 && live) {
+    float t = part[0][ch];
+    int nn = cnts[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { t += part[k][ch]; nn += cnts[k]; }
+    feat[((size_t)b * S + s) * D + c0 + ch] = t / (float)nn;  // 0/0 = NaN for an id without patches
   }
 }
 
@@ -286,13 +295,9 @@ __global__ void segpool_patch_kernel(const int* __restrict__ labels, const float
 
 int wvn_segpool_patch_launch(const int* labels, const float* tok, int ldf, const float* wy, const float* wx,
                              float* feat, int B, int G, int S, int D, hipStream_t st) {
-  if (!labels || !tok || !wy || !wx || !feat || S <= 0 || D <= 0) return WVN_ERR_ARG;
-  int nw = 4;
-  while (nw > 1 && (size_t)nw * S * 65 * 4 > 60 * 1024) nw >>= 1;
-  const size_t shm = (size_t)nw * S * 65 * 4;
-  if (shm > 64 * 1024) return WVN_ERR_ARG;  // S too large for the LDS tables: use wvn_segpool_bilinear_mean
-  hipLaunchKernelGGL(segpool_patch_kernel, dim3(ceil_div(D, 64), B), dim3(64 * nw), shm, st, labels, tok, ldf, wy, wx,
-                     feat, G, S, D);
+  if (!labels || !tok || !wy || !wx || !feat || S <= 0 || D <= 0 || S > 65535 || B > 65535) return WVN_ERR_ARG;
+  hipLaunchKernelGGL(segpool_patch_kernel, dim3(ceil_div(D, 64), S, B), dim3(256), 0, st, labels, tok, ldf, wy, wx, feat,
+                     G, S, D);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
