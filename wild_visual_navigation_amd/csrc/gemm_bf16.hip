@@ -351,12 +351,25 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
   return launch_v<EPI, 1, 0>(p, st);
 }
 
+bool use_a384() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WVN_GEMM_A384");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
+
 }  // namespace
 
 int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
   if (!p.A || !p.W || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
     return WVN_ERR_ARG;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return WVN_ERR_ARG;
+  if (p.K == 384 && use_a384()) {  // A-stationary kernel for the K = 384 linears (WVN_GEMM_A384=0 disables)
+    const int rc = wvn_gemm_a384_launch(p, epi, st);
+    if (rc != WVN_ERR_ARG) return rc;
+  }
   switch (epi) {
     case EPI_BF16: return launch<EPI_BF16>(p, st);
     case EPI_GELU_BF16: return launch<EPI_GELU_BF16>(p, st);
