@@ -217,6 +217,15 @@ int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
   return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
 }
 
+int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
+                              int N, int K, int epi, long long* dbg, void* stream) {
+  if (epi < 0 || epi > EPI_ACCUM_F32 || !C) return WVN_ERR_ARG;
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.dbg = dbg;
+  return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
+}
+
 int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, int transB, const float* bias, float* C,
                  int ldc, int M, int N, int K, int epi, const float* mask, int ldmask, void* stream) {
   if (epi < 0 || epi > F32_EPI_RELUMASK) return WVN_ERR_ARG;

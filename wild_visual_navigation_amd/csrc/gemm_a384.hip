@@ -9,7 +9,7 @@
 //     of A in registers (96 VGPRs, loaded once, already in MFMA operand layout) -- A is never staged
 //     through LDS and never re-read;
 //   * W streams through a 4-deep LDS ring in slices of 64 (n) x 128 (k) bf16 = 16 KB, written by
-//     direct-to-LDS loads (global_load_lds_dwordx4: no VGPR round trip, no ds_write), read by all 8 waves.
+//     direct-to-LDS loads (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write), read by all 8 waves.
 //     The ring never drains: one s_barrier per slice, counted s_waitcnt vmcnt so two slices stay in flight
 //     across every barrier.  LDS rows are 256 B, 16-byte chunks XOR-swizzled by (row & 15) on the SOURCE
 //     address (the DMA writes lane-linear) and on the read -> ds_read_b128 is bank-conflict free;
@@ -23,6 +23,8 @@
 // MFMA: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  "TR" orientation mfma(Wfrag, Afrag) leaves lane =
 // output row m, registers = 4 consecutive columns n (row-major outputs); the V third of the QKV projection
 // uses mfma(Afrag, Wfrag) (lane = n, registers = 4 consecutive tokens) so V^T rows are token-contiguous.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -51,26 +53,33 @@ struct A384Params {
   void* C; int ldc;    // bf16 or fp32 (A_RESID: in/out)
   int M, N;
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad; int ntok_s;
+  long long* dbg;  // TIMING builds: per wave {wait+barrier, mfma, epilogue, total} shader cycles
 };
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 // tanh-form GELU evaluated as x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): |err| < 5e-4 absolute
 // against the exact erf GELU, below the bf16 rounding of the value it is stored as (the fp32 "exact" path
-// keeps erff).  5 VALU + 2 transcendental ops per element instead of 14 + 2.
-__device__ inline float gelu_fast(float x) {
-  const float x2 = x * x;
-  const float t = fmaf(x2, -0.1029432f, -2.3022082f);  // -2*sqrt(2/pi)*log2(e) * (1 + 0.044715 x^2)
-  const float e = __builtin_amdgcn_exp2f(t * x);       // exp(-2u)
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
+// keeps erff).  Two elements per call so the plain arithmetic maps to packed fp32 instructions
+// (v_pk_mul/fma/add_f32): 2.5 VALU + 2 transcendental issues per element instead of 14 + 2.
+__device__ inline f32x2_t gelu_fast2(f32x2_t x) {
+  const f32x2_t c1 = {-0.1029432f, -0.1029432f}, c0 = {-2.3022082f, -2.3022082f}, one = {1.f, 1.f};
+  const f32x2_t t = (x * x) * c1 + c0;  // -2*sqrt(2/pi)*log2(e) * (1 + 0.044715 x^2)
+  const f32x2_t y = t * x;
+  f32x2_t e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};  // exp(-2u)
+  e = e + one;
+  const f32x2_t r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  return x * r;
 }
 
 template <int EPI>
-__device__ inline float act(float v) {
-  if constexpr (EPI == A_GELU) return gelu_fast(v);
-  if constexpr (EPI == A_RELU) return fmaxf(v, 0.f);
+__device__ inline f32x2_t act2(f32x2_t v) {
+  if constexpr (EPI == A_GELU) return gelu_fast2(v);
+  if constexpr (EPI == A_RELU) { f32x2_t r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)}; return r; }
   return v;
 }
 
-template <int EPI>
+template <int EPI, bool TIMING = false, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -84,22 +93,25 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   const float* bias_l = (const float*)(smem + BIAS_OFF);
 
   // ---- W ring producer: 16 wave-instructions of 1 KB (4 rows x 256 B) per slice, 2 per wave ----------
-  const bf16_t* wsrc[2];
+  // (buffer_load ... lds, not global_load_lds: the FLAT-encoded form makes hipcc treat lgkmcnt as out of order
+  // and every LDS wait in the kernel becomes lgkmcnt(0), which exposes the full LDS latency in the MFMA loop)
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)p.N * KD * 2), 0x00020000);
+  unsigned wvoff[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int inst = wave * 2 + u;
     const int row = inst * 4 + (lane >> 4);
     const int chunk = (lane & 15) ^ (row & 15);
-    wsrc[u] = p.W + (size_t)row * KD + chunk * 8;
+    wvoff[u] = (unsigned)((row * KD + chunk * 8) * 2);
   }
   auto issue = [&](int i) {  // slice i = (column tile i / 3, k slice i % 3)
     const int j = i / NSL, ks = i - j * NSL;
-    const size_t off = (size_t)j * BNT * KD + ks * SLK;
+    const unsigned soff = __builtin_amdgcn_readfirstlane((j * BNT * KD + ks * SLK) * 2);
     unsigned char* dst = smem + (i % NS) * SLICE_BYTES + wave * 2048;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[u] + off),
-                                       (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16,
+                                               wvoff[u], soff, 0, 0);
   };
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i)
@@ -118,10 +130,44 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; prev[t][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; prev[t][r] = 0.f; }  // acc is re-initialised per tile
 
   const int xorc = l31 & 15;
   const unsigned rd_base = l31 * 256;
+
+  // ---- epilogue addressing: buffer descriptors (wave-uniform) + one 32-bit byte offset per lane, computed
+  // once; per column tile / chunk row only a scalar offset changes.  Rows >= M fall outside num_records (or get
+  // an out-of-range offset) and the hardware drops their stores.
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned voff[4] = {0, 0, 0, 0};
+  unsigned vt_off = 0;
+  unsigned stg_rd;  // per-lane byte offset into the wave's staging image for part 2
+  const unsigned c_bytes = EPI == A_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == A_RESID ? 4 : 2));
+  const unsigned qk_bytes = EPI == A_QKV ? (unsigned)((size_t)((p.M + p.ntok_s - 1) / p.ntok_s) * p.heads * p.npad * 64 * 2) : 0u;
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(p.q, 0, qk_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(p.k, 0, qk_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(p.vt, 0, qk_bytes, 0x00020000);
+  if constexpr (EPI == A_QKV) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // q / k rows: row = it*8 + lane>>3, 16 B at column (lane&7)*8 of the head
+      const int m = m0w + it * 8 + (lane >> 3);
+      const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
+      voff[it] = m < p.M ? (unsigned)((((size_t)b * p.heads * p.npad + tk) * 64 + (lane & 7) * 8) * 2) : OOB;
+    }
+    {  // v^T: d = it*16 + lane>>2, 8 tokens at m0w + (lane&3)*8 (one frame: M % 8 == ntok_s % 8 == 0)
+      const int m = m0w + (lane & 3) * 8;
+      const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
+      vt_off = m < p.M ? (unsigned)((((size_t)b * p.heads * 64 + (lane >> 2)) * p.npad + tk) * 2) : OOB;
+    }
+    stg_rd = 0;
+  } else if constexpr (EPI == A_RESID) {
+    voff[0] = (unsigned)(((lane >> 4) * p.ldc + (lane & 15) * 4) * 4);
+    stg_rd = (lane >> 4) * 272 + (lane & 15) * 16;
+  } else {
+    voff[0] = (unsigned)(((lane >> 3) * p.ldc + (lane & 7) * 8) * 2);
+    stg_rd = (lane >> 3) * 144 + (lane & 7) * 16;
+  }
 
   // ---- 16 MFMAs on one ring slice: 4 fragments in flight, one ds_read per MFMA --------------------------
   auto mfma_block = [&](int slot, int ks, auto tr_tag) {
@@ -130,27 +176,33 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
     auto rd = [&](int s, int t) {
       return *(const bf16x8_t*)(base + t * 8192 + (((2 * s + hi) ^ xorc) << 4));
     };
-    bf16x8_t wf[4];  // two k-steps of fragments in flight
+    // LA k-steps of fragments in flight (VAR 1: 4 instead of 2; VAR 2 is a TIMING-ONLY experiment that reads half
+    // of the fragments -- wrong results -- to tell LDS bandwidth from LDS latency)
+    constexpr int LA = VAR == 1 ? 4 : 2;
+    bf16x8_t wf[2 * LA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = rd(i >> 1, i & 1);
+    for (int i = 0; i < 2 * LA; ++i) wf[i] = rd(i >> 1, VAR == 2 ? 0 : (i & 1));
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        const int slot = (s % LA) * 2 + (VAR == 2 ? 0 : t);
         if constexpr (TR)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(s & 1) * 2 + t], xf[ks * 8 + s], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[slot], xf[ks * 8 + s], acc[t], 0, 0, 0);
         else
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks * 8 + s], wf[(s & 1) * 2 + t], acc[t], 0, 0, 0);
-        if (s + 2 < 8) wf[(s & 1) * 2 + t] = rd(s + 2, t);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks * 8 + s], wf[slot], acc[t], 0, 0, 0);
+        if (s + LA < 8 && (VAR != 2 || t == 1)) wf[slot] = rd(s + LA, VAR == 2 ? 0 : t);
       }
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    if constexpr (VAR != 2) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * LA, 0);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int i = 0; i < 16 - 2 * LA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * LA, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   };
 
   // ---- one third of the epilogue of column tile jp (accumulators in prev[]) ------------------------------
@@ -159,31 +211,28 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   auto epi_part = [&](int part, int jp, auto tr_tag) {
     constexpr bool TR = decltype(tr_tag)::value;
     const int n0 = jp * BNT;
-    if (part < 2) {
+    if (part < 2) {  // accumulators already contain the bias (see init_acc)
       const int t = part;
       if constexpr (TR) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = 32 * t + 8 * g + 4 * hi;
-          const f32x4_t b4 = *(const f32x4_t*)(bias_l + n0 + c);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act<EPI>(prev[t][4 * g + e] + b4[e]);
+          const f32x2_t a = act2<EPI>(f32x2_t{prev[t][4 * g + 0], prev[t][4 * g + 1]});
+          const f32x2_t b = act2<EPI>(f32x2_t{prev[t][4 * g + 2], prev[t][4 * g + 3]});
           if constexpr (EPI == A_RESID) {
-            f32x4_t o = {v[0], v[1], v[2], v[3]};
+            f32x4_t o = {a[0], a[1], b[0], b[1]};
             *(f32x4_t*)(stg + l31 * 272 + c * 4) = o;
           } else {
-            u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            u32x2_t o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1])};
             *(u32x2_t*)(stg + l31 * 144 + c * 2) = o;
           }
         }
       } else {
-        const float b = bias_l[n0 + 32 * t + l31];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int mloc = 8 * g + 4 * hi;
-          u32x2_t o = {pack_bf16x2(prev[t][4 * g + 0] + b, prev[t][4 * g + 1] + b),
-                       pack_bf16x2(prev[t][4 * g + 2] + b, prev[t][4 * g + 3] + b)};
+          u32x2_t o = {pack_bf16x2(prev[t][4 * g + 0], prev[t][4 * g + 1]),
+                       pack_bf16x2(prev[t][4 * g + 2], prev[t][4 * g + 3])};
           *(u32x2_t*)(stg + (32 * t + l31) * 80 + mloc * 2) = o;
         }
       }
@@ -191,57 +240,69 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
     }
     // part 2: wave-private image -> global, 16 bytes per lane, whole rows per 8 (bf16) / 16 (fp32) lanes
     if constexpr (EPI == A_RESID) {
-      float* C = (float*)p.C;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int ch = it * 64 + lane, row = ch >> 4, c4 = (ch & 15) * 4;
-        const int m = m0w + row;
-        f32x4_t v = *(const f32x4_t*)(stg + row * 272 + c4 * 4);
-        if (m < p.M) {
-          float* dst = C + (size_t)m * p.ldc + n0 + c4;
-          v += *(const f32x4_t*)dst;
-          *(f32x4_t*)dst = v;
-        }
-        if (it & 1) __builtin_amdgcn_sched_barrier(0);  // two rows of chunks in flight at a time (VGPR budget)
+        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 4 * it) * p.ldc + n0) * 4);
+        f32x4_t v = *(const f32x4_t*)(stg + stg_rd + it * 4 * 272);
+        const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs_c, voff[0], so, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(r[e]);  // (not __builtin_bit_cast on a vector element: clang reads element 0)
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, voff[0], so, 0);
+        if (it & 1) __builtin_amdgcn_sched_barrier(0);  // two chunk rows in flight at a time (VGPR budget)
       }
     } else if constexpr (EPI == A_QKV) {
       const int D = p.heads * 64;
       if constexpr (TR) {  // q / k: one column tile = one head; dst[(b*h + head)*npad + t][0..63]
         const int which = n0 / D, head = (n0 - which * D) >> 6;
-        bf16_t* dstb = which == 0 ? p.q : p.k;
+        const unsigned so = __builtin_amdgcn_readfirstlane(head * p.npad * 64 * 2);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int ch = it * 64 + lane, row = ch >> 3, c8 = (ch & 7) * 8;
-          const int m = m0w + row;
-          const u32x4_t val = *(const u32x4_t*)(stg + row * 144 + c8 * 2);
-          if (m < p.M) {
-            const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
-            *(u32x4_t*)(dstb + (((size_t)b * p.heads + head) * p.npad + tk) * 64 + c8) = val;
-          }
-          if (it & 1) __builtin_amdgcn_sched_barrier(0);
+          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 3) + it * 8) * 144 + (lane & 7) * 16);
+          if (which == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_q, voff[it], so, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(val, rs_k, voff[it], so, 0);
         }
       } else {  // v: vt[(b*h + head)*64 + d][t], 8 tokens (16 B) per lane
         const int head = (n0 - 2 * D) >> 6;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int ch = it * 64 + lane, d = ch >> 2, m8 = (ch & 3) * 8;
-          const int m = m0w + m8;
-          const u32x4_t val = *(const u32x4_t*)(stg + d * 80 + m8 * 2);
-          if (m < p.M) {  // M % 8 == 0 and ntok_s % 8 == 0: an 8-token chunk is entirely in or out, one frame
-            const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
-            *(u32x4_t*)(p.vt + (((size_t)b * p.heads + head) * 64 + d) * p.npad + tk) = val;
-          }
-          if (it & 1) __builtin_amdgcn_sched_barrier(0);
+          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+          const unsigned so = __builtin_amdgcn_readfirstlane((head * 64 + it * 16) * p.npad * 2);
+          __builtin_amdgcn_raw_buffer_store_b128(val, rs_v, vt_off, so, 0);
         }
       }
     } else {
-      bf16_t* C = (bf16_t*)p.C;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int ch = it * 64 + lane, row = ch >> 3, c8 = (ch & 7) * 8;
-        const int m = m0w + row;
-        const u32x4_t val = *(const u32x4_t*)(stg + row * 144 + c8 * 2);
-        if (m < p.M) *(u32x4_t*)(C + (size_t)m * p.ldc + n0 + c8) = val;
+        const u32x4_t val = *(const u32x4_t*)(stg + stg_rd + it * 8 * 144);
+        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 8 * it) * p.ldc + n0) * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, voff[0], so, 0);
+      }
+    }
+  };
+
+  // accumulators of column tile j start at the bias (TR: 4 consecutive columns per register group; !TR: the
+  // lane's own column), which removes the bias add from the epilogue
+  auto init_acc = [&](int j, auto tr_tag) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int n0 = j * BNT;
+    if constexpr (TR) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t b4 = *(const f32x4_t*)(bias_l + n0 + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b4[e];
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float b = bias_l[n0 + 32 * t + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b;
       }
     }
   };
@@ -251,7 +312,12 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   // DMA(i+2) with the stores somewhere behind DMA(i) (they are issued in the ks == 2 period, after that
   // period's DMA).  `allow` = operations that may stay outstanding = everything younger than DMA(i).
   constexpr int ST = EPI == A_RESID ? 16 : 4;  // VM operations of one epilogue part 2, per lane
-  auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, bool do_epi) {
+  long long t_wait = 0, t_mfma = 0, t_epi = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, bool do_epi_in) {
+    const bool do_epi = VAR == 3 ? false : do_epi_in;  // VAR 3 / 4: timing-only experiments (no epilogue / no DMA)
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
     if (i + 2 < total) {
       if (ks != 2 && stores_in_window) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + ST) : "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -259,67 +325,110 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (i + NS - 1 < total) issue(i + NS - 1);
+    if (VAR != 4 && i + NS - 1 < total) issue(i + NS - 1);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
     if (epi_first) {
-      if (do_epi) epi_part(ks, j - 1, etr);
+      if (do_epi) {
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(2);  // the VALU-heavy half wins issue arbitration over the partner's MFMA stream
+        epi_part(ks, j - 1, etr);
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = (long long)__builtin_amdgcn_s_memtime(); }
       mfma_block(i % NS, ks, mtr);
     } else {
       mfma_block(i % NS, ks, mtr);
       __builtin_amdgcn_sched_barrier(0);
-      if (do_epi) epi_part(ks, j - 1, etr);
+      if constexpr (TIMING) { asm volatile("s_nop 7\n s_nop 7" ::: "memory"); c2 = (long long)__builtin_amdgcn_s_memtime(); }
+      if (do_epi) {
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(2);
+        epi_part(ks, j - 1, etr);
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TIMING) {
+      c3 = (long long)__builtin_amdgcn_s_memtime();
+      t_wait += c1 - c0;
+      if (epi_first) { t_epi += c2 - c1; t_mfma += c3 - c2; } else { t_mfma += c2 - c1; t_epi += c3 - c2; }
+    }
   };
-  auto tile = [&](int j, auto mtr, auto etr, bool do_epi, bool stores_in_window) {
+  auto tile = [&](int j, auto mtr, auto etr, bool do_epi, bool stores_in_window, auto next_tr) {
 #pragma unroll
     for (int ks = 0; ks < NSL; ++ks) period(j * NSL + ks, ks, j, stores_in_window, mtr, etr, do_epi);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      prev[t] = acc[t];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    }
+    for (int t = 0; t < 2; ++t) prev[t] = acc[t];
+    if (j + 1 < NT) init_acc(j + 1, next_tr);
   };
 
   using T = std::true_type;
   using F = std::false_type;
   __syncthreads();  // bias table visible (nothing DMA'd is read before the first period's wait + barrier)
+  init_acc(0, T{});
   if constexpr (EPI == A_QKV) {
     const int nqk = 2 * (p.heads * 64) / BNT;  // q and k column tiles (TR); the rest are V tiles
-    tile(0, T{}, T{}, false, false);
-    tile(1, T{}, T{}, true, false);
-    for (int j = 2; j < nqk; ++j) tile(j, T{}, T{}, true, true);
-    tile(nqk, F{}, T{}, true, true);
-    for (int j = nqk + 1; j < NT; ++j) tile(j, F{}, F{}, true, true);
+    tile(0, T{}, T{}, false, false, T{});
+    tile(1, T{}, T{}, true, false, T{});
+    for (int j = 2; j < nqk - 1; ++j) tile(j, T{}, T{}, true, true, T{});
+    tile(nqk - 1, T{}, T{}, true, true, F{});
+    tile(nqk, F{}, T{}, true, true, F{});
+    for (int j = nqk + 1; j < NT; ++j) tile(j, F{}, F{}, true, true, F{});
 #pragma unroll
     for (int part = 0; part < 3; ++part) epi_part(part, NT - 1, F{});
   } else {
-    tile(0, T{}, T{}, false, false);
-    if (NT > 1) tile(1, T{}, T{}, true, false);
-    for (int j = 2; j < NT; ++j) tile(j, T{}, T{}, true, true);
+    tile(0, T{}, T{}, false, false, T{});
+    if (NT > 1) tile(1, T{}, T{}, true, false, T{});
+    for (int j = 2; j < NT; ++j) tile(j, T{}, T{}, true, true, T{});
 #pragma unroll
     for (int part = 0; part < 3; ++part) epi_part(part, NT - 1, T{});
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+      d[0] = t_wait; d[1] = t_mfma; d[2] = t_epi; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+    }
   }
 }
 
 constexpr int A384_LDS_MAX = 160 * 1024;
 
+int a384_var() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WVN_A384_VAR");
+    v = e ? atoi(e) : 0;
+    if (v < 0 || v > 4) v = 0;
+  }
+  return v;
+}
+
+template <int EPI, bool TIMING, int VAR>
+int launch_k(const A384Params& p, int lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_a384_kernel<EPI, TIMING, VAR>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, A384_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_a384_kernel<EPI, TIMING, VAR>), dim3(ceil_div(p.M, BM)), dim3(512), lds, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
 template <int EPI>
 int launch(const A384Params& p, hipStream_t st) {
   const int lds = BIAS_OFF + p.N * 4;
   if (lds > A384_LDS_MAX) return WVN_ERR_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_a384_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       A384_LDS_MAX);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
+  if constexpr (EPI == A_BF16 || EPI == A_GELU) {  // experiment variants (scripts/a384_timing.py)
+    const int v = a384_var();
+    if (v == 1) return p.dbg ? launch_k<EPI, true, 1>(p, lds, st) : launch_k<EPI, false, 1>(p, lds, st);
+    if (v == 2) return p.dbg ? launch_k<EPI, true, 2>(p, lds, st) : launch_k<EPI, false, 2>(p, lds, st);
+    if (v == 3) return p.dbg ? launch_k<EPI, true, 3>(p, lds, st) : launch_k<EPI, false, 3>(p, lds, st);
+    if (v == 4) return p.dbg ? launch_k<EPI, true, 4>(p, lds, st) : launch_k<EPI, false, 4>(p, lds, st);
   }
-  hipLaunchKernelGGL((gemm_a384_kernel<EPI>), dim3(ceil_div(p.M, BM)), dim3(512), lds, st, p);
-  WVN_LAUNCH_CHECK();
-  return WVN_OK;
+  return p.dbg ? launch_k<EPI, true, 0>(p, lds, st) : launch_k<EPI, false, 0>(p, lds, st);
 }
 
 }  // namespace
@@ -332,6 +441,7 @@ int wvn_gemm_a384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   A384Params p{};
   p.A = g.A; p.lda = g.lda; p.W = g.W; p.bias = g.bias; p.C = g.C; p.ldc = g.ldc; p.M = g.M; p.N = g.N;
   p.q = g.q; p.k = g.k; p.vt = g.vt; p.heads = g.heads; p.npad = g.npad; p.ntok_s = g.ntok_s;
+  p.dbg = g.dbg;
   switch (epi) {
     case EPI_BF16:
     case EPI_GELU_BF16:
