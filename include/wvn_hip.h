@@ -63,7 +63,7 @@ size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch);
 /* img [B,3,S,S] fp32 in [0,1] (already resized/cropped, dino_interface.py:54-57) ->
  *   tokens_f32  [B, G*G, D]  final-LayerNorm'ed patch tokens (class token dropped), may be NULL
  *   tokens_lowp [B*G*G rows, ld_lowp] same values in the model precision (bf16/f32), may be NULL
- * The workspace must be zero-filled once after allocation (padding rows are never written). */
+ * The workspace needs no initialisation (padding rows are reset by every call). */
 int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
                     int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -87,7 +87,11 @@ int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, i
 int wvn_layernorm(const float* x, const float* gamma, const float* beta, void* y, int y_is_bf16, int rows, int D,
                   float eps, void* stream);
 /* q,k [B,h,npad,64]; v: bf16 path takes V^T [B,h,64,npad], f32 path takes V [B,h,npad,64];
- * out [B*ntok, h*64].  npad % 128 == 0, pad rows must be finite. */
+ * out [B*ntok, h*64].  npad % 128 == 0, pad rows must be finite.
+ * bf16 path: V^T is stored with the tokens of every aligned group of 16 permuted -- position
+ * 16G + 8h + 4a + e holds token 16G + 8a + 4h + e (bits 2 and 3 of the token index swapped; order
+ * 0-3, 8-11, 4-7, 12-15) -- so that the 8 keys a half-wave multiplies with are one 16-byte LDS read.
+ * The QKV projection epilogues of wvn_vit_forward write this layout. */
 int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad,
                        float scale, void* stream);
 int wvn_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok, int npad,

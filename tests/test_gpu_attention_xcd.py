@@ -3,6 +3,7 @@ same answers as the plain order: compare against the fp64 reference, and against
 import pytest
 import torch
 
+from wild_visual_navigation_amd import ops
 from wild_visual_navigation_amd._lib import check, lib, ptr, stream
 
 pytestmark = pytest.mark.gpu
@@ -15,13 +16,13 @@ def test_attention_bf16_xcd_mapping(dev, B, h, ntok):
     q, k, v = (torch.randn(B, h, ntok, 64, generator=g).to(torch.bfloat16) for _ in range(3))
     npad = (ntok + 127) // 128 * 128
 
-    def pad(t):
-        out = torch.full((B, h, npad, 64), float("nan"), dtype=t.dtype)
+    def pad(t):  # the contract (wvn_hip.h) is FINITE padding: large garbage must not leak into the result
+        out = (torch.randn(B, h, npad, 64, generator=g) * 1e3).to(t.dtype)
         out[:, :, :ntok] = t
         return out
 
     qd, kd = pad(q).to(dev), pad(k).to(dev)
-    vt = pad(v).transpose(-1, -2).contiguous().to(dev)
+    vt = pad(v).transpose(-1, -2)[..., ops.vt_token_order(npad)].contiguous().to(dev)
     out = torch.empty(B * ntok, h * 64, dtype=torch.bfloat16, device=dev)
     check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(vt), ptr(out), B, h, ntok, npad, 0.125, stream()))
     att = torch.softmax((q.double() @ k.double().transpose(-1, -2)) * 0.125, dim=-1) @ v.double()

@@ -142,10 +142,11 @@ def test_attention_bf16(dev, ntok):
     q, k, v = (bf(torch.randn(B, h, ntok, 64, generator=g(s))) for s in (1, 2, 3))
     k[0, 1, ntok // 2] = bf(k[0, 1, ntok // 2].float() * 6.0)
     k[0, 0, ntok - 1] = bf(k[0, 0, ntok - 1].float() * 5.0)  # spike in the (masked-tail) last tile
-    npad = (ntok + 127) // 128 * 128
-    vt = _pad(v, npad).transpose(-1, -2).contiguous().to(dev)  # [B,h,64,npad]
+    npad = (ntok + 127) // 128 * 128  # padding: large FINITE garbage (the bf16 kernel's contract, wvn_hip.h)
+    perm = ops.vt_token_order(npad)  # the kernel's V^T layout: tokens permuted inside groups of 16
+    vt = _pad(v, npad, 1e3).transpose(-1, -2)[..., perm].contiguous().to(dev)  # [B,h,64,npad]
     out = torch.empty(B * ntok, h * 64, dtype=torch.bfloat16, device=dev)
-    qd, kd = _pad(q, npad).to(dev), _pad(k, npad).to(dev)
+    qd, kd = _pad(q, npad, 1e3).to(dev), _pad(k, npad, -1e3).to(dev)
     check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(vt), ptr(out), B, h, ntok, npad, scale, stream()))
     ref = _attn_ref(q.float(), k.float(), v.float(), scale).permute(0, 2, 1, 3).reshape(B * ntok, h * 64)
     err = (out.float().cpu().double() - ref).abs().max().item()
@@ -154,7 +155,7 @@ def test_attention_bf16(dev, ntok):
     # uniform V => output must be exactly that constant row (softmax weights sum to 1 within rounding)
     v1 = torch.ones(B, h, npad, 64, dtype=torch.bfloat16)
     v1[:, :, ntok:] = 0
-    v1t = v1.transpose(-1, -2).contiguous().to(dev)
+    v1t = v1.transpose(-1, -2)[..., perm].contiguous().to(dev)
     check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(v1t), ptr(out), B, h, ntok, npad, scale, stream()))
     assert (out.float().cpu() - 1.0).abs().max().item() < 1e-2
 
@@ -261,3 +262,20 @@ def test_kmeans_bit_exact(dev, P, C, K):
     for b in range(2):
         want = OI.relabel_ascending(OI.kmeans_cosine_labels(code[b].numpy(), K, iters=10))
         assert np.array_equal(lab2[b].cpu().numpy(), want)
+
+
+def test_attention_bf16_repeatable(dev):
+    """Race screen for the DMA ring / counted-vmcnt pipeline of the bf16 attention kernel: many workgroups per CU,
+    full-length sequence, other kernels in between -- 20 repeats must be bit-identical (a stale K/V tile or an
+    accumulator read before its MFMA retired shows up as ulp-level run-to-run differences)."""
+    B, h, ntok, npad = 2, 6, 3137, 3200
+    q, k = (bf(torch.randn(B, h, npad, 64, generator=g(s))).to(dev) for s in (1, 2))
+    vt = bf(torch.randn(B, h, 64, npad, generator=g(3))).to(dev)
+    first = torch.empty(B * ntok, h * 64, dtype=torch.bfloat16, device=dev)
+    check(lib().wvn_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(first), B, h, ntok, npad, 0.125, stream()))
+    junk = torch.randn(16 * 1024 * 1024, device=dev)
+    for _ in range(20):
+        junk.mul_(1.0001)
+        out = torch.empty_like(first)
+        check(lib().wvn_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(out), B, h, ntok, npad, 0.125, stream()))
+        assert torch.equal(out, first)

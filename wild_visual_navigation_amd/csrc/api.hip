@@ -49,7 +49,7 @@ VitDims vit_dims(const wvn_vit_model* m, int batch) {
   VitDims d;
   d.B = batch; d.S = m->img_size; d.P = m->patch; d.G = d.S / d.P; d.D = m->dim; d.H = m->heads; d.F = m->mlp_dim;
   d.KP = 3 * d.P * d.P; d.npatch = d.G * d.G; d.ntok = d.npatch + 1;
-  d.ntok_s = (d.ntok + 7) / 8 * 8;  // rows per frame: keeps every 8-token group 16-B aligned and inside one frame
+  d.ntok_s = (d.ntok + 15) / 16 * 16;  // rows per frame: 8-token (16 B) chunks and the 16-token V^T permutation groups never straddle frames
   d.npad = (d.ntok + 127) / 128 * 128;
   d.esz = m->precision == WVN_PREC_BF16 ? 2 : 4;
   d.M = (long long)batch * d.ntok_s; d.Mp = (long long)batch * d.npatch;
@@ -115,6 +115,21 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
 
   { Span s(0, st); RET_IF(wvn_patchify_launch(img, w.patches, bf, d.B, d.S, d.P, st)); }
   RET_IF(wvn_cls_rows_launch(m->cls_pos, w.x, d.B, d.ntok_s, d.D, st));
+  {
+    // Padding hygiene, every call (the carve depends on the batch, so a reused workspace holds stale bytes):
+    // residual-stream rows [ntok, ntok_s) start at zero (they then carry finite values through the blocks), and the
+    // never-written key/value slots [ntok_s, npad) are zero.  The attention kernels mask padded keys by score, but
+    // their V^T / K bytes still enter MFMAs and must be finite.
+    RET_IF(wvn_pad_zero_launch(w.x, d.B, (long long)d.ntok_s * d.D * 4, (long long)d.ntok * d.D * 4,
+                               (long long)(d.ntok_s - d.ntok) * d.D * 4, st));
+    const long long tokb = 64ll * d.esz, nbh = (long long)d.B * d.H;
+    RET_IF(wvn_pad_zero_launch(w.q, nbh, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
+    RET_IF(wvn_pad_zero_launch(w.k, nbh, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
+    if (bf)  // V^T [B*h*64][npad]
+      RET_IF(wvn_pad_zero_launch(w.v, nbh * 64, (long long)d.npad * 2, (long long)d.ntok_s * 2, (long long)(d.npad - d.ntok_s) * 2, st));
+    else     // V [B*h][npad][64]
+      RET_IF(wvn_pad_zero_launch(w.v, nbh, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
+  }
   {
     Span s(1, st);
     if (bf) {
@@ -216,6 +231,8 @@ int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
   p.M = M; p.N = N; p.K = K;
   return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
 }
+
+int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
 
 int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                               int N, int K, int epi, long long* dbg, void* stream) {

@@ -4,31 +4,36 @@
 //   materialising the ntok x ntok score matrix (3.8 GB per 32 frames).
 //
 // Work decomposition: one workgroup = 128 queries of one (frame, head); 256 threads = 4 waves, each
-// wave owns 32 queries; the workgroup streams K / V^T tiles of 64 keys through a double-buffered LDS
-// ring.  K/V tiles travel global -> registers -> LDS with PD tiles in flight (register slots are
-// compile-time: the tile loop is unrolled by PD); one barrier per tile.
+// wave owns 32 queries; the workgroup streams K / V^T tiles of 64 keys through an LDS ring.
+//
+// K / V^T tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write
+// traffic (the LDS pipe is the scarce resource here: every MFMA needs 1 KB of it).  The DMA writes
+// lane-linear, so tiles are unpadded ([64 rows][128 B]) and bank conflicts are removed by XOR-swizzling the
+// 16-byte chunk index with (row >> 1) & 7 on the per-lane SOURCE address and again on the read: every
+// fragment read is one conflict-free ds_read_b128.  One s_barrier per tile; with NST ring stages NST - 1
+// tiles are in flight, waited for with a counted vmcnt.
 //
 // XCD-aware placement: the 25 query blocks of a (frame, head) re-read the same 819 KB of K/V.  The
 // dispatcher puts workgroup b on XCD b % 8, so the 1-D grid is decoded such that ALL query blocks of a
-// (frame, head) land on one XCD, consecutively: ~4 (frame, head) pairs are live per XCD at a time and
-// their K/V (3.3 MB) stay in that XCD's 4 MB L2 instead of thrashing it with 30 pairs.  (Speed only.)
+// (frame, head) land on one XCD, consecutively, and their K/V stay in that XCD's 4 MB L2.  (Speed only.)
 //
 // Everything is computed TRANSPOSED so that the softmax is lane-local:
 //   S^T = K Q^T   : A = K tile (rows = keys, from LDS), B = Q^T (registers, loaded once)
 //                   -> accumulator lane l holds query q = l&31 and 32 of the tile's 64 keys
 //                      (rows (r&3)+8(r>>2)+4(l>>5) of each 32-key sub-tile); the other 32 keys of
 //                      the same query sit in lane l^32  => row max = in-lane max + one lane swap.
-//   O^T = V^T P^T : A = V^T tile (rows = d, keys contiguous; produced by the QKV GEMM epilogue),
-//                   B = P^T straight from the S^T accumulator registers: MFMA sums over its k-slots
-//                   in a fixed but arbitrary order, so it suffices that A and B agree on which key
-//                   sits in slot (l>>5, j).  We define slot (hi, j) <-> key 16*ks + (j&3) + 8*(j>>2)
-//                   + 4*hi, which is exactly where the S^T accumulator already holds it: P needs NO
-//                   cross-lane movement, and V^T fragments are two 8-byte LDS reads.
+//   O^T = V^T P^T : A = V^T tile (rows = d, keys along the row), B = P^T straight from the S^T accumulator
+//                   registers.  MFMA sums over its k-slots in a fixed but arbitrary order, so A and B only have
+//                   to agree on which key sits in slot (l>>5, j): the accumulator already holds, for half-wave
+//                   hi, keys {4hi..4hi+3} and {8+4hi..8+4hi+3} of each group of 16.  V^T is therefore STORED
+//                   with the tokens of every aligned group of 16 permuted (bits 2 and 3 of the token index
+//                   swapped: 0-3, 8-11, 4-7, 12-15), which makes those 8 keys one contiguous 16-byte chunk.
+//                   The QKV GEMM epilogues write V^T in this order (wvn_hip.h documents it for direct callers).
 //                   -> O^T accumulator lane l holds query l&31 again, so the online-softmax rescale
 //                      and the final 1/l are per-lane scalars.
 // exp is evaluated as exp2 with scale*log2(e) folded into one FMA; the O rescale is skipped (wave-
-// uniformly) when no running max moved.  Keys >= ntok (tile tail / padding, content not ours) are
-// neutralised: their scores by select, their V^T columns by zeroing on the way into LDS.
+// uniformly) when no running max moved.  Keys >= ntok (tile tail / padding) are neutralised by a select on
+// their scores (p = 0); K / V^T padding must be finite (0 * finite = 0 in the PV MFMA).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -38,20 +43,29 @@
 
 namespace {
 
-constexpr int QB = 128;       // queries per workgroup (4 waves x 32)
-constexpr int KVB = 64;       // keys per tile
-constexpr int DH = 64;        // head dim
-constexpr int LSTR = DH + 8;  // LDS row stride in bf16 (144 B)
-constexpr int TILE_ELEMS = KVB * LSTR;
+constexpr int QB = 128;            // queries per workgroup (4 waves x 32)
+constexpr int KVB = 64;            // keys per tile
+constexpr int DH = 64;             // head dim
+constexpr int TILE_BYTES = KVB * DH * 2;  // 8 KB (K tile; V^T tile is the same size)
 
-template <int PD, bool XCDMAP, bool PRIO, bool RESCALE_ALWAYS = false>
-__global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ q,
-                                                                const bf16_t* __restrict__ k,
-                                                                const bf16_t* __restrict__ vt,
-                                                                bf16_t* __restrict__ out, int heads, int nbh, int nqb,
-                                                                int ntok, int ntok_s, int npad, float c_exp) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * TILE_ELEMS];  // [stage][K | Vt][64][72]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// The softmax is bounded by per-wave VALU issue, so instruction count matters: the row max uses 3-input max.
+// This file is compiled with -fno-honor-nans so that fmaxf on MFMA results needs no canonicalising v_max (scores
+// are finite; masking uses -1e30, not infinities).  NOT inline asm: hipcc pads no MFMA-result hazards for an asm
+// statement's operands (a v_max3 in asm read accumulator registers before the MFMA had written them).
+__device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+template <int NST, bool XCDMAP, int OCC, bool TIMING = false>
+__global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* __restrict__ q,
+                                                                  const bf16_t* __restrict__ k,
+                                                                  const bf16_t* __restrict__ vt,
+                                                                  bf16_t* __restrict__ out, int heads, int nbh,
+                                                                  int nqb, int ntok, int ntok_s, int npad,
+                                                                  float c_exp, long long* dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE_BYTES];  // [stage][K | Vt][64][128 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   int bh, qb;
   if constexpr (XCDMAP) {  // nbh % 8 == 0 (checked by the launcher)
@@ -65,40 +79,43 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
   const int b = bh / heads, head = bh - b * heads;
   const int q0 = qb * QB + wave * 32;
 
+  // ---- K / V^T DMA: per tile 8 + 8 wave-instructions of 1 KB (8 rows x 128 B); each wave issues 2 + 2 -------
+  const unsigned kv_bytes = (unsigned)((size_t)nbh * npad * DH * 2);
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)k, 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vt, 0, kv_bytes, 0x00020000);
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = (wave * 2 + u) * 8 + (lane >> 3);          // key (K tile) or d (V^T tile)
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);           // source chunk that lands in LDS chunk lane & 7
+    koff[u] = (unsigned)((((size_t)bh * npad + row) * DH + chunk * 8) * 2);   // + kv0 * 128
+    voff[u] = (unsigned)((((size_t)bh * DH + row) * npad + chunk * 8) * 2);   // + kv0 * 2
+  }
+  auto issue = [&](int t) {
+    unsigned char* dst = lds + (t % NST) * 2 * TILE_BYTES + wave * 2048;
+    const unsigned ks = __builtin_amdgcn_readfirstlane(t * KVB * DH * 2), vs = __builtin_amdgcn_readfirstlane(t * KVB * 2);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16,
+                                               koff[u], ks, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (__attribute__((address_space(3))) void*)(dst + TILE_BYTES + u * 1024),
+                                               16, voff[u], vs, 0, 0);
+    }
+  };
+  const int nt = (ntok + KVB - 1) / KVB;
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nt) issue(t);
+
+  // ---- Q^T fragments (B operand): query l31, d = 16 s + 8 hi .. + 7 ------------------------------------------
   const bf16_t* qg = q + ((size_t)bh * npad + q0 + l31) * DH + hi * 8;
   bf16x8_t qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8_t*)(qg + s * 16);
-
-  // staging: 2 K chunks + 2 V^T chunks (16 B) per thread per tile, PD register sets
-  const int srow = tid >> 3, skc = tid & 7;
-  const bf16_t* kg = k + ((size_t)bh * npad + srow) * DH + skc * 8;   // + kv0*DH, rows srow, srow+32
-  const bf16_t* vg = vt + ((size_t)bh * DH + srow) * npad + skc * 8;  // + kv0,    rows srow, srow+32
-  u32x4_t rk[PD][2], rv[PD][2];
-  auto load_regs = [&](int kv0, u32x4_t (&a)[2], u32x4_t (&c)[2]) {
+  // Make the Q fragments "used" here: otherwise hipcc places their vmcnt wait at the first use INSIDE the
+  // tile loop, where it would also drain the K/V DMA queue on every trip.
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a[i] = *(const u32x4_t*)(kg + (size_t)(kv0 + 32 * i) * DH);
-      c[i] = *(const u32x4_t*)(vg + (size_t)(32 * i) * npad + kv0);
-    }
-  };
-  auto store_regs = [&](int stage, int kv0, const u32x4_t (&a)[2], const u32x4_t (&c)[2], bool may_be_tail) {
-    bf16_t* Ks = lds + stage * 2 * TILE_ELEMS;
-    bf16_t* Vs = Ks + TILE_ELEMS;
-    const bool tail = may_be_tail && kv0 + KVB > ntok;  // workgroup-uniform
-    const int kbase = kv0 + skc * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      u32x4_t v = c[i];
-      if (tail) {  // keys >= ntok: zero the V^T columns (0 * NaN would poison the PV MFMA)
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-          v[w] &= (kbase + 2 * w < ntok ? 0x0000ffffu : 0u) | (kbase + 2 * w + 1 < ntok ? 0xffff0000u : 0u);
-      }
-      *(u32x4_t*)(Ks + (srow + 32 * i) * LSTR + skc * 8) = a[i];
-      *(u32x4_t*)(Vs + (srow + 32 * i) * LSTR + skc * 8) = v;
-    }
-  };
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
 
   f32x16_t ot[2];
 #pragma unroll
@@ -107,128 +124,125 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
     for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  const int nt = (ntok + KVB - 1) / KVB;
-#pragma unroll
-  for (int u = 0; u < PD; ++u)
-    if (u < nt) load_regs(u * KVB, rk[u], rv[u]);
-  store_regs(0, 0, rk[0], rv[0], true);
-  if (PD < nt) load_regs(PD * KVB, rk[0], rv[0]);
-  __syncthreads();
-  // Make the Q fragments "used" here: otherwise hipcc places their vmcnt wait at the first use INSIDE the
-  // tile loop, and on every trip that s_waitcnt vmcnt(0) drains the K/V prefetches as well.
-#pragma unroll
-  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+  // per-lane read offset inside a tile: row l31 (+32 per sub-tile), chunk XOR key (row >> 1) & 7 (same for row+32)
+  const unsigned rd_row = l31 * 128;
+  const int xorc = (l31 >> 1) & 7;
 
-  // one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T  (operands from LDS stage `stage`)
-  auto compute_tile = [&](int kv0, int stage, auto steady_tag) {
-      constexpr bool STEADY = decltype(steady_tag)::value;  // steady-state tiles are never the tail tile
-      const bf16_t* Ks = lds + stage * 2 * TILE_ELEMS;
-      const bf16_t* Vs = Ks + TILE_ELEMS;
+  long long tm[5] = {0, 0, 0, 0, 0};  // TIMING: wait+barrier+issue, QK^T, softmax, PV, total
+  auto now = [&]() -> long long {
+    if constexpr (TIMING) { __builtin_amdgcn_sched_barrier(0); return (long long)__builtin_amdgcn_s_memtime(); }
+    return 0;
+  };
+  const long long t_begin = now();
+  auto compute_tile = [&](int kv0, int stage, auto tail_tag) {
+    constexpr bool MAYBE_TAIL = decltype(tail_tag)::value;
+    const long long c0 = now();
+    const unsigned char* Ks = lds + stage * 2 * TILE_BYTES + rd_row;
+    const unsigned char* Vs = Ks + TILE_BYTES;
 
-      // ---- S^T = K Q^T : two 32-key sub-tiles ----
-      f32x16_t st[2];
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    // ---- S^T = K Q^T : two 32-key sub-tiles (first MFMA of each chain takes a literal-zero C) ----
+    f32x16_t st[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-        const bf16_t* kb = Ks + (t * 32 + l31) * LSTR + hi * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bf16x8_t kf = *(const bf16x8_t*)(kb + s * 16);
-          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
-        }
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + t * 4096 + (((2 * s + hi) ^ xorc) << 4));
+        if (s == 0) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], (f32x16_t)(0.f), 0, 0, 0);
+        else st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
       }
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-      // ---- mask the tail of the last tile ----
-      if (!STEADY && kv0 + KVB > ntok) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key >= ntok) st[t][r] = -1e30f;
-          }
-      }
-      // ---- online softmax (lane = query, both half-waves share the running max) ----
-      float mt = st[0][0];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[t][r]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      if (RESCALE_ALWAYS ? true : __any(mt > m_run)) {
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
-      }
-      const float mc = -m_run * c_exp;
-      float psum = 0.f;
+    }
+    if constexpr (TIMING) asm volatile("s_nop 7\ns_nop 7" ::: "memory");
+    const long long c1 = now();
+    // ---- mask the tail of the last tile ----
+    if (MAYBE_TAIL && kv0 + KVB > ntok) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float pv = __builtin_amdgcn_exp2f(fmaf(st[t][r], c_exp, mc));
-          st[t][r] = pv;
-          psum += pv;
+          const int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= ntok) st[t][r] = -1e30f;
         }
-      l_run += psum;
-
-      // ---- O^T += V^T P^T ----
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    }
+    // ---- online softmax (lane = query, both half-waves share the running max) ----
+    // row max: 16 three-input max (two independent chains), then the other half-wave's
+    float ma = max3f(st[0][0], st[0][1], st[0][2]), mb = max3f(st[1][0], st[1][1], st[1][2]);
+    ma = max3f(ma, st[0][3], st[0][4]); mb = max3f(mb, st[1][3], st[1][4]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int t = ks >> 1, h8 = (ks & 1) * 8;
-        union { u32x4_t u; bf16x8_t v; } pf;
-        pf.u[0] = pack_bf16x2(st[t][h8 + 0], st[t][h8 + 1]);
-        pf.u[1] = pack_bf16x2(st[t][h8 + 2], st[t][h8 + 3]);
-        pf.u[2] = pack_bf16x2(st[t][h8 + 4], st[t][h8 + 5]);
-        pf.u[3] = pack_bf16x2(st[t][h8 + 6], st[t][h8 + 7]);
+    for (int r = 5; r < 15; r += 2) { ma = max3f(ma, st[0][r], st[0][r + 1]); mb = max3f(mb, st[1][r], st[1][r + 1]); }
+    float mt = max3f(ma, mb, st[0][15]);
+    mt = max3f(mt, st[1][15], st[1][15]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    // Deferred rescale: the running max only follows when some row's scores outgrow it by more than THR (in
+    // exp2 units).  P is then bounded by 2^THR instead of 1 -- harmless in fp32 accumulators, and P / l cancel
+    // exactly the same factor -- and the wave-uniform O rescale almost never runs after the first tiles.
+    constexpr float THR = 6.0f;
+    if (__any((mt - m_run) * c_exp > THR)) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16_t* vb = Vs + (dt * 32 + l31) * LSTR + ks * 16 + hi * 4;
-          union { u32x2_t h[2]; bf16x8_t v; } vf;
-          vf.h[0] = *(const u32x2_t*)(vb);
-          vf.h[1] = *(const u32x2_t*)(vb + 8);
-          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, ot[dt], 0, 0, 0);
-        }
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    }
+    const float mc = -m_run * c_exp;
+    const f32x2_t c2v = {c_exp, c_exp}, mc2 = {mc, mc};
+    f32x2_t ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2_t y = f32x2_t{st[t][r], st[t][r + 1]} * c2v + mc2;  // v_pk_fma_f32
+        const f32x2_t pv = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+        st[t][r] = pv[0];
+        st[t][r + 1] = pv[1];
+        if (r & 2) ps1 += pv; else ps0 += pv;                                // v_pk_add_f32
       }
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    ps0 += ps1;
+    l_run += ps0[0] + ps0[1];
+
+    const long long c2 = now();
+    // ---- O^T += V^T P^T : 4 groups of 16 keys; the half-wave's 8 keys of a group are one 16-byte chunk ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int t = ks >> 1, h8 = (ks & 1) * 8;
+      union { u32x4_t u; bf16x8_t v; } pf;
+      pf.u[0] = pack_bf16x2(st[t][h8 + 0], st[t][h8 + 1]);
+      pf.u[1] = pack_bf16x2(st[t][h8 + 2], st[t][h8 + 3]);
+      pf.u[2] = pack_bf16x2(st[t][h8 + 4], st[t][h8 + 5]);
+      pf.u[3] = pack_bf16x2(st[t][h8 + 6], st[t][h8 + 7]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8_t vf = *(const bf16x8_t*)(Vs + dt * 4096 + (((2 * ks + hi) ^ xorc) << 4));
+        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, ot[dt], 0, 0, 0);
+      }
+    }
+    if constexpr (TIMING) {
+      const long long c3 = now();
+      tm[1] += c1 - c0; tm[2] += c2 - c1; tm[3] += c3 - c2;
+    }
   };
 
-  int it = 0;
-  // steady state: straight-line per PD tiles, no conditions around the loads -> hipcc counts vmcnt exactly
-  // (waits only for the tile being moved to LDS; the younger PD-1 tiles stay in flight across the barrier)
-  for (; it + 2 * PD < nt; it += PD) {
-#pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      const int t = it + u;
-      compute_tile(t * KVB, t & 1, std::true_type{});
-      store_regs((t + 1) & 1, (t + 1) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD], false);
-      load_regs((t + 1 + PD) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD]);
-      __syncthreads();
-    }
-  }
-  // drain: the last < 2*PD + PD tiles, same slot pattern with the end-of-sequence conditions
-  for (; it < nt; it += PD) {
-#pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      const int t = it + u;
-      if (t >= nt) break;
-      compute_tile(t * KVB, t & 1, std::false_type{});
-      if (t + 1 < nt) {
-        store_regs((t + 1) & 1, (t + 1) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD], true);
-        if (t + 1 + PD < nt) load_regs((t + 1 + PD) * KVB, rk[(u + 1) % PD], rv[(u + 1) % PD]);
-      }
-      __syncthreads();
-    }
+  // tile loop: wait for tile t (NST - 2 younger tiles may stay in flight), barrier (everyone has the tile and
+  // has finished reading tile t - 1, whose slot the next DMA overwrites), issue tile t + NST - 1, compute
+  for (int t = 0; t < nt; ++t) {
+    const long long w0 = now();
+    if (t + NST - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NST - 1 < nt) issue(t + NST - 1);
+    if constexpr (TIMING) tm[0] += now() - w0;
+    if (t + 1 < nt) compute_tile(t * KVB, t % NST, std::false_type{});
+    else compute_tile(t * KVB, t % NST, std::true_type{});
   }
 
+  if constexpr (TIMING) {
+    if (lane == 0 && dbg) {
+      long long* d = dbg + ((size_t)blockIdx.x * 4 + wave) * 5;
+      d[0] = tm[0]; d[1] = tm[1]; d[2] = tm[2]; d[3] = tm[3]; d[4] = now() - t_begin;
+    }
+  }
   // ---- normalise and store: out[b*ntok_s + q][head*64 + d] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -247,33 +261,53 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
   }
 }
 
-// WVN_ATTN_VARIANT (A/B switch): 0 = PD1, plain block order; 1 = PD1 + XCD map; 2 = PD2 + XCD map (default);
-// 3 = PD2 + XCD map + s_setprio around the MFMA clusters
+// WVN_ATTN_VARIANT (A/B switch): ring depth / occupancy target.  0: 2 stages, 4 WG/CU; 1: 3 stages, 3 WG/CU (default);
+// 2: 2 stages, 3 WG/CU; 3: 4 stages, 2 WG/CU
 int attn_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("WVN_ATTN_VARIANT");
-    v = e ? atoi(e) : 2;
-    if (v < 0 || v > 3) v = 2;
+    v = e ? atoi(e) : 1;
+    if (v < 0 || v > 3) v = 1;
   }
   return v;
 }
 
+long long* g_attn_dbg = nullptr;  // set by wvn_debug_attention_timing (scripts/attn_timing.py)
+
+template <int NST, int OCC>
+void launch_v(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
+              int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, float c_exp) {
+  if (g_attn_dbg) {
+    hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb,
+                       ntok, ntok_s, npad, c_exp, g_attn_dbg);
+    return;
+  }
+  if (xcd)
+    hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
+                       ntok_s, npad, c_exp, nullptr);
+  else
+    hipLaunchKernelGGL((attention_bf16_kernel<NST, false, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
+                       ntok_s, npad, c_exp, nullptr);
+}
+
 }  // namespace
+
+void wvn_attention_bf16_set_debug(long long* dbg) { g_attn_dbg = dbg; }
 
 int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
                               int ntok, int ntok_s, int npad, float scale, hipStream_t st) {
   if (!q || !k || !vt || !out || npad % QB != 0 || npad < ntok) return WVN_ERR_ARG;
-  const float c_exp = scale * 1.44269504088896340736f;
   const int nqb = ceil_div(ntok, QB), nbh = B * heads;
-  dim3 grid(nqb * nbh), block(256);
-  int v = attn_variant();
-  if (nbh % 8 != 0 && v > 0) v = 0;  // the XCD decode needs whole groups of 8 (frame, head) pairs
-  switch (v) {
-    case 0: hipLaunchKernelGGL((attention_bf16_kernel<1, false, false>), grid, block, 0, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
-    case 1: hipLaunchKernelGGL((attention_bf16_kernel<1, true, false>), grid, block, 0, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
-    case 3: hipLaunchKernelGGL((attention_bf16_kernel<2, true, true>), grid, block, 0, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
-    default: hipLaunchKernelGGL((attention_bf16_kernel<2, true, false>), grid, block, 0, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
+  if ((size_t)nbh * npad * DH * 2 >= (1ull << 32)) return WVN_ERR_ARG;  // 32-bit buffer offsets
+  const float c_exp = scale * 1.44269504088896340736f;
+  dim3 grid(nqb * nbh);
+  const bool xcd = (nbh % 8) == 0;  // the XCD decode needs whole groups of 8 (frame, head) pairs
+  switch (attn_variant()) {
+    case 0: launch_v<2, 4>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
+    case 2: launch_v<2, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
+    case 3: launch_v<4, 2>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
+    default: launch_v<3, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
   }
   WVN_LAUNCH_CHECK();
   return WVN_OK;

@@ -25,7 +25,7 @@ HEADERS = ["common.h", "wvn_internal.h", os.path.join("..", "..", "include", "wv
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall",
          "-Wno-unused-function"]
 # bit-exact integer outputs need un-fused multiply/add in the k-means kernels (see stego.hip)
-EXTRA = {"stego.hip": ["-ffp-contract=off"]}
+EXTRA = {"stego.hip": ["-ffp-contract=off"], "attention_bf16.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():

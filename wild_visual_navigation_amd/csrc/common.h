@@ -32,11 +32,15 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-// two floats -> packed bf16x2 (lo in bits 0..15) with the hardware converter (RNE)
+// two floats -> packed bf16x2 (lo in bits 0..15) with the hardware converter (RNE): hipcc selects
+// v_cvt_pk_bf16_f32 for the vector conversion.  Deliberately NOT inline asm: the compiler pads no MFMA-result
+// hazards for an asm statement's operands, and accumulators are often converted straight out of an MFMA.
+typedef __attribute__((ext_vector_type(2))) float wvn_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 wvn_bf16x2_t;
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  const wvn_f32x2_t v = {lo, hi};
+  const wvn_bf16x2_t b = __builtin_convertvector(v, wvn_bf16x2_t);
+  return __builtin_bit_cast(uint32_t, b);
 }
 
 template <typename T> struct ElemIO;

@@ -168,6 +168,27 @@ int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, in
   return WVN_OK;
 }
 
+// zero the byte range [col0, col0 + ncol) of every row (4-byte granularity): padding hygiene of the ViT workspace
+__global__ void pad_zero_kernel(unsigned char* __restrict__ base, long long nrows, long long row_stride, long long col0,
+                                int ncol_words) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows * ncol_words) return;
+  const long long r = i / ncol_words;
+  const int w = (int)(i - r * ncol_words);
+  *(unsigned int*)(base + r * row_stride + col0 + (long long)w * 4) = 0u;
+}
+
+int wvn_pad_zero_launch(void* base, long long nrows, long long row_stride_bytes, long long col0_bytes,
+                        long long ncol_bytes, hipStream_t st) {
+  if (!base || (row_stride_bytes & 3) || (col0_bytes & 3) || (ncol_bytes & 3)) return WVN_ERR_ARG;
+  if (nrows <= 0 || ncol_bytes <= 0) return WVN_OK;
+  const long long n = nrows * (ncol_bytes / 4);
+  hipLaunchKernelGGL(pad_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned char*)base, nrows,
+                     row_stride_bytes, col0_bytes, (int)(ncol_bytes / 4));
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
 int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, hipStream_t st) {  // ntok = rows per frame
   hipLaunchKernelGGL(cls_rows_kernel, dim3(ceil_div(B * D, 256)), dim3(256), 0, st, cls_pos, x, B, ntok, D);
   WVN_LAUNCH_CHECK();

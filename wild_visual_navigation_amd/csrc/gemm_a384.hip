@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
       voff[it] = m < p.M ? (unsigned)((((size_t)b * p.heads * p.npad + tk) * 64 + (lane & 7) * 8) * 2) : OOB;
     }
-    {  // v^T: d = it*16 + lane>>2, 8 tokens at m0w + (lane&3)*8 (one frame: M % 8 == ntok_s % 8 == 0)
+    {  // v^T: d = it*16 + lane>>2, 8 tokens at m0w + (lane&3)*8 (one frame: M % 16 == ntok_s % 16 == 0)
       const int m = m0w + (lane & 3) * 8;
       const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
       vt_off = m < p.M ? (unsigned)((((size_t)b * p.heads * 64 + (lane >> 2)) * p.npad + tk) * 2) : OOB;
@@ -230,7 +230,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int mloc = 8 * g + 4 * hi;
+          // tokens 8g + 4hi + e of the wave's 32; V^T is stored with bits 2 and 3 of the token index swapped
+          // inside every aligned group of 16 (attention_bf16.hip): position 16 (g >> 1) + 8 hi + 4 (g & 1) + e
+          const int mloc = 16 * (g >> 1) + 8 * hi + 4 * (g & 1);
           u32x2_t o = {pack_bf16x2(prev[t][4 * g + 0], prev[t][4 * g + 1]),
                        pack_bf16x2(prev[t][4 * g + 2], prev[t][4 * g + 3])};
           *(u32x2_t*)(stg + (32 * t + l31) * 80 + mloc * 2) = o;
@@ -453,7 +455,7 @@ int wvn_gemm_a384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
       if (!g.C || (g.ldc % 4) != 0 || ((uintptr_t)g.C & 15)) return WVN_ERR_ARG;
       return launch<A_RESID>(p, st);
     case EPI_QKV:
-      if (g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 8) || (g.M % 8) || (g.npad % 8)) return WVN_ERR_ARG;
+      if (g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 16) || (g.M % 16) || (g.npad % 16)) return WVN_ERR_ARG;
       return launch<A_QKV>(p, st);
     default: return WVN_ERR_ARG;
   }

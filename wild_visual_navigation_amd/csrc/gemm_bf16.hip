@@ -186,7 +186,9 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
       }
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int c = reg_base + 8 * g4 + 4 * hi;
+        int c = reg_base + 8 * g4 + 4 * hi;
+        if constexpr (EPI == EPI_QKV && !TR)  // V^T: tokens permuted inside aligned groups of 16 (bits 2 <-> 3), see attention_bf16.hip
+          c = reg_base + 16 * (g4 >> 1) + 8 * hi + 4 * (g4 & 1);
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -227,7 +229,7 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
       for (int it = 0; it < 8; ++it) {
         const int ch = tid + 256 * it, row = ch >> 4, c8 = (ch & 15) * 8;
         const int m = m0 + c8;
-        if (m >= p.M) continue;  // M % 8 == 0 (ntok_s % 8 == 0): a chunk is entirely in or out
+        if (m >= p.M) continue;  // M % 16 == 0 (ntok_s % 16 == 0): a chunk (and its permutation group of 16) is entirely in or out
         const int b = m / p.ntok_s, t = m - b * p.ntok_s;
         const int cc = cbase + row, head = cc >> 6, d = cc & 63;
         const u32x4_t val = *(const u32x4_t*)((const bf16_t*)smem + row * CT_BF16_STRIDE + c8);
@@ -381,8 +383,8 @@ int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
       if ((p.ldc & 3) || !p.pos || p.N % 4) return WVN_ERR_ARG;
       return launch<EPI_PATCH>(p, st);
     case EPI_QKV:
-      if ((p.N % 3) != 0 || ((p.N / 3) % BN) != 0 || !p.q || !p.k || !p.vt || (p.ntok_s % 8) || (p.M % 8) ||
-          (p.npad % 8))
+      if ((p.N % 3) != 0 || ((p.N / 3) % BN) != 0 || !p.q || !p.k || !p.vt || (p.ntok_s % 16) || (p.M % 16) ||
+          (p.npad % 16))
         return WVN_ERR_ARG;
       return launch<EPI_QKV>(p, st);
     default: return WVN_ERR_ARG;

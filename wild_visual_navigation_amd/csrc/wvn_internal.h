@@ -60,6 +60,9 @@ int wvn_gemm_f32_launch(const GemmF32Params& p, int epi, hipStream_t st);
 // ---- elementwise / normalisation (elementwise.hip) --------------------------------------------
 int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, int S, int P, hipStream_t st);
 int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok_s, int D, hipStream_t st);
+// zero bytes [col0, col0 + ncol) of each of nrows rows (all multiples of 4)
+int wvn_pad_zero_launch(void* base, long long nrows, long long row_stride_bytes, long long col0_bytes,
+                        long long ncol_bytes, hipStream_t st);
 // LayerNorm over rows of x[rows, D] (fp32) -> y (bf16 or f32, leading dim ldy); optional second fp32 output.
 // row_map: 0 = identity; 1 = drop the class token (input row b*ntok+1+p -> output row b*(ntok-1)+p)
 int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
@@ -70,6 +73,7 @@ int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, i
 // ---- attention (attention_bf16.hip / attention_f32.hip) ---------------------------------------
 int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
                               int ntok, int ntok_s, int npad, float scale, hipStream_t st);
+void wvn_attention_bf16_set_debug(long long* dbg);  // per-wave phase timings (TIMING build), nullptr = off
 int wvn_attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok,
                              int ntok_s, int npad, float scale, hipStream_t st);
 

@@ -200,6 +200,14 @@ def gemm_f32(a, b, bias=None, epi=_lib.F32_NONE, trans_a=False, trans_b=True, ou
     return out
 
 
+def vt_token_order(npad: int, device=None) -> torch.Tensor:
+    """Index map of the bf16 attention kernel's V^T layout (include/wvn_hip.h): stored position p of every
+    aligned group of 16 tokens holds token p with bits 2 and 3 swapped (an involution).
+    ``vt_stored = v.transpose(-1, -2)[..., vt_token_order(npad)]``."""
+    p = torch.arange(npad, device=device)
+    return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)
+
+
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
     x = x.contiguous().float()
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
