@@ -34,13 +34,14 @@ def main():
         w = (torch.randn(N, 384, generator=g) * 0.05).to(torch.bfloat16).to(dev)
         bias = torch.randn(N, generator=g).to(dev)
         out = torch.zeros(M, N, dtype=torch.float32 if epi == _lib.EPI_RESID_F32 else torch.bfloat16, device=dev)
-        nwg = (M + 255) // 256
+        units = ((M + 255) // 256) * (N // 64)
+        nwg = min(units, 256)  # persistent launch: one workgroup per CU
         dbg = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=dev)
         for _ in range(3):
             check(fn(ptr(a), 384, ptr(w), 384, ptr(bias), ptr(out), N, M, N, 384, epi, ptr(dbg), stream()))
         torch.cuda.synchronize()
         d = dbg.cpu().reshape(nwg, 8, 4).double()
-        periods = (N // 64) * 3
+        periods = units * 3 / nwg  # slice periods per workgroup (balanced to +-3)
         for role, sl in (("mfma_first", slice(0, 4)), ("epi_first", slice(4, 8))):
             m = d[:, sl].mean(dim=(0, 1))
             res[f"{name}/{role}"] = {"wait": round(m[0].item() / periods), "mfma": round(m[1].item() / periods),

@@ -25,6 +25,7 @@
 // uses mfma(Afrag, Wfrag) (lane = n, registers = 4 consecutive tokens) so V^T rows are token-contiguous.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -44,7 +45,7 @@ constexpr int STG_OFF = RING_BYTES;
 constexpr int BIAS_OFF = STG_OFF + 8 * STG_BYTES;
 constexpr int BM = 256;
 
-enum { A_BF16 = 0, A_GELU = 1, A_RELU = 2, A_RESID = 3, A_QKV = 4 };
+enum { A_BF16 = 0, A_GELU = 1, A_RELU = 2, A_RESID = 3, A_QK = 4, A_V = 5 };  // QKV runs as two launches: q|k (TR tiles) and v (V^T tiles)
 
 struct A384Params {
   const bf16_t* A; int lda;
@@ -53,6 +54,7 @@ struct A384Params {
   void* C; int ldc;    // bf16 or fp32 (A_RESID: in/out)
   int M, N;
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad; int ntok_s;
+  bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;  // one buffer descriptor for q / k / v^T (byte offsets from qkv_base)
   long long* dbg;  // TIMING builds: per wave {wait+barrier, mfma, epilogue, total} shader cycles
 };
 
@@ -85,9 +87,16 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int m0w = blockIdx.x * BM + wave * 32;  // first row of this wave
   const int NT = p.N / BNT;
-  const int total = NT * NSL;
+  // Persistent, balanced schedule: the work is the list of (256-row block, 64-column tile) units in row-block-major
+  // order; workgroup w of G owns the contiguous range [w U / G, (w + 1) U / G).  A range is walked as segments of
+  // consecutive column tiles of one row block (A rows re-loaded at each row-block change), while the W ring keeps
+  // streaming across segments.  Every workgroup gets the same number of units (+-1) whatever M is.
+  const int NRB = (p.M + BM - 1) / BM;
+  const long long U = (long long)NRB * NT;
+  const int u_begin = (int)(U * blockIdx.x / gridDim.x), u_end = (int)(U * (blockIdx.x + 1) / gridDim.x);
+  const int total = (u_end - u_begin) * NSL;  // ring slices this workgroup consumes
+  int m0w = 0;                                // first row of this wave in the current segment
   const bool epi_first = wave >= 4;
   unsigned char* stg = smem + STG_OFF + wave * STG_BYTES;
   const float* bias_l = (const float*)(smem + BIAS_OFF);
@@ -104,14 +113,15 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
     const int chunk = (lane & 15) ^ (row & 15);
     wvoff[u] = (unsigned)((row * KD + chunk * 8) * 2);
   }
-  auto issue = [&](int i) {  // slice i = (column tile i / 3, k slice i % 3)
-    const int j = i / NSL, ks = i - j * NSL;
-    const unsigned soff = __builtin_amdgcn_readfirstlane((j * BNT * KD + ks * SLK) * 2);
+  int iss_j = u_begin % NT, iss_ks = 0;  // cursor: (column tile, k slice) of the next slice to request (issued in order)
+  auto issue = [&](int i) {  // i = workgroup-local slice index (ring slot i % NS)
+    const unsigned soff = __builtin_amdgcn_readfirstlane((iss_j * BNT * KD + iss_ks * SLK) * 2);
     unsigned char* dst = smem + (i % NS) * SLICE_BYTES + wave * 2048;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16,
                                                wvoff[u], soff, 0, 0);
+    if (++iss_ks == NSL) { iss_ks = 0; if (++iss_j == NT) iss_j = 0; }
   };
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i)
@@ -120,11 +130,11 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   // ---- bias -> LDS, A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7) --------
   for (int i = tid; i < p.N; i += 512) ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
   bf16x8_t xf[KD / 16];
-  {
+  auto load_a = [&]() {
     const bf16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
 #pragma unroll
     for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
-  }
+  };
 
   f32x16_t acc[2], prev[2];
 #pragma unroll
@@ -139,27 +149,31 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   // once; per column tile / chunk row only a scalar offset changes.  Rows >= M fall outside num_records (or get
   // an out-of-range offset) and the hardware drops their stores.
   constexpr unsigned OOB = 0x80000000u;
-  unsigned voff[4] = {0, 0, 0, 0};
+  unsigned voff[2] = {0, 0};
   unsigned vt_off = 0;
   unsigned stg_rd;  // per-lane byte offset into the wave's staging image for part 2
-  const unsigned c_bytes = EPI == A_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == A_RESID ? 4 : 2));
-  const unsigned qk_bytes = EPI == A_QKV ? (unsigned)((size_t)((p.M + p.ntok_s - 1) / p.ntok_s) * p.heads * p.npad * 64 * 2) : 0u;
-  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(p.q, 0, qk_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(p.k, 0, qk_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(p.vt, 0, qk_bytes, 0x00020000);
-  if constexpr (EPI == A_QKV) {
+  constexpr bool IS_QKV = EPI == A_QK || EPI == A_V;
+  using TRK = std::integral_constant<bool, EPI != A_V>;  // orientation of every column tile of this launch
+  const unsigned c_bytes = IS_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == A_RESID ? 4 : 2));
+  const __amdgpu_buffer_rsrc_t rs_c = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base, 0, p.qkv_bytes, 0x00020000)
+                                                   : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
+  auto qkv_offsets = [&]() {  // per row block: the lane's token rows -> (frame, token) byte offsets
+    // q / k rows: row = it*8 + (lane>>3), 16 B at column (lane&7)*8 of the head.  Frames start at multiples of 16 rows
+    // (ntok_s % 16 == 0), so rows 0-15 and 16-31 of the wave's block are each contiguous in one frame:
+    // voff[0] serves it = 0, 1 (+1024 B) and voff[1] serves it = 2, 3.
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {  // q / k rows: row = it*8 + lane>>3, 16 B at column (lane&7)*8 of the head
-      const int m = m0w + it * 8 + (lane >> 3);
+    for (int hblk = 0; hblk < 2; ++hblk) {
+      const int m = m0w + hblk * 16 + (lane >> 3);
       const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
-      voff[it] = m < p.M ? (unsigned)((((size_t)b * p.heads * p.npad + tk) * 64 + (lane & 7) * 8) * 2) : OOB;
+      voff[hblk] = m < p.M ? (unsigned)((((size_t)b * p.heads * p.npad + tk) * 64 + (lane & 7) * 8) * 2) : OOB;
     }
     {  // v^T: d = it*16 + lane>>2, 8 tokens at m0w + (lane&3)*8 (one frame: M % 16 == ntok_s % 16 == 0)
       const int m = m0w + (lane & 3) * 8;
       const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
       vt_off = m < p.M ? (unsigned)((((size_t)b * p.heads * 64 + (lane >> 2)) * p.npad + tk) * 2) : OOB;
     }
+  };
+  if constexpr (IS_QKV) {
     stg_rd = 0;
   } else if constexpr (EPI == A_RESID) {
     voff[0] = (unsigned)(((lane >> 4) * p.ldc + (lane & 15) * 4) * 4);
@@ -173,8 +187,10 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   auto mfma_block = [&](int slot, int ks, auto tr_tag) {
     constexpr bool TR = decltype(tr_tag)::value;
     const unsigned char* base = smem + slot * SLICE_BYTES + rd_base;
+    int xc = xorc;
+    asm volatile("" : "+v"(xc));  // keep the 8 swizzled offsets from being hoisted out of the loop (8 live VGPRs otherwise)
     auto rd = [&](int s, int t) {
-      return *(const bf16x8_t*)(base + t * 8192 + (((2 * s + hi) ^ xorc) << 4));
+      return *(const bf16x8_t*)(base + t * 8192 + (((2 * s + hi) ^ xc) << 4));
     };
     // LA k-steps of fragments in flight (VAR 1: 4 instead of 2; VAR 2 is a TIMING-ONLY experiment that reads half
     // of the fragments -- wrong results -- to tell LDS bandwidth from LDS latency)
@@ -255,25 +271,22 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
         __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, voff[0], so, 0);
         if (it & 1) __builtin_amdgcn_sched_barrier(0);  // two chunk rows in flight at a time (VGPR budget)
       }
-    } else if constexpr (EPI == A_QKV) {
+    } else if constexpr (EPI == A_QK) {  // q / k: one column tile = one head; dst[(b*h + head)*npad + t][0..63]
       const int D = p.heads * 64;
-      if constexpr (TR) {  // q / k: one column tile = one head; dst[(b*h + head)*npad + t][0..63]
-        const int which = n0 / D, head = (n0 - which * D) >> 6;
-        const unsigned so = __builtin_amdgcn_readfirstlane(head * p.npad * 64 * 2);
+      const int which = n0 / D, head = (n0 - which * D) >> 6;
+      const unsigned so = __builtin_amdgcn_readfirstlane((which == 0 ? p.q_off : p.k_off) + head * p.npad * 64 * 2);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 3) + it * 8) * 144 + (lane & 7) * 16);
-          if (which == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_q, voff[it], so, 0);
-          else __builtin_amdgcn_raw_buffer_store_b128(val, rs_k, voff[it], so, 0);
-        }
-      } else {  // v: vt[(b*h + head)*64 + d][t], 8 tokens (16 B) per lane
-        const int head = (n0 - 2 * D) >> 6;
+      for (int it = 0; it < 4; ++it) {
+        const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 3) + it * 8) * 144 + (lane & 7) * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, voff[it >> 1], so + (it & 1) * 1024, 0);
+      }
+    } else if constexpr (EPI == A_V) {  // v: vt[(b*h + head)*64 + d][t], 8 tokens (16 B) per lane
+      const int head = n0 >> 6;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
-          const unsigned so = __builtin_amdgcn_readfirstlane((head * 64 + it * 16) * p.npad * 2);
-          __builtin_amdgcn_raw_buffer_store_b128(val, rs_v, vt_off, so, 0);
-        }
+      for (int it = 0; it < 4; ++it) {
+        const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+        const unsigned so = __builtin_amdgcn_readfirstlane(p.v_off + (head * 64 + it * 16) * p.npad * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, vt_off, so, 0);
       }
     } else {
 #pragma unroll
@@ -356,34 +369,29 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       if (epi_first) { t_epi += c2 - c1; t_mfma += c3 - c2; } else { t_mfma += c2 - c1; t_epi += c3 - c2; }
     }
   };
-  auto tile = [&](int j, auto mtr, auto etr, bool do_epi, bool stores_in_window, auto next_tr) {
+  int si = 0;  // workgroup-local slice counter (ring slot si % NS)
+  // one column tile: 3 slice periods; jj = position of the tile in its segment (the epilogue of tile jj - 1 rides along)
+  auto tile = [&](int j, int jj, int j_end, auto mtr, auto etr, auto next_tr) {
 #pragma unroll
-    for (int ks = 0; ks < NSL; ++ks) period(j * NSL + ks, ks, j, stores_in_window, mtr, etr, do_epi);
+    for (int ks = 0; ks < NSL; ++ks) period(si + ks, ks, j, jj >= 2, mtr, etr, jj >= 1);
+    si += NSL;
 #pragma unroll
     for (int t = 0; t < 2; ++t) prev[t] = acc[t];
-    if (j + 1 < NT) init_acc(j + 1, next_tr);
+    if (j + 1 < j_end) init_acc(j + 1, next_tr);
   };
 
-  using T = std::true_type;
-  using F = std::false_type;
   __syncthreads();  // bias table visible (nothing DMA'd is read before the first period's wait + barrier)
-  init_acc(0, T{});
-  if constexpr (EPI == A_QKV) {
-    const int nqk = 2 * (p.heads * 64) / BNT;  // q and k column tiles (TR); the rest are V tiles
-    tile(0, T{}, T{}, false, false, T{});
-    tile(1, T{}, T{}, true, false, T{});
-    for (int j = 2; j < nqk - 1; ++j) tile(j, T{}, T{}, true, true, T{});
-    tile(nqk - 1, T{}, T{}, true, true, F{});
-    tile(nqk, F{}, T{}, true, true, F{});
-    for (int j = nqk + 1; j < NT; ++j) tile(j, F{}, F{}, true, true, F{});
+  for (int u = u_begin; u < u_end;) {
+    const int rb = u / NT, j0 = u - rb * NT, j1 = min(NT, j0 + (u_end - u));
+    m0w = rb * BM + wave * 32;
+    load_a();
+    if constexpr (IS_QKV) qkv_offsets();
+    init_acc(j0, TRK{});
+    for (int j = j0; j < j1; ++j) tile(j, j - j0, j1, TRK{}, TRK{}, TRK{});
+    // drain: epilogue of the segment's last tile (not overlapped; a few per workgroup)
 #pragma unroll
-    for (int part = 0; part < 3; ++part) epi_part(part, NT - 1, F{});
-  } else {
-    tile(0, T{}, T{}, false, false, T{});
-    if (NT > 1) tile(1, T{}, T{}, true, false, T{});
-    for (int j = 2; j < NT; ++j) tile(j, T{}, T{}, true, true, T{});
-#pragma unroll
-    for (int part = 0; part < 3; ++part) epi_part(part, NT - 1, T{});
+    for (int part = 0; part < 3; ++part) epi_part(part, j1 - 1, TRK{});
+    u += j1 - j0;
   }
   if constexpr (TIMING) {
     if (lane == 0 && p.dbg) {
@@ -405,6 +413,17 @@ int a384_var() {
   return v;
 }
 
+int a384_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <int EPI, bool TIMING, int VAR>
 int launch_k(const A384Params& p, int lds, hipStream_t st) {
   static bool attr_set = false;
@@ -414,7 +433,10 @@ int launch_k(const A384Params& p, int lds, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_a384_kernel<EPI, TIMING, VAR>), dim3(ceil_div(p.M, BM)), dim3(512), lds, st, p);
+  // one persistent workgroup per CU (144 KB of LDS each), never more workgroups than (row block, column tile) units
+  const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
+  const int grid = (int)(units < a384_num_cus() ? units : a384_num_cus());
+  hipLaunchKernelGGL((gemm_a384_kernel<EPI, TIMING, VAR>), dim3(grid), dim3(512), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -454,9 +476,23 @@ int wvn_gemm_a384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
     case EPI_ACCUM_F32:
       if (!g.C || (g.ldc % 4) != 0 || ((uintptr_t)g.C & 15)) return WVN_ERR_ARG;
       return launch<A_RESID>(p, st);
-    case EPI_QKV:
+    case EPI_QKV: {
+      const uintptr_t lo = std::min({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
+      const uintptr_t hi = std::max({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
+      const size_t one = (size_t)(g.M / (g.ntok_s > 0 ? g.ntok_s : 1)) * g.heads * g.npad * 64 * 2;
+      if (hi - lo + one >= (1ull << 31)) return WVN_ERR_ARG;  // one 32-bit-offset buffer descriptor must span q, k and v^T
+      p.qkv_base = (bf16_t*)lo; p.q_off = (unsigned)((uintptr_t)g.q - lo); p.k_off = (unsigned)((uintptr_t)g.k - lo);
+      p.v_off = (unsigned)((uintptr_t)g.vt - lo); p.qkv_bytes = (unsigned)(hi - lo + one);
       if (g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 16) || (g.M % 16) || (g.npad % 16)) return WVN_ERR_ARG;
-      return launch<A_QKV>(p, st);
+      const int D = g.heads * 64;
+      p.N = 2 * D;  // q | k column tiles
+      const int rc = launch<A_QK>(p, st);
+      if (rc != WVN_OK) return rc;
+      p.W = g.W + (size_t)2 * D * KD;  // v rows of the fused qkv weight
+      p.bias = g.bias ? g.bias + 2 * D : nullptr;
+      p.N = D;
+      return launch<A_V>(p, st);
+    }
     default: return WVN_ERR_ARG;
   }
 }
