@@ -238,6 +238,10 @@ __global__ __launch_bounds__(256) void segpool_patch_kernel(const int* __restric
   // The four partial sums are combined in wave order, so the result does not depend on scheduling.
   __shared__ float part[4][64];
   __shared__ int cnts[4];
+  __shared__ unsigned short hits[4][1024];  // per wave: its quarter's patches of this segment, ascending (P / 4 <= 1024)
+  __shared__ float wys[192], wxs[192];       // stencil weights (G <= 64)
+  for (int i = threadIdx.x; i < G * 3; i += 256) { wys[i] = wy[i]; wxs[i] = wx[i]; }
+  __syncthreads();
   const int b = blockIdx.z, s = blockIdx.y, c0 = blockIdx.x * 64;
   const int ch = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int P = G * G;
@@ -246,38 +250,52 @@ __global__ __launch_bounds__(256) void segpool_patch_kernel(const int* __restric
   const bool live = (c0 + ch) < D;
   const float* F = tok + (size_t)b * P * ldf + c0 + ch;
   const int* lab = labels + (size_t)b * P;
-  float sum = 0.f;
+  // pass 1: compact the matching patch indices (ballot + prefix popcount keeps them in ascending order)
   int n = 0;
   for (int base = q0; base < q1; base += 64) {
     const int q = base + ch;
-    const int l = q < q1 ? lab[q] : -1;
-    unsigned long long m = __ballot(l == s);
+    const bool hit = q < q1 && lab[q] == s;
+    const unsigned long long m = __ballot(hit);
+    if (hit) hits[w][n + __popcll(m & ((1ull << ch) - 1ull))] = (unsigned short)(q - q0);
     n += __popcll(m);
-    while (m) {
-      const int j = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int qq = base + j;
-      const int gy = qq / G, gx = qq - gy * G;
-      float acc = 0.f;
-      if (live) {
+  }
+  // (wave-private list: the wave's own LDS writes are visible to its later reads in program order)
+  // pass 2: stencil values of four patches are fetched together (36 independent loads in flight), then added to
+  // the running sum one patch at a time, in ascending patch order -- the summation order is unchanged
+  // Branch-free stencil: taps that fall outside the map (or carry weight 0) are read at a clamped index and multiplied
+  // by their zero weight -- fmaf(0, x, r) == r for finite x, so the value equals the skip-the-tap form bit for bit while
+  // all nine loads of a patch (and of its three batch mates) are independent and issue back to back.
+  auto stencil = [&](int qq) -> float {
+    const int gy = qq / G, gx = qq - gy * G;
+    float acc = 0.f;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const int yy = gy + a - 1;
-          const float wa = wy[gy * 3 + a];
-          if (wa == 0.f || yy < 0 || yy >= G) continue;
-          float row = 0.f;
+    for (int a = 0; a < 3; ++a) {
+      const int yy = gy + a - 1;
+      const bool oky = yy >= 0 && yy < G;
+      const float wa = oky ? wys[gy * 3 + a] : 0.f;
+      const int yc = min(max(yy, 0), G - 1);
+      float row = 0.f;
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int xx = gx + c - 1;
-            const float wc = wx[gx * 3 + c];
-            if (wc == 0.f || xx < 0 || xx >= G) continue;
-            row = fmaf(wc, F[(size_t)(yy * G + xx) * ldf], row);
-          }
-          acc = fmaf(wa, row, acc);
-        }
-        sum += acc;
+      for (int c = 0; c < 3; ++c) {
+        const int xx = gx + c - 1;
+        const bool okx = xx >= 0 && xx < G;
+        const float wc = okx ? wxs[gx * 3 + c] : 0.f;
+        const int xc = min(max(xx, 0), G - 1);
+        row = fmaf(wc, F[(size_t)(yc * G + xc) * ldf], row);
       }
+      acc = fmaf(wa, row, acc);
     }
+    return acc;
+  };
+  float sum = 0.f;
+  if (live) {
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+      const float a0 = stencil(q0 + hits[w][i]), a1 = stencil(q0 + hits[w][i + 1]);
+      const float a2 = stencil(q0 + hits[w][i + 2]), a3 = stencil(q0 + hits[w][i + 3]);
+      sum += a0; sum += a1; sum += a2; sum += a3;
+    }
+    for (; i < n; ++i) sum += stencil(q0 + hits[w][i]);
   }
   part[w][ch] = sum;
   if (ch == 0) cnts[w] = n;
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(256) void segpool_patch_kernel(const int* __restric
 
 int wvn_segpool_patch_launch(const int* labels, const float* tok, int ldf, const float* wy, const float* wx,
                              float* feat, int B, int G, int S, int D, hipStream_t st) {
-  if (!labels || !tok || !wy || !wx || !feat || S <= 0 || D <= 0 || S > 65535 || B > 65535) return WVN_ERR_ARG;
+  if (!labels || !tok || !wy || !wx || !feat || S <= 0 || D <= 0 || S > 65535 || B > 65535 || G > 64) return WVN_ERR_ARG;
   hipLaunchKernelGGL(segpool_patch_kernel, dim3(ceil_div(D, 64), S, B), dim3(256), 0, st, labels, tok, ldf, wy, wx, feat,
                      G, S, D);
   WVN_LAUNCH_CHECK();

@@ -25,15 +25,60 @@ namespace {
 constexpr int KM_MAXK = 64;
 constexpr int KM_CHUNK = 64;
 
+// Rows of [rows][C] (C <= 128) are staged through LDS so that global traffic is coalesced (a row is 360 B at
+// C = 90; one thread walking its own row touches 64 cache lines per load instruction) while each thread still
+// reduces ITS row sequentially in index order -- the arithmetic, and therefore every bit of the result, is unchanged.
+constexpr int ROWS_PER_BLOCK = 128;
+// LDS tile = plain copy of the rows ([r][C], pitch C): for C = 90 thread r reading column d hits bank (26 r + d) % 64,
+// distinct for the 32 lanes of a half-wave; the odd-pitch variant is used when rows are not contiguous in memory.
+__host__ __device__ inline int row_pitch(int C, bool contiguous) { return contiguous ? C : (C | 1); }
+
+__device__ inline void stage_rows_in(const float* __restrict__ src, int ld, int row0, int rows, int C, float* tile) {
+  const int nrow = min(ROWS_PER_BLOCK, rows - row0);
+  if (ld == C && ((C * ROWS_PER_BLOCK) & 3) == 0 && (((uintptr_t)(src + (size_t)row0 * C)) & 15) == 0) {
+    const int n4 = nrow * C / 4;  // contiguous block: 16-byte coalesced copy (tail elements below)
+    const f32x4_t* s4 = (const f32x4_t*)(src + (size_t)row0 * C);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) ((f32x4_t*)tile)[i] = s4[i];
+    for (int i = n4 * 4 + threadIdx.x; i < nrow * C; i += blockDim.x) tile[i] = src[(size_t)row0 * C + i];
+  } else {
+    const int pitch = row_pitch(C, false);
+    for (int r = 0; r < nrow; ++r) {
+      const int d = threadIdx.x;
+      if (d < C) tile[r * pitch + d] = src[(size_t)(row0 + r) * ld + d];
+    }
+  }
+}
+__device__ inline bool rows_contiguous(const float* src, int ld, int row0, int C) {
+  return ld == C && ((C * ROWS_PER_BLOCK) & 3) == 0 && (((uintptr_t)(src + (size_t)row0 * C)) & 15) == 0;
+}
+
 // xn[p][:] = code[p][:] / max(||code[p]||, 1e-12)
-__global__ void normalize_rows_kernel(const float* __restrict__ code, int ldc, float* __restrict__ xn, int rows, int C) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= rows) return;
-  const float* r = code + (size_t)p * ldc;
-  float n2 = 0.f;
-  for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(r[d], r[d]));
-  float n = fmaxf(__fsqrt_rn(n2), 1e-12f);
-  for (int d = 0; d < C; ++d) xn[(size_t)p * C + d] = __fdiv_rn(r[d], n);
+__global__ __launch_bounds__(ROWS_PER_BLOCK) void normalize_rows_kernel(const float* __restrict__ code, int ldc,
+                                                                        float* __restrict__ xn, int rows, int C) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [128][pitch]
+  const int row0 = blockIdx.x * ROWS_PER_BLOCK;
+  const int pitch = row_pitch(C, rows_contiguous(code, ldc, row0, C));
+  stage_rows_in(code, ldc, row0, rows, C, tile);
+  __syncthreads();
+  const int p = row0 + threadIdx.x;
+  if (p < rows) {
+    float* r = tile + threadIdx.x * pitch;
+    float n2 = 0.f;
+    for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(r[d], r[d]));
+    const float n = fmaxf(__fsqrt_rn(n2), 1e-12f);
+    for (int d = 0; d < C; ++d) r[d] = __fdiv_rn(r[d], n);
+  }
+  __syncthreads();
+  const int nrow = min(ROWS_PER_BLOCK, rows - row0);
+  if (pitch == C && ((nrow * C) & 3) == 0 && (((uintptr_t)(xn + (size_t)row0 * C)) & 15) == 0) {
+    f32x4_t* d4 = (f32x4_t*)(xn + (size_t)row0 * C);
+    for (int i = threadIdx.x; i < nrow * C / 4; i += blockDim.x) d4[i] = ((const f32x4_t*)tile)[i];
+  } else {
+    for (int i = threadIdx.x; i < nrow * C; i += blockDim.x) {
+      const int r = i / C, d = i - r * C;
+      xn[(size_t)row0 * C + i] = tile[r * pitch + d];
+    }
+  }
 }
 
 // cent[b][k][:] = xn[b][floor((2k+1) P / 2K)][:]
@@ -46,6 +91,8 @@ __global__ void km_init_kernel(const float* __restrict__ xn, float* __restrict__
   }
 }
 
+// (points are read straight from global memory, one row per thread: the LDS-staged variant measured 2.7x slower here --
+// its 53 KB tile leaves two 128-thread blocks per CU, and the L2 absorbs the row-strided reads of this small array)
 template <int C>
 __global__ __launch_bounds__(256) void km_assign_kernel(const float* __restrict__ xn, const float* __restrict__ cent,
                                                         int* __restrict__ labels, int P, int K) {
@@ -177,7 +224,9 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
 
 int wvn_normalize_rows_launch(const float* code, int ldc, float* xn, int rows, int C, hipStream_t st) {
   if (!code || !xn) return WVN_ERR_ARG;
-  hipLaunchKernelGGL(normalize_rows_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, code, ldc, xn, rows, C);
+  if (C > ROWS_PER_BLOCK) return WVN_ERR_ARG;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(ceil_div(rows, ROWS_PER_BLOCK)), dim3(ROWS_PER_BLOCK),
+                     ROWS_PER_BLOCK * (C | 1) * sizeof(float), st, code, ldc, xn, rows, C);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
