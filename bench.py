@@ -26,6 +26,19 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "attention_traffic.json")  # PMC-derived HBM bytes of the dominant kernel
+
+
+def attention_traffic_per_launch(frames_per_launch):
+    """HBM bytes per attention launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, separate passes; profiles/attention_traffic.json says how it was collected).  Traffic of this kernel
+    is proportional to the (frame, head) pairs of a launch, so the profiled figure is rescaled to this run's launch
+    size.  None when no profile is committed."""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+        return (t["fetch_bytes_corrected"] + t["write_bytes"]) * frames_per_launch / t["frames_per_launch"]
+    except Exception:
+        return None
 
 
 def vit_flops_per_frame(S=448, P=8, D=384, depth=12):
@@ -42,7 +55,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE configs[2]: 64)")
     ap.add_argument("--size", type=int, default=448)
-    ap.add_argument("--chunk", type=int, default=16, help="frames pushed through the backbone at a time")
+    ap.add_argument("--chunk", type=int, default=64, help="frames pushed through the backbone per launch sequence")
     ap.add_argument("--segmentation", default="stego", choices=["stego", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -191,7 +204,7 @@ def main():
             "final_loss": loss_val,
             "roofline": {"bound": "mfma", "kernel": "attention_bf16_kernel", "achieved": round(att_tflops, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tflops / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "avg_launch_ms": round(att_avg_ms, 4),
+                         "traffic": attention_traffic_per_launch(frames_per_launch), "avg_launch_ms": round(att_avg_ms, 4),
                          "algorithmic_flops_per_launch": attn_flops_block * frames_per_launch},
             "kernel_ms": kern,
         }

@@ -188,6 +188,18 @@ int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* gra
 int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,
                        float* trav, float* conf, int R, int D, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Instrumentation (scripts/a384_timing.py, scripts/attn_timing.py): in-kernel s_memtime phase timings of
+ * the two MFMA kernels.  Not part of the drop-in surface.
+ * ------------------------------------------------------------------------------------------- */
+/* wvn_gemm_bf16 with per-wave phase counters: dbg[(workgroup * 8 + wave) * 4 + {0 wait+barrier, 1 MFMA block,
+ * 2 epilogue part, 3 total}] in shader cycles (K == 384 shapes only; dbg may be NULL). */
+int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
+                              int N, int K, int epi, long long* dbg, void* stream);
+/* subsequent wvn_attention_bf16 launches write dbg[(workgroup * 4 + wave) * 5 + {0 wait, 1 QK^T, 2 softmax, 3 PV,
+ * 4 total}]; NULL switches the instrumented build off again. */
+int wvn_debug_attention_timing(long long* dbg);
+
 #ifdef __cplusplus
 }
 #endif

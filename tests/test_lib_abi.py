@@ -46,8 +46,8 @@ def test_host_only_queries():
     one = h.wvn_vit_workspace_bytes(C.byref(m), 1)
     two = h.wvn_vit_workspace_bytes(C.byref(m), 2)
     # x fp32 + xn bf16 + q/k/v^T bf16 (3200-padded) + hidden bf16 + patches bf16, per frame
-    # (3137 tokens are stored with a per-frame row stride of 3144 = next multiple of 8)
-    expect = 3144 * 384 * 4 + 3144 * 384 * 2 + 3 * 6 * 3200 * 64 * 2 + 3144 * 1536 * 2 + 3136 * 192 * 2
+    # (3137 tokens are stored with a per-frame row stride of 3152 = next multiple of 16)
+    expect = 3152 * 384 * 4 + 3152 * 384 * 2 + 3 * 6 * 3200 * 64 * 2 + 3152 * 1536 * 2 + 3136 * 192 * 2
     assert expect <= one <= expect + 8 * 256 and two > one
 
 

@@ -80,6 +80,8 @@ _SIGNATURES = {
     "wvn_mlp_train_phase_b": ([_p, _p, _p, _i, _p, _p, _i, _p, _f, _f, _f, _p, _p, _p, _sz, _p], _i),
     "wvn_mlp_train_phase_c": ([_p, _p, _p, _p, _p, _i, _f, _p, _f, _f, _p, _p], _i),
     "wvn_mlp_confidence": ([_p, _i, _p, _i, _f, _f, _f, _p, _p, _i, _i, _p], _i),
+    "wvn_debug_gemm_bf16_timed": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p], _i),
+    "wvn_debug_attention_timing": ([_p], _i),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     for (int r = 5; r < 15; r += 2) { ma = max3f(ma, st[0][r], st[0][r + 1]); mb = max3f(mb, st[1][r], st[1][r + 1]); }
     float mt = max3f(ma, mb, st[0][15]);
     mt = max3f(mt, st[1][15], st[1][15]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    {  // the other half-wave's max of the same query: v_permlane32_swap (VALU) instead of a ds_bpermute LDS round trip
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = max3f(mt, __uint_as_float(sw[0]), __uint_as_float(sw[1]));  // one of the two is this lane's own value
+    }
     // Deferred rescale: the running max only follows when some row's scores outgrow it by more than THR (in
     // exp2 units).  P is then bounded by 2^THR instead of 1 -- harmless in fp32 accumulators, and P / l cancel
     // exactly the same factor -- and the wave-uniform O rescale almost never runs after the first tiles.
