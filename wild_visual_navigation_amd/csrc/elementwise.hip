@@ -34,6 +34,30 @@ __global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ o
   for (int px = 0; px < P; ++px) ElemIO<T>::store(dst + px, (src[px] - mean[c]) / stdv[c]);
 }
 
+// bf16, P = 8 fast path: one workgroup per (patch row gy, frame).  The 3 x 8 image rows the patch row needs are read
+// as float4 (fully coalesced, 43 KB), normalised, converted, and scattered into an LDS image that already has the output
+// order [gx][c][py][px]; the 21 KB image then leaves as contiguous 16-byte stores (the element-order kernel above writes
+// 16-byte fragments 384 B apart).
+__global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
+                                                                   int S) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192]
+  const int G = S / 8, gy = blockIdx.x, b = blockIdx.y;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const int q = S / 4;  // float4 per image row
+  for (int i = threadIdx.x; i < 3 * 8 * q; i += 256) {
+    const int c = i / (8 * q), r = i - c * 8 * q, py = r / q, x4 = r - py * q;
+    const f32x4_t v = *(const f32x4_t*)(img + (((size_t)b * 3 + c) * S + gy * 8 + py) * S + x4 * 4);
+    const int gx = x4 >> 1, px = (x4 & 1) * 4;
+    const float m = mean[c], sd = stdv[c];
+    u32x2_t o = {pack_bf16x2((v[0] - m) / sd, (v[1] - m) / sd), pack_bf16x2((v[2] - m) / sd, (v[3] - m) / sd)};
+    *(u32x2_t*)(prow + gx * 192 + c * 64 + py * 8 + px) = o;
+  }
+  __syncthreads();
+  u32x4_t* dst = (u32x4_t*)(out + ((size_t)b * G * G + (size_t)gy * G) * 192);
+  for (int i = threadIdx.x; i < G * 192 / 8; i += 256) dst[i] = ((const u32x4_t*)prow)[i];
+}
+
 __global__ void cls_rows_kernel(const float* __restrict__ cls_pos, float* __restrict__ x, int B, int ntok, int D) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
@@ -156,7 +180,9 @@ int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, in
   long long total = (long long)B * G * G * 3 * P;
   dim3 grid((unsigned)((total + 255) / 256));
   if (P == 8) {
-    if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 8>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
+    if (out_bf16 && (S % 8) == 0 && (((uintptr_t)img | (uintptr_t)patches) & 15) == 0 && (S / 8) * 192 * 2 <= 64 * 1024)
+      hipLaunchKernelGGL(patchify8_bf16_rows_kernel, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st, img, (bf16_t*)patches, S);
+    else if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 8>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
     else hipLaunchKernelGGL((patchify_kernel<float, 8>), grid, dim3(256), 0, st, img, (float*)patches, B, S);
   } else if (P == 16) {
     if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 16>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
