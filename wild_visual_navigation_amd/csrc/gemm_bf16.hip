@@ -353,6 +353,15 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
   return launch_v<EPI, 1, 0>(p, st);
 }
 
+bool use_n384() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WVN_GEMM_N384");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
+
 bool use_a384() {
   static int v = -1;
   if (v < 0) {
@@ -370,6 +379,10 @@ int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return WVN_ERR_ARG;
   if (p.K == 384 && use_a384()) {  // A-stationary kernel for the K = 384 linears (WVN_GEMM_A384=0 disables)
     const int rc = wvn_gemm_a384_launch(p, epi, st);
+    if (rc != WVN_ERR_ARG) return rc;
+  }
+  if (p.N == 384 && p.K > 384 && use_n384()) {  // row-panel kernel for the fc2 residual update (WVN_GEMM_N384=0 disables)
+    const int rc = wvn_gemm_n384_launch(p, epi, st);
     if (rc != WVN_ERR_ARG) return rc;
   }
   switch (epi) {
