@@ -60,3 +60,23 @@ def test_n384_repeatable_under_load(dev):
         again = c0.clone()
         ops.gemm_bf16(a, w, bias, _lib.EPI_RESID_F32, out=again)
         assert torch.equal(again, first)
+
+
+def test_n384_rows_do_not_depend_on_their_position(dev):
+    """With more row blocks than CUs the thin last round is computed by the tiled kernel: a row must get the same bits
+    there as in the row-panel kernel (same k order, same (acc + bias) + C association) -- batch-slot invariance."""
+    K = 1536
+    M = 256 * 260 + 24  # 261 row blocks on 256 CUs: 256 in the row-panel kernel, 5 (the last one ragged) in the tiled kernel
+    a = torch.randn(M, K, generator=g(11)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(384, K, generator=g(12)) * 0.03).to(torch.bfloat16).to(dev)
+    bias = torch.randn(384, generator=g(13)).to(dev)
+    c0 = torch.randn(M, 384, generator=g(14)).to(dev)
+    big = c0.clone()
+    ops.gemm_bf16(a, w, bias, _lib.EPI_RESID_F32, out=big)
+    tail = slice(256 * 256, M)  # rows the big launch left to the tiled kernel
+    small = c0[tail].clone()     # the same rows as a small problem of their own: all in the row-panel kernel
+    ops.gemm_bf16(a[tail], w, bias, _lib.EPI_RESID_F32, out=small)
+    assert torch.equal(big[tail], small)
+    head = c0[:300].clone()
+    ops.gemm_bf16(a[:300], w, bias, _lib.EPI_RESID_F32, out=head)
+    assert torch.equal(big[:300], head)

@@ -382,8 +382,16 @@ int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
     if (rc != WVN_ERR_ARG) return rc;
   }
   if (p.N == 384 && p.K > 384 && use_n384()) {  // row-panel kernel for the fc2 residual update (WVN_GEMM_N384=0 disables)
-    const int rc = wvn_gemm_n384_launch(p, epi, st);
-    if (rc != WVN_ERR_ARG) return rc;
+    int done = 0;
+    const int rc = wvn_gemm_n384_launch(p, epi, st, &done);
+    if (rc != WVN_ERR_ARG) {
+      if (rc != WVN_OK || done >= p.M) return rc;
+      GemmBf16Params rest = p;  // the rows of a thin last round go through the tiled kernel below
+      rest.A = p.A + (size_t)done * p.lda;
+      rest.C = (epi == EPI_RESID_F32 || epi == EPI_ACCUM_F32) ? (void*)((float*)p.C + (size_t)done * p.ldc) : p.C;
+      rest.M = p.M - done;
+      return launch<EPI_RESID_F32>(rest, st);
+    }
   }
   switch (epi) {
     case EPI_BF16: return launch<EPI_BF16>(p, st);

@@ -93,15 +93,13 @@ __global__ __launch_bounds__(512, 2) void gemm_n384_kernel(N384Params p) {
     issue(0);
     if (nk > 1) issue(1);
 
+    // accumulators start at zero and the bias is added after the K loop, then the residual: (acc + bias) + C is the
+    // association of the tiled kernel too, so a row's result does not depend on which of the two kernels computed it
     f32x16_t acc[NTILE];
 #pragma unroll
     for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4_t b4 = *(const f32x4_t*)(bias_l + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b4[e];
-      }
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     for (int i = 0; i < nk; ++i) {
       if (i + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // slice i landed; slice i + 1 (5 DMAs) may be in flight
@@ -149,6 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm_n384_kernel(N384Params p) {
           const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
           *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
         }
+      const f32x4_t b4 = *(const f32x4_t*)(bias_l + 128 * c + (lane & 31) * 4);
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldc + 128 * c) * 4);
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm_n384_kernel(N384Params p) {
         const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff, so, 0);
         u32x4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e] + __uint_as_float(r[e]));
+        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) + __uint_as_float(r[e]));
         __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, cvoff, so, 0);  // rows >= M fall outside num_records: dropped
         if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
@@ -178,24 +177,33 @@ int n384_num_cus() {
 }  // namespace
 
 // Eligibility: N == 384, K % 32 == 0, residual epilogue, 16-byte aligned operands, 32-bit byte offsets;
-// WVN_ERR_ARG otherwise (the caller then uses the generic tiled kernel).
-int wvn_gemm_n384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
+// WVN_ERR_ARG otherwise (the caller then uses the generic tiled kernel).  *rows_done = number of leading rows handled
+// here (a multiple of 256 unless it is M); the caller finishes rows [*rows_done, M).
+int wvn_gemm_n384_launch(const GemmBf16Params& g, int epi, hipStream_t st, int* rows_done) {
   if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
   if (g.N != NN || g.K <= 0 || (g.K % BKS) != 0 || g.M <= 0 || !g.A || !g.W || !g.C) return WVN_ERR_ARG;
   if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 4)) return WVN_ERR_ARG;
   if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15) || ((uintptr_t)g.C & 15)) return WVN_ERR_ARG;
   if ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.M * g.ldc * 4 >= (1ull << 32) || (size_t)NN * g.ldw * 2 >= (1ull << 32))
     return WVN_ERR_ARG;
+  // Row blocks are dealt round-robin to one persistent workgroup per CU; a last round that would occupy less than a
+  // quarter of the CUs is left to the caller's tiled kernel instead (rows are independent): 786 row blocks on 256 CUs
+  // are 3 full rounds here + 18 row blocks there, not 4 rounds.
+  const int ncu = n384_num_cus();
+  int nrb_all = ceil_div(g.M, BM), m_here = g.M;
+  const int full = (nrb_all / ncu) * ncu, rem = nrb_all - full;
+  if (rows_done && full > 0 && rem > 0 && rem * 4 <= ncu) m_here = full * BM;
+  if (rows_done) *rows_done = m_here;
   N384Params p{};
-  p.A = g.A; p.lda = g.lda; p.W = g.W; p.ldw = g.ldw; p.bias = g.bias; p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K;
+  p.A = g.A; p.lda = g.lda; p.W = g.W; p.ldw = g.ldw; p.bias = g.bias; p.C = (float*)g.C; p.ldc = g.ldc; p.M = m_here; p.K = g.K;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_n384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int nrb = ceil_div(g.M, BM);
-  const int grid = nrb < n384_num_cus() ? nrb : n384_num_cus();
+  const int nrb = ceil_div(m_here, BM);
+  const int grid = nrb < ncu ? nrb : ncu;
   hipLaunchKernelGGL(gemm_n384_kernel, dim3(grid), dim3(512), LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
