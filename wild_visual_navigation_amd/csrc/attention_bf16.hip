@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     return 0;
   };
   const long long t_begin = now();
-  auto compute_tile = [&](int kv0, int stage, auto tail_tag) {
+  auto compute_tile = [&](int kv0, int stage, int t_issue, auto tail_tag) {
     constexpr bool MAYBE_TAIL = decltype(tail_tag)::value;
     const long long c0 = now();
     const unsigned char* Ks = lds + stage * 2 * TILE_BYTES + rd_row;
@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
         else st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t_issue >= 0) issue(t_issue);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (TIMING) asm volatile("s_nop 7\ns_nop 7" ::: "memory");
     const long long c1 = now();
     // ---- mask the tail of the last tile ----
@@ -234,10 +237,11 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     if (t + NST - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + NST - 1 < nt) issue(t + NST - 1);
     if constexpr (TIMING) tm[0] += now() - w0;
-    if (t + 1 < nt) compute_tile(t * KVB, t % NST, std::false_type{});
-    else compute_tile(t * KVB, t % NST, std::true_type{});
+    // (the next tile's DMA is requested inside compute_tile, after the QK^T MFMAs have been issued: the four DMA
+    // instructions cost the wave a few hundred cycles of issue time, which then overlap the matrix pipe's work)
+    if (t + 1 < nt) compute_tile(t * KVB, t % NST, t + NST - 1 < nt ? t + NST - 1 : -1, std::false_type{});
+    else compute_tile(t * KVB, t % NST, -1, std::true_type{});
   }
 
   if constexpr (TIMING) {
