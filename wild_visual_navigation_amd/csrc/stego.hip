@@ -142,34 +142,35 @@ __global__ void km_partial_kernel(const float* __restrict__ xn, const int* __res
   for (int i = threadIdx.x; i < K; i += blockDim.x) pcnt[((size_t)b * nchunk + chunk) * K + i] = cn[i];
 }
 
-// cent[b][k][:] = normalise(sum over chunks, ascending) if the cluster is non-empty
-__global__ __launch_bounds__(1024) void km_update_kernel(const float* __restrict__ part, const int* __restrict__ pcnt,
-                                                         float* __restrict__ cent, int C, int K, int nchunk) {
-  extern __shared__ float sums[];  // [K][C] + nrm[K] + cnt[K]
-  float* nrm = sums + K * C;
-  int* cnt = (int*)(nrm + K);
-  const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+// cent[b][k][:] = normalise(sum over chunks, ascending) if the cluster is non-empty.
+// One workgroup per (cluster, frame): thread d adds the chunk partials of (k, d) in ascending chunk order (the loads are
+// independent, only the adds are chained), thread 0 forms the squared norm over d in index order -- the same arithmetic,
+// in the same order, as a single workgroup per frame would do, on K times as many CUs.
+__global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict__ part, const int* __restrict__ pcnt,
+                                                        float* __restrict__ cent, int C, int K, int nchunk) {
+  __shared__ float sums[128];
+  __shared__ float nrm_s;
+  __shared__ int cnt_s;
+  const int k = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  if (d < C) {
     float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s = __fadd_rn(s, part[((size_t)b * nchunk + c) * K * C + i]);
-    sums[i] = s;
+#pragma unroll 7
+    for (int c = 0; c < nchunk; ++c) s = __fadd_rn(s, part[(((size_t)b * nchunk + c) * K + k) * C + d]);
+    sums[d] = s;
   }
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+  if (d == 127) {
     int n = 0;
     for (int c = 0; c < nchunk; ++c) n += pcnt[((size_t)b * nchunk + c) * K + k];
-    cnt[k] = n;
+    cnt_s = n;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+  if (d == 0) {
     float n2 = 0.f;
-    for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(sums[k * C + d], sums[k * C + d]));
-    nrm[k] = fmaxf(__fsqrt_rn(n2), 1e-12f);
+    for (int i = 0; i < C; ++i) n2 = __fadd_rn(n2, __fmul_rn(sums[i], sums[i]));
+    nrm_s = fmaxf(__fsqrt_rn(n2), 1e-12f);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
-    const int k = i / C;
-    if (cnt[k] > 0) cent[(size_t)b * K * C + i] = __fdiv_rn(sums[i], nrm[k]);
-  }
+  if (d < C && cnt_s > 0) cent[((size_t)b * K + k) * C + d] = __fdiv_rn(sums[d], nrm_s);
 }
 
 // compaction of the used ids to 0..K'-1 in ascending order (feature_extractor.py:245-246) + distinct count
@@ -211,8 +212,7 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
     hipLaunchKernelGGL(km_partial_kernel, dim3(nchunk, B), dim3(threads_c), shm_kc + K * sizeof(int), st, xn, labels,
                        part, pcnt, P, C, K, nchunk);
     WVN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(km_update_kernel, dim3(B), dim3(1024), shm_kc + 2 * K * sizeof(float), st, part, pcnt, cent, C, K,
-                       nchunk);
+    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, part, pcnt, cent, C, K, nchunk);
     WVN_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(km_relabel_kernel, dim3(B), dim3(1024), 0, st, labels, nseg, P, K, relabel);
