@@ -67,6 +67,12 @@ size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch);
 int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
                     int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same, for raw 8-bit frames: img [B,3,S,S] uint8 (4-byte aligned).  x/255 is fused into the patch gather, bit-identical
+ * to wvn_vit_forward on img.float()/255 (what quick_start.py:160-161 and ros_converter.py:113-126 hand the reference),
+ * with a quarter of the upload/HBM bytes.  bf16 models with patch 8 only (WVN_ERR_ARG otherwise). */
+int wvn_vit_forward_u8(const wvn_vit_model* m, const unsigned char* img, int batch, float* tokens_f32, void* tokens_lowp,
+                       int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-kernel-category HIP-event timing of wvn_vit_forward (bench.py roofline leg).  Categories:
  * 0 patchify 1 patch_gemm 2 layernorm 3 qkv_gemm 4 attention 5 proj_gemm 6 fc1_gemm 7 fc2_gemm */
 #define WVN_PROF_NCAT 8
@@ -97,6 +103,7 @@ int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, 
 int wvn_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok, int npad,
                       float scale, void* stream);
 int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream);
+int wvn_patchify_u8(const unsigned char* img, void* patches_bf16, int B, int S, int P, void* stream); /* P == 8 */
 int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
 
 /* F.interpolate(features, (H,H), mode="bilinear", align_corners=True) of dino_interface.py:87-90 /
@@ -187,6 +194,30 @@ int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* gra
 /* quick_start.py:194-210 / loss.py:162-164: trav[r] = out[r][0], conf[r] = confidence(mse(out[r][1:], x[r])) */
 int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,
                        float* trav, float* conf, int R, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused per-pixel traversability inference: the live node's per-frame path with prediction_per_pixel
+ * (wvn_feature_extractor_node.py:319-363, quick_start.py:183-210):
+ *   dense = bilinear(align_corners) upsample of the patch tokens to [out_h,out_w]  (dino_interface.py:87-90)
+ *   out   = SimpleMLP(dense rows); trav = out[:,0] (after its sigmoid); conf = confidence(mse(out[:,1:], dense))
+ * without building the dense tensor (308 MB / frame at 448^2) and with layer 1 evaluated at token resolution
+ * (csrc/pixel_mlp.hip).  bf16 MFMA operands, fp32 accumulation: the speed mode; the exact mode is
+ * wvn_upsample_bilinear + wvn_mlp_forward + wvn_mlp_confidence.  D = 384, H1 = 256, H2 = 32 only (0 / WVN_ERR_ARG otherwise).
+ *
+ * packed : wvn_pixel_mlp_pack_bytes() bytes, rebuilt by wvn_pixel_mlp_pack whenever the parameters change
+ *          (the node reloads them at 1 Hz, wvn_feature_extractor_node.py:407-432).
+ * zx     : [batch*grid*grid rows][ldzx >= 640] bf16.  Columns [256,640) hold the final patch tokens on entry (hand
+ *          wvn_vit_forward tokens_lowp = zx + 256, ld_lowp = ldzx); columns [0,256) are scratch (layer-1 pre-activations).
+ * trav / conf / loss_reco : [batch][out_h][out_w] fp32, each may be NULL.  mean/std/std_factor: ConfidenceGenerator state.
+ * Requires 15*(grid-1)/(out-1) < 2 in both directions (out >= ~7.5 x grid: 224/28, 448/56 ...), WVN_ERR_ARG otherwise.
+ * ------------------------------------------------------------------------------------------- */
+#define WVN_PIXEL_ZX_COLS 640
+#define WVN_PIXEL_X_COL 256
+size_t wvn_pixel_mlp_pack_bytes(const wvn_mlp_desc* d);
+int wvn_pixel_mlp_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream);
+int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int ldzx, int batch, int grid, int out_h,
+                        int out_w, float mean, float std, float std_factor, float* trav, float* conf, float* loss_reco,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation (scripts/a384_timing.py, scripts/attn_timing.py): in-kernel s_memtime phase timings of

@@ -62,6 +62,25 @@ def test_batch_invariance_and_chunking(dev):
         assert torch.equal(a, b) and torch.equal(a[3:4], c), prec
 
 
+def test_uint8_frames_equal_float_frames(dev, golden):
+    """Frame ingest: the reference's callers turn 8-bit camera frames into fp32/255 on the host
+    (quick_start.py:160-161, ros_converter.py:113-126); handing the uint8 frame straight to the drop-in classes gives
+    bit-identical features in the bf16 mode (fused) and in the exact mode (converted on the GPU)."""
+    frames = golden("demo_frames_224.pt")["frames_u8"][:2].to(dev)                      # [2,3,224,299]-like uint8
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=5, depth=2)
+    for prec in ("bf16", "fp32"):
+        di = DinoInterface(dev, input_size=224, backbone_type="vit_small", patch_size=8, pretrained_weights=sd, precision=prec)
+        a = di.inference_tokens(frames.float() / 255)
+        b = di.inference_tokens(frames)
+        assert torch.equal(a, b), prec
+    fe = FeatureExtractor(device=dev, segmentation_type="grid", feature_type="dino", patch_size=8, backbone_type="vit_small",
+                          input_size=224, pretrained_weights=sd, precision="bf16")
+    fa = fe.extract(img=frames[:1].float() / 255)
+    fb = fe.extract(img=frames[:1])
+    assert torch.equal(fa[2], fb[2]) and torch.equal(fa[0], fb[0])
+    assert (fa[1] - fb[1]).abs().max().item() < 1e-5      # same tokens; the generic segment mean sums with atomics
+
+
 def test_dino_interface_inference_matches_oracle(dev):
     """Non-square frame like assets/demo_data (299x224): resize(NEAREST)+center-crop, normalise, backbone,
     bilinear(align_corners) to (H, H)."""

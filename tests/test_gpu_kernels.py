@@ -175,6 +175,23 @@ def test_patchify(dev, S, P):
     assert torch.equal(outb.cpu(), bf(out.cpu()))
 
 
+@pytest.mark.parametrize("S", [64, 224, 448])
+def test_patchify_u8_equals_float_path(dev, S):
+    """Frame ingest: raw 8-bit pixels give bit-identical bf16 patches to x.float()/255 through the fp32 entry."""
+    u8 = torch.randint(0, 256, (3, 3, S, S), generator=g(5), dtype=torch.uint8)
+    u8[0, :, :2, :] = 0
+    u8[0, :, 2:4, :] = 255
+    G = S // 8
+    a = torch.empty(3 * G * G, 192, dtype=torch.bfloat16, device=dev)
+    b = torch.empty_like(a)
+    u8d = u8.to(dev)
+    fd = u8d.float() / 255
+    check(lib().wvn_patchify(ptr(fd), ptr(a), 1, 3, S, 8, stream()))
+    check(lib().wvn_patchify_u8(ptr(u8d), ptr(b), 3, S, 8, stream()))
+    assert torch.equal(a, b)
+    assert lib().wvn_patchify_u8(ptr(u8d), ptr(b), 3, S, 16, stream()) == 1001   # P = 8 only
+
+
 @pytest.mark.parametrize("G,H,D", [(8, 64, 40), (28, 224, 90), (56, 448, 384), (14, 100, 33)])
 def test_upsample_bilinear_and_nearest(dev, G, H, D):
     tok = torch.randn(2, G * G, D, generator=g(1))

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "wvn_version": ([], _i),
     "wvn_vit_workspace_bytes": ([_p, _i], _sz),
     "wvn_vit_forward": ([_p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
+    "wvn_vit_forward_u8": ([_p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
     "wvn_prof_enable": ([_i], _i),
     "wvn_prof_collect": ([_p, _p], _i),
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
@@ -61,6 +62,7 @@ _SIGNATURES = {
     "wvn_attention_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "wvn_attention_f32": ([_p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "wvn_patchify": ([_p, _p, _i, _i, _i, _i, _p], _i),
+    "wvn_patchify_u8": ([_p, _p, _i, _i, _i, _p], _i),
     "wvn_cast_f32_to_bf16": ([_p, _p, _ll, _p], _i),
     "wvn_upsample_bilinear": ([_p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_upsample_nearest_i32": ([_p, _p, _i, _i, _i, _p], _i),
@@ -80,6 +82,9 @@ _SIGNATURES = {
     "wvn_mlp_train_phase_b": ([_p, _p, _p, _i, _p, _p, _i, _p, _f, _f, _f, _p, _p, _p, _sz, _p], _i),
     "wvn_mlp_train_phase_c": ([_p, _p, _p, _p, _p, _i, _f, _p, _f, _f, _p, _p], _i),
     "wvn_mlp_confidence": ([_p, _i, _p, _i, _f, _f, _f, _p, _p, _i, _i, _p], _i),
+    "wvn_pixel_mlp_pack_bytes": ([_p], _sz),
+    "wvn_pixel_mlp_pack": ([_p, _p, _p, _p], _i),
+    "wvn_pixel_mlp_infer": ([_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p], _i),
     "wvn_debug_gemm_bf16_timed": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p], _i),
     "wvn_debug_attention_timing": ([_p], _i),
 }

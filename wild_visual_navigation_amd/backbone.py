@@ -136,7 +136,8 @@ class VitBackbone:
 
     def forward_tokens(self, img: torch.Tensor, out: Optional[torch.Tensor] = None,
                        lowp_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """img [B,3,S,S] fp32 in [0,1] -> final-LN patch tokens [B, G*G, D] fp32 (fresh tensor unless
+        """img [B,3,S,S] fp32 in [0,1] (or raw uint8 frames: x/255 is then fused into the patch gather of the
+        bf16 path, bit-identical to passing ``img.float() / 255``) -> final-LN patch tokens [B, G*G, D] fp32 (fresh tensor unless
         ``out`` is given).  ``lowp_out`` (optional, [B*G*G, ld] in the model precision) receives the same
         values for a following MFMA GEMM (STEGO head).  Frames are pushed through in chunks of
         ``max_chunk`` so a chunk's activations stay resident in the 256 MB Infinity Cache."""
@@ -144,7 +145,14 @@ class VitBackbone:
         B, Cc, S, S2 = img.shape
         if Cc != 3 or S != self.img_size or S2 != self.img_size:
             raise _lib.WvnError(f"expected [B,3,{self.img_size},{self.img_size}], got {tuple(img.shape)}")
-        img = img.contiguous().float()
+        u8 = img.dtype == torch.uint8 and self.precision == _lib.PREC_BF16 and self.patch == 8
+        if u8:
+            img = img.contiguous()
+        elif img.dtype == torch.uint8:
+            img = img.contiguous().float() / 255
+        else:
+            img = img.contiguous().float()
+        fwd, fwd_name = (self.lib.wvn_vit_forward_u8, "wvn_vit_forward_u8") if u8 else (self.lib.wvn_vit_forward, "wvn_vit_forward")
         P = self.grid * self.grid
         if out is None:
             out = torch.empty(B, P, self.dim, dtype=torch.float32, device=self.device)
@@ -158,9 +166,8 @@ class VitBackbone:
             if lowp_out is not None:
                 ld = lowp_out.stride(0)
                 lp = lowp_out.data_ptr() + b0 * P * ld * esz
-            rc = self.lib.wvn_vit_forward(C.byref(self.model), img[b0:].data_ptr(), nb, out[b0:].data_ptr(), lp, ld,
-                                          ws.data_ptr(), ws.numel(), st)
-            _lib.check(rc, "wvn_vit_forward")
+            rc = fwd(C.byref(self.model), img[b0:].data_ptr(), nb, out[b0:].data_ptr(), lp, ld, ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, fwd_name)
         return out
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:

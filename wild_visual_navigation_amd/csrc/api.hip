@@ -99,8 +99,24 @@ size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch) {
   return vit_carve(d, nullptr).total;
 }
 
+static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, int batch, float* tokens_f32,
+                            void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
+
 int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
                     int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
+  return vit_forward_impl(m, img, 0, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
+}
+
+int wvn_vit_forward_u8(const wvn_vit_model* m, const unsigned char* img, int batch, float* tokens_f32, void* tokens_lowp,
+                       int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
+  if (m && m->precision != WVN_PREC_BF16) return WVN_ERR_ARG;
+  return vit_forward_impl(m, img, 1, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, int batch, float* tokens_f32,
+                            void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
   if (!m || !img || !workspace || batch <= 0) return WVN_ERR_ARG;
   if (m->dim != m->heads * 64 || m->depth <= 0 || m->depth > WVN_MAX_DEPTH || m->img_size % m->patch) return WVN_ERR_ARG;
   if (m->dim % 128 || m->mlp_dim % 128) return WVN_ERR_ARG;
@@ -113,7 +129,7 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
   const float scale = 1.0f / sqrtf(64.f);
   const int M = (int)d.M, Mp = (int)d.Mp;
 
-  { Span s(0, st); RET_IF(wvn_patchify_launch(img, w.patches, bf, d.B, d.S, d.P, st)); }
+  { Span s(0, st); RET_IF(wvn_patchify_launch(img, img_u8, w.patches, bf, d.B, d.S, d.P, st)); }
   RET_IF(wvn_cls_rows_launch(m->cls_pos, w.x, d.B, d.ntok_s, d.D, st));
   {
     // Padding hygiene, every call (the carve depends on the batch, so a reused workspace holds stale bytes):
@@ -220,6 +236,8 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
   return WVN_OK;
 }
 
+extern "C" {
+
 // ---------------------------------------------------------------------------------------------
 // building blocks
 // ---------------------------------------------------------------------------------------------
@@ -268,7 +286,11 @@ int wvn_attention_f32(const float* q, const float* k, const float* v, float* out
   return wvn_attention_f32_launch(q, k, v, out, B, heads, ntok, ntok, npad, scale, (hipStream_t)stream);
 }
 int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream) {
-  return wvn_patchify_launch(img, patches, out_is_bf16, B, S, P, (hipStream_t)stream);
+  return wvn_patchify_launch(img, 0, patches, out_is_bf16, B, S, P, (hipStream_t)stream);
+}
+
+int wvn_patchify_u8(const unsigned char* img, void* patches_bf16, int B, int S, int P, void* stream) {
+  return wvn_patchify_launch(img, 1, patches_bf16, 1, B, S, P, (hipStream_t)stream);
 }
 int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
   if (!src || !dst || n <= 0 || n > 0x7fffffffll) return WVN_ERR_ARG;
@@ -445,6 +467,23 @@ int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* gra
   RET_IF(wvn_adam_launch(params, grads, adam_m, adam_v, (int)o.total, step, lr, 0.9f, 0.999f, 1e-8f, st));
   if (losses) RET_IF(wvn_mlp_losses_launch(stats, grads + o.total, w_trav, w_reco, losses, st));
   return WVN_OK;
+}
+
+// fused per-pixel inference (pixel_mlp.hip)
+size_t wvn_pixel_mlp_pack_bytes(const wvn_mlp_desc* d) {
+  if (!d || d->D != 384 || d->H1 != 256 || d->H2 != 32) return 0;
+  return wvn_pixel_mlp_pack_bytes_impl();
+}
+int wvn_pixel_mlp_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream) {
+  if (!d) return WVN_ERR_ARG;
+  return wvn_pixel_mlp_pack_launch(d->D, d->H1, d->H2, params, packed, (hipStream_t)stream);
+}
+int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int ldzx, int batch, int grid, int out_h,
+                        int out_w, float mean, float std, float std_factor, float* trav, float* conf, float* loss_reco,
+                        void* stream) {
+  if (!d) return WVN_ERR_ARG;
+  return wvn_pixel_mlp_infer_launch(d->D, d->H1, d->H2, packed, zx, ldzx, batch, grid, out_h, out_w, mean, std, std_factor,
+                                    trav, conf, loss_reco, (hipStream_t)stream);
 }
 
 int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,

@@ -38,16 +38,24 @@ __global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ o
 // as float4 (fully coalesced, 43 KB), normalised, converted, and scattered into an LDS image that already has the output
 // order [gx][c][py][px]; the 21 KB image then leaves as contiguous 16-byte stores (the element-order kernel above writes
 // 16-byte fragments 384 B apart).
-__global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
-                                                                   int S) {
+template <typename TIN>  // float: pixels in [0,1]; unsigned char: raw 8-bit pixels, x / 255 is fused (frame ingest without the
+                         // 4x larger fp32 upload: quick_start.py:160-161 / ros_converter.py:113-126 do the division on the host side)
+__global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const TIN* __restrict__ img, bf16_t* __restrict__ out, int S) {
   extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192]
   const int G = S / 8, gy = blockIdx.x, b = blockIdx.y;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
-  const int q = S / 4;  // float4 per image row
+  const int q = S / 4;  // 4-pixel groups per image row
   for (int i = threadIdx.x; i < 3 * 8 * q; i += 256) {
     const int c = i / (8 * q), r = i - c * 8 * q, py = r / q, x4 = r - py * q;
-    const f32x4_t v = *(const f32x4_t*)(img + (((size_t)b * 3 + c) * S + gy * 8 + py) * S + x4 * 4);
+    const size_t src = (((size_t)b * 3 + c) * S + gy * 8 + py) * S + x4 * 4;
+    f32x4_t v;
+    if constexpr (sizeof(TIN) == 1) {
+      const uchar4 u = *(const uchar4*)(img + src);
+      v = f32x4_t{(float)u.x / 255.0f, (float)u.y / 255.0f, (float)u.z / 255.0f, (float)u.w / 255.0f};  // == torch's x.float() / 255
+    } else {
+      v = *(const f32x4_t*)(img + src);
+    }
     const int gx = x4 >> 1, px = (x4 & 1) * 4;
     const float m = mean[c], sd = stdv[c];
     u32x2_t o = {pack_bf16x2((v[0] - m) / sd, (v[1] - m) / sd), pack_bf16x2((v[2] - m) / sd, (v[3] - m) / sd)};
@@ -174,14 +182,24 @@ __global__ void upsample_nearest_i32_kernel(const int* __restrict__ lab, int* __
 
 }  // namespace
 
-int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, int S, int P, hipStream_t st) {
+int wvn_patchify_launch(const void* img_v, int img_u8, void* patches, int out_bf16, int B, int S, int P, hipStream_t st) {
+  const float* img = (const float*)img_v;
+  if (img_u8) {  // 8-bit frames: bf16 / P = 8 row-panel kernel only
+    if (!img_v || !patches || !out_bf16 || P != 8 || (S % 8) != 0 || (((uintptr_t)img_v & 3) != 0) || (((uintptr_t)patches & 15) != 0) ||
+        (S / 8) * 192 * 2 > 64 * 1024)
+      return WVN_ERR_ARG;
+    hipLaunchKernelGGL(patchify8_bf16_rows_kernel<unsigned char>, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st,
+                       (const unsigned char*)img_v, (bf16_t*)patches, S);
+    WVN_LAUNCH_CHECK();
+    return WVN_OK;
+  }
   if (!img || !patches || S % P != 0) return WVN_ERR_ARG;
   const int G = S / P;
   long long total = (long long)B * G * G * 3 * P;
   dim3 grid((unsigned)((total + 255) / 256));
   if (P == 8) {
     if (out_bf16 && (S % 8) == 0 && (((uintptr_t)img | (uintptr_t)patches) & 15) == 0 && (S / 8) * 192 * 2 <= 64 * 1024)
-      hipLaunchKernelGGL(patchify8_bf16_rows_kernel, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st, img, (bf16_t*)patches, S);
+      hipLaunchKernelGGL(patchify8_bf16_rows_kernel<float>, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st, img, (bf16_t*)patches, S);
     else if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 8>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
     else hipLaunchKernelGGL((patchify_kernel<float, 8>), grid, dim3(256), 0, st, img, (float*)patches, B, S);
   } else if (P == 16) {

@@ -60,7 +60,8 @@ struct GemmF32Params {
 int wvn_gemm_f32_launch(const GemmF32Params& p, int epi, hipStream_t st);
 
 // ---- elementwise / normalisation (elementwise.hip) --------------------------------------------
-int wvn_patchify_launch(const float* img, void* patches, int out_bf16, int B, int S, int P, hipStream_t st);
+// img: fp32 in [0,1], or raw uint8 pixels when img_u8 != 0 (bf16 output, P == 8 only)
+int wvn_patchify_launch(const void* img, int img_u8, void* patches, int out_bf16, int B, int S, int P, hipStream_t st);
 int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok_s, int D, hipStream_t st);
 // zero bytes [col0, col0 + ncol) of each of nrows rows (all multiples of 4)
 int wvn_pad_zero_launch(void* base, long long nrows, long long row_stride_bytes, long long col0_bytes,
@@ -113,3 +114,10 @@ int wvn_segpool_patch_launch(const int* labels, const float* tok, int ldf, const
                              float* feat, int B, int G, int S, int D, hipStream_t st);
 int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, int B, int P, int S, int D,
                               hipStream_t st);
+
+// ---- fused per-pixel traversability inference (pixel_mlp.hip) ------------------------------------
+size_t wvn_pixel_mlp_pack_bytes_impl();
+int wvn_pixel_mlp_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st);
+int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* zx, int ldzx, int B, int G, int out_h,
+                               int out_w, float mean, float std, float std_factor, float* trav, float* conf, float* loss,
+                               hipStream_t st);

@@ -86,7 +86,8 @@ class FeatureExtractor:
     # ------------------------------------------------------------------------------------------ extract
     @torch.no_grad()
     def extract(self, img: torch.Tensor, **kwargs):
-        """feature_extractor.py:95-128.  img [1,3,H,W] fp32 in [0,1].
+        """feature_extractor.py:95-128.  img [1,3,H,W] fp32 in [0,1], or the raw uint8 frame (then x/255 is fused into
+        the backbone's patch gather: same features, a quarter of the upload).
         Returns (edges [2,E] i64, feat [S,D] f32, seg [H,W] i64, center [S,2] f32, dense [1,D,H,H] | None)."""
         img = img.to(self._device)
         want_dense = kwargs.get("return_dense_features", False)
@@ -145,6 +146,30 @@ class FeatureExtractor:
         return feat, seg, nseg
 
     # ------------------------------------------------------------------------------------------ pieces
+    @torch.no_grad()
+    def predict_per_pixel(self, img: torch.Tensor, model, confidence_generator=None, want_loss: bool = False):
+        """The live node's per-frame prediction with ``prediction_per_pixel`` (wvn_feature_extractor_node.py:311-363;
+        quick_start.py:176-210) in one call: img [B,3,H,W] (fp32 in [0,1] or uint8) -> (trav [B,H,H], conf [B,H,H],
+        loss_reco | None).  Equivalent to ``extract(..., return_dense_features=True)`` -> ``model.forward(Data(x=dense
+        rows))`` -> column 0 / ``confidence_generator.inference_without_update(mse(pred[:, 1:], x))``, but the dense
+        [B,384,H,H] tensor is never built and layer 1 runs at patch resolution (csrc/pixel_mlp.hip).  bf16 DINO
+        features only.  Like the reference (dino_interface.py:87-90) the map is H x H for an H x W frame."""
+        if self._feature_type != "dino":
+            raise _lib.WvnError("predict_per_pixel: dino features only")
+        bb = self._extractor._model
+        if bb.lowp_dtype != torch.bfloat16:
+            raise _lib.WvnError("predict_per_pixel is the bf16 speed path; use extract + model.forward in exact mode")
+        img = img.to(self._device)
+        B, H = img.shape[0], img.shape[2]
+        G = self._grid()
+        zx = torch.empty(B * G * G, model.ZX_COLS, dtype=torch.bfloat16, device=self._device)
+        from .transforms import resize_nearest_center_crop
+        bb.forward_tokens(resize_nearest_center_crop(img, self._extractor.input_size), lowp_out=zx[:, model.X_COL:])
+        mean, std, f = 0.0, 1.0, 0.5
+        if confidence_generator is not None:
+            mean, std, f = float(confidence_generator.mean), float(confidence_generator.std), float(confidence_generator.std_factor)
+        return model.forward_per_pixel(zx, B, G, (H, H), mean, std, f, want_loss=want_loss)
+
     def _grid(self) -> int:
         return self._extractor.grid
 
@@ -199,7 +224,8 @@ class FeatureExtractor:
         import numpy as np
 
         img_np = img[0].permute(1, 2, 0).cpu().numpy()
-        seg = self.slic.iterate(np.uint8(np.ascontiguousarray(img_np) * 255))[None, None]
+        u8 = img_np if img_np.dtype == np.uint8 else np.uint8(np.ascontiguousarray(img_np) * 255)
+        seg = self.slic.iterate(np.ascontiguousarray(u8))[None, None]
         return torch.from_numpy(seg).to(self._device).type(torch.long)
 
     def segment_random(self, img, **kwargs):

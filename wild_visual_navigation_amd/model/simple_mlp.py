@@ -34,6 +34,7 @@ class SimpleMLP(torch.nn.Module):
         self.desc = _lib.MlpDesc(input_size, hidden_sizes[0], hidden_sizes[1], 0)
         self._flat: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
+        self._pix_packed: Optional[torch.Tensor] = None
 
     # ---- flat parameter storage --------------------------------------------------------------------
     def _params_in_order(self):
@@ -82,3 +83,42 @@ class SimpleMLP(torch.nn.Module):
                                         out.data_ptr(), 0, 0, ws.data_ptr(), ws.numel(), _lib.stream())
         _lib.check(rc, "wvn_mlp_forward")
         return out
+
+    # ---- fused per-pixel inference ---------------------------------------------------
+    ZX_COLS, X_COL = 640, 256   # include/wvn_hip.h: WVN_PIXEL_ZX_COLS / WVN_PIXEL_X_COL
+
+    def pack_per_pixel(self) -> torch.Tensor:
+        """Re-pack the current parameters for ``forward_per_pixel`` (bf16, MFMA fragment order).  Call after every
+        parameter change (the node reloads weights at 1 Hz, wvn_feature_extractor_node.py:407-432)."""
+        flat = self.flat_params()
+        _lib.require_cuda(flat, "parameters")
+        n = _lib.lib().wvn_pixel_mlp_pack_bytes(C.byref(self.desc))
+        if n == 0:
+            raise _lib.WvnError("fused per-pixel inference needs SimpleMLP(384, [256, 32, 1], reconstruction=True)")
+        if self._pix_packed is None or self._pix_packed.device != flat.device:
+            self._pix_packed = torch.empty(n, dtype=torch.uint8, device=flat.device)
+        rc = _lib.lib().wvn_pixel_mlp_pack(C.byref(self.desc), flat.data_ptr(), self._pix_packed.data_ptr(), _lib.stream())
+        _lib.check(rc, "wvn_pixel_mlp_pack")
+        return self._pix_packed
+
+    @torch.no_grad()
+    def forward_per_pixel(self, zx: torch.Tensor, batch: int, grid: int, out_hw, mean: float = 0.0, std: float = 1.0,
+                          std_factor: float = 0.5, want_loss: bool = False, repack: bool = True):
+        """What wvn_feature_extractor_node.py:319-363 computes with prediction_per_pixel -- upsample, forward, column 0,
+        reconstruction confidence -- from the PATCH tokens, without the dense feature tensor:
+        ``zx`` [batch*grid*grid, 640] bf16 with the tokens in columns [256, 640) (columns [0, 256) are scratch) ->
+        (trav [batch,H,W], conf [batch,H,W], loss_reco [batch,H,W] | None), fp32."""
+        _lib.require_cuda(zx, "zx")
+        if zx.dtype != torch.bfloat16 or zx.dim() != 2 or zx.shape[0] != batch * grid * grid or zx.stride(1) != 1 \
+                or zx.shape[1] < self.ZX_COLS:
+            raise _lib.WvnError(f"zx must be bf16 [batch*grid*grid, >= {self.ZX_COLS}], got {tuple(zx.shape)} {zx.dtype}")
+        packed = self.pack_per_pixel() if (repack or self._pix_packed is None) else self._pix_packed
+        H, W = out_hw
+        trav = torch.empty(batch, H, W, dtype=torch.float32, device=zx.device)
+        conf = torch.empty_like(trav)
+        loss = torch.empty_like(trav) if want_loss else None
+        rc = _lib.lib().wvn_pixel_mlp_infer(C.byref(self.desc), packed.data_ptr(), zx.data_ptr(), zx.stride(0), batch, grid,
+                                            H, W, float(mean), float(std), float(std_factor), trav.data_ptr(),
+                                            conf.data_ptr(), loss.data_ptr() if want_loss else 0, _lib.stream())
+        _lib.check(rc, "wvn_pixel_mlp_infer")
+        return trav, conf, loss
