@@ -117,6 +117,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// D = 384 with bf16 output (LN1 / LN2 of every ViT-S block: 24 launches per forward, HBM-bound at 1536 B read + 768 B
+// written per row).  16 lanes per row, each lane owns 3 groups of 8 consecutive columns: every access is a 16-byte load or
+// store, a wave handles 4 rows per pass and LN_RPW rows in all (gamma / beta stay in registers).  Same two-pass fp32
+// statistics as the generic kernel.
+constexpr int LN_RPW = 16;
+__global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                int ldy, int rows, float eps) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, rsel = lane >> 4;
+  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  f32x4_t gm[6], bt[6];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gm[2 * i] = *(const f32x4_t*)(gamma + 128 * i + 8 * sub);
+    gm[2 * i + 1] = *(const f32x4_t*)(gamma + 128 * i + 8 * sub + 4);
+    bt[2 * i] = *(const f32x4_t*)(beta + 128 * i + 8 * sub);
+    bt[2 * i + 1] = *(const f32x4_t*)(beta + 128 * i + 8 * sub + 4);
+  }
+  auto sum16 = [](float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+#pragma unroll 2
+  for (int it = 0; it < LN_RPW / 4; ++it) {
+    const int row = wg * LN_RPW + it * 4 + rsel;
+    const bool ok = row < rows;
+    const float* xr = x + (size_t)(ok ? row : rows - 1) * 384 + 8 * sub;
+    f32x4_t v[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[2 * i] = *(const f32x4_t*)(xr + 128 * i);
+      v[2 * i + 1] = *(const f32x4_t*)(xr + 128 * i + 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = sum16(s) / 384.f;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    const float rstd = 1.0f / sqrtf(sum16(q) / 384.f + eps);
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[2 * i + (e >> 2)][e & 3] - mean) * rstd * gm[2 * i + (e >> 2)][e & 3] + bt[2 * i + (e >> 2)][e & 3];
+        const u32x4_t u = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *(u32x4_t*)(y + (size_t)row * ldy + 128 * i + 8 * sub) = u;
+      }
+    }
+  }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd,
                                      int rows, int cols) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,6 +319,13 @@ int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, 
                          float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
                          int ntok_s, hipStream_t st) {
   if (!x || !gamma || !beta || (D % 64) != 0 || rows_out <= 0) return WVN_ERR_ARG;
+  if (y_bf16 && y && !y2 && !drop_cls && D == 384 && (ldy % 8) == 0 &&
+      ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0) {
+    hipLaunchKernelGGL(layernorm384_bf16_kernel, dim3(ceil_div(rows_out, 4 * LN_RPW)), dim3(256), 0, st, x, gamma, beta,
+                       (bf16_t*)y, ldy, rows_out, eps);
+    WVN_LAUNCH_CHECK();
+    return WVN_OK;
+  }
   if (y_bf16) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, st);
   return ln_dispatch<float>(x, gamma, beta, (float*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, st);
 }
