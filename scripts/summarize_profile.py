@@ -3,6 +3,7 @@
 
     python scripts/summarize_profile.py stats  <dir with *_kernel_stats.csv>        > profiles/rNN_kernel_stats.md
     python scripts/summarize_profile.py pmc    <dir with *_counter_collection.csv>... > profiles/rNN_pmc.md
+    python scripts/summarize_profile.py db     <rocprofv3 *_results.db (rocpd sqlite)>   > profiles/rNN_kernel_stats.md
 
 `pmc` averages every counter per kernel over its dispatches (rocprofv3 sums over XCDs / SEs: GRBM_GUI_ACTIVE
 is the sum over the 8 XCDs).  FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE
@@ -28,6 +29,16 @@ def stats(d):
     for r in rows[:24]:
         print(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
               f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+
+
+def db(path):
+    """rocprofv3's default output in ROCm 7.2 is a rocpd sqlite file; its `top_kernels` view is the --stats table."""
+    import sqlite3
+
+    c = sqlite3.connect(path)
+    print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+    for name, calls, total, avg, pct in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 28"):
+        print(f"| `{short(name)}` | {calls} | {total / 1e3:.3f} | {avg:.1f} | {pct:.2f} |")
 
 
 def pmc(dirs):
@@ -62,5 +73,7 @@ def pmc(dirs):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "db":
+        db(sys.argv[2])
     else:
         pmc(sys.argv[2:])
