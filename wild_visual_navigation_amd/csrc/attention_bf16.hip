@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
 
   // tile loop: wait for tile t (NST - 2 younger tiles may stay in flight), barrier (everyone has the tile and
   // has finished reading tile t - 1, whose slot the next DMA overwrites), issue tile t + NST - 1, compute
-  for (int t = 0; t < nt; ++t) {
+  // The last tile (the only one that may need masking) is peeled: with both instantiations of compute_tile inside one
+  // loop body hipcc gave the O^T accumulators different registers on the two paths and copied all 32 of them twice per
+  // tile (32 v_mov_b64 that also wait for the PV MFMAs to drain).
+  for (int t = 0; t + 1 < nt; ++t) {
     const long long w0 = now();
     if (t + NST - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -240,8 +243,14 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     if constexpr (TIMING) tm[0] += now() - w0;
     // (the next tile's DMA is requested inside compute_tile, after the QK^T MFMAs have been issued: the four DMA
     // instructions cost the wave a few hundred cycles of issue time, which then overlap the matrix pipe's work)
-    if (t + 1 < nt) compute_tile(t * KVB, t % NST, t + NST - 1 < nt ? t + NST - 1 : -1, std::false_type{});
-    else compute_tile(t * KVB, t % NST, -1, std::true_type{});
+    compute_tile(t * KVB, t % NST, t + NST - 1 < nt ? t + NST - 1 : -1, std::false_type{});
+  }
+  {
+    const long long w0 = now();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (TIMING) tm[0] += now() - w0;
+    compute_tile((nt - 1) * KVB, (nt - 1) % NST, -1, std::true_type{});
   }
 
   if constexpr (TIMING) {
