@@ -97,7 +97,10 @@ int wvn_layernorm(const float* x, const float* gamma, const float* beta, void* y
  * bf16 path: V^T is stored with the tokens of every aligned group of 16 permuted -- position
  * 16G + 8h + 4a + e holds token 16G + 8a + 4h + e (bits 2 and 3 of the token index swapped; order
  * 0-3, 8-11, 4-7, 12-15) -- so that the 8 keys a half-wave multiplies with are one 16-byte LDS read.
- * The QKV projection epilogues of wvn_vit_forward write this layout. */
+ * The QKV projection epilogues of wvn_vit_forward write this layout.
+ * scale > 0: q holds the raw projections, scores = scale * q.k.  scale == 0 (bf16 path only): q is already multiplied by
+ * softmax_scale * log2(e) (wvn_vit_forward's QKV epilogue does that before rounding q to bf16); the kernel then feeds the
+ * running max into the S^T MFMA chain as its C operand and the accumulators come out as exp2 arguments. */
 int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad,
                        float scale, void* stream);
 int wvn_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok, int npad,

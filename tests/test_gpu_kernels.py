@@ -136,18 +136,30 @@ def test_attention_f32(dev, ntok):
     assert (out.cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("ntok", [65, 197, 785, 130, 3137])
-def test_attention_bf16(dev, ntok):
+def test_attention_bf16(dev, ntok, prescaled):
+    """prescaled: q carries softmax_scale * log2(e) (what wvn_vit_forward's QKV epilogue writes) and the kernel is called
+    with scale = 0 -- the variant with the running max as the S^T MFMA's C operand.  The reference is computed from the
+    q the kernel actually sees."""
     B, h, scale = (1, 2, 0.125) if ntok > 1000 else (2, 3, 0.125)
     q, k, v = (bf(torch.randn(B, h, ntok, 64, generator=g(s))) for s in (1, 2, 3))
+    if ntok == 197:
+        q[0, 0, 5] = bf(q[0, 0, 5] * 40)      # a row whose scores sit far from 0 on the first tile (either sign)
+        k[0, 0, :64] = bf(-q[0, 0, 5][None] * 0.1 + 0.01 * k[0, 0, :64])
+    c = scale * 1.4426950408889634
+    q_in = bf(q * c) if prescaled else q
+    if prescaled:
+        q = q_in / c
     k[0, 1, ntok // 2] = bf(k[0, 1, ntok // 2].float() * 6.0)
     k[0, 0, ntok - 1] = bf(k[0, 0, ntok - 1].float() * 5.0)  # spike in the (masked-tail) last tile
     npad = (ntok + 127) // 128 * 128  # padding: large FINITE garbage (the bf16 kernel's contract, wvn_hip.h)
     perm = ops.vt_token_order(npad)  # the kernel's V^T layout: tokens permuted inside groups of 16
     vt = _pad(v, npad, 1e3).transpose(-1, -2)[..., perm].contiguous().to(dev)  # [B,h,64,npad]
     out = torch.empty(B * ntok, h * 64, dtype=torch.bfloat16, device=dev)
-    qd, kd = _pad(q, npad, 1e3).to(dev), _pad(k, npad, -1e3).to(dev)
-    check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(vt), ptr(out), B, h, ntok, npad, scale, stream()))
+    qd, kd = _pad(q_in, npad, 1e3 * (c if prescaled else 1)).to(dev), _pad(k, npad, -1e3).to(dev)
+    kscale = 0.0 if prescaled else scale
+    check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(vt), ptr(out), B, h, ntok, npad, kscale, stream()))
     ref = _attn_ref(q.float(), k.float(), v.float(), scale).permute(0, 2, 1, 3).reshape(B * ntok, h * 64)
     err = (out.float().cpu().double() - ref).abs().max().item()
     # P is rounded to bf16 before PV (rel 2^-9 per term, averaging down) and O to bf16 on store
@@ -156,7 +168,7 @@ def test_attention_bf16(dev, ntok):
     v1 = torch.ones(B, h, npad, 64, dtype=torch.bfloat16)
     v1[:, :, ntok:] = 0
     v1t = v1.transpose(-1, -2)[..., perm].contiguous().to(dev)
-    check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(v1t), ptr(out), B, h, ntok, npad, scale, stream()))
+    check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(v1t), ptr(out), B, h, ntok, npad, kscale, stream()))
     assert (out.float().cpu() - 1.0).abs().max().item() < 1e-2
 
 
@@ -281,18 +293,19 @@ def test_kmeans_bit_exact(dev, P, C, K):
         assert np.array_equal(lab2[b].cpu().numpy(), want)
 
 
-def test_attention_bf16_repeatable(dev):
+@pytest.mark.parametrize("kscale", [0.125, 0.0])
+def test_attention_bf16_repeatable(dev, kscale):
     """Race screen for the DMA ring / counted-vmcnt pipeline of the bf16 attention kernel: many workgroups per CU,
     full-length sequence, other kernels in between -- 20 repeats must be bit-identical (a stale K/V tile or an
     accumulator read before its MFMA retired shows up as ulp-level run-to-run differences)."""
     B, h, ntok, npad = 2, 6, 3137, 3200
-    q, k = (bf(torch.randn(B, h, npad, 64, generator=g(s))).to(dev) for s in (1, 2))
+    q, k = (bf(torch.randn(B, h, npad, 64, generator=g(s)) * (0.18 if (kscale == 0 and s == 1) else 1)).to(dev) for s in (1, 2))
     vt = bf(torch.randn(B, h, 64, npad, generator=g(3))).to(dev)
     first = torch.empty(B * ntok, h * 64, dtype=torch.bfloat16, device=dev)
-    check(lib().wvn_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(first), B, h, ntok, npad, 0.125, stream()))
+    check(lib().wvn_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(first), B, h, ntok, npad, kscale, stream()))
     junk = torch.randn(16 * 1024 * 1024, device=dev)
     for _ in range(20):
         junk.mul_(1.0001)
         out = torch.empty_like(first)
-        check(lib().wvn_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(out), B, h, ntok, npad, 0.125, stream()))
+        check(lib().wvn_attention_bf16(ptr(q), ptr(k), ptr(vt), ptr(out), B, h, ntok, npad, kscale, stream()))
         assert torch.equal(out, first)

@@ -6,6 +6,8 @@
 #include <vector>
 
 #include "../../include/wvn_hip.h"
+#include <cstdlib>
+
 #include "common.h"
 #include "wvn_internal.h"
 
@@ -127,6 +129,10 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
   const bool bf = m->precision == WVN_PREC_BF16;
   const float scale = 1.0f / sqrtf(64.f);
+  // bf16: the softmax scale is folded into q by the QKV epilogue and attention takes the running max as an MFMA operand
+  // (attention_bf16.hip, PRE).  WVN_ATTN_PRE=0 keeps the raw-q kernel (A/B switch).
+  static const bool attn_pre_env = [] { const char* e = getenv("WVN_ATTN_PRE"); return !e || atoi(e) != 0; }();
+  const bool attn_pre = bf && attn_pre_env;
   const int M = (int)d.M, Mp = (int)d.Mp;
 
   { Span s(0, st); RET_IF(wvn_patchify_launch(img, img_u8, w.patches, bf, d.B, d.S, d.P, st)); }
@@ -171,6 +177,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
         p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.qkv_w; p.ldw = d.D; p.bias = L.qkv_b;
         p.M = M; p.N = 3 * d.D; p.K = d.D; p.q = (bf16_t*)w.q; p.k = (bf16_t*)w.k; p.vt = (bf16_t*)w.v;
         p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
+        if (attn_pre) p.q_scale = scale * 1.44269504088896340736f;  // q leaves the epilogue as an exp2 argument
         RET_IF(wvn_gemm_bf16_launch(p, EPI_QKV, st));
       } else {
         GemmF32Params p{};
@@ -182,7 +189,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     }
     {
       Span s(4, st);
-      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
+      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, attn_pre ? 0.f : scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
     {

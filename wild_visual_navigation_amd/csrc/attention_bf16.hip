@@ -49,6 +49,7 @@ constexpr int DH = 64;             // head dim
 constexpr int TILE_BYTES = KVB * DH * 2;  // 8 KB (K tile; V^T tile is the same size)
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
 
 // The softmax is bounded by per-wave VALU issue, so instruction count matters: the row max uses 3-input max.
 // This file is compiled with -fno-honor-nans so that fmaxf on MFMA results needs no canonicalising v_max (scores
@@ -56,7 +57,10 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // statement's operands (a v_max3 in asm read accumulator registers before the MFMA had written them).
 __device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-template <int NST, bool XCDMAP, int OCC, bool TIMING = false>
+// PRE: q arrives pre-multiplied by scale * log2(e) (the QKV GEMM epilogue does it before rounding to bf16, so no extra
+// rounding) and the running max enters the S^T MFMA chain as its C operand (a 16-register block holding -M, rewritten
+// only when the max moves): the accumulators come out as exp2 arguments and the 16 v_pk_fma per tile disappear.
+template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false>
 __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* __restrict__ q,
                                                                   const bf16_t* __restrict__ k,
                                                                   const bf16_t* __restrict__ vt,
@@ -122,11 +126,18 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = PRE ? 0.f : -1e30f, l_run = 0.f;  // PRE: the running max in exp2 units (0 until the first tile sets it)
+  f32x16_t cneg;                                  // PRE: -m_run in every register (C operand of the S^T chains)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
+  bool fresh = true;                              // PRE: no tile processed yet (wave-uniform)
 
   // per-lane read offset inside a tile: row l31 (+32 per sub-tile), chunk XOR key (row >> 1) & 7 (same for row+32)
   const unsigned rd_row = l31 * 128;
   const int xorc = (l31 >> 1) & 7;
+  unsigned rdo[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rdo[s] = rd_row + (((2 * s + hi) ^ xorc) << 4);
 
   long long tm[5] = {0, 0, 0, 0, 0};  // TIMING: wait+barrier+issue, QK^T, softmax, PV, total
   auto now = [&]() -> long long {
@@ -137,8 +148,15 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
   auto compute_tile = [&](int kv0, int stage, int t_issue, auto tail_tag) {
     constexpr bool MAYBE_TAIL = decltype(tail_tag)::value;
     const long long c0 = now();
-    const unsigned char* Ks = lds + stage * 2 * TILE_BYTES + rd_row;
-    const unsigned char* Vs = Ks + TILE_BYTES;
+    // four per-lane addresses per tile (stage base + swizzled chunk of row l31); every fragment read below is one of them
+    // plus an immediate (K sub-tile +4096, V^T +8192, +12288).  Opaque to the optimiser, which otherwise re-derives an
+    // address per ds_read (16 v_add3_u32 per tile).
+    unsigned fa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fa[s] = rdo[s] + (unsigned)(stage * 2 * TILE_BYTES);
+      asm volatile("" : "+v"(fa[s]));
+    }
 
     // ---- S^T = K Q^T : two 32-key sub-tiles (first MFMA of each chain takes a literal-zero C) ----
     f32x16_t st[2];
@@ -146,8 +164,8 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Ks + t * 4096 + (((2 * s + hi) ^ xorc) << 4));
-        if (s == 0) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], (f32x16_t)(0.f), 0, 0, 0);
+        const bf16x8_t kf = *(const bf16x8_t*)(lds + fa[s] + t * 4096);
+        if (s == 0) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], PRE ? cneg : (f32x16_t)(0.f), 0, 0, 0);
         else st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
       }
     }
@@ -182,31 +200,53 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     // exp2 units).  P is then bounded by 2^THR instead of 1 -- harmless in fp32 accumulators, and P / l cancel
     // exactly the same factor -- and the wave-uniform O rescale almost never runs after the first tiles.
     constexpr float THR = 6.0f;
-    if (__any((mt - m_run) * c_exp > THR)) {
-      const float m_new = fmaxf(m_run, mt);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
-      m_run = m_new;
-      l_run *= alpha;
+    float lacc0 = 0.f, lacc1 = 0.f;  // row sum of the bf16-rounded P (what the PV MFMA multiplies), v_dot2c_f32_bf16
+    if constexpr (PRE) {
+      // st = c s - m_run already.  The max follows when a row outgrows it by THR, or unconditionally on the first tile
+      // (m_run = 0 there: rows whose scores are all far below 0 must not underflow).
+      if (fresh || __any(mt > THR)) {
+        const float delta = fresh ? mt : fmaxf(mt, 0.f);
+        const float alpha = fresh ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        fresh = false;
+        m_run += delta;
+        l_run *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
-    }
-    const float mc = -m_run * c_exp;
-    const f32x2_t c2v = {c_exp, c_exp}, mc2 = {mc, mc};
-    f32x2_t ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
+          for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2_t y = f32x2_t{st[t][r], st[t][r + 1]} * c2v + mc2;  // v_pk_fma_f32
-        const f32x2_t pv = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
-        st[t][r] = pv[0];
-        st[t][r + 1] = pv[1];
-        if (r & 2) ps1 += pv; else ps0 += pv;                                // v_pk_add_f32
+          for (int r = 0; r < 16; ++r) st[t][r] -= delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cneg[r] = -m_run;
       }
-    ps0 += ps1;
-    l_run += ps0[0] + ps0[1];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] = __builtin_amdgcn_exp2f(st[t][r]);
+    } else {
+      if (__any((mt - m_run) * c_exp > THR)) {
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+      }
+      const float mc = -m_run * c_exp;
+      const f32x2_t c2v = {c_exp, c_exp}, mc2 = {mc, mc};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t y = f32x2_t{st[t][r], st[t][r + 1]} * c2v + mc2;  // v_pk_fma_f32
+          st[t][r] = __builtin_amdgcn_exp2f(y[0]);
+          st[t][r + 1] = __builtin_amdgcn_exp2f(y[1]);
+        }
+    }
 
     const long long c2 = now();
     // ---- O^T += V^T P^T : 4 groups of 16 keys; the half-wave's 8 keys of a group are one 16-byte chunk ----
@@ -214,16 +254,21 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     for (int ks = 0; ks < 4; ++ks) {
       const int t = ks >> 1, h8 = (ks & 1) * 8;
       union { u32x4_t u; bf16x8_t v; } pf;
-      pf.u[0] = pack_bf16x2(st[t][h8 + 0], st[t][h8 + 1]);
-      pf.u[1] = pack_bf16x2(st[t][h8 + 2], st[t][h8 + 3]);
-      pf.u[2] = pack_bf16x2(st[t][h8 + 4], st[t][h8 + 5]);
-      pf.u[3] = pack_bf16x2(st[t][h8 + 6], st[t][h8 + 7]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t pk = pack_bf16x2(st[t][h8 + 2 * e], st[t][h8 + 2 * e + 1]);
+        pf.u[e] = pk;  // (bit_cast of the scalar, not of the vector element: clang reads element 0 for the latter)
+        const bf16x2v_t pp = __builtin_bit_cast(bf16x2v_t, pk), one2 = __builtin_bit_cast(bf16x2v_t, 0x3f803f80u);
+        if (e & 1) lacc1 = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, lacc1, false);
+        else lacc0 = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, lacc0, false);
+      }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8_t vf = *(const bf16x8_t*)(Vs + dt * 4096 + (((2 * ks + hi) ^ xorc) << 4));
+        const bf16x8_t vf = *(const bf16x8_t*)(lds + fa[ks] + TILE_BYTES + dt * 4096);
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, ot[dt], 0, 0, 0);
       }
     }
+    l_run += lacc0 + lacc1;
     if constexpr (TIMING) {
       const long long c3 = now();
       tm[1] += c1 - c0; tm[2] += c2 - c1; tm[3] += c3 - c2;
@@ -291,6 +336,16 @@ int attn_variant() {
 
 long long* g_attn_dbg = nullptr;  // set by wvn_debug_attention_timing (scripts/attn_timing.py)
 
+void launch_pre(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
+                int heads, int nbh, int nqb, int ntok, int ntok_s, int npad) {
+  if (xcd)
+    hipLaunchKernelGGL((attention_bf16_kernel<3, true, 3, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr);
+  else
+    hipLaunchKernelGGL((attention_bf16_kernel<3, false, 3, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr);
+}
+
 template <int NST, int OCC>
 void launch_v(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
               int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, float c_exp) {
@@ -311,6 +366,8 @@ void launch_v(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t
 
 void wvn_attention_bf16_set_debug(long long* dbg) { g_attn_dbg = dbg; }
 
+// scale > 0: q holds the raw projections.  scale == 0: q is pre-multiplied by softmax_scale * log2(e) (EPI_QKV with
+// q_scale set), the kernel with the running max folded into the S^T MFMA chain runs.
 int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
                               int ntok, int ntok_s, int npad, float scale, hipStream_t st) {
   if (!q || !k || !vt || !out || npad % QB != 0 || npad < ntok) return WVN_ERR_ARG;
@@ -319,6 +376,12 @@ int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt
   const float c_exp = scale * 1.44269504088896340736f;
   dim3 grid(nqb * nbh);
   const bool xcd = (nbh % 8) == 0;  // the XCD decode needs whole groups of 8 (frame, head) pairs
+  if (scale == 0.f && !g_attn_dbg) {
+    launch_pre(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad);
+    WVN_LAUNCH_CHECK();
+    return WVN_OK;
+  }
+  if (scale == 0.f) return WVN_ERR_ARG;
   switch (attn_variant()) {
     case 0: launch_v<2, 4>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
     case 2: launch_v<2, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;

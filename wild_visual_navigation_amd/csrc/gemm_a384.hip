@@ -54,6 +54,7 @@ struct A384Params {
   void* C; int ldc;    // bf16 or fp32 (A_RESID: in/out)
   int M, N;
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad; int ntok_s;
+  float q_scale;       // A_QK: multiplier of the q column tiles (1 = none)
   bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;  // one buffer descriptor for q / k / v^T (byte offsets from qkv_base)
   long long* dbg;  // TIMING builds: per wave {wait+barrier, mfma, epilogue, total} shader cycles
 };
@@ -233,8 +234,13 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = 32 * t + 8 * g + 4 * hi;
-          const f32x2_t a = act2<EPI>(f32x2_t{prev[t][4 * g + 0], prev[t][4 * g + 1]});
-          const f32x2_t b = act2<EPI>(f32x2_t{prev[t][4 * g + 2], prev[t][4 * g + 3]});
+          f32x2_t a = act2<EPI>(f32x2_t{prev[t][4 * g + 0], prev[t][4 * g + 1]});
+          f32x2_t b = act2<EPI>(f32x2_t{prev[t][4 * g + 2], prev[t][4 * g + 3]});
+          if constexpr (EPI == A_QK) {  // q tiles carry the softmax scale (wave-uniform per column tile)
+            const float qs = n0 < p.heads * 64 ? p.q_scale : 1.f;
+            a *= f32x2_t{qs, qs};
+            b *= f32x2_t{qs, qs};
+          }
           if constexpr (EPI == A_RESID) {
             f32x4_t o = {a[0], a[1], b[0], b[1]};
             *(f32x4_t*)(stg + l31 * 272 + c * 4) = o;
@@ -465,6 +471,7 @@ int wvn_gemm_a384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   A384Params p{};
   p.A = g.A; p.lda = g.lda; p.W = g.W; p.bias = g.bias; p.C = g.C; p.ldc = g.ldc; p.M = g.M; p.N = g.N;
   p.q = g.q; p.k = g.k; p.vt = g.vt; p.heads = g.heads; p.npad = g.npad; p.ntok_s = g.ntok_s;
+  p.q_scale = g.q_scale != 0.f ? g.q_scale : 1.f;
   p.dbg = g.dbg;
   switch (epi) {
     case EPI_BF16:

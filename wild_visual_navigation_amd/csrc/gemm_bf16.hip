@@ -195,6 +195,9 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
           float b = bl;
           if constexpr (TR) b = (p.bias && n0 + c + e < p.N) ? p.bias[n0 + c + e] : 0.f;
           v[e] = activate<EPI>(acc[i][j][4 * g4 + e] + b);
+          if constexpr (EPI == EPI_QKV && TR) {
+            if (p.q_scale != 0.f && n0 < p.N / 3) v[e] *= p.q_scale;  // q third (tile-uniform): softmax scale folded in
+          }
         }
         if constexpr (OB) {
           u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};

@@ -26,6 +26,7 @@ struct GemmBf16Params {
   int ntok_s;  // rows per frame in the token matrices (ntok rounded up to 8); row of (b,t) = b*ntok_s + t
   // EPI_QKV
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad;
+  float q_scale;  // EPI_QKV: the q third is multiplied by this before it is rounded to bf16 (0 = leave as is)
   long long* dbg;  // optional: per-wave phase timings of the A-stationary kernel (scripts/ab_kernels.py --timing)
 };
 int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st);
