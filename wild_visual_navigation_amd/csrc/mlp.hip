@@ -115,17 +115,31 @@ __global__ __launch_bounds__(1024) void mlp_losssum_kernel(const float* __restri
   }
 }
 
-// out[n] = sum_r A[r][n]  : 64 columns per workgroup, 4 row phases, fixed-order combine
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int lda, int R, int N,
-                                                     float* __restrict__ outv) {
-  __shared__ float sh[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < N)
-    for (int r = g; r < R; r += 4) s += A[(size_t)r * lda + c];
-  sh[g][threadIdx.x & 63] = s;
+// out[n] = sum_r A[r][n]  : 64 columns per workgroup, 16 row phases (1024 threads: the sum is latency-bound, R/16 loads
+// per thread, 4 in flight), fixed-order combine
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ A, int lda, int R, int N,
+                                                      float* __restrict__ outv) {
+  __shared__ float sh[16][64];
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 64 + lane, g = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < N) {
+    int r = g;
+    for (; r + 48 < R; r += 64) {
+      s0 += A[(size_t)r * lda + c];
+      s1 += A[(size_t)(r + 16) * lda + c];
+      s2 += A[(size_t)(r + 32) * lda + c];
+      s3 += A[(size_t)(r + 48) * lda + c];
+    }
+    for (; r < R; r += 16) s0 += A[(size_t)r * lda + c];
+  }
+  sh[g][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (g == 0 && c < N) outv[c] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+  if (g == 0 && c < N) {
+    float t = sh[0][lane];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t += sh[i][lane];
+    outv[c] = t;
+  }
 }
 
 // torch.optim.Adam single-tensor update (no amsgrad / weight decay / maximize)
@@ -202,7 +216,7 @@ int wvn_mlp_gradout_launch(const float* out, int ldo, const float* x, int ldx, c
 }
 
 int wvn_colsum_launch(const float* A, int lda, int R, int N, float* outv, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, st, A, lda, R, N, outv);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, A, lda, R, N, outv);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
