@@ -211,7 +211,9 @@ int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float
  *          (the node reloads them at 1 Hz, wvn_feature_extractor_node.py:407-432).
  * zx     : [batch*grid*grid rows][ldzx >= 640] bf16.  Columns [256,640) hold the final patch tokens on entry (hand
  *          wvn_vit_forward tokens_lowp = zx + 256, ld_lowp = ldzx); columns [0,256) are scratch (layer-1 pre-activations).
- * trav / conf / loss_reco : [batch][out_h][out_w] fp32, each may be NULL.  mean/std/std_factor: ConfidenceGenerator state.
+ * trav / conf / loss_reco : [batch][out_h][out_w] fp32, each may be NULL.  mean/std/std_factor: ConfidenceGenerator state;
+ * conf_state (may be NULL): the same three floats in DEVICE memory, read by the kernel instead of the scalars -- lets the call
+ * sit in a captured HIP graph while the confidence statistics keep moving.
  * Requires 15*(grid-1)/(out-1) < 2 in both directions (out >= ~7.5 x grid: 224/28, 448/56 ...), WVN_ERR_ARG otherwise.
  * ------------------------------------------------------------------------------------------- */
 #define WVN_PIXEL_ZX_COLS 640
@@ -219,8 +221,8 @@ int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float
 size_t wvn_pixel_mlp_pack_bytes(const wvn_mlp_desc* d);
 int wvn_pixel_mlp_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream);
 int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int ldzx, int batch, int grid, int out_h,
-                        int out_w, float mean, float std, float std_factor, float* trav, float* conf, float* loss_reco,
-                        void* stream);
+                        int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
+                        float* conf, float* loss_reco, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation (scripts/a384_timing.py, scripts/attn_timing.py): in-kernel s_memtime phase timings of

@@ -1,0 +1,50 @@
+"""Single-frame latency of the live node's per-frame path (wvn_feature_extractor_node.py:305-363 with prediction_per_pixel):
+8-bit 448x448 frame already on the GPU -> DINO ViT-S/8 (bf16) -> fused per-pixel traversability + confidence maps.
+One JSON line.  (A HIP graph of the same ~115-launch sequence was measured too: 2.18 ms against 2.22 ms eager -- at one frame
+the time is the sum of small-grid kernels, 150 attention workgroups on 256 CUs, not launch overhead -- so it is not kept.)"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wild_visual_navigation_amd.backbone import synthetic_vit_state_dict  # noqa: E402
+from wild_visual_navigation_amd.cfg import ExperimentParams  # noqa: E402
+from wild_visual_navigation_amd.feature_extractor import FeatureExtractor  # noqa: E402
+from wild_visual_navigation_amd.model import get_model  # noqa: E402
+from wild_visual_navigation_amd.utils import ConfidenceGenerator  # noqa: E402
+
+
+def wall(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    S = 448
+    sd = synthetic_vit_state_dict(depth=12, pretrain_grid=28)
+    fe = FeatureExtractor(device=dev, segmentation_type="grid", feature_type="dino", patch_size=8, backbone_type="vit_small",
+                          input_size=S, pretrained_weights=sd, precision="bf16")
+    params = ExperimentParams()
+    params.model.simple_mlp_cfg.input_size = 384
+    model = get_model(params.model).to(dev)
+    model.eval()
+    cg = ConfidenceGenerator(method="latest_measurement", std_factor=0.5).to(dev)
+    cg.mean[0], cg.std[0] = 0.9, 0.25
+    frame = torch.randint(0, 256, (1, 3, S, S), dtype=torch.uint8, device=dev)
+    eager = wall(lambda: fe.predict_per_pixel(frame, model, cg), 50)
+    out = {"frame": f"{S}x{S} uint8", "eager_ms": round(eager, 3)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

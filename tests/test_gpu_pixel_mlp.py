@@ -129,3 +129,15 @@ def test_predict_per_pixel_equals_unfused_sequence(dev, golden):
         assert (trav[i].reshape(-1) - pred[:, 0]).abs().max().item() < 1e-2
         assert ((loss[i].reshape(-1) - lr).abs() / lr).max().item() < 1e-2
         assert (conf[i].reshape(-1) - c).abs().max().item() < 5e-2
+
+
+def test_confidence_state_from_device_memory(dev):
+    """conf_state (device {mean, std, std_factor}) overrides the scalar arguments: the form a captured HIP graph needs."""
+    sd = OM.make_mlp_state_dict(384, seed=7)
+    model = _model(dev, sd)
+    zx = torch.zeros(28 * 28, 640, dtype=torch.bfloat16, device=dev)
+    zx[:, 256:] = (2.0 * torch.randn(28 * 28, 384, generator=g(3))).to(torch.bfloat16).to(dev)
+    a = model.forward_per_pixel(zx, 1, 28, (224, 224), MEAN, STD, FAC)
+    state = torch.tensor([MEAN, STD, FAC], dtype=torch.float32, device=dev)
+    b = model.forward_per_pixel(zx, 1, 28, (224, 224), 123.0, 456.0, 7.0, conf_state=state)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -486,11 +486,11 @@ int wvn_pixel_mlp_pack(const wvn_mlp_desc* d, const float* params, void* packed,
   return wvn_pixel_mlp_pack_launch(d->D, d->H1, d->H2, params, packed, (hipStream_t)stream);
 }
 int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int ldzx, int batch, int grid, int out_h,
-                        int out_w, float mean, float std, float std_factor, float* trav, float* conf, float* loss_reco,
-                        void* stream) {
+                        int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
+                        float* conf, float* loss_reco, void* stream) {
   if (!d) return WVN_ERR_ARG;
   return wvn_pixel_mlp_infer_launch(d->D, d->H1, d->H2, packed, zx, ldzx, batch, grid, out_h, out_w, mean, std, std_factor,
-                                    trav, conf, loss_reco, (hipStream_t)stream);
+                                    conf_state, trav, conf, loss_reco, (hipStream_t)stream);
 }
 
 int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,

@@ -56,6 +56,7 @@ struct PixParams {
   int B, G, Ho, Wo, nty, ntx;
   float sy, sx;                     // (G-1)/(Ho-1), (G-1)/(Wo-1)
   float mean, std, std_factor;
+  const float* conf_dev;            // optional {mean, std, std_factor} in device memory (overrides the three scalars)
 };
 
 // confidence_generator.py:182-193 (same arithmetic as mlp.hip's row kernel)
@@ -203,7 +204,11 @@ __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
       const float lr = lsum / (float)DF;
       if (p.trav) p.trav[o] = sigmoid_f(at[0]);
       if (p.loss) p.loss[o] = lr;
-      if (p.conf) p.conf[o] = pix_confidence(lr, p.mean, p.std, p.std_factor);
+      if (p.conf) {
+        const float cm = p.conf_dev ? p.conf_dev[0] : p.mean, cs = p.conf_dev ? p.conf_dev[1] : p.std;
+        const float cf = p.conf_dev ? p.conf_dev[2] : p.std_factor;
+        p.conf[o] = pix_confidence(lr, cm, cs, cf);
+      }
     }
     __syncthreads();  // every wave is done with this tile's token image
   }
@@ -269,8 +274,8 @@ int wvn_pixel_mlp_pack_launch(int D, int h1, int h2, const float* params, void* 
 }
 
 int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* zx, int ldzx, int B, int G, int out_h,
-                               int out_w, float mean, float std, float std_factor, float* trav, float* conf, float* loss,
-                               hipStream_t st) {
+                               int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
+                               float* conf, float* loss, hipStream_t st) {
   if (D != DF || h1 != H1 || h2 != H2 || !packed || !zx || B <= 0 || G < 2 || out_h < 2 || out_w < 2) return WVN_ERR_ARG;
   if (ldzx < NCH || (ldzx % 8) || ((uintptr_t)zx & 15) || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
   const float sy = (float)(G - 1) / (float)(out_h - 1), sx = (float)(G - 1) / (float)(out_w - 1);
@@ -292,7 +297,7 @@ int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* 
   p.trav = trav; p.conf = conf; p.loss = loss;
   p.B = B; p.G = G; p.Ho = out_h; p.Wo = out_w;
   p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
-  p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor;
+  p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor; p.conf_dev = conf_state;
   static const int split = [] {
     const char* e = getenv("WVN_PIXEL_WSPLIT");
     return e ? atoi(e) : 1;

@@ -120,5 +120,5 @@ int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int*
 size_t wvn_pixel_mlp_pack_bytes_impl();
 int wvn_pixel_mlp_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st);
 int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* zx, int ldzx, int B, int G, int out_h,
-                               int out_w, float mean, float std, float std_factor, float* trav, float* conf, float* loss,
-                               hipStream_t st);
+                               int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
+                               float* conf, float* loss, hipStream_t st);

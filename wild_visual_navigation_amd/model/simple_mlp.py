@@ -103,11 +103,13 @@ class SimpleMLP(torch.nn.Module):
 
     @torch.no_grad()
     def forward_per_pixel(self, zx: torch.Tensor, batch: int, grid: int, out_hw, mean: float = 0.0, std: float = 1.0,
-                          std_factor: float = 0.5, want_loss: bool = False, repack: bool = True):
+                          std_factor: float = 0.5, want_loss: bool = False, repack: bool = True,
+                          conf_state: Optional[torch.Tensor] = None):
         """What wvn_feature_extractor_node.py:319-363 computes with prediction_per_pixel -- upsample, forward, column 0,
         reconstruction confidence -- from the PATCH tokens, without the dense feature tensor:
         ``zx`` [batch*grid*grid, 640] bf16 with the tokens in columns [256, 640) (columns [0, 256) are scratch) ->
-        (trav [batch,H,W], conf [batch,H,W], loss_reco [batch,H,W] | None), fp32."""
+        (trav [batch,H,W], conf [batch,H,W], loss_reco [batch,H,W] | None), fp32.  ``conf_state``: optional fp32 device
+        tensor {mean, std, std_factor} read by the kernel instead of the three floats (for HIP-graph capture)."""
         _lib.require_cuda(zx, "zx")
         if zx.dtype != torch.bfloat16 or zx.dim() != 2 or zx.shape[0] != batch * grid * grid or zx.stride(1) != 1 \
                 or zx.shape[1] < self.ZX_COLS:
@@ -118,7 +120,8 @@ class SimpleMLP(torch.nn.Module):
         conf = torch.empty_like(trav)
         loss = torch.empty_like(trav) if want_loss else None
         rc = _lib.lib().wvn_pixel_mlp_infer(C.byref(self.desc), packed.data_ptr(), zx.data_ptr(), zx.stride(0), batch, grid,
-                                            H, W, float(mean), float(std), float(std_factor), trav.data_ptr(),
+                                            H, W, float(mean), float(std), float(std_factor),
+                                            conf_state.data_ptr() if conf_state is not None else 0, trav.data_ptr(),
                                             conf.data_ptr(), loss.data_ptr() if want_loss else 0, _lib.stream())
         _lib.check(rc, "wvn_pixel_mlp_infer")
         return trav, conf, loss
