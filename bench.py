@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run every step on one stream (default: the backbone of step i+1 runs on a second HIP stream while "
+                         "clustering / pooling / the MLP step of step i -- small kernels that do not fill the GPU -- finish)")
     return ap.parse_args()
 
 
@@ -78,9 +81,9 @@ def make_pipeline(args, dev):
     return fe, model, MlpTrainer(model)
 
 
-def hot_path_step(fe, trainer, img, labels_u, args):
+def hot_path_step(fe, trainer, img, labels_u, args, backbone_out=None):
     """One pass: frames -> features/segments -> pooled rows -> one MLP optimisation step."""
-    feat, seg, nseg = fe.extract_batch(img)
+    feat, seg, nseg = fe.extract_batch(img, backbone_out=backbone_out)
     B, S, D = feat.shape
     if args.segmentation == "stego":
         keep = (torch.arange(S, device=feat.device)[None] < nseg[:, None]).reshape(-1)  # ids that exist per image
@@ -92,6 +95,47 @@ def hot_path_step(fe, trainer, img, labels_u, args):
     y_valid = u[:, 0] < 0.16  # 16 % labelled segments, like assets/graph/graph.pt (16 / 100)
     y = y_valid.float() * (0.5 + 0.5 * u[:, 1])
     return trainer.train_step(x, y, y_valid), x.shape[0]
+
+
+class TwoStreamPipeline:
+    """Steps are independent through the backbone, so a throughput pipeline skews them by one: stream A runs the backbone
+    (+ STEGO head) of step i+1 while stream B runs clustering, pooling and the MLP optimisation step (and, multi-GPU, its two
+    all-reduces) of step i.  Every step still trains on its own frames' features; only the schedule changes.  A runs at most
+    one step ahead of B."""
+
+    def __init__(self, fe, trainer, args, dev):
+        self.fe, self.trainer, self.args = fe, trainer, args
+        self.a, self.b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.pending = None     # (tokens, event) of a backbone stage already enqueued for the next step
+        self.tail_done = None   # event: the previous step's tail has finished
+
+    def _enqueue_backbone(self, img):
+        if self.tail_done is not None:
+            self.a.wait_event(self.tail_done)              # A runs at most one step ahead of B (bounded memory)
+        with torch.cuda.stream(self.a):
+            tok = self.fe.backbone_stage(img)
+            tok.record_stream(self.b)
+            ready = torch.cuda.Event()
+            ready.record(self.a)
+        return tok, ready
+
+    def step(self, img, labels_u, next_img=None):
+        """Runs one step on ``img``; ``next_img`` (the following step's frames, None for the last step) gets its backbone
+        stage enqueued FIRST, so that the host-side synchronisation inside this step's tail (boolean-mask row selection)
+        does not keep the GPU from starting it."""
+        tok, ready = self.pending if self.pending is not None else self._enqueue_backbone(img)
+        self.pending = self._enqueue_backbone(next_img) if next_img is not None else None
+        with torch.cuda.stream(self.b):
+            self.b.wait_event(ready)
+            out = hot_path_step(self.fe, self.trainer, img, labels_u, self.args, backbone_out=tok)
+            self.tail_done = torch.cuda.Event()
+            self.tail_done.record(self.b)
+        return out
+
+    def drain(self):
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.a)
+        cur.wait_stream(self.b)
 
 
 def cpu_baseline(args):
@@ -155,16 +199,26 @@ def main():
     n_lab = 20 if args.segmentation == "stego" else (args.size // 32) ** 2
     labels_u = torch.rand(B, n_lab, 2, generator=gen).to(dev)
 
-    for _ in range(args.warmup):
-        hot_path_step(fe, trainer, img, labels_u, args)
+    pipe = None if args.no_overlap else TwoStreamPipeline(fe, trainer, args, dev)
+    def run_step(last):
+        if pipe is None:
+            return hot_path_step(fe, trainer, img, labels_u, args)
+        return pipe.step(img, labels_u, next_img=None if last else img)
+
+    for i in range(args.warmup):
+        run_step(i == args.warmup - 1)      # the pipeline is empty again when the timed region starts
+    if pipe is not None:
+        pipe.drain()
     torch.cuda.synchronize()
     D.barrier()
     ops.prof_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rows = 0
-    for _ in range(args.steps):
-        losses, rows = hot_path_step(fe, trainer, img, labels_u, args)
+    for i in range(args.steps):
+        losses, rows = run_step(i == args.steps - 1)   # exactly `steps` backbone stages and `steps` tails in the timed region
+    if pipe is not None:
+        pipe.drain()
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
@@ -199,7 +253,9 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU + STEGO head + "
                                    f"{args.segmentation} segmentation + fused segment pooling + 1 traversability-MLP "
                                    f"Adam step on {rows} rows/GPU", "frames_per_gpu_per_step": B,
-                       "backbone_chunk": chunk, "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP grads)"},
+                       "backbone_chunk": chunk, "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP grads)",
+                       "schedule": "one stream" if args.no_overlap else
+                                   "two HIP streams: backbone of step i+1 overlaps clustering / pooling / MLP step of step i"},
             "backbone_tflops": round(total_flops * frames / dt / 1e12 / world, 1),
             "final_loss": loss_val,
             "roofline": {"bound": "mfma", "kernel": "attention_bf16_kernel", "achieved": round(att_tflops, 1),

@@ -81,6 +81,26 @@ def test_uint8_frames_equal_float_frames(dev, golden):
     assert (fa[1] - fb[1]).abs().max().item() < 1e-5      # same tokens; the generic segment mean sums with atomics
 
 
+@pytest.mark.parametrize("seg,ftype", [("stego", "stego"), ("grid", "dino")])
+def test_two_stage_extract_batch_is_the_same_computation(dev, seg, ftype):
+    """backbone_stage + extract_batch(backbone_out=...) (the split bench.py pipelines over two HIP streams) must give
+    exactly what the one-call form gives, also when the first stage ran on another stream."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=11, depth=2)
+    fe = FeatureExtractor(device=dev, segmentation_type=seg, feature_type=ftype, patch_size=8, backbone_type="vit_small",
+                          input_size=64, pretrained_weights=sd, precision="bf16", n_image_clusters=6)
+    img = torch.rand(3, 3, 64, 64, generator=g(12)).to(dev)
+    feat, segm, nseg = fe.extract_batch(img)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tok = fe.backbone_stage(img)
+        tok.record_stream(torch.cuda.current_stream())
+    torch.cuda.current_stream().wait_stream(side)
+    feat2, segm2, nseg2 = fe.extract_batch(img, backbone_out=tok)
+    assert torch.equal(segm, segm2) and torch.equal(nseg, nseg2)
+    assert torch.equal(torch.nan_to_num(feat, nan=-7.0), torch.nan_to_num(feat2, nan=-7.0))
+
+
 def test_dino_interface_inference_matches_oracle(dev):
     """Non-square frame like assets/demo_data (299x224): resize(NEAREST)+center-crop, normalise, backbone,
     bilinear(align_corners) to (H, H)."""

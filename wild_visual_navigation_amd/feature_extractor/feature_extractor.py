@@ -112,10 +112,22 @@ class FeatureExtractor:
         return edges, feat, seg, center, dense
 
     @torch.no_grad()
-    def extract_batch(self, img: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def backbone_stage(self, img: torch.Tensor) -> torch.Tensor:
+        """First stage of ``extract_batch`` on its own: the ViT (and, for stego features, the STEGO head) -> the
+        patch-resolution feature tokens [B, G*G, D].  Everything after it (clustering, pooling, the MLP step) consists of
+        small kernels that do not fill the GPU; a throughput pipeline runs this stage for batch i+1 on one HIP stream while
+        the rest of batch i runs on another (``extract_batch(img, backbone_out=...)``, bench.py)."""
+        img = img.to(self._device)
+        if self._feature_type == "stego":
+            return self._extractor.code_tokens(img)
+        return self._extractor.inference_tokens(img)
+
+    @torch.no_grad()
+    def extract_batch(self, img: torch.Tensor, backbone_out: Optional[torch.Tensor] = None,
+                      **kwargs) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Batched hot path (no graph structure): img [B,3,H,H] -> (feat [B,S,D], seg [B,H,H] int32,
         n_segments [B] int32).  Rows of ids that do not occur in an image are NaN (the reference's empty
-        mean).  Supported segmentations: grid, stego."""
+        mean).  Supported segmentations: grid, stego.  ``backbone_out``: the tokens ``backbone_stage(img)`` returned."""
         img = img.to(self._device)
         B, _, H, W = img.shape
         G = self._grid()
@@ -125,12 +137,14 @@ class FeatureExtractor:
             seg = self.segment_grid(img, **kwargs)[0, 0].to(torch.int32)[None].expand(B, H, W).contiguous()
             n_seg = (H // cell) * (W // cell)
             nseg = torch.full((B,), n_seg, dtype=torch.int32, device=self._device)
-            tokens = self._feature_tokens(img)
+            tokens = backbone_out if backbone_out is not None else self._feature_tokens(img)
             P = H // G
             if H == W and G * P == H and cell % P == 0:
                 labels_patch = seg[:, ::P, ::P]
         elif self._segmentation_type == "stego":
-            self._extractor.inference(img)
+            if backbone_out is not None and self._feature_type != "stego":
+                raise _lib.WvnError("extract_batch: backbone_out with stego segmentation needs feature_type='stego'")
+            self._extractor.inference(img, code=backbone_out)
             seg = self._extractor.cluster_segments[0]
             nseg = self._extractor._n_segments
             n_seg = self._extractor._cfg.n_image_clusters

@@ -113,12 +113,14 @@ class StegoInterface:
         return code.reshape(B, P, STEGO_CODE_DIM)
 
     @torch.no_grad()
-    def inference(self, img: torch.Tensor):
+    def inference(self, img: torch.Tensor, code: torch.Tensor = None):
         """stego_interface.py:73-111: returns (linear_pred, cluster_pred), both [1,B,H,H] int32, and keeps
-        ``features`` = code [B,90,H,H] (bilinear, align_corners=True)."""
+        ``features`` = code [B,90,H,H] (bilinear, align_corners=True).  ``code``: the result of ``code_tokens(img)`` if
+        the caller already ran that stage (e.g. on another stream, FeatureExtractor.backbone_stage)."""
         G = self._bb.grid
         H = img.shape[2]
-        code = self.code_tokens(img)
+        if code is None:
+            code = self.code_tokens(img)
         B = code.shape[0]
         self._code_tokens = code
         if self._cfg.run_clustering:
