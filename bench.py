@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=64, help="frames pushed through the backbone per launch sequence")
     ap.add_argument("--segmentation", default="stego", choices=["stego", "grid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (about 15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-overlap", action="store_true",
