@@ -15,6 +15,14 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def n384_forced(a, w, bias, out):
+    """The row-panel kernel itself on every row block (wvn_gemm_bf16 only dispatches to it from ~0.75 x #CU row blocks on)."""
+    h = _lib.lib()
+    rc = h.wvn_debug_gemm_n384(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else 0,
+                               out.data_ptr(), out.stride(0), a.shape[0], a.shape[1], _lib.stream())
+    _lib.check(rc, "wvn_debug_gemm_n384")
+
+
 @pytest.mark.parametrize("M", [8, 256, 300, 777])
 @pytest.mark.parametrize("K", [1536, 768, 448])
 def test_n384_residual_update(dev, M, K):
@@ -23,10 +31,13 @@ def test_n384_residual_update(dev, M, K):
     bias = torch.randn(384, generator=g(3))
     ref = a.float() @ w.float().T + bias
     c0 = torch.randn(M, 384, generator=g(4))
-    cd = c0.clone().to(dev)
-    ops.gemm_bf16(a.to(dev), w.to(dev), bias.to(dev), _lib.EPI_RESID_F32, out=cd)
-    err = (cd.cpu() - (c0 + ref)).abs().max().item()
+    cd, cf = c0.clone().to(dev), c0.clone().to(dev)
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    ops.gemm_bf16(ad, wd, bd, _lib.EPI_RESID_F32, out=cd)    # dispatcher: the tiled kernel at these sizes
+    n384_forced(ad, wd, bd, cf)                              # the row-panel kernel
+    err = (cf.cpu() - (c0 + ref)).abs().max().item()
     assert err < 2e-5 * ref.abs().max().item() * math.sqrt(K), err
+    assert torch.equal(cd, cf)                               # same association in both kernels: same bits
 
 
 def test_n384_transpose_detecting_strided(dev):
@@ -41,7 +52,7 @@ def test_n384_transpose_detecting_strided(dev):
     big = torch.zeros(M, 2 * K, dtype=torch.bfloat16, device=dev)
     big[:, K:] = a.to(torch.bfloat16).to(dev)
     out = torch.ones(M, 384 + 4, device=dev)
-    ops.gemm_bf16(big[:, K:], w.to(torch.bfloat16).to(dev), None, _lib.EPI_RESID_F32, out=out[:, :384])
+    n384_forced(big[:, K:], w.to(torch.bfloat16).to(dev), None, out[:, :384])
     want = 1.0 + (torch.arange(M).float() % 100)[:, None] + w[:, 1300][None]
     assert torch.equal(out[:, :384].cpu(), want) and torch.equal(out[:, 384:].cpu(), torch.ones(M, 4))
 
@@ -75,7 +86,7 @@ def test_n384_rows_do_not_depend_on_their_position(dev):
     ops.gemm_bf16(a, w, bias, _lib.EPI_RESID_F32, out=big)
     tail = slice(256 * 256, M)  # rows the big launch left to the tiled kernel
     small = c0[tail].clone()     # the same rows as a small problem of their own: all in the row-panel kernel
-    ops.gemm_bf16(a[tail], w, bias, _lib.EPI_RESID_F32, out=small)
+    n384_forced(a[tail], w, bias, small)
     assert torch.equal(big[tail], small)
     head = c0[:300].clone()
     ops.gemm_bf16(a[:300], w, bias, _lib.EPI_RESID_F32, out=head)

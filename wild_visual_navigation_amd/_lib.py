@@ -87,6 +87,7 @@ _SIGNATURES = {
     "wvn_pixel_mlp_infer": ([_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _p], _i),
     "wvn_debug_gemm_bf16_timed": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p], _i),
     "wvn_debug_attention_timing": ([_p], _i),
+    "wvn_debug_gemm_n384": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _p], _i),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

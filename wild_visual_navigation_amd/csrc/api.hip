@@ -268,6 +268,14 @@ int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, co
   return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
 }
 
+int wvn_debug_gemm_n384(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int K,
+                        void* stream) {
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = 384; p.K = K;
+  return wvn_gemm_n384_launch(p, EPI_RESID_F32, (hipStream_t)stream, nullptr, 1);
+}
+
 int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, int transB, const float* bias, float* C,
                  int ldc, int M, int N, int K, int epi, const float* mask, int ldmask, void* stream) {
   if (epi < 0 || epi > F32_EPI_RELUMASK) return WVN_ERR_ARG;

@@ -179,7 +179,8 @@ int n384_num_cus() {
 // Eligibility: N == 384, K % 32 == 0, residual epilogue, 16-byte aligned operands, 32-bit byte offsets;
 // WVN_ERR_ARG otherwise (the caller then uses the generic tiled kernel).  *rows_done = number of leading rows handled
 // here (a multiple of 256 unless it is M); the caller finishes rows [*rows_done, M).
-int wvn_gemm_n384_launch(const GemmBf16Params& g, int epi, hipStream_t st, int* rows_done) {
+// force != 0 (tests): take every row block here, whatever their number
+int wvn_gemm_n384_launch(const GemmBf16Params& g, int epi, hipStream_t st, int* rows_done, int force) {
   if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
   if (g.N != NN || g.K <= 0 || (g.K % BKS) != 0 || g.M <= 0 || !g.A || !g.W || !g.C) return WVN_ERR_ARG;
   if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 4)) return WVN_ERR_ARG;
@@ -191,6 +192,10 @@ int wvn_gemm_n384_launch(const GemmBf16Params& g, int epi, hipStream_t st, int* 
   // are 3 full rounds here + 18 row blocks there, not 4 rounds.
   const int ncu = n384_num_cus();
   int nrb_all = ceil_div(g.M, BM), m_here = g.M;
+  // One workgroup owns 256 rows x all 384 columns, so M / 256 workgroups is all the parallelism there is: below about three
+  // quarters of a round the tiled kernel (3 column tiles per row block) is faster (measured: 1-8 frames of 3152 rows 0.33 /
+  // 0.49 / 0.74 ms there vs 0.80 / 0.81 / 0.91 ms here per 12 launches; 16 frames 1.32 vs 1.26).  Same association, same bits.
+  if (!force && nrb_all * 4 < ncu * 3) return WVN_ERR_ARG;
   const int full = (nrb_all / ncu) * ncu, rem = nrb_all - full;
   if (rows_done && full > 0 && rem > 0 && rem * 4 <= ncu) m_here = full * BM;
   if (rows_done) *rows_done = m_here;

@@ -33,7 +33,7 @@ int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 // A-stationary kernel for K == 384 (gemm_a384.hip); WVN_ERR_ARG when the shape is not eligible
 int wvn_gemm_a384_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 // row-panel kernel for N == 384 residual updates with long K (gemm_n384.hip); WVN_ERR_ARG when not eligible
-int wvn_gemm_n384_launch(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done);
+int wvn_gemm_n384_launch(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done, int force = 0);
 
 // ---- fp32 GEMM (gemm_f32.hip): exact-mode linears + the traversability MLP ---------------------
 enum GemmF32Epilogue {
