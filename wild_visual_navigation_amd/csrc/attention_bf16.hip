@@ -349,6 +349,18 @@ long long* g_attn_dbg = nullptr;  // set by wvn_debug_attention_timing (scripts/
 
 void launch_pre(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
                 int heads, int nbh, int nqb, int ntok, int ntok_s, int npad) {
+  // default: 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for
+  // 3 stages / 3 workgroups and 13.2 for 4 stages / 2).  WVN_ATTN_PRE_OCC=3 selects the 3 / 3 form (A/B switch).
+  static const int pre_occ = [] { const char* e = getenv("WVN_ATTN_PRE_OCC"); return e ? atoi(e) : 4; }();
+  if (pre_occ == 4) {
+    if (xcd)
+      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+    else
+      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+    return;
+  }
   static const int summode = [] { const char* e = getenv("WVN_ATTN_SUM"); return e ? atoi(e) : 0; }();
   if (xcd && summode == 1)
     hipLaunchKernelGGL((attention_bf16_kernel<3, true, 3, false, true, 1>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
