@@ -176,6 +176,10 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     }
     __builtin_amdgcn_sched_barrier(0);
     if (t_issue >= 0) issue(t_issue);
+    // From here to the end of the tile the wave is VALU-heavy (softmax, packing, PV with its fillers); it wins issue
+    // arbitration over the waves that are in their MFMA-only S^T phase, which need few issue slots (same-box A/B: -0.6 %).
+    // (A second s_setprio between softmax and PV fences hipcc's interleaving of the exps with the PV MFMAs: +4 %.)
+    if constexpr (PRE) __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TIMING) asm volatile("s_nop 7\ns_nop 7" ::: "memory");
     const long long c1 = now();
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, ot[dt], 0, 0, 0);
       }
     }
+    if constexpr (PRE) __builtin_amdgcn_s_setprio(0);
     if constexpr (TIMING) {
       const long long c3 = now();
       tm[1] += c1 - c0; tm[2] += c2 - c1; tm[3] += c3 - c2;
