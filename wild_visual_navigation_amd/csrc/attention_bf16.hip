@@ -31,9 +31,16 @@
 //                   The QKV GEMM epilogues write V^T in this order (wvn_hip.h documents it for direct callers).
 //                   -> O^T accumulator lane l holds query l&31 again, so the online-softmax rescale
 //                      and the final 1/l are per-lane scalars.
-// exp is evaluated as exp2 with scale*log2(e) folded into one FMA; the O rescale is skipped (wave-
-// uniformly) when no running max moved.  Keys >= ntok (tile tail / padding) are neutralised by a select on
-// their scores (p = 0); K / V^T padding must be finite (0 * finite = 0 in the PV MFMA).
+// Softmax, two forms of the same online algorithm:
+//   raw q (scale > 0)   : exp2 with scale*log2(e) folded into one v_pk_fma per two scores;
+//   pre-scaled q (PRE)  : q already carries scale*log2(e) (the QKV epilogue multiplies before the bf16 rounding) and the
+//                         running max enters the S^T chains as the MFMA C operand, so the accumulators come out as exp2
+//                         arguments and the per-element fma disappears.  This is the form wvn_vit_forward uses.
+// In both the O rescale is deferred and wave-uniform (it runs when some row's score outgrows the running max by 2^6,
+// i.e. almost only on the first tiles).  The kernel is bound by VALU issue, not by the matrix pipe or LDS (DESIGN.md
+// section 4): what is left of the softmax is 32 v_exp, 16 v_max3, 16 v_cvt_pk, 16 v_dot2c per 16 MFMAs.
+// Keys >= ntok (tile tail / padding) are neutralised by a select on their scores (p = 0); K / V^T padding must be
+// finite (0 * finite = 0 in the PV MFMA).  The masked last tile is peeled out of the tile loop.
 #include <stdlib.h>
 
 #include <type_traits>
