@@ -87,3 +87,18 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_resize_crop_commutes_with_uint8_to_float():
+    """Frame ingest: NEAREST resize + centre crop is an index operation, so doing it on the raw uint8 frame
+    and converting afterwards (what the fused uint8 entry point does) equals the reference order (convert, then resize)."""
+    import torch
+
+    from wild_visual_navigation_amd.feature_extractor.transforms import resize_nearest_center_crop
+
+    g = torch.Generator().manual_seed(0)
+    for (h, w, size) in [(224, 299, 224), (300, 224, 224), (448, 448, 448), (540, 720, 448)]:
+        u8 = torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8)
+        a = resize_nearest_center_crop(u8, size).float() / 255
+        b = resize_nearest_center_crop(u8.float() / 255, size)
+        assert a.shape == (2, 3, size, size) and torch.equal(a, b)
