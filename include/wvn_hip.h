@@ -224,6 +224,20 @@ int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int
                         int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
                         float* conf, float* loss_reco, void* stream);
 
+/* Exact-mode form of the same fused kernel: every MFMA operand is split into hi + lo bf16 parts and every product is formed
+ * as hi*hi + hi*lo + lo*hi (fp32 accumulation), the token-resolution layer-1 GEMM runs on the fp32 FMA path: results agree
+ * with the fp32 reference sequence to ~1e-5 relative (the 1e-3 bar of the exact mode), at 2.3x the MFMA work of the bf16
+ * form.  tokens: [batch*grid*grid][ld_tokens >= 384] fp32 final patch tokens (wvn_vit_forward tokens_f32);
+ * params: the flat fp32 parameter buffer (W1 is read from it); packed: wvn_pixel_mlp_exact_pack_bytes() bytes from
+ * wvn_pixel_mlp_exact_pack; workspace: wvn_pixel_mlp_exact_workspace_bytes() bytes, no initialisation needed. */
+size_t wvn_pixel_mlp_exact_pack_bytes(const wvn_mlp_desc* d);
+size_t wvn_pixel_mlp_exact_workspace_bytes(const wvn_mlp_desc* d, int batch, int grid);
+int wvn_pixel_mlp_exact_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream);
+int wvn_pixel_mlp_infer_exact(const wvn_mlp_desc* d, const float* params, const void* packed, const float* tokens,
+                              int ld_tokens, int batch, int grid, int out_h, int out_w, float mean, float std,
+                              float std_factor, const float* conf_state, float* trav, float* conf, float* loss_reco,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation (scripts/a384_timing.py, scripts/attn_timing.py): in-kernel s_memtime phase timings of
  * the two MFMA kernels.  Not part of the drop-in surface.

@@ -50,11 +50,21 @@ def main():
         return pred[:, 0], cg.inference_without_update(lr)
 
     unfused_ms = timed(unfused, 3)
+    tok2d = tokens.reshape(B * G * G, 384)
+    exact_ms = timed(lambda: model.forward_per_pixel_exact(tok2d, B, G, (H, H), 0.9, 0.25, 0.5), 10) / B
+    # accuracy of both fused forms against the un-fused fp32 sequence on frame 0
+    t_ref, c_ref = unfused()
+    t_x3, c_x3, _ = model.forward_per_pixel_exact(tok2d[: G * G], 1, G, (H, H), 0.9, 0.25, 0.5)
+    t_bf, c_bf, _ = model.forward_per_pixel(zx[: G * G], 1, G, (H, H), 0.9, 0.25, 0.5, repack=False)
+    err = lambda a, b: round(float((a.reshape(-1) - b.reshape(-1)).abs().max()), 6)  # noqa: E731
     mfma = 82 if os.environ.get("WVN_PIXEL_WSPLIT", "1") != "0" else 62
     flops = (H * H / 32) * mfma * 32 * 32 * 16 * 2 + G * G * 384 * 256 * 2
     print(json.dumps({"frame": f"{H}x{H}", "grid": G, "batch": B, "fused_ms_per_frame": round(fused_ms, 4),
                       "fused_frames_per_s": round(1e3 / fused_ms, 1), "fused_mfma_tflops": round(flops / fused_ms / 1e9, 1),
                       "unfused_ms_per_frame": round(unfused_ms, 3), "speedup": round(unfused_ms / fused_ms, 1),
+                      "exact_fused_ms_per_frame": round(exact_ms, 4), "exact_speedup": round(unfused_ms / exact_ms, 1),
+                      "max_abs_err_trav": {"exact_fused": err(t_x3, t_ref), "bf16_fused": err(t_bf, t_ref)},
+                      "max_abs_err_conf": {"exact_fused": err(c_x3, c_ref), "bf16_fused": err(c_bf, c_ref)},
                       "weight_split": mfma == 82}))
 
 

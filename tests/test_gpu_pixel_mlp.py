@@ -141,3 +141,42 @@ def test_confidence_state_from_device_memory(dev):
     state = torch.tensor([MEAN, STD, FAC], dtype=torch.float32, device=dev)
     b = model.forward_per_pixel(zx, 1, 28, (224, 224), 123.0, 456.0, 7.0, conf_state=state)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("B,G,H,W", [(1, 28, 224, 224), (2, 28, 230, 251), (1, 56, 448, 448)])
+def test_exact_mode_fused_per_pixel_within_1e3(dev, B, G, H, W):
+    """Exact mode (hi + lo split MFMA operands, fp32 layer-1 GEMM): <= 1e-3 absolute on the traversability logit's sigmoid and
+    on the reconstruction loss against the fp32 reference sequence on the SAME fp32 tokens and fp32 weights (north_star bar)."""
+    sd = OM.make_mlp_state_dict(384, seed=7)
+    tokens = 2.0 * torch.randn(B, G * G, 384, generator=g(B + G))
+    model = _model(dev, sd)
+    trav, conf, loss = model.forward_per_pixel_exact(tokens.reshape(B * G * G, 384).to(dev), B, G, (H, W), MEAN, STD, FAC,
+                                                     want_loss=True)
+    t0, l0, c0 = _oracle(tokens, G, H, W, sd)
+    assert (trav.cpu() - t0).abs().max().item() < 1e-3
+    assert (loss.cpu() - l0).abs().max().item() < 1e-3
+    assert (conf.cpu() - c0).abs().max().item() < 2e-3            # conf = 1 - (loss - lo) / (2 std), std = 0.25
+
+
+def test_predict_per_pixel_exact_mode_on_demo_frames(dev, golden):
+    """fp32 extractor -> predict_per_pixel takes the exact fused kernel: <= 1e-3 against the CPU oracle of the reference
+    sequence (dense up-sample -> MLP -> MSE -> confidence) on the reference's demo frames."""
+    from oracle import interfaces as OI
+
+    frames = golden("demo_frames_224.pt")["frames_u8"][:1]
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=21, depth=3)
+    mlp_sd = OM.make_mlp_state_dict(384, seed=42)
+    fe = FeatureExtractor(device=dev, segmentation_type="grid", feature_type="dino", patch_size=8, backbone_type="vit_small",
+                          input_size=224, pretrained_weights=sd, precision="fp32")
+    model = _model(dev, mlp_sd)
+    cg = ConfidenceGenerator(method="latest_measurement", std_factor=FAC).to(dev)
+    cg.mean[0], cg.std[0] = MEAN, STD
+    trav, conf, loss = fe.predict_per_pixel(frames.to(dev), model, cg, want_loss=True)
+    img = frames.float() / 255
+    dense = OI.dino_inference(sd, img, 224, 8, 6)
+    x = dense[0].permute(1, 2, 0).reshape(-1, 384)
+    pred = OM.mlp_forward(mlp_sd, x)
+    lr = ((pred[:, 1:] - x) ** 2).mean(1)
+    assert (trav[0].reshape(-1).cpu() - pred[:, 0]).abs().max().item() < 1e-3
+    assert (loss[0].reshape(-1).cpu() - lr).abs().max().item() < 1e-3
+    assert (conf[0].reshape(-1).cpu() - OM.confidence_from_stats(lr, MEAN, STD, FAC)).abs().max().item() < 2e-3

@@ -84,6 +84,10 @@ _SIGNATURES = {
     "wvn_mlp_confidence": ([_p, _i, _p, _i, _f, _f, _f, _p, _p, _i, _i, _p], _i),
     "wvn_pixel_mlp_pack_bytes": ([_p], _sz),
     "wvn_pixel_mlp_pack": ([_p, _p, _p, _p], _i),
+    "wvn_pixel_mlp_exact_pack_bytes": ([_p], _sz),
+    "wvn_pixel_mlp_exact_workspace_bytes": ([_p, _i, _i], _sz),
+    "wvn_pixel_mlp_exact_pack": ([_p, _p, _p, _p], _i),
+    "wvn_pixel_mlp_infer_exact": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _p, _sz, _p], _i),
     "wvn_pixel_mlp_infer": ([_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _p], _i),
     "wvn_debug_gemm_bf16_timed": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p], _i),
     "wvn_debug_attention_timing": ([_p], _i),

@@ -501,6 +501,28 @@ int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int
                                     conf_state, trav, conf, loss_reco, (hipStream_t)stream);
 }
 
+size_t wvn_pixel_mlp_exact_pack_bytes(const wvn_mlp_desc* d) {
+  if (!d || d->D != 384 || d->H1 != 256 || d->H2 != 32) return 0;
+  return wvn_pixel_mlp_exact_pack_bytes_impl();
+}
+size_t wvn_pixel_mlp_exact_workspace_bytes(const wvn_mlp_desc* d, int batch, int grid) {
+  if (!d || d->D != 384 || d->H1 != 256 || d->H2 != 32 || batch <= 0 || grid <= 0) return 0;
+  return wvn_pixel_mlp_exact_workspace_bytes_impl(batch, grid);
+}
+int wvn_pixel_mlp_exact_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream) {
+  if (!d) return WVN_ERR_ARG;
+  return wvn_pixel_mlp_exact_pack_launch(d->D, d->H1, d->H2, params, packed, (hipStream_t)stream);
+}
+int wvn_pixel_mlp_infer_exact(const wvn_mlp_desc* d, const float* params, const void* packed, const float* tokens,
+                              int ld_tokens, int batch, int grid, int out_h, int out_w, float mean, float std,
+                              float std_factor, const float* conf_state, float* trav, float* conf, float* loss_reco,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d) return WVN_ERR_ARG;
+  return wvn_pixel_mlp_infer_exact_launch(d->D, d->H1, d->H2, params, packed, tokens, ld_tokens, batch, grid, out_h, out_w,
+                                          mean, std, std_factor, conf_state, trav, conf, loss_reco, workspace,
+                                          workspace_bytes, (hipStream_t)stream);
+}
+
 int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,
                        float* trav, float* conf, int R, int D, void* stream) {
   if (!out || !x) return WVN_ERR_ARG;

@@ -251,6 +251,239 @@ __global__ void pixel_mlp_pack_kernel(const float* __restrict__ prm, unsigned ch
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Exact-mode variant: every bf16 MFMA operand is split into hi + lo (v = hi + lo to 16 mantissa bits) and every product
+// is formed as hi*hi + hi*lo + lo*hi (three MFMAs, fp32 accumulation): the result matches the fp32 reference sequence to
+// ~1e-5 relative, inside the 1e-3 bar of the exact mode, at 186 instead of 82 MFMAs per 32 pixels.  The token-resolution
+// layer-1 GEMM (Z = tokens * W1^T) runs on the exact fp32 FMA path.  Layout: zxh / zxl = hi / lo parts of [ Z | x ].
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int X3_TOKL = TOK_BYTES;                          // lo planes after the hi planes
+constexpr int X3_OFF_W = 2 * TOK_BYTES;                     // W2H | W3H | W2L | W3L | bias
+constexpr int X3_W2H = X3_OFF_W, X3_W3H = X3_W2H + W2_BYTES, X3_W2L = X3_W3H + W3_BYTES, X3_W3L = X3_W2L + W2_BYTES;
+constexpr int X3_BIAS = X3_W3L + W3_BYTES;
+constexpr int X3_WIMG_BYTES = 2 * (W2_BYTES + W3_BYTES) + NBIAS * 4;
+constexpr int X3_LDS_BYTES = X3_BIAS + NBIAS * 4;           // 130,048
+constexpr int X3_NFETCH = 2 * NFETCH;
+
+struct PixX3Params {
+  const bf16_t* zxh; const bf16_t* zxl; int ldzx;
+  const unsigned char* wimg;
+  float* trav; float* conf; float* loss;
+  int B, G, Ho, Wo, nty, ntx;
+  float sy, sx;
+  float mean, std, std_factor;
+  const float* conf_dev;
+};
+
+__device__ inline uint32_t split_lo(float v0, float v1, uint32_t hi) {
+  return pack_bf16x2(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u));
+}
+// relu + hi / lo split of 8 accumulator registers
+__device__ inline void relu_split8(const f32x16_t& a, int r0, bf16x8_t& hi, bf16x8_t& lo) {
+  u32x4_t uh, ul;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float v0 = fmaxf(a[r0 + 2 * q], 0.f), v1 = fmaxf(a[r0 + 2 * q + 1], 0.f);
+    uh[q] = pack_bf16x2(v0, v1);
+    ul[q] = split_lo(v0, v1, uh[q]);
+  }
+  hi = __builtin_bit_cast(bf16x8_t, uh);
+  lo = __builtin_bit_cast(bf16x8_t, ul);
+}
+#define MFMA3(acc, ah, al, bh, bl)                                       \
+  do {                                                                   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0); \
+  } while (0)
+
+__global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int tiles_per_frame = p.nty * p.ntx;
+  const int ntiles = p.B * tiles_per_frame;
+
+  for (int i = tid; i < X3_WIMG_BYTES / 16; i += 512) *(u32x4_t*)(smem + X3_OFF_W + i * 16) = ((const u32x4_t*)p.wimg)[i];
+  const float* bias_l = (const float*)(smem + X3_BIAS);
+
+  u32x4_t pre[5];
+  auto fetch = [&](int tile) {
+    const int b = tile / tiles_per_frame, r = tile - b * tiles_per_frame;
+    const int tyi = r / p.ntx, txi = r - tyi * p.ntx;
+    const int by = (int)(p.sy * (float)(tyi * TILE)), bx = (int)(p.sx * (float)(txi * TILE));
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = tid + 512 * k;  // < 2560 always
+      const int part = idx >= NFETCH, id = idx - part * NFETCH;
+      const int tok = id & 15, chunk = id >> 4;
+      const int gy = min(by + (tok >> 2), p.G - 1), gx = min(bx + (tok & 3), p.G - 1);
+      const bf16_t* src = part ? p.zxl : p.zxh;
+      pre[k] = *(const u32x4_t*)(src + ((size_t)b * p.G * p.G + (size_t)gy * p.G + gx) * p.ldzx + chunk * 8);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = tid + 512 * k;
+      const int part = idx >= NFETCH, id = idx - part * NFETCH;
+      const int tok = id & 15, chunk = id >> 4;
+      unsigned char* dst = smem + part * X3_TOKL + (tok >> 3) * PLANE + chunk * 128 + (tok & 7) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *(bf16_t*)(dst + e * 16) = (bf16_t)(pre[k][e >> 1] >> ((e & 1) * 16));
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    stash();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+
+    const int b = tile / tiles_per_frame, r = tile - b * tiles_per_frame;
+    const int tyi = r / p.ntx, txi = r - tyi * p.ntx;
+    const int by = (int)(p.sy * (float)(tyi * TILE)), bx = (int)(p.sx * (float)(txi * TILE));
+    const int py = tyi * TILE + 2 * wave + (n >> 4), px = txi * TILE + (n & 15);
+    const float fsy = p.sy * (float)min(py, p.Ho - 1), fsx = p.sx * (float)min(px, p.Wo - 1);
+    const int gy0 = (int)fsy, gx0 = (int)fsx;
+    const float wy1 = fsy - (float)gy0, wx1 = fsx - (float)gx0;
+    const int ty0 = gy0 - by, tx0 = gx0 - bx;
+    float wyv[2], wxv[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wyv[q] = ((2 * h + q) == ty0 ? 1.f - wy1 : 0.f) + ((2 * h + q) == ty0 + 1 ? wy1 : 0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wxv[q] = (q == tx0 ? 1.f - wx1 : 0.f) + (q == tx0 + 1 ? wx1 : 0.f);
+    u32x4_t whi_u, wlo_u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float w0 = wyv[q >> 1] * wxv[(2 * q) & 3], w1 = wyv[q >> 1] * wxv[(2 * q + 1) & 3];
+      whi_u[q] = pack_bf16x2(w0, w1);
+      wlo_u[q] = split_lo(w0, w1, whi_u[q]);
+    }
+    const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, whi_u), wlo = __builtin_bit_cast(bf16x8_t, wlo_u);
+    const bf16x8_t nhi = __builtin_bit_cast(bf16x8_t, whi_u ^ 0x80008000u), nlo = __builtin_bit_cast(bf16x8_t, wlo_u ^ 0x80008000u);
+
+    const unsigned char* tokh = smem + h * PLANE + n * 16;
+    const unsigned char* tokl = tokh + X3_TOKL;
+    const unsigned lw = (h * 32 + n) * 16;  // lane's fragment inside one [k-step] image block of 1024 bytes
+
+    f32x16_t a2 = bias16(bias_l + H1, h);
+#pragma unroll
+    for (int blk = 0; blk < H1 / 32; ++blk) {
+      f32x16_t az = bias16(bias_l + 32 * blk, h);
+      const bf16x8_t th = *(const bf16x8_t*)(tokh + blk * 512), tl = *(const bf16x8_t*)(tokl + blk * 512);
+      MFMA3(az, th, tl, whi, wlo);
+      bf16x8_t hh[2], hl[2];
+      relu_split8(az, 0, hh[0], hl[0]);
+      relu_split8(az, 8, hh[1], hl[1]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8_t wh = *(const bf16x8_t*)(smem + X3_W2H + (2 * blk + u) * 1024 + lw);
+        const bf16x8_t wl = *(const bf16x8_t*)(smem + X3_W2L + (2 * blk + u) * 1024 + lw);
+        MFMA3(a2, wh, wl, hh[u], hl[u]);
+      }
+    }
+    bf16x8_t gh[2], gl[2];
+    relu_split8(a2, 0, gh[0], gl[0]);
+    relu_split8(a2, 8, gh[1], gl[1]);
+
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < DF / 32; ++t) {
+      f32x16_t a3 = bias16(bias_l + H1 + H2 + 32 * t, h);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8_t wh = *(const bf16x8_t*)(smem + X3_W3H + (2 * t + u) * 1024 + lw);
+        const bf16x8_t wl = *(const bf16x8_t*)(smem + X3_W3L + (2 * t + u) * 1024 + lw);
+        MFMA3(a3, wh, wl, gh[u], gl[u]);
+      }
+      const bf16x8_t th = *(const bf16x8_t*)(tokh + (H1 / 32 + t) * 512), tl = *(const bf16x8_t*)(tokl + (H1 / 32 + t) * 512);
+      MFMA3(a3, th, tl, nhi, nlo);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) lsum = fmaf(a3[q], a3[q], lsum);
+    }
+    f32x16_t at = bias16(bias_l + H1 + H2 + DF, h);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bf16x8_t wh = *(const bf16x8_t*)(smem + X3_W3H + (2 * (DF / 32) + u) * 1024 + lw);
+      const bf16x8_t wl = *(const bf16x8_t*)(smem + X3_W3L + (2 * (DF / 32) + u) * 1024 + lw);
+      MFMA3(at, wh, wl, gh[u], gl[u]);
+    }
+
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (h == 0 && py < p.Ho && px < p.Wo) {
+      const size_t o = ((size_t)b * p.Ho + py) * p.Wo + px;
+      const float lr = lsum / (float)DF;
+      if (p.trav) p.trav[o] = sigmoid_f(at[0]);
+      if (p.loss) p.loss[o] = lr;
+      if (p.conf) {
+        const float cm = p.conf_dev ? p.conf_dev[0] : p.mean, cs = p.conf_dev ? p.conf_dev[1] : p.std;
+        const float cf = p.conf_dev ? p.conf_dev[2] : p.std_factor;
+        p.conf[o] = pix_confidence(lr, cm, cs, cf);
+      }
+    }
+    __syncthreads();
+  }
+}
+#undef MFMA3
+
+// packed blob of the exact mode: W2 hi | W3 hi | W2 lo | W3 lo | biases (same fragment order as the bf16 pack)
+__global__ void pixel_mlp_pack_x3_kernel(const float* __restrict__ prm, unsigned char* __restrict__ out) {
+  const float* W1 = prm;
+  const float* b1 = W1 + H1 * DF;
+  const float* W2 = b1 + H1;
+  const float* b2 = W2 + H2 * H1;
+  const float* W3 = b2 + H2;
+  const float* b3 = W3 + (1 + DF) * H2;
+  bf16_t* w2h = (bf16_t*)out;
+  bf16_t* w3h = (bf16_t*)(out + W2_BYTES);
+  bf16_t* w2l = (bf16_t*)(out + W2_BYTES + W3_BYTES);
+  bf16_t* w3l = (bf16_t*)(out + 2 * W2_BYTES + W3_BYTES);
+  float* bo = (float*)(out + 2 * (W2_BYTES + W3_BYTES));
+  const int gsz = gridDim.x * blockDim.x, g0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = g0; i < W2_BYTES / 2; i += gsz) {
+    const int e = i & 7, m = (i >> 3) & 31, hh = (i >> 8) & 1, s = i >> 9;
+    const int c = 32 * (s >> 1) + 16 * (s & 1) + 8 * (e >> 2) + 4 * hh + (e & 3);
+    const float v = W2[m * H1 + c];
+    const bf16_t hi = f32_to_bf16(v);
+    w2h[i] = hi;
+    w2l[i] = f32_to_bf16(v - bf16_to_f32(hi));
+  }
+  for (int i = g0; i < W3_BYTES / 2; i += gsz) {
+    const int e = i & 7, m = (i >> 3) & 31, hh = (i >> 8) & 1, u = (i >> 9) & 1, t = i >> 10;
+    const int r = 16 * u + 8 * (e >> 2) + 4 * hh + (e & 3);
+    const int row = t < DF / 32 ? 1 + 32 * t + m : (m == 0 ? 0 : -1);
+    const float v = row < 0 ? 0.f : W3[row * H2 + r];
+    const bf16_t hi = f32_to_bf16(v);
+    w3h[i] = hi;
+    w3l[i] = f32_to_bf16(v - bf16_to_f32(hi));
+  }
+  for (int i = g0; i < NBIAS; i += gsz) {
+    float v;
+    if (i < H1) v = b1[i];
+    else if (i < H1 + H2) v = b2[i - H1];
+    else if (i < H1 + H2 + DF) v = b3[1 + i - H1 - H2];
+    else v = (i == H1 + H2 + DF) ? b3[0] : 0.f;
+    bo[i] = v;
+  }
+}
+
+// zf [rows][256] fp32 (layer-1 pre-activations) and tokens [rows][ldt] fp32 -> hi / lo rows [ Z | x ] of 640 bf16
+__global__ void pixel_split_rows_kernel(const float* __restrict__ zf, const float* __restrict__ tok, int ldt,
+                                        bf16_t* __restrict__ zxh, bf16_t* __restrict__ zxl, long long rows) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * NCH) return;
+  const long long r = i / NCH;
+  const int c = (int)(i - r * NCH);
+  const float v = c < H1 ? zf[r * H1 + c] : tok[r * ldt + (c - H1)];
+  const bf16_t hi = f32_to_bf16(v);
+  zxh[i] = hi;
+  zxl[i] = f32_to_bf16(v - bf16_to_f32(hi));
+}
+
 int pix_num_cus() {
   static int n = 0;
   if (!n) {
@@ -312,6 +545,65 @@ int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* 
   const int ntiles = B * p.nty * p.ntx;
   const int cap = 2 * pix_num_cus();
   hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(512), LDS_BYTES, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+size_t wvn_pixel_mlp_exact_pack_bytes_impl() { return (size_t)X3_WIMG_BYTES; }
+size_t wvn_pixel_mlp_exact_workspace_bytes_impl(int B, int G) {
+  const size_t rows = (size_t)B * G * G;
+  return rows * H1 * 4 + 2 * rows * NCH * 2 + 256;
+}
+
+int wvn_pixel_mlp_exact_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st) {
+  if (D != DF || h1 != H1 || h2 != H2 || !params || !packed || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
+  hipLaunchKernelGGL(pixel_mlp_pack_x3_kernel, dim3(96), dim3(256), 0, st, params, (unsigned char*)packed);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_pixel_mlp_infer_exact_launch(int D, int h1, int h2, const float* params, const void* packed, const float* tokens,
+                                     int ldt, int B, int G, int out_h, int out_w, float mean, float std, float std_factor,
+                                     const float* conf_state, float* trav, float* conf, float* loss, void* workspace,
+                                     size_t workspace_bytes, hipStream_t st) {
+  if (D != DF || h1 != H1 || h2 != H2 || !params || !packed || !tokens || !workspace || B <= 0 || G < 2 || out_h < 2 || out_w < 2)
+    return WVN_ERR_ARG;
+  if (ldt < DF || ((uintptr_t)workspace & 15) || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
+  if (workspace_bytes < wvn_pixel_mlp_exact_workspace_bytes_impl(B, G)) return WVN_ERR_WORKSPACE;
+  const float sy = (float)(G - 1) / (float)(out_h - 1), sx = (float)(G - 1) / (float)(out_w - 1);
+  if (15.f * sy > 1.99f || 15.f * sx > 1.99f) return WVN_ERR_ARG;
+  const long long rows = (long long)B * G * G;
+  float* zf = (float*)workspace;
+  bf16_t* zxh = (bf16_t*)(zf + rows * H1);
+  bf16_t* zxl = zxh + rows * NCH;
+  // layer 1 at token resolution on the exact fp32 path: Z = tokens * W1^T (bias is added after the interpolation)
+  GemmF32Params g{};
+  g.A = tokens; g.lda = ldt; g.transA = 0;
+  g.B = params; g.ldb = DF; g.transB = 1;   // W1 [256][384], Linear layout, first in the flat parameter buffer
+  g.bias = nullptr;
+  g.C = zf; g.ldc = H1; g.M = (int)rows; g.N = H1; g.K = DF; g.batch = 1; g.splitk = 1;
+  int rc = wvn_gemm_f32_launch(g, F32_EPI_NONE, st);
+  if (rc != WVN_OK) return rc;
+  const long long nel = rows * NCH;
+  hipLaunchKernelGGL(pixel_split_rows_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, zf, tokens, ldt, zxh, zxl, rows);
+  WVN_LAUNCH_CHECK();
+
+  PixX3Params p{};
+  p.zxh = zxh; p.zxl = zxl; p.ldzx = NCH;
+  p.wimg = (const unsigned char*)packed;
+  p.trav = trav; p.conf = conf; p.loss = loss;
+  p.B = B; p.G = G; p.Ho = out_h; p.Wo = out_w;
+  p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
+  p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor; p.conf_dev = conf_state;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = B * p.nty * p.ntx;
+  const int cap = pix_num_cus();
+  hipLaunchKernelGGL(pixel_mlp_x3_kernel, dim3(ntiles < cap ? ntiles : cap), dim3(512), X3_LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

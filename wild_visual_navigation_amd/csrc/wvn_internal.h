@@ -122,3 +122,11 @@ int wvn_pixel_mlp_pack_launch(int D, int h1, int h2, const float* params, void* 
 int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* zx, int ldzx, int B, int G, int out_h,
                                int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
                                float* conf, float* loss, hipStream_t st);
+// exact mode (hi + lo split operands, three MFMAs per product)
+size_t wvn_pixel_mlp_exact_pack_bytes_impl();
+size_t wvn_pixel_mlp_exact_workspace_bytes_impl(int B, int G);
+int wvn_pixel_mlp_exact_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st);
+int wvn_pixel_mlp_infer_exact_launch(int D, int h1, int h2, const float* params, const void* packed, const float* tokens,
+                                     int ldt, int B, int G, int out_h, int out_w, float mean, float std, float std_factor,
+                                     const float* conf_state, float* trav, float* conf, float* loss, void* workspace,
+                                     size_t workspace_bytes, hipStream_t st);

@@ -35,6 +35,8 @@ class SimpleMLP(torch.nn.Module):
         self._flat: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._pix_packed: Optional[torch.Tensor] = None
+        self._pix_packed_x3: Optional[torch.Tensor] = None
+        self._pix_ws: Optional[torch.Tensor] = None
 
     # ---- flat parameter storage --------------------------------------------------------------------
     def _params_in_order(self):
@@ -124,4 +126,39 @@ class SimpleMLP(torch.nn.Module):
                                             conf_state.data_ptr() if conf_state is not None else 0, trav.data_ptr(),
                                             conf.data_ptr(), loss.data_ptr() if want_loss else 0, _lib.stream())
         _lib.check(rc, "wvn_pixel_mlp_infer")
+        return trav, conf, loss
+
+    @torch.no_grad()
+    def forward_per_pixel_exact(self, tokens: torch.Tensor, batch: int, grid: int, out_hw, mean: float = 0.0,
+                                std: float = 1.0, std_factor: float = 0.5, want_loss: bool = False,
+                                conf_state: Optional[torch.Tensor] = None):
+        """Exact-mode form of ``forward_per_pixel`` (hi + lo split MFMA operands, fp32 layer-1 GEMM at token resolution):
+        ``tokens`` [batch*grid*grid, 384] fp32 (the backbone's final patch tokens) -> (trav, conf, loss_reco | None),
+        within 1e-3 of the reference sequence on the dense fp32 features."""
+        _lib.require_cuda(tokens, "tokens")
+        if tokens.dtype != torch.float32 or tokens.dim() != 2 or tokens.shape[0] != batch * grid * grid or tokens.stride(1) != 1 \
+                or tokens.shape[1] < self.input_size:
+            raise _lib.WvnError(f"tokens must be fp32 [batch*grid*grid, >= {self.input_size}], got {tuple(tokens.shape)} {tokens.dtype}")
+        h = _lib.lib()
+        flat = self.flat_params()
+        n = h.wvn_pixel_mlp_exact_pack_bytes(C.byref(self.desc))
+        if n == 0:
+            raise _lib.WvnError("fused per-pixel inference needs SimpleMLP(384, [256, 32, 1], reconstruction=True)")
+        if self._pix_packed_x3 is None or self._pix_packed_x3.device != flat.device:
+            self._pix_packed_x3 = torch.empty(n, dtype=torch.uint8, device=flat.device)
+        _lib.check(h.wvn_pixel_mlp_exact_pack(C.byref(self.desc), flat.data_ptr(), self._pix_packed_x3.data_ptr(), _lib.stream()),
+                   "wvn_pixel_mlp_exact_pack")
+        need = h.wvn_pixel_mlp_exact_workspace_bytes(C.byref(self.desc), batch, grid)
+        if self._pix_ws is None or self._pix_ws.numel() < need or self._pix_ws.device != flat.device:
+            self._pix_ws = torch.empty(need, dtype=torch.uint8, device=flat.device)
+        H, W = out_hw
+        trav = torch.empty(batch, H, W, dtype=torch.float32, device=tokens.device)
+        conf = torch.empty_like(trav)
+        loss = torch.empty_like(trav) if want_loss else None
+        rc = h.wvn_pixel_mlp_infer_exact(C.byref(self.desc), flat.data_ptr(), self._pix_packed_x3.data_ptr(), tokens.data_ptr(),
+                                         tokens.stride(0), batch, grid, H, W, float(mean), float(std), float(std_factor),
+                                         conf_state.data_ptr() if conf_state is not None else 0, trav.data_ptr(), conf.data_ptr(),
+                                         loss.data_ptr() if want_loss else 0, self._pix_ws.data_ptr(), self._pix_ws.numel(),
+                                         _lib.stream())
+        _lib.check(rc, "wvn_pixel_mlp_infer_exact")
         return trav, conf, loss
