@@ -51,6 +51,24 @@ def test_host_only_queries():
     assert expect <= one <= expect + 8 * 256 and two > one
 
 
+def test_per_pixel_host_queries():
+    """Sizes of the fused per-pixel kernels' packed weights / workspace (host-only arithmetic)."""
+    h = _lib.lib()
+    d = _lib.MlpDesc(384, 256, 32, 0)
+    w23 = 16 * 2 * 32 * 16 + 13 * 2 * 2 * 32 * 16                    # W2 and W3 fragment images (bf16)
+    nbias = (256 + 32 + 13 * 32) * 4
+    assert h.wvn_pixel_mlp_pack_bytes(C.byref(d)) == 256 * 384 * 2 + w23 + nbias
+    assert h.wvn_pixel_mlp_exact_pack_bytes(C.byref(d)) == 2 * w23 + nbias
+    rows = 2 * 56 * 56
+    ws = h.wvn_pixel_mlp_exact_workspace_bytes(C.byref(d), 2, 56)
+    assert rows * 256 * 4 + 2 * rows * 640 * 2 <= ws <= rows * 256 * 4 + 2 * rows * 640 * 2 + 256
+    d90 = _lib.MlpDesc(90, 256, 32, 0)
+    assert h.wvn_pixel_mlp_pack_bytes(C.byref(d90)) == 0 and h.wvn_pixel_mlp_exact_pack_bytes(C.byref(d90)) == 0
+    assert h.wvn_pixel_mlp_infer(C.byref(d90), None, None, 640, 1, 28, 224, 224, 0.0, 1.0, 0.5, None, None, None, None, None) == 1001
+    assert h.wvn_pixel_mlp_infer_exact(C.byref(d), None, None, None, 384, 1, 28, 224, 224, 0.0, 1.0, 0.5, None, None, None, None,
+                                       None, 0, None) == 1001
+
+
 def test_argument_validation_without_gpu():
     h = _lib.lib()
     assert h.wvn_gemm_bf16(None, 0, None, 0, None, None, 0, 1, 1, 64, 0, None) == 1001
