@@ -205,12 +205,14 @@ int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float
  *   out   = SimpleMLP(dense rows); trav = out[:,0] (after its sigmoid); conf = confidence(mse(out[:,1:], dense))
  * without building the dense tensor (308 MB / frame at 448^2) and with layer 1 evaluated at token resolution
  * (csrc/pixel_mlp.hip).  bf16 MFMA operands, fp32 accumulation: the speed mode; the exact mode is
- * wvn_upsample_bilinear + wvn_mlp_forward + wvn_mlp_confidence.  D = 384, H1 = 256, H2 = 32 only (0 / WVN_ERR_ARG otherwise).
+ * wvn_upsample_bilinear + wvn_mlp_forward + wvn_mlp_confidence (or the exact-mode form below).  H1 = 256, H2 = 32 and D = 384 (DINO
+ * ViT-S features) or D = 90 (STEGO code, the live node's default feature_type); 0 / WVN_ERR_ARG otherwise.
  *
  * packed : wvn_pixel_mlp_pack_bytes() bytes, rebuilt by wvn_pixel_mlp_pack whenever the parameters change
  *          (the node reloads them at 1 Hz, wvn_feature_extractor_node.py:407-432).
- * zx     : [batch*grid*grid rows][ldzx >= 640] bf16.  Columns [256,640) hold the final patch tokens on entry (hand
- *          wvn_vit_forward tokens_lowp = zx + 256, ld_lowp = ldzx); columns [0,256) are scratch (layer-1 pre-activations).
+ * zx     : [batch*grid*grid rows][ldzx >= wvn_pixel_mlp_zx_cols()] bf16 (640 for D = 384, 384 for D = 90).  Columns from 256 on
+ *          hold the features on entry (D = 384: hand wvn_vit_forward tokens_lowp = zx + 256, ld_lowp = ldzx; D = 90: the 90
+ *          code values followed by ZEROS up to column 384); columns [0,256) are scratch (layer-1 pre-activations).
  * trav / conf / loss_reco : [batch][out_h][out_w] fp32, each may be NULL.  mean/std/std_factor: ConfidenceGenerator state;
  * conf_state (may be NULL): the same three floats in DEVICE memory, read by the kernel instead of the scalars -- lets the call
  * sit in a captured HIP graph while the confidence statistics keep moving.
@@ -219,6 +221,7 @@ int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float
 #define WVN_PIXEL_ZX_COLS 640
 #define WVN_PIXEL_X_COL 256
 size_t wvn_pixel_mlp_pack_bytes(const wvn_mlp_desc* d);
+int wvn_pixel_mlp_zx_cols(const wvn_mlp_desc* d);
 int wvn_pixel_mlp_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream);
 int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int ldzx, int batch, int grid, int out_h,
                         int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
@@ -227,7 +230,7 @@ int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int
 /* Exact-mode form of the same fused kernel: every MFMA operand is split into hi + lo bf16 parts and every product is formed
  * as hi*hi + hi*lo + lo*hi (fp32 accumulation), the token-resolution layer-1 GEMM runs on the fp32 FMA path: results agree
  * with the fp32 reference sequence to ~1e-5 relative (the 1e-3 bar of the exact mode), at 2.3x the MFMA work of the bf16
- * form.  tokens: [batch*grid*grid][ld_tokens >= 384] fp32 final patch tokens (wvn_vit_forward tokens_f32);
+ * form.  tokens: [batch*grid*grid][ld_tokens >= D] fp32 features (D = 384: wvn_vit_forward tokens_f32; D = 90: the STEGO code);
  * params: the flat fp32 parameter buffer (W1 is read from it); packed: wvn_pixel_mlp_exact_pack_bytes() bytes from
  * wvn_pixel_mlp_exact_pack; workspace: wvn_pixel_mlp_exact_workspace_bytes() bytes, no initialisation needed. */
 size_t wvn_pixel_mlp_exact_pack_bytes(const wvn_mlp_desc* d);

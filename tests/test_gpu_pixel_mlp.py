@@ -35,9 +35,9 @@ def bf(x):
     return x.to(torch.bfloat16).float()
 
 
-def _model(dev, mlp_sd):
+def _model(dev, mlp_sd, D=384):
     params = ExperimentParams()
-    params.model.simple_mlp_cfg.input_size = 384
+    params.model.simple_mlp_cfg.input_size = D
     model = get_model(params.model).to(dev)
     model.eval()
     model.load_state_dict(mlp_sd, strict=False)
@@ -45,10 +45,10 @@ def _model(dev, mlp_sd):
 
 
 def _oracle(tokens, G, H, W, sd):
-    """tokens [B, G*G, 384] fp32 -> trav, loss_reco, conf [B,H,W] (reference order of operations, fp32)."""
-    B = tokens.shape[0]
-    dense = F.interpolate(tokens.reshape(B, G, G, 384).permute(0, 3, 1, 2), (H, W), mode="bilinear", align_corners=True)
-    x = dense.permute(0, 2, 3, 1).reshape(-1, 384)
+    """tokens [B, G*G, D] fp32 -> trav, loss_reco, conf [B,H,W] (reference order of operations, fp32)."""
+    B, D = tokens.shape[0], tokens.shape[2]
+    dense = F.interpolate(tokens.reshape(B, G, G, D).permute(0, 3, 1, 2), (H, W), mode="bilinear", align_corners=True)
+    x = dense.permute(0, 2, 3, 1).reshape(-1, D)
     pred = OM.mlp_forward(sd, x)
     loss = ((pred[:, 1:] - x) ** 2).mean(1)
     conf = OM.confidence_from_stats(loss, MEAN, STD, FAC)
@@ -102,8 +102,8 @@ def test_unsupported_configurations_are_refused(dev):
         model.forward_per_pixel(zx, 1, 28, (112, 112))                   # 15 * 27/111 > 2: window would exceed 4x4 tokens
     with pytest.raises(_lib.WvnError):
         model.forward_per_pixel(zx[:, :512], 1, 28, (224, 224))          # row too short
-    d90 = _lib.MlpDesc(90, 256, 32, 0)
-    assert _lib.lib().wvn_pixel_mlp_pack_bytes(C.byref(d90)) == 0        # stego features: not supported by this kernel
+    d64 = _lib.MlpDesc(64, 256, 32, 0)
+    assert _lib.lib().wvn_pixel_mlp_pack_bytes(C.byref(d64)) == 0        # only D = 384 (DINO) and D = 90 (STEGO code)
 
 
 def test_predict_per_pixel_equals_unfused_sequence(dev, golden):
@@ -180,3 +180,50 @@ def test_predict_per_pixel_exact_mode_on_demo_frames(dev, golden):
     assert (trav[0].reshape(-1).cpu() - pred[:, 0]).abs().max().item() < 1e-3
     assert (loss[0].reshape(-1).cpu() - lr).abs().max().item() < 1e-3
     assert (conf[0].reshape(-1).cpu() - OM.confidence_from_stats(lr, MEAN, STD, FAC)).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("B,G,H,W", [(1, 28, 224, 224), (2, 28, 230, 251)])
+def test_stego_code_features_90d(dev, B, G, H, W):
+    """The live node's default configuration (feature_type: stego, prediction_per_pixel: True, default.yaml:22-29): 90-d
+    code features, MLP 90 -> 256 -> 32 -> 91.  bf16 form against the same-operand oracle, exact form within 1e-3."""
+    sd = OM.make_mlp_state_dict(90, seed=17)
+    tokens = 0.5 * torch.randn(B, G * G, 90, generator=g(B + G + 1))
+    model = _model(dev, sd, D=90)
+    assert model.ZX_COLS == 384
+    # exact
+    trav, conf, loss = model.forward_per_pixel_exact(tokens.reshape(B * G * G, 90).to(dev), B, G, (H, W), MEAN, STD, FAC, want_loss=True)
+    t0, l0, c0 = _oracle(tokens, G, H, W, sd)
+    assert (trav.cpu() - t0).abs().max().item() < 1e-3 and (loss.cpu() - l0).abs().max().item() < 1e-3
+    assert (conf.cpu() - c0).abs().max().item() < 2e-3
+    # bf16
+    tb = tokens.to(torch.bfloat16)
+    zx = torch.zeros(B * G * G, 384, dtype=torch.bfloat16, device=dev)
+    zx[:, :256] = float("nan")                                        # scratch columns need no init
+    zx[:, 256:346] = tb.reshape(B * G * G, 90).to(dev)
+    trav, conf, loss = model.forward_per_pixel(zx, B, G, (H, W), MEAN, STD, FAC, want_loss=True)
+    sd_bf = {k: (bf(v) if k.endswith("weight") else v) for k, v in sd.items()}
+    t1, l1, c1 = _oracle(tb.float(), G, H, W, sd_bf)
+    assert (trav.cpu() - t1).abs().max().item() < 4e-3
+    assert ((loss.cpu() - l1).abs() / l1).max().item() < 4e-3
+
+
+def test_predict_per_pixel_with_stego_features(dev, golden):
+    """Drop-in level with feature_type='stego' (code features), both precisions, against the reference call sequence on the
+    same extractor: dense code features -> model.forward -> column 0 / confidence."""
+    frames = golden("demo_frames_224.pt")["frames_u8"][:1].to(dev)
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=23, depth=2)
+    mlp_sd = OM.make_mlp_state_dict(90, seed=43)
+    for prec, tol in (("fp32", 1e-3), ("bf16", 2e-2)):
+        fe = FeatureExtractor(device=dev, segmentation_type="stego", feature_type="stego", patch_size=8, backbone_type="vit_small",
+                              input_size=224, pretrained_weights=sd, precision=prec, n_image_clusters=8)
+        model = _model(dev, mlp_sd, D=90)
+        cg = ConfidenceGenerator(method="latest_measurement", std_factor=FAC).to(dev)
+        cg.mean[0], cg.std[0] = 0.05, 0.02
+        trav, conf, loss = fe.predict_per_pixel(frames, model, cg, want_loss=True)
+        _, _, _, _, dense = fe.extract(img=frames.float() / 255, return_centers=False, return_dense_features=True)
+        x = dense[0].permute(1, 2, 0).reshape(-1, 90)
+        pred = model.forward(Data(x=x))
+        lr = ((pred[:, 1:] - x) ** 2).mean(1)
+        assert trav.shape == (1, 224, 224)
+        assert (trav[0].reshape(-1) - pred[:, 0]).abs().max().item() < tol, prec
+        assert ((loss[0].reshape(-1) - lr).abs() / lr).max().item() < 10 * tol, prec

@@ -62,9 +62,16 @@ def test_per_pixel_host_queries():
     rows = 2 * 56 * 56
     ws = h.wvn_pixel_mlp_exact_workspace_bytes(C.byref(d), 2, 56)
     assert rows * 256 * 4 + 2 * rows * 640 * 2 <= ws <= rows * 256 * 4 + 2 * rows * 640 * 2 + 256
-    d90 = _lib.MlpDesc(90, 256, 32, 0)
-    assert h.wvn_pixel_mlp_pack_bytes(C.byref(d90)) == 0 and h.wvn_pixel_mlp_exact_pack_bytes(C.byref(d90)) == 0
-    assert h.wvn_pixel_mlp_infer(C.byref(d90), None, None, 640, 1, 28, 224, 224, 0.0, 1.0, 0.5, None, None, None, None, None) == 1001
+    assert h.wvn_pixel_mlp_zx_cols(C.byref(d)) == 640
+    d90 = _lib.MlpDesc(90, 256, 32, 0)                                # STEGO code: x zero-padded to 128 columns, 3 + 1 W3 tiles
+    w23_90 = 16 * 2 * 32 * 16 + 4 * 2 * 2 * 32 * 16
+    nbias_90 = (256 + 32 + 4 * 32) * 4
+    assert h.wvn_pixel_mlp_zx_cols(C.byref(d90)) == 384
+    assert h.wvn_pixel_mlp_pack_bytes(C.byref(d90)) == 256 * 128 * 2 + w23_90 + nbias_90
+    assert h.wvn_pixel_mlp_exact_pack_bytes(C.byref(d90)) == 2 * w23_90 + nbias_90
+    d64 = _lib.MlpDesc(64, 256, 32, 0)
+    assert h.wvn_pixel_mlp_pack_bytes(C.byref(d64)) == 0 and h.wvn_pixel_mlp_exact_pack_bytes(C.byref(d64)) == 0
+    assert h.wvn_pixel_mlp_infer(C.byref(d64), None, None, 640, 1, 28, 224, 224, 0.0, 1.0, 0.5, None, None, None, None, None) == 1001
     assert h.wvn_pixel_mlp_infer_exact(C.byref(d), None, None, None, 384, 1, 28, 224, 224, 0.0, 1.0, 0.5, None, None, None, None,
                                        None, 0, None) == 1001
 

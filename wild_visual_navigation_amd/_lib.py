@@ -83,6 +83,7 @@ _SIGNATURES = {
     "wvn_mlp_train_phase_c": ([_p, _p, _p, _p, _p, _i, _f, _p, _f, _f, _p, _p], _i),
     "wvn_mlp_confidence": ([_p, _i, _p, _i, _f, _f, _f, _p, _p, _i, _i, _p], _i),
     "wvn_pixel_mlp_pack_bytes": ([_p], _sz),
+    "wvn_pixel_mlp_zx_cols": ([_p], _i),
     "wvn_pixel_mlp_pack": ([_p, _p, _p, _p], _i),
     "wvn_pixel_mlp_exact_pack_bytes": ([_p], _sz),
     "wvn_pixel_mlp_exact_workspace_bytes": ([_p, _i, _i], _sz),

@@ -486,8 +486,12 @@ int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* gra
 
 // fused per-pixel inference (pixel_mlp.hip)
 size_t wvn_pixel_mlp_pack_bytes(const wvn_mlp_desc* d) {
-  if (!d || d->D != 384 || d->H1 != 256 || d->H2 != 32) return 0;
-  return wvn_pixel_mlp_pack_bytes_impl();
+  if (!d || d->H1 != 256 || d->H2 != 32) return 0;
+  return wvn_pixel_mlp_pack_bytes_impl(d->D);
+}
+int wvn_pixel_mlp_zx_cols(const wvn_mlp_desc* d) {
+  if (!d || d->H1 != 256 || d->H2 != 32) return 0;
+  return wvn_pixel_mlp_zx_cols_impl(d->D);
 }
 int wvn_pixel_mlp_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream) {
   if (!d) return WVN_ERR_ARG;
@@ -502,12 +506,12 @@ int wvn_pixel_mlp_infer(const wvn_mlp_desc* d, const void* packed, void* zx, int
 }
 
 size_t wvn_pixel_mlp_exact_pack_bytes(const wvn_mlp_desc* d) {
-  if (!d || d->D != 384 || d->H1 != 256 || d->H2 != 32) return 0;
-  return wvn_pixel_mlp_exact_pack_bytes_impl();
+  if (!d || d->H1 != 256 || d->H2 != 32) return 0;
+  return wvn_pixel_mlp_exact_pack_bytes_impl(d->D);
 }
 size_t wvn_pixel_mlp_exact_workspace_bytes(const wvn_mlp_desc* d, int batch, int grid) {
-  if (!d || d->D != 384 || d->H1 != 256 || d->H2 != 32 || batch <= 0 || grid <= 0) return 0;
-  return wvn_pixel_mlp_exact_workspace_bytes_impl(batch, grid);
+  if (!d || d->H1 != 256 || d->H2 != 32 || batch <= 0 || grid <= 0) return 0;
+  return wvn_pixel_mlp_exact_workspace_bytes_impl(d->D, batch, grid);
 }
 int wvn_pixel_mlp_exact_pack(const wvn_mlp_desc* d, const float* params, void* packed, void* stream) {
   if (!d) return WVN_ERR_ARG;

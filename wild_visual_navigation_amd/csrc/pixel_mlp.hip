@@ -32,22 +32,41 @@
 
 namespace {
 
-constexpr int DF = 384, H1 = 256, H2 = 32;
-constexpr int NCH = H1 + DF;                        // 640 interpolated channels per token
-constexpr int PLANE = NCH * 16 + 64;                // bytes of one 8-token plane [640 ch][8 tok] (+64: planes 16 banks apart)
-constexpr int TOK_BYTES = 2 * PLANE;                // 20,608
+constexpr int H1 = 256, H2 = 32;
 constexpr int W2_BYTES = 16 * 2 * 32 * 16;          // [16 k-steps][2 lane halves][32 rows][8 bf16] = 16,384
-constexpr int W3_TILES = DF / 32 + 1;               // 12 reconstruction tiles + 1 tile whose row 0 is the traversability unit
-constexpr int W3_BYTES = W3_TILES * 2 * 2 * 32 * 16;  // 26,624
-constexpr int NBIAS = H1 + H2 + W3_TILES * 32;      // b1 | b2 | b3[1:] | (b3[0], 31 zeros) = 704 floats
-constexpr int W1_BYTES = H1 * DF * 2;               // packed blob starts with W1 as bf16 [256][384] (the Z GEMM's weight)
-constexpr int WIMG_BYTES = W2_BYTES + W3_BYTES + NBIAS * 4;  // what the kernel copies to LDS: 45,824
-constexpr int OFF_W2 = TOK_BYTES;
-constexpr int OFF_W3 = OFF_W2 + W2_BYTES;
-constexpr int OFF_BIAS = OFF_W3 + W3_BYTES;
-constexpr int LDS_BYTES = OFF_BIAS + NBIAS * 4;     // 66,432: two workgroups per CU
 constexpr int TILE = 16;                            // pixels per tile edge; a wave owns 2 rows x 16 columns
-constexpr int NFETCH = 16 * (NCH / 8);              // 16-byte chunks of one token window: 1280
+
+// D = MLP input size: 384 (DINO ViT-S features) or 90 (STEGO code, the live node's default feature_type).  For D = 90 the
+// x part of a zx row is zero-padded to 128 columns (K of the layer-1 GEMM) and three 32-channel blocks are interpolated.
+template <int D>
+struct Cfg {
+  static constexpr int DREAL = D;
+  static constexpr int NT = (D + 31) / 32;              // 32-channel reconstruction tiles (12 / 3)
+  static constexpr int DX = D == 384 ? 384 : 128;       // x columns of a zx row
+  static constexpr int ZXC = H1 + DX;                   // zx row length the caller provides (640 / 384)
+  static constexpr int NCH = H1 + 32 * NT;              // channels staged and interpolated per token (640 / 352)
+  static constexpr int PLANE = NCH * 16 + 64;           // bytes of one 8-token plane [NCH ch][8 tok] (+64: planes 16 banks apart)
+  static constexpr int TOK_BYTES = 2 * PLANE;
+  static constexpr int W3_TILES = NT + 1;               // + 1 tile whose row 0 is the traversability unit
+  static constexpr int W3_BYTES = W3_TILES * 2 * 2 * 32 * 16;
+  static constexpr int NBIAS = H1 + H2 + W3_TILES * 32; // b1 | b2 | b3[1:] (padded) | (b3[0], 31 zeros)
+  static constexpr int W1_BYTES = H1 * DX * 2;          // packed blob starts with W1 as bf16 [256][DX] (the Z GEMM's weight)
+  static constexpr int WIMG_BYTES = W2_BYTES + W3_BYTES + NBIAS * 4;  // what the kernel copies to LDS
+  static constexpr int OFF_W2 = TOK_BYTES;
+  static constexpr int OFF_W3 = OFF_W2 + W2_BYTES;
+  static constexpr int OFF_BIAS = OFF_W3 + W3_BYTES;
+  static constexpr int LDS_BYTES = OFF_BIAS + NBIAS * 4; // 66,432 at D = 384: two workgroups per CU
+  static constexpr int NFETCH = 16 * (NCH / 8);          // 16-byte chunks of one token window
+  static constexpr int NPRE = (NFETCH + 511) / 512;
+  // exact mode (hi + lo): lo planes after the hi planes, then W2H | W3H | W2L | W3L | bias
+  static constexpr int XTOKL = TOK_BYTES;
+  static constexpr int XOFFW = 2 * TOK_BYTES;
+  static constexpr int XW2H = XOFFW, XW3H = XW2H + W2_BYTES, XW2L = XW3H + W3_BYTES, XW3L = XW2L + W2_BYTES;
+  static constexpr int XBIAS = XW3L + W3_BYTES;
+  static constexpr int XWIMG_BYTES = 2 * (W2_BYTES + W3_BYTES) + NBIAS * 4;
+  static constexpr int XLDS_BYTES = XBIAS + NBIAS * 4;   // 130,048 at D = 384
+  static constexpr int XNPRE = (2 * NFETCH + 511) / 512;
+};
 
 struct PixParams {
   const bf16_t* zx; int ldzx;       // [B*G*G][ldzx]: columns [0,256) = Z, [256,640) = tokens
@@ -88,8 +107,9 @@ __device__ inline bf16x8_t relu_pack8(const f32x16_t& a, int r0) {
   return __builtin_bit_cast(bf16x8_t, u);
 }
 
-template <int WSPLIT>
+template <int WSPLIT, int D>
 __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
+  using K = Cfg<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,19 +117,19 @@ __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
   const int tiles_per_frame = p.nty * p.ntx;
   const int ntiles = p.B * tiles_per_frame;
 
-  for (int i = tid; i < WIMG_BYTES / 16; i += 512) *(u32x4_t*)(smem + OFF_W2 + i * 16) = ((const u32x4_t*)p.wimg)[i];
-  const float* bias_l = (const float*)(smem + OFF_BIAS);
+  for (int i = tid; i < K::WIMG_BYTES / 16; i += 512) *(u32x4_t*)(smem + K::OFF_W2 + i * 16) = ((const u32x4_t*)p.wimg)[i];
+  const float* bias_l = (const float*)(smem + K::OFF_BIAS);
 
   // this thread's share of a token window: chunks tid, tid + 512, tid + 1024 of [16 tokens][80 x 16 B]
-  u32x4_t pre[3];
+  u32x4_t pre[K::NPRE];
   auto fetch = [&](int tile) {
     const int b = tile / tiles_per_frame, r = tile - b * tiles_per_frame;
     const int tyi = r / p.ntx, txi = r - tyi * p.ntx;
     const int by = (int)(p.sy * (float)(tyi * TILE)), bx = (int)(p.sx * (float)(txi * TILE));
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < K::NPRE; ++k) {
       const int idx = tid + 512 * k;
-      if (idx < NFETCH) {
+      if (idx < K::NFETCH) {
         const int tok = idx & 15, chunk = idx >> 4;
         const int gy = min(by + (tok >> 2), p.G - 1), gx = min(bx + (tok & 3), p.G - 1);
         pre[k] = *(const u32x4_t*)(p.zx + ((size_t)b * p.G * p.G + (size_t)gy * p.G + gx) * p.ldzx + chunk * 8);
@@ -118,11 +138,11 @@ __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < K::NPRE; ++k) {
       const int idx = tid + 512 * k;
-      if (idx < NFETCH) {
+      if (idx < K::NFETCH) {
         const int tok = idx & 15, chunk = idx >> 4;
-        unsigned char* dst = smem + (tok >> 3) * PLANE + chunk * 128 + (tok & 7) * 2;
+        unsigned char* dst = smem + (tok >> 3) * K::PLANE + chunk * 128 + (tok & 7) * 2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) *(bf16_t*)(dst + e * 16) = (bf16_t)(pre[k][e >> 1] >> ((e & 1) * 16));
       }
@@ -163,9 +183,9 @@ __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
     const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, whi_u), wlo = __builtin_bit_cast(bf16x8_t, wlo_u);
     const bf16x8_t nhi = __builtin_bit_cast(bf16x8_t, whi_u ^ 0x80008000u), nlo = __builtin_bit_cast(bf16x8_t, wlo_u ^ 0x80008000u);
 
-    const unsigned char* tokl = smem + h * PLANE + n * 16;         // + 512 per 32-channel block
-    const unsigned char* w2l = smem + OFF_W2 + (h * 32 + n) * 16;  // + 1024 per k-step
-    const unsigned char* w3l = smem + OFF_W3 + (h * 32 + n) * 16;  // + 1024 per (tile, k-step)
+    const unsigned char* tokl = smem + h * K::PLANE + n * 16;         // + 512 per 32-channel block
+    const unsigned char* w2l = smem + K::OFF_W2 + (h * 32 + n) * 16;  // + 1024 per k-step
+    const unsigned char* w3l = smem + K::OFF_W3 + (h * 32 + n) * 16;  // + 1024 per (tile, k-step)
 
     // ---- layers 1 + 2: h1 block = relu(b1 + interp(Z block)); a2 += W2[:, block] * h1 block
     f32x16_t a2 = bias16(bias_l + H1, h);
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
     // ---- layer 3 + reconstruction error, 32 channels at a time: a3 = b3 + W3 h2 - interp(x)
     float lsum = 0.f;
 #pragma unroll
-    for (int t = 0; t < DF / 32; ++t) {
+    for (int t = 0; t < K::NT; ++t) {
       f32x16_t a3 = bias16(bias_l + H1 + H2 + 32 * t, h);
       a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(w3l + (2 * t) * 1024), g0, a3, 0, 0, 0);
       a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(w3l + (2 * t + 1) * 1024), g1, a3, 0, 0, 0);
@@ -194,14 +214,14 @@ __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) lsum = fmaf(a3[q], a3[q], lsum);
     }
-    f32x16_t at = bias16(bias_l + H1 + H2 + DF, h);
-    at = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(w3l + (2 * (DF / 32)) * 1024), g0, at, 0, 0, 0);
-    at = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(w3l + (2 * (DF / 32) + 1) * 1024), g1, at, 0, 0, 0);
+    f32x16_t at = bias16(bias_l + H1 + H2 + 32 * K::NT, h);
+    at = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(w3l + (2 * (K::NT)) * 1024), g0, at, 0, 0, 0);
+    at = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(w3l + (2 * (K::NT) + 1) * 1024), g1, at, 0, 0, 0);
 
     lsum += __shfl_xor(lsum, 32, 64);
     if (h == 0 && py < p.Ho && px < p.Wo) {
       const size_t o = ((size_t)b * p.Ho + py) * p.Wo + px;
-      const float lr = lsum / (float)DF;
+      const float lr = lsum / (float)K::DREAL;  // (padded channels contribute exact zeros)
       if (p.trav) p.trav[o] = sigmoid_f(at[0]);
       if (p.loss) p.loss[o] = lr;
       if (p.conf) {
@@ -217,36 +237,41 @@ __global__ __launch_bounds__(512, 2) void pixel_mlp_kernel(PixParams p) {
 // fp32 flat parameters [W1 | b1 | W2 | b2 | W3 | b3] (Linear layout) -> packed blob.
 // k permutations (see the file header): the B fragment of k-step u built from an accumulator holds, in slot (h, e), row
 //   16u + 8(e >> 2) + 4h + (e & 3)   of the 32-row block the accumulator covers.
+template <int D>
 __global__ void pixel_mlp_pack_kernel(const float* __restrict__ prm, unsigned char* __restrict__ out) {
+  using K = Cfg<D>;
   const float* W1 = prm;
-  const float* b1 = W1 + H1 * DF;
+  const float* b1 = W1 + H1 * D;
   const float* W2 = b1 + H1;
   const float* b2 = W2 + H2 * H1;
   const float* W3 = b2 + H2;
-  const float* b3 = W3 + (1 + DF) * H2;
+  const float* b3 = W3 + (1 + D) * H2;
   bf16_t* w1o = (bf16_t*)out;
-  bf16_t* w2o = (bf16_t*)(out + W1_BYTES);
-  bf16_t* w3o = (bf16_t*)(out + W1_BYTES + W2_BYTES);
-  float* bo = (float*)(out + W1_BYTES + W2_BYTES + W3_BYTES);
+  bf16_t* w2o = (bf16_t*)(out + K::W1_BYTES);
+  bf16_t* w3o = (bf16_t*)(out + K::W1_BYTES + W2_BYTES);
+  float* bo = (float*)(out + K::W1_BYTES + W2_BYTES + K::W3_BYTES);
   const int gsz = gridDim.x * blockDim.x, g0 = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int i = g0; i < H1 * DF; i += gsz) w1o[i] = f32_to_bf16(W1[i]);
+  for (int i = g0; i < H1 * K::DX; i += gsz) {  // [256][DX], zero beyond column D
+    const int r = i / K::DX, c = i - r * K::DX;
+    w1o[i] = c < D ? f32_to_bf16(W1[r * D + c]) : (bf16_t)0;
+  }
   for (int i = g0; i < W2_BYTES / 2; i += gsz) {  // [s][h][m][e]
     const int e = i & 7, m = (i >> 3) & 31, hh = (i >> 8) & 1, s = i >> 9;
     const int c = 32 * (s >> 1) + 16 * (s & 1) + 8 * (e >> 2) + 4 * hh + (e & 3);
     w2o[i] = f32_to_bf16(W2[m * H1 + c]);
   }
-  for (int i = g0; i < W3_BYTES / 2; i += gsz) {  // [t][u][h][m][e]
+  for (int i = g0; i < K::W3_BYTES / 2; i += gsz) {  // [t][u][h][m][e]
     const int e = i & 7, m = (i >> 3) & 31, hh = (i >> 8) & 1, u = (i >> 9) & 1, t = i >> 10;
     const int r = 16 * u + 8 * (e >> 2) + 4 * hh + (e & 3);
-    const int row = t < DF / 32 ? 1 + 32 * t + m : (m == 0 ? 0 : -1);
+    const int row = t < K::NT ? (32 * t + m < D ? 1 + 32 * t + m : -1) : (m == 0 ? 0 : -1);
     w3o[i] = row < 0 ? (bf16_t)0 : f32_to_bf16(W3[row * H2 + r]);
   }
-  for (int i = g0; i < NBIAS; i += gsz) {
+  for (int i = g0; i < K::NBIAS; i += gsz) {
     float v;
     if (i < H1) v = b1[i];
     else if (i < H1 + H2) v = b2[i - H1];
-    else if (i < H1 + H2 + DF) v = b3[1 + i - H1 - H2];
-    else v = (i == H1 + H2 + DF) ? b3[0] : 0.f;
+    else if (i < H1 + H2 + 32 * K::NT) v = (i - H1 - H2 < D) ? b3[1 + i - H1 - H2] : 0.f;
+    else v = (i == H1 + H2 + 32 * K::NT) ? b3[0] : 0.f;
     bo[i] = v;
   }
 }
@@ -257,14 +282,6 @@ __global__ void pixel_mlp_pack_kernel(const float* __restrict__ prm, unsigned ch
 // ~1e-5 relative, inside the 1e-3 bar of the exact mode, at 186 instead of 82 MFMAs per 32 pixels.  The token-resolution
 // layer-1 GEMM (Z = tokens * W1^T) runs on the exact fp32 FMA path.  Layout: zxh / zxl = hi / lo parts of [ Z | x ].
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int X3_TOKL = TOK_BYTES;                          // lo planes after the hi planes
-constexpr int X3_OFF_W = 2 * TOK_BYTES;                     // W2H | W3H | W2L | W3L | bias
-constexpr int X3_W2H = X3_OFF_W, X3_W3H = X3_W2H + W2_BYTES, X3_W2L = X3_W3H + W3_BYTES, X3_W3L = X3_W2L + W2_BYTES;
-constexpr int X3_BIAS = X3_W3L + W3_BYTES;
-constexpr int X3_WIMG_BYTES = 2 * (W2_BYTES + W3_BYTES) + NBIAS * 4;
-constexpr int X3_LDS_BYTES = X3_BIAS + NBIAS * 4;           // 130,048
-constexpr int X3_NFETCH = 2 * NFETCH;
-
 struct PixX3Params {
   const bf16_t* zxh; const bf16_t* zxl; int ldzx;
   const unsigned char* wimg;
@@ -297,7 +314,9 @@ __device__ inline void relu_split8(const f32x16_t& a, int r0, bf16x8_t& hi, bf16
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0); \
   } while (0)
 
+template <int D>
 __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
+  using K = Cfg<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,18 +324,18 @@ __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
   const int tiles_per_frame = p.nty * p.ntx;
   const int ntiles = p.B * tiles_per_frame;
 
-  for (int i = tid; i < X3_WIMG_BYTES / 16; i += 512) *(u32x4_t*)(smem + X3_OFF_W + i * 16) = ((const u32x4_t*)p.wimg)[i];
-  const float* bias_l = (const float*)(smem + X3_BIAS);
+  for (int i = tid; i < K::XWIMG_BYTES / 16; i += 512) *(u32x4_t*)(smem + K::XOFFW + i * 16) = ((const u32x4_t*)p.wimg)[i];
+  const float* bias_l = (const float*)(smem + K::XBIAS);
 
-  u32x4_t pre[5];
+  u32x4_t pre[K::XNPRE];
   auto fetch = [&](int tile) {
     const int b = tile / tiles_per_frame, r = tile - b * tiles_per_frame;
     const int tyi = r / p.ntx, txi = r - tyi * p.ntx;
     const int by = (int)(p.sy * (float)(tyi * TILE)), bx = (int)(p.sx * (float)(txi * TILE));
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int idx = tid + 512 * k;  // < 2560 always
-      const int part = idx >= NFETCH, id = idx - part * NFETCH;
+    for (int k = 0; k < K::XNPRE; ++k) {
+      const int idx = min(tid + 512 * k, 2 * K::NFETCH - 1);  // (clamped duplicates re-read / rewrite the same bytes)
+      const int part = idx >= K::NFETCH, id = idx - part * K::NFETCH;
       const int tok = id & 15, chunk = id >> 4;
       const int gy = min(by + (tok >> 2), p.G - 1), gx = min(bx + (tok & 3), p.G - 1);
       const bf16_t* src = part ? p.zxl : p.zxh;
@@ -325,11 +344,11 @@ __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int idx = tid + 512 * k;
-      const int part = idx >= NFETCH, id = idx - part * NFETCH;
+    for (int k = 0; k < K::XNPRE; ++k) {
+      const int idx = min(tid + 512 * k, 2 * K::NFETCH - 1);
+      const int part = idx >= K::NFETCH, id = idx - part * K::NFETCH;
       const int tok = id & 15, chunk = id >> 4;
-      unsigned char* dst = smem + part * X3_TOKL + (tok >> 3) * PLANE + chunk * 128 + (tok & 7) * 2;
+      unsigned char* dst = smem + part * K::XTOKL + (tok >> 3) * K::PLANE + chunk * 128 + (tok & 7) * 2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) *(bf16_t*)(dst + e * 16) = (bf16_t)(pre[k][e >> 1] >> ((e & 1) * 16));
     }
@@ -366,8 +385,8 @@ __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
     const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, whi_u), wlo = __builtin_bit_cast(bf16x8_t, wlo_u);
     const bf16x8_t nhi = __builtin_bit_cast(bf16x8_t, whi_u ^ 0x80008000u), nlo = __builtin_bit_cast(bf16x8_t, wlo_u ^ 0x80008000u);
 
-    const unsigned char* tokh = smem + h * PLANE + n * 16;
-    const unsigned char* tokl = tokh + X3_TOKL;
+    const unsigned char* tokh = smem + h * K::PLANE + n * 16;
+    const unsigned char* tokl = tokh + K::XTOKL;
     const unsigned lw = (h * 32 + n) * 16;  // lane's fragment inside one [k-step] image block of 1024 bytes
 
     f32x16_t a2 = bias16(bias_l + H1, h);
@@ -381,8 +400,8 @@ __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
       relu_split8(az, 8, hh[1], hl[1]);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const bf16x8_t wh = *(const bf16x8_t*)(smem + X3_W2H + (2 * blk + u) * 1024 + lw);
-        const bf16x8_t wl = *(const bf16x8_t*)(smem + X3_W2L + (2 * blk + u) * 1024 + lw);
+        const bf16x8_t wh = *(const bf16x8_t*)(smem + K::XW2H + (2 * blk + u) * 1024 + lw);
+        const bf16x8_t wl = *(const bf16x8_t*)(smem + K::XW2L + (2 * blk + u) * 1024 + lw);
         MFMA3(a2, wh, wl, hh[u], hl[u]);
       }
     }
@@ -392,12 +411,12 @@ __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
 
     float lsum = 0.f;
 #pragma unroll
-    for (int t = 0; t < DF / 32; ++t) {
+    for (int t = 0; t < K::NT; ++t) {
       f32x16_t a3 = bias16(bias_l + H1 + H2 + 32 * t, h);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const bf16x8_t wh = *(const bf16x8_t*)(smem + X3_W3H + (2 * t + u) * 1024 + lw);
-        const bf16x8_t wl = *(const bf16x8_t*)(smem + X3_W3L + (2 * t + u) * 1024 + lw);
+        const bf16x8_t wh = *(const bf16x8_t*)(smem + K::XW3H + (2 * t + u) * 1024 + lw);
+        const bf16x8_t wl = *(const bf16x8_t*)(smem + K::XW3L + (2 * t + u) * 1024 + lw);
         MFMA3(a3, wh, wl, gh[u], gl[u]);
       }
       const bf16x8_t th = *(const bf16x8_t*)(tokh + (H1 / 32 + t) * 512), tl = *(const bf16x8_t*)(tokl + (H1 / 32 + t) * 512);
@@ -405,18 +424,18 @@ __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) lsum = fmaf(a3[q], a3[q], lsum);
     }
-    f32x16_t at = bias16(bias_l + H1 + H2 + DF, h);
+    f32x16_t at = bias16(bias_l + H1 + H2 + 32 * K::NT, h);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const bf16x8_t wh = *(const bf16x8_t*)(smem + X3_W3H + (2 * (DF / 32) + u) * 1024 + lw);
-      const bf16x8_t wl = *(const bf16x8_t*)(smem + X3_W3L + (2 * (DF / 32) + u) * 1024 + lw);
+      const bf16x8_t wh = *(const bf16x8_t*)(smem + K::XW3H + (2 * (K::NT) + u) * 1024 + lw);
+      const bf16x8_t wl = *(const bf16x8_t*)(smem + K::XW3L + (2 * (K::NT) + u) * 1024 + lw);
       MFMA3(at, wh, wl, gh[u], gl[u]);
     }
 
     lsum += __shfl_xor(lsum, 32, 64);
     if (h == 0 && py < p.Ho && px < p.Wo) {
       const size_t o = ((size_t)b * p.Ho + py) * p.Wo + px;
-      const float lr = lsum / (float)DF;
+      const float lr = lsum / (float)K::DREAL;
       if (p.trav) p.trav[o] = sigmoid_f(at[0]);
       if (p.loss) p.loss[o] = lr;
       if (p.conf) {
@@ -431,18 +450,20 @@ __global__ __launch_bounds__(512, 1) void pixel_mlp_x3_kernel(PixX3Params p) {
 #undef MFMA3
 
 // packed blob of the exact mode: W2 hi | W3 hi | W2 lo | W3 lo | biases (same fragment order as the bf16 pack)
+template <int D>
 __global__ void pixel_mlp_pack_x3_kernel(const float* __restrict__ prm, unsigned char* __restrict__ out) {
+  using K = Cfg<D>;
   const float* W1 = prm;
-  const float* b1 = W1 + H1 * DF;
+  const float* b1 = W1 + H1 * D;
   const float* W2 = b1 + H1;
   const float* b2 = W2 + H2 * H1;
   const float* W3 = b2 + H2;
-  const float* b3 = W3 + (1 + DF) * H2;
+  const float* b3 = W3 + (1 + D) * H2;
   bf16_t* w2h = (bf16_t*)out;
   bf16_t* w3h = (bf16_t*)(out + W2_BYTES);
-  bf16_t* w2l = (bf16_t*)(out + W2_BYTES + W3_BYTES);
-  bf16_t* w3l = (bf16_t*)(out + 2 * W2_BYTES + W3_BYTES);
-  float* bo = (float*)(out + 2 * (W2_BYTES + W3_BYTES));
+  bf16_t* w2l = (bf16_t*)(out + W2_BYTES + K::W3_BYTES);
+  bf16_t* w3l = (bf16_t*)(out + 2 * W2_BYTES + K::W3_BYTES);
+  float* bo = (float*)(out + 2 * (W2_BYTES + K::W3_BYTES));
   const int gsz = gridDim.x * blockDim.x, g0 = blockIdx.x * blockDim.x + threadIdx.x;
   for (int i = g0; i < W2_BYTES / 2; i += gsz) {
     const int e = i & 7, m = (i >> 3) & 31, hh = (i >> 8) & 1, s = i >> 9;
@@ -452,33 +473,35 @@ __global__ void pixel_mlp_pack_x3_kernel(const float* __restrict__ prm, unsigned
     w2h[i] = hi;
     w2l[i] = f32_to_bf16(v - bf16_to_f32(hi));
   }
-  for (int i = g0; i < W3_BYTES / 2; i += gsz) {
+  for (int i = g0; i < K::W3_BYTES / 2; i += gsz) {
     const int e = i & 7, m = (i >> 3) & 31, hh = (i >> 8) & 1, u = (i >> 9) & 1, t = i >> 10;
     const int r = 16 * u + 8 * (e >> 2) + 4 * hh + (e & 3);
-    const int row = t < DF / 32 ? 1 + 32 * t + m : (m == 0 ? 0 : -1);
+    const int row = t < K::NT ? (32 * t + m < D ? 1 + 32 * t + m : -1) : (m == 0 ? 0 : -1);
     const float v = row < 0 ? 0.f : W3[row * H2 + r];
     const bf16_t hi = f32_to_bf16(v);
     w3h[i] = hi;
     w3l[i] = f32_to_bf16(v - bf16_to_f32(hi));
   }
-  for (int i = g0; i < NBIAS; i += gsz) {
+  for (int i = g0; i < K::NBIAS; i += gsz) {
     float v;
     if (i < H1) v = b1[i];
     else if (i < H1 + H2) v = b2[i - H1];
-    else if (i < H1 + H2 + DF) v = b3[1 + i - H1 - H2];
-    else v = (i == H1 + H2 + DF) ? b3[0] : 0.f;
+    else if (i < H1 + H2 + 32 * K::NT) v = (i - H1 - H2 < D) ? b3[1 + i - H1 - H2] : 0.f;
+    else v = (i == H1 + H2 + 32 * K::NT) ? b3[0] : 0.f;
     bo[i] = v;
   }
 }
 
 // zf [rows][256] fp32 (layer-1 pre-activations) and tokens [rows][ldt] fp32 -> hi / lo rows [ Z | x ] of 640 bf16
+template <int D>
 __global__ void pixel_split_rows_kernel(const float* __restrict__ zf, const float* __restrict__ tok, int ldt,
                                         bf16_t* __restrict__ zxh, bf16_t* __restrict__ zxl, long long rows) {
+  using K = Cfg<D>;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * NCH) return;
-  const long long r = i / NCH;
-  const int c = (int)(i - r * NCH);
-  const float v = c < H1 ? zf[r * H1 + c] : tok[r * ldt + (c - H1)];
+  if (i >= rows * K::NCH) return;
+  const long long r = i / K::NCH;
+  const int c = (int)(i - r * K::NCH);
+  const float v = c < H1 ? zf[r * H1 + c] : (c - H1 < D ? tok[r * ldt + (c - H1)] : 0.f);
   const bf16_t hi = f32_to_bf16(v);
   zxh[i] = hi;
   zxl[i] = f32_to_bf16(v - bf16_to_f32(hi));
@@ -495,38 +518,27 @@ int pix_num_cus() {
   return n;
 }
 
-}  // namespace
-
-size_t wvn_pixel_mlp_pack_bytes_impl() { return (size_t)W1_BYTES + WIMG_BYTES; }
-
-int wvn_pixel_mlp_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st) {
-  if (D != DF || h1 != H1 || h2 != H2 || !params || !packed || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
-  hipLaunchKernelGGL(pixel_mlp_pack_kernel, dim3(96), dim3(256), 0, st, params, (unsigned char*)packed);
-  WVN_LAUNCH_CHECK();
-  return WVN_OK;
-}
-
-int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* zx, int ldzx, int B, int G, int out_h,
-                               int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
-                               float* conf, float* loss, hipStream_t st) {
-  if (D != DF || h1 != H1 || h2 != H2 || !packed || !zx || B <= 0 || G < 2 || out_h < 2 || out_w < 2) return WVN_ERR_ARG;
-  if (ldzx < NCH || (ldzx % 8) || ((uintptr_t)zx & 15) || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
+template <int D>
+int pix_infer(const void* packed, void* zx, int ldzx, int B, int G, int out_h, int out_w, float mean, float std,
+              float std_factor, const float* conf_state, float* trav, float* conf, float* loss, hipStream_t st) {
+  using K = Cfg<D>;
+  if (ldzx < K::ZXC || (ldzx % 8) || ((uintptr_t)zx & 15) || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
   const float sy = (float)(G - 1) / (float)(out_h - 1), sx = (float)(G - 1) / (float)(out_w - 1);
   // a 16-pixel span must stay inside 3 consecutive source cells (4 tokens): 15 * scale < 2
   if (15.f * sy > 1.99f || 15.f * sx > 1.99f) return WVN_ERR_ARG;
-  // Z = tokens * W1^T, bf16, into columns [0,256) of the same rows
+  // Z = x * W1^T, bf16, into columns [0,256) of the same rows (K = the zero-padded x width)
   GemmBf16Params g{};
   g.A = (const bf16_t*)zx + H1; g.lda = ldzx;
-  g.W = (const bf16_t*)packed; g.ldw = DF;
+  g.W = (const bf16_t*)packed; g.ldw = K::DX;
   g.bias = nullptr;
   g.C = zx; g.ldc = ldzx;
-  g.M = B * G * G; g.N = H1; g.K = DF;
+  g.M = B * G * G; g.N = H1; g.K = K::DX;
   int rc = wvn_gemm_bf16_launch(g, EPI_BF16, st);
   if (rc != WVN_OK) return rc;
 
   PixParams p{};
   p.zx = (const bf16_t*)zx; p.ldzx = ldzx;
-  p.wimg = (const unsigned char*)packed + W1_BYTES;
+  p.wimg = (const unsigned char*)packed + K::W1_BYTES;
   p.trav = trav; p.conf = conf; p.loss = loss;
   p.B = B; p.G = G; p.Ho = out_h; p.Wo = out_w;
   p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
@@ -535,29 +547,108 @@ int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* 
     const char* e = getenv("WVN_PIXEL_WSPLIT");
     return e ? atoi(e) : 1;
   }();
-  auto kern = split ? pixel_mlp_kernel<1> : pixel_mlp_kernel<0>;
+  auto kern = split ? pixel_mlp_kernel<1, D> : pixel_mlp_kernel<0, D>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[split ? 1 : 0]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set[split ? 1 : 0] = true;
   }
   const int ntiles = B * p.nty * p.ntx;
   const int cap = 2 * pix_num_cus();
-  hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(512), K::LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
 
-size_t wvn_pixel_mlp_exact_pack_bytes_impl() { return (size_t)X3_WIMG_BYTES; }
-size_t wvn_pixel_mlp_exact_workspace_bytes_impl(int B, int G) {
+template <int D>
+size_t pix_exact_ws(int B, int G) {
   const size_t rows = (size_t)B * G * G;
-  return rows * H1 * 4 + 2 * rows * NCH * 2 + 256;
+  return rows * H1 * 4 + 2 * rows * Cfg<D>::NCH * 2 + 256;
+}
+
+template <int D>
+int pix_infer_exact(const float* params, const void* packed, const float* tokens, int ldt, int B, int G, int out_h, int out_w,
+                    float mean, float std, float std_factor, const float* conf_state, float* trav, float* conf, float* loss,
+                    void* workspace, size_t workspace_bytes, hipStream_t st) {
+  using K = Cfg<D>;
+  if (ldt < D || ((uintptr_t)workspace & 15) || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
+  if (workspace_bytes < pix_exact_ws<D>(B, G)) return WVN_ERR_WORKSPACE;
+  const float sy = (float)(G - 1) / (float)(out_h - 1), sx = (float)(G - 1) / (float)(out_w - 1);
+  if (15.f * sy > 1.99f || 15.f * sx > 1.99f) return WVN_ERR_ARG;
+  const long long rows = (long long)B * G * G;
+  float* zf = (float*)workspace;
+  bf16_t* zxh = (bf16_t*)(zf + rows * H1);
+  bf16_t* zxl = zxh + rows * K::NCH;
+  // layer 1 at token resolution on the exact fp32 path: Z = x * W1^T (bias is added after the interpolation)
+  GemmF32Params g{};
+  g.A = tokens; g.lda = ldt; g.transA = 0;
+  g.B = params; g.ldb = D; g.transB = 1;   // W1 [256][D], Linear layout, first in the flat parameter buffer
+  g.bias = nullptr;
+  g.C = zf; g.ldc = H1; g.M = (int)rows; g.N = H1; g.K = D; g.batch = 1; g.splitk = 1;
+  int rc = wvn_gemm_f32_launch(g, F32_EPI_NONE, st);
+  if (rc != WVN_OK) return rc;
+  const long long nel = rows * K::NCH;
+  hipLaunchKernelGGL(pixel_split_rows_kernel<D>, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, zf, tokens, ldt, zxh, zxl, rows);
+  WVN_LAUNCH_CHECK();
+
+  PixX3Params p{};
+  p.zxh = zxh; p.zxl = zxl; p.ldzx = K::NCH;
+  p.wimg = (const unsigned char*)packed;
+  p.trav = trav; p.conf = conf; p.loss = loss;
+  p.B = B; p.G = G; p.Ho = out_h; p.Wo = out_w;
+  p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
+  p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor; p.conf_dev = conf_state;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_x3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, K::XLDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int ntiles = B * p.nty * p.ntx;
+  const int cap = pix_num_cus();
+  hipLaunchKernelGGL(pixel_mlp_x3_kernel<D>, dim3(ntiles < cap ? ntiles : cap), dim3(512), K::XLDS_BYTES, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+bool pix_supported(int D, int h1, int h2) { return (D == 384 || D == 90) && h1 == H1 && h2 == H2; }
+
+}  // namespace
+
+// D = 384 (DINO ViT-S features) or 90 (STEGO code); 0 / WVN_ERR_ARG for anything else
+size_t wvn_pixel_mlp_pack_bytes_impl(int D) {
+  return D == 384 ? (size_t)Cfg<384>::W1_BYTES + Cfg<384>::WIMG_BYTES : D == 90 ? (size_t)Cfg<90>::W1_BYTES + Cfg<90>::WIMG_BYTES : 0;
+}
+int wvn_pixel_mlp_zx_cols_impl(int D) { return D == 384 ? Cfg<384>::ZXC : D == 90 ? Cfg<90>::ZXC : 0; }
+
+int wvn_pixel_mlp_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st) {
+  if (!pix_supported(D, h1, h2) || !params || !packed || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
+  if (D == 384) hipLaunchKernelGGL(pixel_mlp_pack_kernel<384>, dim3(96), dim3(256), 0, st, params, (unsigned char*)packed);
+  else hipLaunchKernelGGL(pixel_mlp_pack_kernel<90>, dim3(96), dim3(256), 0, st, params, (unsigned char*)packed);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* zx, int ldzx, int B, int G, int out_h,
+                               int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
+                               float* conf, float* loss, hipStream_t st) {
+  if (!pix_supported(D, h1, h2) || !packed || !zx || B <= 0 || G < 2 || out_h < 2 || out_w < 2) return WVN_ERR_ARG;
+  return D == 384 ? pix_infer<384>(packed, zx, ldzx, B, G, out_h, out_w, mean, std, std_factor, conf_state, trav, conf, loss, st)
+                  : pix_infer<90>(packed, zx, ldzx, B, G, out_h, out_w, mean, std, std_factor, conf_state, trav, conf, loss, st);
+}
+
+size_t wvn_pixel_mlp_exact_pack_bytes_impl(int D) {
+  return D == 384 ? (size_t)Cfg<384>::XWIMG_BYTES : D == 90 ? (size_t)Cfg<90>::XWIMG_BYTES : 0;
+}
+size_t wvn_pixel_mlp_exact_workspace_bytes_impl(int D, int B, int G) {
+  return D == 384 ? pix_exact_ws<384>(B, G) : D == 90 ? pix_exact_ws<90>(B, G) : 0;
 }
 
 int wvn_pixel_mlp_exact_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st) {
-  if (D != DF || h1 != H1 || h2 != H2 || !params || !packed || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
-  hipLaunchKernelGGL(pixel_mlp_pack_x3_kernel, dim3(96), dim3(256), 0, st, params, (unsigned char*)packed);
+  if (!pix_supported(D, h1, h2) || !params || !packed || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
+  if (D == 384) hipLaunchKernelGGL(pixel_mlp_pack_x3_kernel<384>, dim3(96), dim3(256), 0, st, params, (unsigned char*)packed);
+  else hipLaunchKernelGGL(pixel_mlp_pack_x3_kernel<90>, dim3(96), dim3(256), 0, st, params, (unsigned char*)packed);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -566,44 +657,10 @@ int wvn_pixel_mlp_infer_exact_launch(int D, int h1, int h2, const float* params,
                                      int ldt, int B, int G, int out_h, int out_w, float mean, float std, float std_factor,
                                      const float* conf_state, float* trav, float* conf, float* loss, void* workspace,
                                      size_t workspace_bytes, hipStream_t st) {
-  if (D != DF || h1 != H1 || h2 != H2 || !params || !packed || !tokens || !workspace || B <= 0 || G < 2 || out_h < 2 || out_w < 2)
+  if (!pix_supported(D, h1, h2) || !params || !packed || !tokens || !workspace || B <= 0 || G < 2 || out_h < 2 || out_w < 2)
     return WVN_ERR_ARG;
-  if (ldt < DF || ((uintptr_t)workspace & 15) || ((uintptr_t)packed & 15)) return WVN_ERR_ARG;
-  if (workspace_bytes < wvn_pixel_mlp_exact_workspace_bytes_impl(B, G)) return WVN_ERR_WORKSPACE;
-  const float sy = (float)(G - 1) / (float)(out_h - 1), sx = (float)(G - 1) / (float)(out_w - 1);
-  if (15.f * sy > 1.99f || 15.f * sx > 1.99f) return WVN_ERR_ARG;
-  const long long rows = (long long)B * G * G;
-  float* zf = (float*)workspace;
-  bf16_t* zxh = (bf16_t*)(zf + rows * H1);
-  bf16_t* zxl = zxh + rows * NCH;
-  // layer 1 at token resolution on the exact fp32 path: Z = tokens * W1^T (bias is added after the interpolation)
-  GemmF32Params g{};
-  g.A = tokens; g.lda = ldt; g.transA = 0;
-  g.B = params; g.ldb = DF; g.transB = 1;   // W1 [256][384], Linear layout, first in the flat parameter buffer
-  g.bias = nullptr;
-  g.C = zf; g.ldc = H1; g.M = (int)rows; g.N = H1; g.K = DF; g.batch = 1; g.splitk = 1;
-  int rc = wvn_gemm_f32_launch(g, F32_EPI_NONE, st);
-  if (rc != WVN_OK) return rc;
-  const long long nel = rows * NCH;
-  hipLaunchKernelGGL(pixel_split_rows_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, zf, tokens, ldt, zxh, zxl, rows);
-  WVN_LAUNCH_CHECK();
-
-  PixX3Params p{};
-  p.zxh = zxh; p.zxl = zxl; p.ldzx = NCH;
-  p.wimg = (const unsigned char*)packed;
-  p.trav = trav; p.conf = conf; p.loss = loss;
-  p.B = B; p.G = G; p.Ho = out_h; p.Wo = out_w;
-  p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
-  p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor; p.conf_dev = conf_state;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int ntiles = B * p.nty * p.ntx;
-  const int cap = pix_num_cus();
-  hipLaunchKernelGGL(pixel_mlp_x3_kernel, dim3(ntiles < cap ? ntiles : cap), dim3(512), X3_LDS_BYTES, st, p);
-  WVN_LAUNCH_CHECK();
-  return WVN_OK;
+  return D == 384 ? pix_infer_exact<384>(params, packed, tokens, ldt, B, G, out_h, out_w, mean, std, std_factor, conf_state, trav,
+                                         conf, loss, workspace, workspace_bytes, st)
+                  : pix_infer_exact<90>(params, packed, tokens, ldt, B, G, out_h, out_w, mean, std, std_factor, conf_state, trav,
+                                        conf, loss, workspace, workspace_bytes, st);
 }

@@ -117,14 +117,15 @@ int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int*
                               hipStream_t st);
 
 // ---- fused per-pixel traversability inference (pixel_mlp.hip) ------------------------------------
-size_t wvn_pixel_mlp_pack_bytes_impl();
+size_t wvn_pixel_mlp_pack_bytes_impl(int D);
+int wvn_pixel_mlp_zx_cols_impl(int D);
 int wvn_pixel_mlp_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st);
 int wvn_pixel_mlp_infer_launch(int D, int h1, int h2, const void* packed, void* zx, int ldzx, int B, int G, int out_h,
                                int out_w, float mean, float std, float std_factor, const float* conf_state, float* trav,
                                float* conf, float* loss, hipStream_t st);
 // exact mode (hi + lo split operands, three MFMAs per product)
-size_t wvn_pixel_mlp_exact_pack_bytes_impl();
-size_t wvn_pixel_mlp_exact_workspace_bytes_impl(int B, int G);
+size_t wvn_pixel_mlp_exact_pack_bytes_impl(int D);
+size_t wvn_pixel_mlp_exact_workspace_bytes_impl(int D, int B, int G);
 int wvn_pixel_mlp_exact_pack_launch(int D, int h1, int h2, const float* params, void* packed, hipStream_t st);
 int wvn_pixel_mlp_infer_exact_launch(int D, int h1, int h2, const float* params, const void* packed, const float* tokens,
                                      int ldt, int B, int G, int out_h, int out_w, float mean, float std, float std_factor,

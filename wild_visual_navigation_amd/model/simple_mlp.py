@@ -87,7 +87,12 @@ class SimpleMLP(torch.nn.Module):
         return out
 
     # ---- fused per-pixel inference ---------------------------------------------------
-    ZX_COLS, X_COL = 640, 256   # include/wvn_hip.h: WVN_PIXEL_ZX_COLS / WVN_PIXEL_X_COL
+    X_COL = 256   # include/wvn_hip.h: WVN_PIXEL_X_COL
+
+    @property
+    def ZX_COLS(self) -> int:
+        """Row length of the zx buffer: 640 for 384-d DINO features, 384 for the 90-d STEGO code (0: unsupported size)."""
+        return int(_lib.lib().wvn_pixel_mlp_zx_cols(C.byref(self.desc)))
 
     def pack_per_pixel(self) -> torch.Tensor:
         """Re-pack the current parameters for ``forward_per_pixel`` (bf16, MFMA fragment order).  Call after every
@@ -96,7 +101,7 @@ class SimpleMLP(torch.nn.Module):
         _lib.require_cuda(flat, "parameters")
         n = _lib.lib().wvn_pixel_mlp_pack_bytes(C.byref(self.desc))
         if n == 0:
-            raise _lib.WvnError("fused per-pixel inference needs SimpleMLP(384, [256, 32, 1], reconstruction=True)")
+            raise _lib.WvnError("fused per-pixel inference needs SimpleMLP(384 | 90, [256, 32, 1], reconstruction=True)")
         if self._pix_packed is None or self._pix_packed.device != flat.device:
             self._pix_packed = torch.empty(n, dtype=torch.uint8, device=flat.device)
         rc = _lib.lib().wvn_pixel_mlp_pack(C.byref(self.desc), flat.data_ptr(), self._pix_packed.data_ptr(), _lib.stream())
@@ -109,7 +114,8 @@ class SimpleMLP(torch.nn.Module):
                           conf_state: Optional[torch.Tensor] = None):
         """What wvn_feature_extractor_node.py:319-363 computes with prediction_per_pixel -- upsample, forward, column 0,
         reconstruction confidence -- from the PATCH tokens, without the dense feature tensor:
-        ``zx`` [batch*grid*grid, 640] bf16 with the tokens in columns [256, 640) (columns [0, 256) are scratch) ->
+        ``zx`` [batch*grid*grid, ZX_COLS] bf16 with the features from column 256 on (zero-padded to the row end for the 90-d
+        STEGO code; columns [0, 256) are scratch) ->
         (trav [batch,H,W], conf [batch,H,W], loss_reco [batch,H,W] | None), fp32.  ``conf_state``: optional fp32 device
         tensor {mean, std, std_factor} read by the kernel instead of the three floats (for HIP-graph capture)."""
         _lib.require_cuda(zx, "zx")
