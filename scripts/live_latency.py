@@ -28,22 +28,25 @@ def wall(fn, iters):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-def main():
-    dev = torch.device("cuda:0")
-    S = 448
+def run(dev, S, ftype):
     sd = synthetic_vit_state_dict(depth=12, pretrain_grid=28)
-    fe = FeatureExtractor(device=dev, segmentation_type="grid", feature_type="dino", patch_size=8, backbone_type="vit_small",
-                          input_size=S, pretrained_weights=sd, precision="bf16")
+    fe = FeatureExtractor(device=dev, segmentation_type="stego" if ftype == "stego" else "grid", feature_type=ftype, patch_size=8,
+                          backbone_type="vit_small", input_size=S, pretrained_weights=sd, precision="bf16")
     params = ExperimentParams()
-    params.model.simple_mlp_cfg.input_size = 384
+    params.model.simple_mlp_cfg.input_size = fe.feature_dim
     model = get_model(params.model).to(dev)
     model.eval()
     cg = ConfidenceGenerator(method="latest_measurement", std_factor=0.5).to(dev)
     cg.mean[0], cg.std[0] = 0.9, 0.25
     frame = torch.randint(0, 256, (1, 3, S, S), dtype=torch.uint8, device=dev)
     eager = wall(lambda: fe.predict_per_pixel(frame, model, cg), 50)
-    out = {"frame": f"{S}x{S} uint8", "eager_ms": round(eager, 3)}
-    print(json.dumps(out))
+    return {"frame": f"{S}x{S} uint8", "features": ftype, "ms_per_frame": round(eager, 3)}
+
+
+def main():
+    dev = torch.device("cuda:0")
+    # BASELINE's 448x448 DINO configuration, and the node's own default (default.yaml: 224x224, feature_type stego)
+    print(json.dumps([run(dev, 448, "dino"), run(dev, 224, "stego"), run(dev, 224, "dino")]))
 
 
 if __name__ == "__main__":
