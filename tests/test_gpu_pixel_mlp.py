@@ -227,3 +227,4 @@ def test_predict_per_pixel_with_stego_features(dev, golden):
         assert trav.shape == (1, 224, 224)
         assert (trav[0].reshape(-1) - pred[:, 0]).abs().max().item() < tol, prec
         assert ((loss[0].reshape(-1) - lr).abs() / lr).max().item() < 10 * tol, prec
+

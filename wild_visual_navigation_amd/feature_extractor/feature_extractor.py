@@ -168,17 +168,20 @@ class FeatureExtractor:
         rows))`` -> column 0 / ``confidence_generator.inference_without_update(mse(pred[:, 1:], x))``, but the dense
         [B,D,H,H] tensor is never built and layer 1 runs at patch resolution (csrc/pixel_mlp.hip).  DINO (384-d) or STEGO
         (90-d code) features; bf16 extractor -> bf16 MFMA kernel, fp32 (exact) extractor -> the hi + lo split form (<= 1e-3 of the reference).  Like the reference (dino_interface.py:87-90) the map is H x H for an H x W frame."""
-        img = img.to(self._device)
-        B, H = img.shape[0], img.shape[2]
-        G = self._grid()
         mean, std, f = 0.0, 1.0, 0.5
         if confidence_generator is not None:
             mean, std, f = float(confidence_generator.mean), float(confidence_generator.std), float(confidence_generator.std_factor)
+        return self._predict_per_pixel(img.to(self._device), model, mean, std, f, None, want_loss)
+
+    def _predict_per_pixel(self, img, model, mean, std, f, conf_state, want_loss):
+        B, H = img.shape[0], img.shape[2]
+        G = self._grid()
         stego = self._feature_type == "stego"
         exact = (self._extractor._precision != "bf16") if stego else (self._extractor._model.lowp_dtype != torch.bfloat16)
         if exact:   # fp32 extractor: hi + lo split MFMA operands in the fused kernel
             tokens = self.backbone_stage(img)
-            return model.forward_per_pixel_exact(tokens.reshape(B * G * G, -1), B, G, (H, H), mean, std, f, want_loss=want_loss)
+            return model.forward_per_pixel_exact(tokens.reshape(B * G * G, -1), B, G, (H, H), mean, std, f, want_loss=want_loss,
+                                                 conf_state=conf_state)
         if stego:   # 90-d code (the live node's default feature_type), zero-padded to the 128 columns the layer-1 GEMM reads
             code = self._extractor.code_tokens(img).reshape(B * G * G, -1)
             zx = torch.zeros(B * G * G, model.ZX_COLS, dtype=torch.bfloat16, device=self._device)
@@ -188,7 +191,7 @@ class FeatureExtractor:
             from .transforms import resize_nearest_center_crop
             self._extractor._model.forward_tokens(resize_nearest_center_crop(img, self._extractor.input_size),
                                                   lowp_out=zx[:, model.X_COL:])
-        return model.forward_per_pixel(zx, B, G, (H, H), mean, std, f, want_loss=want_loss)
+        return model.forward_per_pixel(zx, B, G, (H, H), mean, std, f, want_loss=want_loss, conf_state=conf_state)
 
     def _grid(self) -> int:
         return self._extractor.grid
