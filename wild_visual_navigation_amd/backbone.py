@@ -122,7 +122,7 @@ class VitBackbone:
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
 
-    # ---- workspace (zero-filled once: pad rows of q/k/v^T are never written by the kernels) -------------
+    # ---- workspace (needs no initialisation: wvn_vit_forward resets the padding rows it relies on at every call) ----
     def _workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch < batch:
             n = self.lib.wvn_vit_workspace_bytes(C.byref(self.model), batch)
