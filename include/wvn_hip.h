@@ -23,14 +23,19 @@ extern "C" {
 #define WVN_MAX_DEPTH 32
 #define WVN_PREC_F32 0  /* exact mode: fp32 storage + fp32 FMA everywhere (parity gate, <= 1e-3) */
 #define WVN_PREC_BF16 1 /* fast mode: bf16 operands on MFMA, fp32 accumulate / statistics / residual */
+#define WVN_PREC_X3 2   /* exact mode ON THE MATRIX PIPE: every MFMA operand is two bf16 planes (hi + lo, 16 significant bits),  \
+                           every product hi*hi + hi*lo + lo*hi in fp32 accumulators (fp32-class results, <= 1e-3 gate), erf GELU, \
+                           fp32 residual / LayerNorm / softmax */
 
 int wvn_version(void);
 
 /* ---------------------------------------------------------------------------------------------
  * DINO ViT backbone  (replaces stego.backbones.backbone.get_backbone(cfg)(img), called from
  * wild_visual_navigation/feature_extractor/dino_interface.py:45,84, plus the T.Normalize of :52).
- * Weights: matrices in torch.nn.Linear layout [out][in]; bf16 bits (uint16) when precision ==
- * WVN_PREC_BF16, float otherwise.  Biases, LayerNorm affine and the position table are always fp32.
+ * Weights: matrices in torch.nn.Linear layout [out][in]; bf16 bits (uint16) when precision == WVN_PREC_BF16, float for
+ * WVN_PREC_F32, and for WVN_PREC_X3 TWO stacked bf16 planes [2][out][in]: hi = bf16(w), lo = bf16(w - hi).  For the two MFMA
+ * precisions the patch weight rows are zero-padded to a multiple of 64 columns (588 -> 640 for patch 14).
+ * Biases, LayerNorm affine, LayerScale and the position table are always fp32.
  * ------------------------------------------------------------------------------------------- */
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
@@ -39,18 +44,19 @@ typedef struct wvn_vit_layer {
   const void* fc2_w;  /* [D][F]    blocks.i.mlp.fc2.weight   */
   const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const float *ls1, *ls2; /* [D] LayerScale of the attention / MLP branch (DINOv2 blocks.i.ls{1,2}.gamma); NULL = none (DINO) */
 } wvn_vit_layer;
 
 typedef struct wvn_vit_model {
   int img_size; /* network input side S (448)            */
-  int patch;    /* P (8 or 16)                           */
+  int patch;    /* P (8, 14 or 16)                       */
   int dim;      /* D (384); heads * 64                   */
   int depth;    /* number of blocks (12)                 */
   int heads;    /* h (6); head dim is fixed at 64        */
   int mlp_dim;  /* F (1536)                              */
   int precision;
   int reserved;
-  const void* patch_w;  /* [D][3*P*P] conv weight flattened (c, py, px)            */
+  const void* patch_w;  /* [D][3*P*P (padded, see above)] conv weight flattened (c, py, px) */
   const float* patch_b; /* [D]                                                      */
   const float* cls_pos; /* [D]  = cls_token + pos_embed[0]                          */
   const float* pos;     /* [1+G*G][D] position table already resampled to the grid  */
@@ -62,7 +68,8 @@ size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch);
 
 /* img [B,3,S,S] fp32 in [0,1] (already resized/cropped, dino_interface.py:54-57) ->
  *   tokens_f32  [B, G*G, D]  final-LayerNorm'ed patch tokens (class token dropped), may be NULL
- *   tokens_lowp [B*G*G rows, ld_lowp] same values in the model precision (bf16/f32), may be NULL
+ *   tokens_lowp [B*G*G rows, ld_lowp] same values in the model precision (bf16/f32), may be NULL (must be NULL for
+ *               WVN_PREC_X3: split the fp32 tokens with wvn_split_planes where planes are needed)
  * The workspace needs no initialisation (padding rows are reset by every call). */
 int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
                     int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
@@ -86,6 +93,18 @@ int wvn_prof_collect(double* ms_by_cat_host, long long* launches_by_cat_host); /
  * 4 f32 out += (residual), 5 same as 4.  A/W bf16, K % 64 == 0. */
 int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
                   int K, int epi, void* stream);
+/* The same GEMM in exact mode (WVN_PREC_X3): A and W as hi / lo bf16 planes (same leading dimensions), three MFMAs per
+ * product.  epi 0-2 write C as hi / lo planes (C, C_lo, bf16 [M, ldc] each; gelu = exact erf form), epi 3-5 write fp32 C
+ * (C_lo ignored). */
+int wvn_gemm_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,
+                void* C, void* C_lo, int ldc, int M, int N, int K, int epi, void* stream);
+/* fp32 [rows, lds] -> hi = bf16(x), lo = bf16(x - hi), both [rows, ldd] */
+int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream);
+/* exact-mode attention: q / k planes [B,h,npad,64], V^T planes [B,h,64,npad] (token permutation of the bf16 path),
+ * out planes [B*ntok, h*64]; scale > 0 */
+int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                     const void* vt_lo, void* out_hi, void* out_lo, int B, int heads, int ntok, int npad, float scale,
+                     void* stream);
 /* fp32 GEMM C = epilogue(op(A) op(B) + bias); transA: A stored [K,M]; transB: B stored [N,K].
  * epi: 0 none, 1 relu, 2 gelu, 3 C +=, 4 sigmoid on column 0, 5 relu-mask (mask > 0 ? acc : 0). */
 int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, int transB, const float* bias, float* C,

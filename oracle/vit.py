@@ -7,7 +7,8 @@ wild_visual_navigation/feature_extractor/dino_interface.py:12,45,84).  That pack
 (facebookresearch/dino, vision_transformer.py) as used by STEGO's featurizer:
 patch-embed conv(k=P,s=P) -> [cls]+tokens + bicubic-interpolated pos-embed -> 12 pre-LN blocks
 (LN eps 1e-6, qkv Linear with bias, softmax(QK^T/sqrt(dh))V, proj, +res, LN, fc1, exact GELU,
-fc2, +res) -> final LN -> drop cls -> [B, D, G, G].   PARITY UNPINNED (no reference golden
+fc2, +res) -> final LN -> drop cls -> [B, D, G, G]; with ``blocks.i.ls{1,2}.gamma`` present the block is the published
+DINOv2 one (LayerScale on both branch outputs, facebookresearch/dinov2).   PARITY UNPINNED (no reference golden
 vectors exist for it); guarded by the HF ViTModel weight-copy cross-check in tests/.
 
 State-dict layout = upstream DINO names, so real checkpoints load unchanged:
@@ -72,6 +73,22 @@ def make_vit_state_dict(
     return sd
 
 
+def make_dinov2_state_dict(arch: str = "vit_base", patch: int = 14, pretrain_grid: int = 37, seed: int = 0,
+                           depth: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights in the published DINOv2 layout (facebookresearch/dinov2, vision_transformer.py / hub
+    ``dinov2_vit{s,b}14``): the DINO layout plus ``blocks.i.ls{1,2}.gamma`` (LayerScale on the attention / MLP branch outputs).
+    ``mask_token`` (training only) is omitted.  The architecture difference to DINO that matters at inference is LayerScale and
+    the patch size; the position table is resampled by the same bicubic (grid + 0.1) / g rule."""
+    sd = make_vit_state_dict(arch, patch, pretrain_grid, seed, depth)
+    D = ARCH[arch][0]
+    g = torch.Generator().manual_seed(seed + 77)
+    for i in range(vit_depth(sd)):
+        # released DINOv2 gammas are O(0.01 .. 1); random positive values so that a kernel that forgets them fails parity
+        sd[f"blocks.{i}.ls1.gamma"] = 0.2 + 0.8 * torch.rand(D, generator=g)
+        sd[f"blocks.{i}.ls2.gamma"] = 0.2 + 0.8 * torch.rand(D, generator=g)
+    return sd
+
+
 def vit_depth(sd: Dict[str, torch.Tensor]) -> int:
     return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
 
@@ -129,10 +146,12 @@ def vit_tokens(
         q, k, v = qkv[0], qkv[1], qkv[2]
         att = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
         y = (att @ v).transpose(1, 2).reshape(B, -1, D)
-        x = x + F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        y = F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        x = x + (y * sd[p + "ls1.gamma"] if p + "ls1.gamma" in sd else y)  # DINOv2: LayerScale on the branch output
         y = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
         y = F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
-        x = x + F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        y = F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        x = x + (y * sd[p + "ls2.gamma"] if p + "ls2.gamma" in sd else y)
         if taps is not None:
             taps.append(x.clone())
     return F.layer_norm(x, (D,), sd["norm.weight"], sd["norm.bias"], eps=1e-6)

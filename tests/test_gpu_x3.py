@@ -1,0 +1,145 @@
+"""Exact mode ON THE MATRIX PIPE (precision "exact" = WVN_PREC_X3): every MFMA operand is two bf16 planes (hi + lo) and every
+product hi*hi + hi*lo + lo*hi with fp32 accumulation.  Building blocks against fp64 references, then the whole backbone against
+the CPU oracle at the north_star tolerance (<= 1e-3 absolute on the final LayerNorm'ed tokens), including the shipped kernel
+instantiations bench.py runs (448^2, (frame, head) count a multiple of 8 -> XCD block order; 25 query blocks; masked last tile)."""
+import pytest
+import torch
+
+from oracle import interfaces as OI, vit as OV
+from wild_visual_navigation_amd import _lib, ops
+from wild_visual_navigation_amd.backbone import VitBackbone, split_planes
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def unsplit(p):
+    return p[0].double() + p[1].double()
+
+
+def test_split_planes_carries_16_bits(dev):
+    x = (torch.randn(300, 77, generator=g(0)) * 3).to(dev)
+    p = ops.split_planes(x)
+    assert torch.equal(p, split_planes(x))                       # the device kernel == the torch restatement used for weights
+    rel = ((unsplit(p) - x.double()).abs() / x.double().abs().clamp_min(1e-30)).max().item()
+    assert rel < 2.0 ** -16, rel
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 1536, 384), (515, 384, 1536), (128, 90, 768), (200, 384, 192),
+                                   (130, 768, 640)])
+@pytest.mark.parametrize("epi", ["planes", "gelu", "relu", "f32", "resid"])
+def test_gemm_x3_is_fp32_class(dev, M, N, K, epi):
+    a = torch.randn(M, K, generator=g(1)).to(dev)
+    w = (torch.randn(N, K, generator=g(2)) * 0.05).to(dev)
+    bias = (torch.randn(N, generator=g(3)) * 0.1).to(dev)
+    ref = a.double() @ w.double().T + bias.double()
+    mag = a.double().abs() @ w.double().abs().T + bias.double().abs()     # scale of the rounding error of any summation order
+    ap, wp = ops.split_planes(a), ops.split_planes(w)
+    if epi == "planes":
+        got = unsplit(ops.gemm_x3(ap, wp, bias, _lib.EPI_BF16))
+    elif epi == "gelu":
+        got = unsplit(ops.gemm_x3(ap, wp, bias, _lib.EPI_GELU_BF16))
+        ref = torch.nn.functional.gelu(ref)                                 # exact erf form
+    elif epi == "relu":
+        got = unsplit(ops.gemm_x3(ap, wp, bias, _lib.EPI_RELU_BF16))
+        ref = ref.clamp_min(0)
+    elif epi == "f32":
+        got = ops.gemm_x3(ap, wp, bias, _lib.EPI_F32).double()
+    else:
+        c0 = torch.randn(M, N, generator=g(4)).to(dev)
+        got = ops.gemm_x3(ap, wp, bias, _lib.EPI_RESID_F32, out=c0.clone()).double()
+        ref = ref + c0.double()
+        mag = mag + c0.double().abs()
+    err = ((got - ref).abs() / mag).max().item()
+    # operands carry 2^-17 relative error each, the dropped lo*lo term 2^-16 of a product, planes of the output 2^-17
+    assert err < 4e-5, err
+    # and it is at least 50x closer than single-plane bf16 would be (guards against a dropped lo term)
+    assert err < (2.0 ** -9) / 50
+
+
+def _attention_ref(q, k, v, scale):
+    s = (q.double() @ k.double().transpose(-1, -2)) * scale
+    return (s.softmax(-1) @ v.double())
+
+
+@pytest.mark.parametrize("B,heads,ntok", [(1, 6, 330), (4, 6, 197), (2, 12, 3137)])
+def test_attention_x3_is_fp32_class(dev, B, heads, ntok):
+    """nbh = 6 (plain block order), 24 and 24 (XCD block order); ntok 3137 = the 448^2 sequence (25 query blocks, 50 tiles,
+    masked tail of 63 keys)."""
+    npad = (ntok + 127) // 128 * 128
+    q = torch.randn(B, heads, ntok, 64, generator=g(5)).to(dev)
+    k = torch.randn(B, heads, ntok, 64, generator=g(6)).to(dev)
+    v = torch.randn(B, heads, ntok, 64, generator=g(7)).to(dev)
+    ref = _attention_ref(q, k, v, 0.125).transpose(1, 2).reshape(B * ntok, heads * 64)
+
+    def padded(t):
+        o = torch.zeros(B, heads, npad, 64, device=dev)
+        o[:, :, :ntok] = t
+        return o
+
+    qp = ops.split_planes(padded(q).reshape(-1, 64)).reshape(2, B, heads, npad, 64)
+    kp = ops.split_planes(padded(k).reshape(-1, 64)).reshape(2, B, heads, npad, 64)
+    vt = padded(v).transpose(-1, -2)[..., ops.vt_token_order(npad, dev)].contiguous()      # [B,h,64,npad], token-permuted
+    vp = ops.split_planes(vt.reshape(-1, npad)).reshape(2, B, heads, 64, npad)
+    out = torch.zeros(2, B * ntok, heads * 64, dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().wvn_attention_x3(qp[0].data_ptr(), qp[1].data_ptr(), kp[0].data_ptr(), kp[1].data_ptr(), vp[0].data_ptr(),
+                                           vp[1].data_ptr(), out[0].data_ptr(), out[1].data_ptr(), B, heads, ntok, npad, 0.125,
+                                           _lib.stream()), "wvn_attention_x3")
+    err = (unsplit(out) - ref).abs().max().item()
+    assert err < 5e-5, err      # outputs are convex combinations of O(1) values
+
+
+@pytest.mark.parametrize("S,depth,B", [(64, 2, 3), (224, 12, 2), (448, 12, 1), (448, 2, 8)])
+def test_vit_exact_mode_on_mfma_within_1e3(dev, S, depth, B):
+    """The north_star gate on the matrix-pipe path; (448, 2, 8): nbh = 48 -> the XCD-ordered attention instantiation."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=depth)
+    img = torch.rand(B, 3, S, S, generator=g(1))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    bb = VitBackbone(sd, S, 8, 6, device=dev, precision="exact", max_chunk=8)
+    got = bb.forward_tokens(img.to(dev)).cpu()
+    err = (got - want).abs().max().item()
+    print(f"exact (x3 MFMA) tokens S={S} depth={depth} B={B}: max|err| = {err:.3e}")
+    assert err < 1e-3, f"exact-mode tokens differ by {err}"
+
+
+def test_exact_agrees_with_fp32_fma_mode_and_is_batch_invariant(dev):
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=3)
+    img = torch.rand(5, 3, 64, 64, generator=g(2)).to(dev)
+    a = VitBackbone(sd, 64, 8, 6, device=dev, precision="exact", max_chunk=5).forward_tokens(img)
+    b = VitBackbone(sd, 64, 8, 6, device=dev, precision="exact", max_chunk=2).forward_tokens(img)
+    c = VitBackbone(sd, 64, 8, 6, device=dev, precision="exact", max_chunk=1).forward_tokens(img[3:4])
+    assert torch.equal(a, b) and torch.equal(a[3:4], c)
+    f = VitBackbone(sd, 64, 8, 6, device=dev, precision="fp32", max_chunk=5).forward_tokens(img)
+    assert (a - f).abs().max().item() < 2e-4
+
+
+def test_vit_base_exact_and_bf16(dev):
+    """ViT-Base/8 (D = 768, 12 heads): the backbone of the reference's released STEGO checkpoint (stego_interface.py:23)."""
+    sd = OV.make_vit_state_dict("vit_base", 8, pretrain_grid=28, seed=4, depth=3)
+    img = torch.rand(2, 3, 96, 96, generator=g(8))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 12)[:, 1:]
+    got = VitBackbone(sd, 96, 8, 12, device=dev, precision="exact").forward_tokens(img.to(dev)).cpu()
+    assert (got - want).abs().max().item() < 1e-3
+    got = VitBackbone(sd, 96, 8, 12, device=dev, precision="fp32").forward_tokens(img.to(dev)).cpu()
+    assert (got - want).abs().max().item() < 1e-3
+    got = VitBackbone(sd, 96, 8, 12, device=dev, precision="bf16").forward_tokens(img.to(dev)).cpu()
+    assert ((got - want).norm() / want.norm()).item() < 2.5e-2
+
+
+@pytest.mark.parametrize("arch,heads,S,depth,B", [("vit_small", 6, 70, 2, 3), ("vit_base", 12, 518, 2, 1), ("vit_base", 12, 224, 12, 2)])
+def test_dinov2_layerscale_patch14(dev, arch, heads, S, depth, B):
+    """DINOv2 ViT-{S,B}/14 (BASELINE configs[4]: ViT-B/14 at 518^2 -> 37 x 37 + 1 = 1370 tokens): LayerScale on both branch
+    outputs, patch 14 (588-wide patch rows padded to 640 for the MFMA GEMMs), D = 768 through the generic tiled kernels."""
+    sd = OV.make_dinov2_state_dict(arch, 14, pretrain_grid=37, seed=3, depth=depth)
+    img = torch.rand(B, 3, S, S, generator=g(9))
+    want = OV.vit_tokens(sd, OI.normalize(img), 14, heads)[:, 1:]
+    for prec, tol in (("exact", 1e-3), ("fp32", 1e-3)):
+        got = VitBackbone(sd, S, 14, heads, device=dev, precision=prec, max_chunk=2).forward_tokens(img.to(dev)).cpu()
+        err = (got - want).abs().max().item()
+        print(f"dinov2 {arch} S={S} depth={depth} [{prec}]: max|err| = {err:.3e}")
+        assert err < tol, (prec, err)
+    got = VitBackbone(sd, S, 14, heads, device=dev, precision="bf16", max_chunk=2).forward_tokens(img.to(dev)).cpu()
+    assert ((got - want).norm() / want.norm()).item() < 2.5e-2

@@ -31,8 +31,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.VitLayer) == 12 * 8
-    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 12 * 8
+    assert C.sizeof(_lib.VitLayer) == 14 * 8
+    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 14 * 8
     assert C.sizeof(_lib.MlpDesc) == 16
 
 
@@ -49,6 +49,16 @@ def test_host_only_queries():
     # (3137 tokens are stored with a per-frame row stride of 3152 = next multiple of 16)
     expect = 3152 * 384 * 4 + 3152 * 384 * 2 + 3 * 6 * 3200 * 64 * 2 + 3152 * 1536 * 2 + 3136 * 192 * 2
     assert expect <= one <= expect + 8 * 256 and two > one
+    # exact mode on the matrix pipe: two bf16 planes per operand = the fp32 mode's footprint
+    m.precision = _lib.PREC_X3
+    x3 = h.wvn_vit_workspace_bytes(C.byref(m), 1)
+    m.precision = _lib.PREC_F32
+    assert x3 == h.wvn_vit_workspace_bytes(C.byref(m), 1)
+    # DINOv2 ViT-B/14 at 518^2 (BASELINE configs[4]): 1370 tokens, patch rows 588 -> 640 for the MFMA precisions
+    m.img_size, m.patch, m.dim, m.heads, m.mlp_dim, m.precision = 518, 14, 768, 12, 3072, _lib.PREC_BF16
+    v2 = h.wvn_vit_workspace_bytes(C.byref(m), 1)
+    expect = 1376 * 768 * 4 + 1376 * 768 * 2 + 3 * 12 * 1408 * 64 * 2 + 1376 * 3072 * 2 + 1369 * 640 * 2
+    assert expect <= v2 <= expect + 8 * 256
 
 
 def test_per_pixel_host_queries():
@@ -79,6 +89,9 @@ def test_per_pixel_host_queries():
 def test_argument_validation_without_gpu():
     h = _lib.lib()
     assert h.wvn_gemm_bf16(None, 0, None, 0, None, None, 0, 1, 1, 64, 0, None) == 1001
+    assert h.wvn_gemm_x3(None, None, 0, None, None, 0, None, None, None, 0, 1, 1, 64, 0, None) == 1001
+    assert h.wvn_attention_x3(None, None, None, None, None, None, None, None, 1, 6, 100, 128, 0.125, None) == 1001
+    assert h.wvn_split_planes(None, 0, None, None, 0, 1, 1, None) == 1001
     assert h.wvn_vit_forward(None, None, 1, None, None, 0, None, 0, None) == 1001
     with pytest.raises(_lib.WvnError):
         _lib.check(1002, "x")

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwvn_hip.so")
 
 WVN_MAX_DEPTH = 32
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_X3 = 0, 1, 2
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -28,7 +28,7 @@ class WvnError(RuntimeError):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2")]
 
 
 class VitModel(C.Structure):
@@ -57,6 +57,9 @@ _SIGNATURES = {
     "wvn_prof_enable": ([_i], _i),
     "wvn_prof_collect": ([_p, _p], _i),
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_gemm_x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_split_planes": ([_p, _i, _p, _p, _i, _i, _i, _p], _i),
+    "wvn_attention_x3": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "wvn_gemm_f32": ([_p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p], _i),
     "wvn_layernorm": ([_p, _p, _p, _p, _i, _i, _i, _f, _p], _i),
     "wvn_attention_bf16": ([_p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),

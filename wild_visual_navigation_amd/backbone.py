@@ -53,8 +53,16 @@ def synthetic_vit_state_dict(arch="vit_small", patch=8, pretrain_grid=28, seed=0
     return sd
 
 
+def split_planes(t: torch.Tensor) -> torch.Tensor:
+    """fp32 [...] -> bf16 [2, ...]: hi = bf16(t), lo = bf16(t - hi) (the exact-mode operand representation)."""
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).contiguous()
+
+
 def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
-    """DINO's position-table resampling (bicubic, scale (grid+0.1)/g), done ONCE when the model is
+    """DINO's position-table resampling (bicubic, scale (grid+0.1)/g; DINOv2 keeps the same rule with its default
+    interpolate_offset = 0.1, antialias off), done ONCE when the model is
     built -- it depends only on the input size, so it is weight preparation, not per-frame work."""
     n_pre = pos_embed.shape[1] - 1
     g = int(round(math.sqrt(n_pre)))
@@ -71,7 +79,9 @@ def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
 
 
 class VitBackbone:
-    """Device-resident DINO ViT.  ``precision``: "bf16" (MFMA fast path) or "fp32" (exact mode)."""
+    """Device-resident DINO / DINOv2 ViT.  ``precision``: "bf16" (MFMA fast path), "exact" (hi + lo split bf16 operands, three
+    MFMAs per product: fp32-class results on the matrix pipe, the <= 1e-3 parity mode) or "fp32" (the same gate on fp32 FMA
+    kernels; slow, kept as the independent cross-check of "exact")."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
                  device="cuda", precision: str = "bf16", max_chunk: int = 16):
@@ -79,7 +89,8 @@ class VitBackbone:
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
         self.lib = _lib.lib()
-        self.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_F32}[precision]
+        self.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_F32, "exact": _lib.PREC_X3}[precision]
+        self.precision_name = precision
         self.img_size, self.patch, self.heads = img_size, patch, heads
         self.grid = img_size // patch
         self.dim = state_dict["cls_token"].shape[-1]
@@ -87,10 +98,18 @@ class VitBackbone:
         self.mlp_dim = state_dict["blocks.0.mlp.fc1.weight"].shape[0]
         self.max_chunk = max_chunk
         self._keep = []  # device tensors referenced by raw pointers in the C struct
-        wdt = torch.bfloat16 if self.precision == _lib.PREC_BF16 else torch.float32
 
-        def mat(t):
-            t = t.detach().to(self.device, dtype=wdt).contiguous()
+        def mat(t, pad_cols=0):
+            t = t.detach().float()
+            if pad_cols:
+                t = F.pad(t, (0, pad_cols))
+            t = t.to(self.device)
+            if self.precision == _lib.PREC_BF16:
+                t = t.to(torch.bfloat16).contiguous()
+            elif self.precision == _lib.PREC_X3:  # two stacked bf16 planes: hi = bf16(w), lo = bf16(w - hi)
+                t = split_planes(t)
+            else:
+                t = t.contiguous()
             self._keep.append(t)
             return t.data_ptr()
 
@@ -103,8 +122,11 @@ class VitBackbone:
         m = _lib.VitModel()
         m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim = img_size, patch, self.dim, self.depth, heads, self.mlp_dim
         m.precision = self.precision
-        m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1))
+        kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
+        m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
+                        0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
         m.patch_b = vec(sd["patch_embed.proj.bias"])
+        self.dinov2 = any(k.endswith("ls1.gamma") for k in sd)
         pos = resample_pos_embed(sd["pos_embed"].float().cpu(), self.grid)[0]  # [1+G*G, D]
         m.cls_pos = vec(sd["cls_token"].reshape(-1).float().cpu() + pos[0])
         m.pos = vec(pos)
@@ -118,6 +140,8 @@ class VitBackbone:
             L.fc2_w, L.fc2_b = mat(sd[p + "mlp.fc2.weight"]), vec(sd[p + "mlp.fc2.bias"])
             L.ln1_g, L.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
             L.ln2_g, L.ln2_b = vec(sd[p + "norm2.weight"]), vec(sd[p + "norm2.bias"])
+            if p + "ls1.gamma" in sd:  # DINOv2 LayerScale
+                L.ls1, L.ls2 = vec(sd[p + "ls1.gamma"]), vec(sd[p + "ls2.gamma"])
         self.model = m
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
@@ -132,7 +156,8 @@ class VitBackbone:
 
     @property
     def lowp_dtype(self):
-        return torch.bfloat16 if self.precision == _lib.PREC_BF16 else torch.float32
+        """dtype of ``lowp_out`` rows (None: the exact mode hands out fp32 tokens only)."""
+        return {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_F32: torch.float32}.get(self.precision)
 
     def forward_tokens(self, img: torch.Tensor, out: Optional[torch.Tensor] = None,
                        lowp_out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -145,6 +170,8 @@ class VitBackbone:
         B, Cc, S, S2 = img.shape
         if Cc != 3 or S != self.img_size or S2 != self.img_size:
             raise _lib.WvnError(f"expected [B,3,{self.img_size},{self.img_size}], got {tuple(img.shape)}")
+        if lowp_out is not None and self.precision == _lib.PREC_X3:
+            raise _lib.WvnError("precision 'exact' returns fp32 tokens only (split them with ops.split_planes)")
         u8 = img.dtype == torch.uint8 and self.precision == _lib.PREC_BF16 and self.patch == 8
         if u8:
             img = img.contiguous()

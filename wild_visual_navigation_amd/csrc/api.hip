@@ -43,7 +43,7 @@ struct Span {
 };
 
 struct VitDims {
-  int B, S, P, G, D, H, F, KP, ntok, ntok_s, npad, npatch;
+  int B, S, P, G, D, H, F, KP, KPs, ntok, ntok_s, npad, npatch;
   size_t esz;
   long long M, Mp;
 };
@@ -51,9 +51,12 @@ VitDims vit_dims(const wvn_vit_model* m, int batch) {
   VitDims d;
   d.B = batch; d.S = m->img_size; d.P = m->patch; d.G = d.S / d.P; d.D = m->dim; d.H = m->heads; d.F = m->mlp_dim;
   d.KP = 3 * d.P * d.P; d.npatch = d.G * d.G; d.ntok = d.npatch + 1;
+  // patch rows as the MFMA GEMMs read them: K padded to a multiple of 64 (588 -> 640 for patch 14; 192 and 768 unchanged);
+  // the fp32 FMA path reads the unpadded rows
+  d.KPs = m->precision == WVN_PREC_F32 ? d.KP : (d.KP + 63) / 64 * 64;
   d.ntok_s = (d.ntok + 15) / 16 * 16;  // rows per frame: 8-token (16 B) chunks and the 16-token V^T permutation groups never straddle frames
   d.npad = (d.ntok + 127) / 128 * 128;
-  d.esz = m->precision == WVN_PREC_BF16 ? 2 : 4;
+  d.esz = m->precision == WVN_PREC_BF16 ? 2 : 4;  // exact mode (X3): two bf16 planes = 4 bytes per element
   d.M = (long long)batch * d.ntok_s; d.Mp = (long long)batch * d.npatch;
   return d;
 }
@@ -67,7 +70,7 @@ VitWs vit_carve(const VitDims& d, void* base) {
   size_t qkv = (size_t)d.B * d.H * d.npad * 64 * d.esz;
   w.q = take(qkv); w.k = take(qkv); w.v = take(qkv);
   w.hid = take((size_t)d.M * d.F * d.esz);
-  w.patches = take((size_t)d.Mp * d.KP * d.esz);
+  w.patches = take((size_t)d.Mp * d.KPs * d.esz);
   w.total = off;
   return w;
 }
@@ -111,7 +114,7 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
 
 int wvn_vit_forward_u8(const wvn_vit_model* m, const unsigned char* img, int batch, float* tokens_f32, void* tokens_lowp,
                        int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
-  if (m && m->precision != WVN_PREC_BF16) return WVN_ERR_ARG;
+  if (m && (m->precision != WVN_PREC_BF16 || m->patch != 8)) return WVN_ERR_ARG;
   return vit_forward_impl(m, img, 1, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
 }
 
@@ -122,20 +125,60 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (!m || !img || !workspace || batch <= 0) return WVN_ERR_ARG;
   if (m->dim != m->heads * 64 || m->depth <= 0 || m->depth > WVN_MAX_DEPTH || m->img_size % m->patch) return WVN_ERR_ARG;
   if (m->dim % 128 || m->mlp_dim % 128) return WVN_ERR_ARG;
+  if (m->precision != WVN_PREC_F32 && m->precision != WVN_PREC_BF16 && m->precision != WVN_PREC_X3) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const VitDims d = vit_dims(m, batch);
-  if (d.KP % 64) return WVN_ERR_ARG;
   const VitWs w = vit_carve(d, workspace);
   if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
-  const bool bf = m->precision == WVN_PREC_BF16;
+  const bool bf = m->precision == WVN_PREC_BF16, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
+  if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
   const float scale = 1.0f / sqrtf(64.f);
-  // bf16: the softmax scale is folded into q by the QKV epilogue and attention takes the running max as an MFMA operand
-  // (attention_bf16.hip, PRE).  WVN_ATTN_PRE=0 keeps the raw-q kernel (A/B switch).
-  static const bool attn_pre_env = [] { const char* e = getenv("WVN_ATTN_PRE"); return !e || atoi(e) != 0; }();
-  const bool attn_pre = bf && attn_pre_env;
   const int M = (int)d.M, Mp = (int)d.Mp;
+  // exact mode: an activation / weight "matrix" is two stacked bf16 planes, hi then lo
+  const size_t pl_xn = (size_t)d.M * d.D, pl_hid = (size_t)d.M * d.F, pl_qkv = (size_t)d.B * d.H * d.npad * 64,
+               pl_pat = (size_t)d.Mp * d.KPs;
+  auto lo = [](const void* base, size_t plane_elems) { return (bf16_t*)base + plane_elems; };
 
-  { Span s(0, st); RET_IF(wvn_patchify_launch(img, img_u8, w.patches, bf, d.B, d.S, d.P, st)); }
+  // One linear of the chain in the model's precision.  A: activation matrix (bf16 | hi+lo planes | fp32), W: weight in the
+  // same representation ([N][K], planes stacked), epilogue codes of GemmEpilogue.
+  auto linear = [&](const void* A, size_t a_plane, int lda, const void* W, const float* bias, void* C, size_t c_plane, int ldc,
+                    int rows, int N, int K, int epi, const float* ls, GemmBf16Params* extra) -> int {
+    if (f32) {
+      GemmF32Params p{};
+      p.A = (const float*)A; p.lda = lda; p.B = (const float*)W; p.ldb = K; p.transB = 1; p.bias = bias;
+      p.C = (float*)C; p.ldc = ldc; p.M = rows; p.N = N; p.K = K; p.batch = 1; p.splitk = 1; p.ls = ls;
+      int fe = F32_EPI_NONE;
+      switch (epi) {
+        case EPI_GELU_BF16: fe = F32_EPI_GELU; break;
+        case EPI_RESID_F32: fe = F32_EPI_RESID; break;
+        case EPI_PATCH: fe = F32_EPI_PATCH; p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok; p.ntok_s = d.ntok_s; break;
+        case EPI_QKV:
+          fe = F32_EPI_QKV; p.C = (float*)w.q; p.q = (float*)w.q; p.k = (float*)w.k; p.v = (float*)w.v; p.heads = d.H;
+          p.npad = d.npad; p.ntok = d.ntok; p.ntok_s = d.ntok_s; break;
+        default: return WVN_ERR_ARG;
+      }
+      return wvn_gemm_f32_launch(p, fe, st);
+    }
+    GemmBf16Params p{};
+    if (extra) p = *extra;
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = K; p.bias = bias; p.C = C; p.ldc = ldc;
+    p.M = rows; p.N = N; p.K = K; p.ls = ls;
+    if (x3) {
+      p.A_lo = lo(A, a_plane); p.W_lo = lo(W, (size_t)N * K); p.C_lo = C ? lo(C, c_plane) : nullptr;
+      return wvn_gemm_x3_launch(p, epi, st);
+    }
+    return wvn_gemm_bf16_launch(p, epi, st);
+  };
+
+  {
+    Span s(0, st);
+    RET_IF(wvn_patchify_launch(img, img_u8, w.patches, x3 ? lo(w.patches, pl_pat) : nullptr, f32 ? 0 : (x3 ? 2 : 1), d.KPs, d.B,
+                               d.S, d.P, st));
+    if (d.KPs != d.KP) {  // zero the K padding of the patch rows (weights are zero there too, but NaN * 0 must not happen)
+      RET_IF(wvn_pad_zero_launch(w.patches, (long long)Mp * (x3 ? 2 : 1), (long long)d.KPs * 2, (long long)d.KP * 2,
+                                 (long long)(d.KPs - d.KP) * 2, st));
+    }
+  }
   RET_IF(wvn_cls_rows_launch(m->cls_pos, w.x, d.B, d.ntok_s, d.D, st));
   {
     // Padding hygiene, every call (the carve depends on the batch, so a reused workspace holds stale bytes):
@@ -144,97 +187,44 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     // their V^T / K bytes still enter MFMAs and must be finite.
     RET_IF(wvn_pad_zero_launch(w.x, d.B, (long long)d.ntok_s * d.D * 4, (long long)d.ntok * d.D * 4,
                                (long long)(d.ntok_s - d.ntok) * d.D * 4, st));
-    const long long tokb = 64ll * d.esz, nbh = (long long)d.B * d.H;
-    RET_IF(wvn_pad_zero_launch(w.q, nbh, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
-    RET_IF(wvn_pad_zero_launch(w.k, nbh, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
-    if (bf)  // V^T [B*h*64][npad]
-      RET_IF(wvn_pad_zero_launch(w.v, nbh * 64, (long long)d.npad * 2, (long long)d.ntok_s * 2, (long long)(d.npad - d.ntok_s) * 2, st));
+    const long long nbh = (long long)d.B * d.H;
+    const long long tokb = f32 ? 256 : 128, npl = x3 ? 2 : 1;  // bytes per token row of q / k; planes per tensor
+    RET_IF(wvn_pad_zero_launch(w.q, nbh * npl, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
+    RET_IF(wvn_pad_zero_launch(w.k, nbh * npl, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
+    if (!f32)  // V^T [B*h*64][npad] (bf16, or hi / lo planes)
+      RET_IF(wvn_pad_zero_launch(w.v, nbh * 64 * npl, (long long)d.npad * 2, (long long)d.ntok_s * 2, (long long)(d.npad - d.ntok_s) * 2, st));
     else     // V [B*h][npad][64]
       RET_IF(wvn_pad_zero_launch(w.v, nbh, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
   }
   {
     Span s(1, st);
-    if (bf) {
-      GemmBf16Params p{};
-      p.A = (const bf16_t*)w.patches; p.lda = d.KP; p.W = (const bf16_t*)m->patch_w; p.ldw = d.KP; p.bias = m->patch_b;
-      p.C = w.x; p.ldc = d.D; p.M = Mp; p.N = d.D; p.K = d.KP; p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
-      RET_IF(wvn_gemm_bf16_launch(p, EPI_PATCH, st));
-    } else {
-      GemmF32Params p{};
-      p.A = (const float*)w.patches; p.lda = d.KP; p.B = (const float*)m->patch_w; p.ldb = d.KP; p.transB = 1;
-      p.bias = m->patch_b; p.C = w.x; p.ldc = d.D; p.M = Mp; p.N = d.D; p.K = d.KP; p.batch = 1; p.splitk = 1;
-      p.pos = m->pos; p.npatch = d.npatch; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
-      RET_IF(wvn_gemm_f32_launch(p, F32_EPI_PATCH, st));
-    }
+    GemmBf16Params e{};
+    e.pos = m->pos; e.npatch = d.npatch; e.ntok = d.ntok; e.ntok_s = d.ntok_s;
+    RET_IF(linear(w.patches, pl_pat, d.KPs, m->patch_w, m->patch_b, w.x, 0, d.D, Mp, d.D, d.KPs, EPI_PATCH, nullptr, &e));
   }
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
-    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st)); }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     {
       Span s(3, st);
-      if (bf) {
-        GemmBf16Params p{};
-        p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.qkv_w; p.ldw = d.D; p.bias = L.qkv_b;
-        p.M = M; p.N = 3 * d.D; p.K = d.D; p.q = (bf16_t*)w.q; p.k = (bf16_t*)w.k; p.vt = (bf16_t*)w.v;
-        p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
-        if (attn_pre) p.q_scale = scale * 1.44269504088896340736f;  // q leaves the epilogue as an exp2 argument
-        RET_IF(wvn_gemm_bf16_launch(p, EPI_QKV, st));
-      } else {
-        GemmF32Params p{};
-        p.A = (const float*)w.xn; p.lda = d.D; p.B = (const float*)L.qkv_w; p.ldb = d.D; p.transB = 1; p.bias = L.qkv_b;
-        p.C = (float*)w.q; p.M = M; p.N = 3 * d.D; p.K = d.D; p.batch = 1; p.splitk = 1;
-        p.q = (float*)w.q; p.k = (float*)w.k; p.v = (float*)w.v; p.heads = d.H; p.npad = d.npad; p.ntok = d.ntok; p.ntok_s = d.ntok_s;
-        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_QKV, st));
-      }
+      GemmBf16Params e{};
+      e.q = (bf16_t*)w.q; e.k = (bf16_t*)w.k; e.vt = (bf16_t*)w.v; e.heads = d.H; e.npad = d.npad; e.ntok = d.ntok; e.ntok_s = d.ntok_s;
+      // bf16: the softmax scale is folded into q by the QKV epilogue (q leaves it as an exp2 argument) and attention takes
+      // the running max as an MFMA operand (attention_bf16.hip, PRE)
+      if (bf) e.q_scale = scale * 1.44269504088896340736f;
+      if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
+      RET_IF(linear(w.xn, pl_xn, d.D, L.qkv_w, L.qkv_b, nullptr, 0, 0, M, 3 * d.D, d.D, EPI_QKV, nullptr, &e));
     }
     {
       Span s(4, st);
-      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, attn_pre ? 0.f : scale, st));
+      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st));
+      else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
-    {
-      Span s(5, st);
-      if (bf) {
-        GemmBf16Params p{};
-        p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.proj_w; p.ldw = d.D; p.bias = L.proj_b;
-        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.D;
-        RET_IF(wvn_gemm_bf16_launch(p, EPI_RESID_F32, st));
-      } else {
-        GemmF32Params p{};
-        p.A = (const float*)w.xn; p.lda = d.D; p.B = (const float*)L.proj_w; p.ldb = d.D; p.transB = 1; p.bias = L.proj_b;
-        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.D; p.batch = 1; p.splitk = 1;
-        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RESID, st));
-      }
-    }
-    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, bf, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st)); }
-    {
-      Span s(6, st);
-      if (bf) {
-        GemmBf16Params p{};
-        p.A = (const bf16_t*)w.xn; p.lda = d.D; p.W = (const bf16_t*)L.fc1_w; p.ldw = d.D; p.bias = L.fc1_b;
-        p.C = w.hid; p.ldc = d.F; p.M = M; p.N = d.F; p.K = d.D;
-        RET_IF(wvn_gemm_bf16_launch(p, EPI_GELU_BF16, st));
-      } else {
-        GemmF32Params p{};
-        p.A = (const float*)w.xn; p.lda = d.D; p.B = (const float*)L.fc1_w; p.ldb = d.D; p.transB = 1; p.bias = L.fc1_b;
-        p.C = (float*)w.hid; p.ldc = d.F; p.M = M; p.N = d.F; p.K = d.D; p.batch = 1; p.splitk = 1;
-        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_GELU, st));
-      }
-    }
-    {
-      Span s(7, st);
-      if (bf) {
-        GemmBf16Params p{};
-        p.A = (const bf16_t*)w.hid; p.lda = d.F; p.W = (const bf16_t*)L.fc2_w; p.ldw = d.F; p.bias = L.fc2_b;
-        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.F;
-        RET_IF(wvn_gemm_bf16_launch(p, EPI_RESID_F32, st));
-      } else {
-        GemmF32Params p{};
-        p.A = (const float*)w.hid; p.lda = d.F; p.B = (const float*)L.fc2_w; p.ldb = d.F; p.transB = 1; p.bias = L.fc2_b;
-        p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.F; p.batch = 1; p.splitk = 1;
-        RET_IF(wvn_gemm_f32_launch(p, F32_EPI_RESID, st));
-      }
-    }
+    { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    { Span s(6, st); RET_IF(linear(w.xn, pl_xn, d.D, L.fc1_w, L.fc1_b, w.hid, pl_hid, d.F, M, d.F, d.D, EPI_GELU_BF16, nullptr, nullptr)); }
+    { Span s(7, st); RET_IF(linear(w.hid, pl_hid, d.F, L.fc2_w, L.fc2_b, w.x, 0, d.D, M, d.D, d.F, EPI_RESID_F32, L.ls2, nullptr)); }
   }
   {
     Span s(2, st);
@@ -255,6 +245,25 @@ int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
+}
+
+int wvn_gemm_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,
+                void* C, void* C_lo, int ldc, int M, int N, int K, int epi, void* stream) {
+  if (epi < 0 || epi > EPI_ACCUM_F32 || !C) return WVN_ERR_ARG;
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A_hi; p.A_lo = (const bf16_t*)A_lo; p.lda = lda; p.W = (const bf16_t*)W_hi; p.W_lo = (const bf16_t*)W_lo;
+  p.ldw = ldw; p.bias = bias; p.C = C; p.C_lo = C_lo; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  return wvn_gemm_x3_launch(p, epi, (hipStream_t)stream);
+}
+int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream) {
+  return wvn_split_planes_launch(src, lds, (bf16_t*)hi, (bf16_t*)lo, ldd, rows, cols, (hipStream_t)stream);
+}
+int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                     const void* vt_lo, void* out_hi, void* out_lo, int B, int heads, int ntok, int npad, float scale,
+                     void* stream) {
+  return wvn_attention_x3_launch((const bf16_t*)q_hi, (const bf16_t*)q_lo, (const bf16_t*)k_hi, (const bf16_t*)k_lo,
+                                 (const bf16_t*)vt_hi, (const bf16_t*)vt_lo, (bf16_t*)out_hi, (bf16_t*)out_lo, B, heads, ntok,
+                                 ntok, npad, scale, (hipStream_t)stream);
 }
 
 int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
@@ -301,11 +310,11 @@ int wvn_attention_f32(const float* q, const float* k, const float* v, float* out
   return wvn_attention_f32_launch(q, k, v, out, B, heads, ntok, ntok, npad, scale, (hipStream_t)stream);
 }
 int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream) {
-  return wvn_patchify_launch(img, 0, patches, out_is_bf16, B, S, P, (hipStream_t)stream);
+  return wvn_patchify_launch(img, 0, patches, nullptr, out_is_bf16 ? 1 : 0, 0, B, S, P, (hipStream_t)stream);
 }
 
 int wvn_patchify_u8(const unsigned char* img, void* patches_bf16, int B, int S, int P, void* stream) {
-  return wvn_patchify_launch(img, 1, patches_bf16, 1, B, S, P, (hipStream_t)stream);
+  return wvn_patchify_launch(img, 1, patches_bf16, nullptr, 1, 0, B, S, P, (hipStream_t)stream);
 }
 int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
   if (!src || !dst || n <= 0 || n > 0x7fffffffll) return WVN_ERR_ARG;

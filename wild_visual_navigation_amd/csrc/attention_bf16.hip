@@ -345,53 +345,19 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
   }
 }
 
-// WVN_ATTN_VARIANT (A/B switch): ring depth / occupancy target.  0: 2 stages, 4 WG/CU; 1: 3 stages, 3 WG/CU (default);
-// 2: 2 stages, 3 WG/CU; 3: 4 stages, 2 WG/CU
-int attn_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WVN_ATTN_VARIANT");
-    v = e ? atoi(e) : 1;
-    if (v < 0 || v > 3) v = 1;
-  }
-  return v;
-}
-
 long long* g_attn_dbg = nullptr;  // set by wvn_debug_attention_timing (scripts/attn_timing.py)
 
 void launch_pre(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
                 int heads, int nbh, int nqb, int ntok, int ntok_s, int npad) {
-  // default: 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for
-  // 3 stages / 3 workgroups and 13.2 for 4 stages / 2).  WVN_ATTN_PRE_OCC=3 selects the 3 / 3 form (A/B switch).
-  static const int pre_occ = [] { const char* e = getenv("WVN_ATTN_PRE_OCC"); return e ? atoi(e) : 4; }();
-  // row sums: v_dot2c_f32_bf16 on the packed P by default; WVN_ATTN_SUM=1 selects plain fp32 adds (hipcc packs them into
-  // v_pk_add_f32: 12.0 ms per step against 11.7, same-box A/B.  Single v_add_f32 through inline asm measured 11.35 but is
-  // not safe: the asm reads v_exp results and hipcc pads the transcendental-result hazard only for its own instructions.)
-  static const int sum4 = [] { const char* e = getenv("WVN_ATTN_SUM"); return e ? atoi(e) : 0; }();
-  if (pre_occ == 4) {
-    if (xcd && sum4 == 1)
-      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 1>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
-    else if (xcd)
-      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
-    else if (sum4 == 1)  // (the same arithmetic with and without the XCD block order: results must not depend on the batch)
-      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 1>), grid, dim3(256), 0, st, q, k, vt, out, heads,
-                         nbh, nqb, ntok, ntok_s, npad, 1.f, nullptr);
-    else
-      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
-    return;
-  }
-  static const int summode = [] { const char* e = getenv("WVN_ATTN_SUM"); return e ? atoi(e) : 0; }();
-  if (xcd && summode == 1)
-    hipLaunchKernelGGL((attention_bf16_kernel<3, true, 3, false, true, 1>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                       nqb, ntok, ntok_s, npad, 1.f, nullptr);
-  else if (xcd)
-    hipLaunchKernelGGL((attention_bf16_kernel<3, true, 3, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+  // 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for 3 stages /
+  // 3 workgroups and 13.2 for 4 stages / 2); row sums by v_dot2c_f32_bf16 on the packed P (plain fp32 adds, which hipcc packs
+  // into v_pk_add_f32, measured 12.0 ms per step against 11.7).  The same arithmetic with and without the XCD block order:
+  // results must not depend on the batch size (tests/test_gpu_attention_xcd.py).
+  if (xcd)
+    hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
                        nqb, ntok, ntok_s, npad, 1.f, nullptr);
   else
-    hipLaunchKernelGGL((attention_bf16_kernel<3, false, 3, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+    hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
                        nqb, ntok, ntok_s, npad, 1.f, nullptr);
 }
 
@@ -431,12 +397,7 @@ int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt
     return WVN_OK;
   }
   if (scale == 0.f) return WVN_ERR_ARG;
-  switch (attn_variant()) {
-    case 0: launch_v<2, 4>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
-    case 2: launch_v<2, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
-    case 3: launch_v<4, 2>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
-    default: launch_v<3, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp); break;
-  }
+  launch_v<3, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp);  // raw-q form: 3-stage ring, 3 workgroups / CU
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

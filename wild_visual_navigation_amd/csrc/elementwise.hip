@@ -13,8 +13,10 @@ namespace {
 // (the flattening order of the conv weight [D,3,P,P]).  dino_interface.py:52 normalisation fused.
 // One thread per (patch, c, py): reads P contiguous floats, writes P contiguous outputs.
 // ---------------------------------------------------------------------------------------------
+// ldp: row stride of the patch matrix in elements (>= 3*P*P; the pad columns, if any, are zeroed by the caller).
+// out_lo != nullptr (T = bf16_t only): exact mode, out receives the hi plane and out_lo the lo plane of the same value.
 template <typename T, int P>
-__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int S) {
+__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, T* __restrict__ out_lo, int ldp, int B, int S) {
   const int G = S / P;
   const long long total = (long long)B * G * G * 3 * P;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,9 +31,16 @@ __global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ o
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
   const float* src = img + (((size_t)b * 3 + c) * S + (gy * P + py)) * S + gx * P;
-  T* dst = out + ((size_t)b * G * G + gy * G + gx) * (3 * P * P) + c * P * P + py * P;
+  const size_t doff = ((size_t)b * G * G + gy * G + gx) * ldp + c * P * P + py * P;
+  T* dst = out + doff;
 #pragma unroll
-  for (int px = 0; px < P; ++px) ElemIO<T>::store(dst + px, (src[px] - mean[c]) / stdv[c]);
+  for (int px = 0; px < P; ++px) {
+    const float v = (src[px] - mean[c]) / stdv[c];
+    ElemIO<T>::store(dst + px, v);
+    if constexpr (sizeof(T) == 2) {
+      if (out_lo) out_lo[doff + px] = f32_to_bf16(v - bf16_to_f32(f32_to_bf16(v)));
+    }
+  }
 }
 
 // bf16, P = 8 fast path: one workgroup per (patch row gy, frame).  The 3 x 8 image rows the patch row needs are read
@@ -81,7 +90,8 @@ template <typename T, int VPT>  // VPT = D / 64 values per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y, int ldy,
                                                         float* __restrict__ y2, int ldy2, int rows_out, int D,
-                                                        float eps, int drop_cls, int ntok, int ntok_s) {
+                                                        float eps, int drop_cls, int ntok, int ntok_s,
+                                                        T* __restrict__ y_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows_out) return;
@@ -113,6 +123,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     int c = lane + 64 * i;
     float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
     if (y) ElemIO<T>::store(y + (size_t)row * ldy + c, o);
+    if constexpr (sizeof(T) == 2) {  // exact mode: lo plane of the same value
+      if (y_lo) y_lo[(size_t)row * ldy + c] = f32_to_bf16(o - bf16_to_f32(f32_to_bf16(o)));
+    }
     if (y2) y2[(size_t)row * ldy2 + c] = o;
   }
 }
@@ -122,9 +135,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // store, a wave handles 4 rows per pass and LN_RPW rows in all (gamma / beta stay in registers).  Same two-pass fp32
 // statistics as the generic kernel.
 constexpr int LN_RPW = 16;
+template <bool PLANES>  // PLANES: exact mode, y_lo receives the lo plane (x - bf16(x)) of every output value
 __global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                                int ldy, int rows, float eps) {
+                                                                bf16_t* __restrict__ y_lo, int ldy, int rows, float eps) {
   const int lane = threadIdx.x & 63, sub = lane & 15, rsel = lane >> 4;
   const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   f32x4_t gm[6], bt[6];
@@ -172,6 +186,13 @@ __global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __r
         for (int e = 0; e < 8; ++e) o[e] = (v[2 * i + (e >> 2)][e & 3] - mean) * rstd * gm[2 * i + (e >> 2)][e & 3] + bt[2 * i + (e >> 2)][e & 3];
         const u32x4_t u = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         *(u32x4_t*)(y + (size_t)row * ldy + 128 * i + 8 * sub) = u;
+        if constexpr (PLANES) {
+          u32x4_t w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            w[e] = pack_bf16x2(o[2 * e] - __uint_as_float(u[e] << 16), o[2 * e + 1] - __uint_as_float(u[e] & 0xffff0000u));
+          *(u32x4_t*)(y_lo + (size_t)row * ldy + 128 * i + 8 * sub) = w;
+        }
       }
     }
   }
@@ -183,6 +204,18 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, int lds_, bf
   if (i >= (long long)rows * cols) return;
   int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
   dst[(size_t)r * ldd + c] = f32_to_bf16(src[(size_t)r * lds_ + c]);
+}
+
+// fp32 [rows, cols] -> hi / lo bf16 planes (exact-mode operands of gemm_x3.hip)
+__global__ void split_planes_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                    int ldd, int rows, int cols) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * cols) return;
+  int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+  const float v = src[(size_t)r * lds_ + c];
+  const bf16_t h = f32_to_bf16(v);
+  hi[(size_t)r * ldd + c] = h;
+  lo[(size_t)r * ldd + c] = f32_to_bf16(v - bf16_to_f32(h));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,11 +275,17 @@ __global__ void upsample_nearest_i32_kernel(const int* __restrict__ lab, int* __
 
 }  // namespace
 
-int wvn_patchify_launch(const void* img_v, int img_u8, void* patches, int out_bf16, int B, int S, int P, hipStream_t st) {
+// out_mode: 0 fp32, 1 bf16, 2 hi/lo bf16 planes (exact mode; lo plane = patches_lo).  ldp: row stride of the patch
+// matrix in elements (0 = 3*P*P).  P in {8, 14, 16}.
+int wvn_patchify_launch(const void* img_v, int img_u8, void* patches, void* patches_lo, int out_mode, int ldp, int B, int S, int P,
+                        hipStream_t st) {
   const float* img = (const float*)img_v;
+  const int KP = 3 * P * P;
+  if (ldp == 0) ldp = KP;
+  if (ldp < KP || (out_mode == 2 && !patches_lo)) return WVN_ERR_ARG;
   if (img_u8) {  // 8-bit frames: bf16 / P = 8 row-panel kernel only
-    if (!img_v || !patches || !out_bf16 || P != 8 || (S % 8) != 0 || (((uintptr_t)img_v & 3) != 0) || (((uintptr_t)patches & 15) != 0) ||
-        (S / 8) * 192 * 2 > 64 * 1024)
+    if (!img_v || !patches || out_mode != 1 || P != 8 || ldp != KP || (S % 8) != 0 || (((uintptr_t)img_v & 3) != 0) ||
+        (((uintptr_t)patches & 15) != 0) || (S / 8) * 192 * 2 > 64 * 1024)
       return WVN_ERR_ARG;
     hipLaunchKernelGGL(patchify8_bf16_rows_kernel<unsigned char>, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st,
                        (const unsigned char*)img_v, (bf16_t*)patches, S);
@@ -257,14 +296,18 @@ int wvn_patchify_launch(const void* img_v, int img_u8, void* patches, int out_bf
   const int G = S / P;
   long long total = (long long)B * G * G * 3 * P;
   dim3 grid((unsigned)((total + 255) / 256));
+  bf16_t* lo = out_mode == 2 ? (bf16_t*)patches_lo : nullptr;
   if (P == 8) {
-    if (out_bf16 && (S % 8) == 0 && (((uintptr_t)img | (uintptr_t)patches) & 15) == 0 && (S / 8) * 192 * 2 <= 64 * 1024)
+    if (out_mode == 1 && ldp == KP && (S % 8) == 0 && (((uintptr_t)img | (uintptr_t)patches) & 15) == 0 && (S / 8) * 192 * 2 <= 64 * 1024)
       hipLaunchKernelGGL(patchify8_bf16_rows_kernel<float>, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st, img, (bf16_t*)patches, S);
-    else if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 8>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
-    else hipLaunchKernelGGL((patchify_kernel<float, 8>), grid, dim3(256), 0, st, img, (float*)patches, B, S);
+    else if (out_mode) hipLaunchKernelGGL((patchify_kernel<bf16_t, 8>), grid, dim3(256), 0, st, img, (bf16_t*)patches, lo, ldp, B, S);
+    else hipLaunchKernelGGL((patchify_kernel<float, 8>), grid, dim3(256), 0, st, img, (float*)patches, (float*)nullptr, ldp, B, S);
   } else if (P == 16) {
-    if (out_bf16) hipLaunchKernelGGL((patchify_kernel<bf16_t, 16>), grid, dim3(256), 0, st, img, (bf16_t*)patches, B, S);
-    else hipLaunchKernelGGL((patchify_kernel<float, 16>), grid, dim3(256), 0, st, img, (float*)patches, B, S);
+    if (out_mode) hipLaunchKernelGGL((patchify_kernel<bf16_t, 16>), grid, dim3(256), 0, st, img, (bf16_t*)patches, lo, ldp, B, S);
+    else hipLaunchKernelGGL((patchify_kernel<float, 16>), grid, dim3(256), 0, st, img, (float*)patches, (float*)nullptr, ldp, B, S);
+  } else if (P == 14) {
+    if (out_mode) hipLaunchKernelGGL((patchify_kernel<bf16_t, 14>), grid, dim3(256), 0, st, img, (bf16_t*)patches, lo, ldp, B, S);
+    else hipLaunchKernelGGL((patchify_kernel<float, 14>), grid, dim3(256), 0, st, img, (float*)patches, (float*)nullptr, ldp, B, S);
   } else {
     return WVN_ERR_ARG;
   }
@@ -301,39 +344,52 @@ int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok, int D, 
 
 template <typename T>
 static int ln_dispatch(const float* x, const float* g, const float* b, T* y, int ldy, float* y2, int ldy2, int rows_out,
-                       int D, float eps, int drop_cls, int ntok, int ntok_s, hipStream_t st) {
+                       int D, float eps, int drop_cls, int ntok, int ntok_s, T* y_lo, hipStream_t st) {
   dim3 grid(ceil_div(rows_out, 4)), block(256);
   switch (D / 64) {
-    case 6: hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
-    case 12: hipLaunchKernelGGL((layernorm_kernel<T, 12>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
-    case 16: hipLaunchKernelGGL((layernorm_kernel<T, 16>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
-    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
-    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s); break;
+    case 6: hipLaunchKernelGGL((layernorm_kernel<T, 6>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, y_lo); break;
+    case 12: hipLaunchKernelGGL((layernorm_kernel<T, 12>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, y_lo); break;
+    case 16: hipLaunchKernelGGL((layernorm_kernel<T, 16>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, y_lo); break;
+    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, y_lo); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, x, g, b, y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, y_lo); break;
     default: return WVN_ERR_ARG;
   }
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
 
+// y_lo != nullptr (with y_bf16): exact mode, y / y_lo receive the hi / lo planes
 int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
                          float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
-                         int ntok_s, hipStream_t st) {
-  if (!x || !gamma || !beta || (D % 64) != 0 || rows_out <= 0) return WVN_ERR_ARG;
+                         int ntok_s, hipStream_t st, void* y_lo) {
+  if (!x || !gamma || !beta || (D % 64) != 0 || rows_out <= 0 || (y_lo && (!y_bf16 || !y))) return WVN_ERR_ARG;
   if (y_bf16 && y && !y2 && !drop_cls && D == 384 && (ldy % 8) == 0 &&
-      ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0) {
-    hipLaunchKernelGGL(layernorm384_bf16_kernel, dim3(ceil_div(rows_out, 4 * LN_RPW)), dim3(256), 0, st, x, gamma, beta,
-                       (bf16_t*)y, ldy, rows_out, eps);
+      ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)y_lo) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0) {
+    if (y_lo)
+      hipLaunchKernelGGL(layernorm384_bf16_kernel<true>, dim3(ceil_div(rows_out, 4 * LN_RPW)), dim3(256), 0, st, x, gamma, beta,
+                         (bf16_t*)y, (bf16_t*)y_lo, ldy, rows_out, eps);
+    else
+      hipLaunchKernelGGL(layernorm384_bf16_kernel<false>, dim3(ceil_div(rows_out, 4 * LN_RPW)), dim3(256), 0, st, x, gamma, beta,
+                         (bf16_t*)y, (bf16_t*)nullptr, ldy, rows_out, eps);
     WVN_LAUNCH_CHECK();
     return WVN_OK;
   }
-  if (y_bf16) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, st);
-  return ln_dispatch<float>(x, gamma, beta, (float*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, st);
+  if (y_bf16) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, (bf16_t*)y_lo, st);
+  return ln_dispatch<float>(x, gamma, beta, (float*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, (float*)nullptr, st);
 }
 
 int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st) {
   long long n = (long long)rows * cols;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds_, dst, ldd,
                      rows, cols);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int wvn_split_planes_launch(const float* src, int lds_, bf16_t* hi, bf16_t* lo, int ldd, int rows, int cols, hipStream_t st) {
+  if (!src || !hi || !lo || rows <= 0 || cols <= 0) return WVN_ERR_ARG;
+  long long n = (long long)rows * cols;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds_, hi, lo, ldd, rows, cols);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

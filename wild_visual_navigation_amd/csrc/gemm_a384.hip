@@ -409,16 +409,6 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
 
 constexpr int A384_LDS_MAX = 160 * 1024;
 
-int a384_var() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WVN_A384_VAR");
-    v = e ? atoi(e) : 0;
-    if (v < 0 || v > 4) v = 0;
-  }
-  return v;
-}
-
 int a384_num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -451,13 +441,6 @@ template <int EPI>
 int launch(const A384Params& p, hipStream_t st) {
   const int lds = BIAS_OFF + p.N * 4;
   if (lds > A384_LDS_MAX) return WVN_ERR_ARG;
-  if constexpr (EPI == A_BF16 || EPI == A_GELU) {  // experiment variants (scripts/a384_timing.py)
-    const int v = a384_var();
-    if (v == 1) return p.dbg ? launch_k<EPI, true, 1>(p, lds, st) : launch_k<EPI, false, 1>(p, lds, st);
-    if (v == 2) return p.dbg ? launch_k<EPI, true, 2>(p, lds, st) : launch_k<EPI, false, 2>(p, lds, st);
-    if (v == 3) return p.dbg ? launch_k<EPI, true, 3>(p, lds, st) : launch_k<EPI, false, 3>(p, lds, st);
-    if (v == 4) return p.dbg ? launch_k<EPI, true, 4>(p, lds, st) : launch_k<EPI, false, 4>(p, lds, st);
-  }
   return p.dbg ? launch_k<EPI, true, 0>(p, lds, st) : launch_k<EPI, false, 0>(p, lds, st);
 }
 

@@ -23,7 +23,6 @@
 // B: lane l holds col l&31, same k-slots; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
 #include "common.h"
 #include "wvn_internal.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -195,6 +194,9 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
           float b = bl;
           if constexpr (TR) b = (p.bias && n0 + c + e < p.N) ? p.bias[n0 + c + e] : 0.f;
           v[e] = activate<EPI>(acc[i][j][4 * g4 + e] + b);
+          if constexpr (EPI == EPI_RESID_F32 && TR) {
+            if (p.ls) v[e] *= (n0 + c + e < p.N) ? p.ls[n0 + c + e] : 0.f;  // LayerScale (DINOv2): x += ls * (acc + bias)
+          }
           if constexpr (EPI == EPI_QKV && TR) {
             if (p.q_scale != 0.f && n0 < p.N / 3) v[e] *= p.q_scale;  // q third (tile-uniform): softmax scale folded in
           }
@@ -316,26 +318,10 @@ int launch_v(const GemmBf16Params& p, hipStream_t st) {
   return WVN_OK;
 }
 
-// WVN_GEMM_PD (A/B switch): register prefetch depth of the unrolled K pipelines, 1 | 2 | 3 (default);
-// 0 selects the generic runtime-K loop everywhere.
-int prefetch_depth() {
-  static int pd = -1;
-  if (pd < 0) {
-    const char* e = getenv("WVN_GEMM_PD");
-    pd = e ? atoi(e) : 3;
-    if (pd < 0 || pd > 3) pd = 3;
-  }
-  return pd;
-}
-
+// register prefetch depth of the unrolled K pipelines: 3 K-tiles in flight per workgroup (measured best of 1 / 2 / 3)
 template <int EPI, int NK>
 int launch_nk(const GemmBf16Params& p, hipStream_t st) {
-  switch (prefetch_depth()) {
-    case 0: return launch_v<EPI, 1, 0>(p, st);
-    case 1: return launch_v<EPI, 1, NK>(p, st);
-    case 2: return launch_v<EPI, 2, NK>(p, st);
-    default: return launch_v<EPI, 3, NK>(p, st);
-  }
+  return launch_v<EPI, 3, NK>(p, st);
 }
 
 // K of the hot-path GEMMs is known: 384 (qkv / proj / fc1 / STEGO hidden), 1536 (fc2), 192 (patch embed),
@@ -356,35 +342,17 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
   return launch_v<EPI, 1, 0>(p, st);
 }
 
-bool use_n384() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WVN_GEMM_N384");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
-}
-
-bool use_a384() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WVN_GEMM_A384");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
-}
-
 }  // namespace
 
 int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
   if (!p.A || !p.W || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
     return WVN_ERR_ARG;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return WVN_ERR_ARG;
-  if (p.K == 384 && use_a384()) {  // A-stationary kernel for the K = 384 linears (WVN_GEMM_A384=0 disables)
+  if (p.K == 384 && !p.ls) {  // A-stationary kernel for the K = 384 linears
     const int rc = wvn_gemm_a384_launch(p, epi, st);
     if (rc != WVN_ERR_ARG) return rc;
   }
-  if (p.N == 384 && p.K > 384 && use_n384()) {  // row-panel kernel for the fc2 residual update (WVN_GEMM_N384=0 disables)
+  if (p.N == 384 && p.K > 384 && !p.ls) {  // row-panel kernel for the fc2 residual update
     int done = 0;
     const int rc = wvn_gemm_n384_launch(p, epi, st, &done);
     if (rc != WVN_ERR_ARG) {

@@ -24,6 +24,7 @@ __device__ inline void f32_store(const GemmF32Params& p, float* C, int m, int n,
     C[(size_t)m * p.ldc + n] = gelu_exact(v);
   } else if constexpr (EPI == F32_EPI_RESID) {
     float* c = C + (size_t)m * p.ldc + n;
+    if (p.ls) v *= p.ls[n];  // LayerScale (DINOv2)
     *c = *c + v;
   } else if constexpr (EPI == F32_EPI_SIGMOID0) {
     C[(size_t)m * p.ldc + n] = (n == 0) ? sigmoid_f(v) : v;

@@ -543,16 +543,12 @@ int pix_infer(const void* packed, void* zx, int ldzx, int B, int G, int out_h, i
   p.B = B; p.G = G; p.Ho = out_h; p.Wo = out_w;
   p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
   p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor; p.conf_dev = conf_state;
-  static const int split = [] {
-    const char* e = getenv("WVN_PIXEL_WSPLIT");
-    return e ? atoi(e) : 1;
-  }();
-  auto kern = split ? pixel_mlp_kernel<1, D> : pixel_mlp_kernel<0, D>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[split ? 1 : 0]) {
+  auto kern = pixel_mlp_kernel<1, D>;  // bilinear weights split hi + lo (16 mantissa bits)
+  static bool attr_set = false;
+  if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set[split ? 1 : 0] = true;
+    attr_set = true;
   }
   const int ntiles = B * p.nty * p.ntx;
   const int cap = 2 * pix_num_cus();

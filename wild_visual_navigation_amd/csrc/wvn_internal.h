@@ -27,6 +27,9 @@ struct GemmBf16Params {
   // EPI_QKV
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad;
   float q_scale;  // EPI_QKV: the q third is multiplied by this before it is rounded to bf16 (0 = leave as is)
+  const float* ls;  // EPI_RESID_F32: optional LayerScale vector [N] (DINOv2): C += ls * (acc + bias); nullptr = plain residual
+  // exact mode (gemm_x3.hip): the lo planes of the operands and of plane-typed outputs (hi planes are A / W / C / q / k / vt)
+  const bf16_t* A_lo; const bf16_t* W_lo; void* C_lo; bf16_t* q_lo; bf16_t* k_lo; bf16_t* vt_lo;
   long long* dbg;  // optional: per-wave phase timings of the A-stationary kernel (scripts/ab_kernels.py --timing)
 };
 int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st);
@@ -34,6 +37,9 @@ int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 int wvn_gemm_a384_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 // row-panel kernel for N == 384 residual updates with long K (gemm_n384.hip); WVN_ERR_ARG when not eligible
 int wvn_gemm_n384_launch(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done, int force = 0);
+// exact mode: hi/lo bf16 planes, three MFMAs per product (gemm_x3.hip); same epilogue codes, plane-typed outputs for the
+// "bf16" ones
+int wvn_gemm_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 
 // ---- fp32 GEMM (gemm_f32.hip): exact-mode linears + the traversability MLP ---------------------
 enum GemmF32Epilogue {
@@ -57,12 +63,16 @@ struct GemmF32Params {
   const float* mask; int ldmask;                   // F32_EPI_RELUMASK
   const float* pos; int npatch; int ntok; int ntok_s;  // F32_EPI_PATCH (ntok_s: rows per frame)
   float* q; float* k; float* v; int heads; int npad;  // F32_EPI_QKV
+  const float* ls;                                    // F32_EPI_RESID: optional LayerScale vector [N]
 };
 int wvn_gemm_f32_launch(const GemmF32Params& p, int epi, hipStream_t st);
 
 // ---- elementwise / normalisation (elementwise.hip) --------------------------------------------
-// img: fp32 in [0,1], or raw uint8 pixels when img_u8 != 0 (bf16 output, P == 8 only)
-int wvn_patchify_launch(const void* img, int img_u8, void* patches, int out_bf16, int B, int S, int P, hipStream_t st);
+// img: fp32 in [0,1], or raw uint8 pixels when img_u8 != 0 (bf16 output, P == 8 only).  out_mode: 0 fp32, 1 bf16, 2 hi / lo
+// bf16 planes (patches_lo); ldp: row stride in elements (0 = 3*P*P; pad columns are NOT written)
+int wvn_patchify_launch(const void* img, int img_u8, void* patches, void* patches_lo, int out_mode, int ldp, int B, int S, int P,
+                        hipStream_t st);
+int wvn_split_planes_launch(const float* src, int lds_, bf16_t* hi, bf16_t* lo, int ldd, int rows, int cols, hipStream_t st);
 int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok_s, int D, hipStream_t st);
 // zero bytes [col0, col0 + ncol) of each of nrows rows (all multiples of 4)
 int wvn_pad_zero_launch(void* base, long long nrows, long long row_stride_bytes, long long col0_bytes,
@@ -71,7 +81,7 @@ int wvn_pad_zero_launch(void* base, long long nrows, long long row_stride_bytes,
 // row_map: 0 = identity; 1 = drop the class token (input row b*ntok+1+p -> output row b*(ntok-1)+p)
 int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
                          float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
-                         int ntok_s, hipStream_t st);
+                         int ntok_s, hipStream_t st, void* y_lo = nullptr);  // y_lo: exact mode, lo plane of the bf16 output
 int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st);
 
 // ---- attention (attention_bf16.hip / attention_f32.hip) ---------------------------------------
@@ -80,6 +90,11 @@ int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt
 void wvn_attention_bf16_set_debug(long long* dbg);  // per-wave phase timings (TIMING build), nullptr = off
 int wvn_attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok,
                              int ntok_s, int npad, float scale, hipStream_t st);
+// exact mode on the matrix pipe (attention_x3.hip): hi / lo planes of q, k [B,h,npad,64], v^T [B,h,64,npad] (token-permuted),
+// out planes [B*ntok_s, h*64]
+int wvn_attention_x3_launch(const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* k_hi, const bf16_t* k_lo, const bf16_t* vt_hi,
+                            const bf16_t* vt_lo, bf16_t* out_hi, bf16_t* out_lo, int B, int heads, int ntok, int ntok_s,
+                            int npad, float scale, hipStream_t st);
 
 // ---- misc launchers defined across the translation units ---------------------------------------
 int wvn_splitk_reduce_launch(const float* part, int splitk, size_t n, const float* bias, int ncols, float* out,

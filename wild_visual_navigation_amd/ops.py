@@ -200,6 +200,31 @@ def gemm_f32(a, b, bias=None, epi=_lib.F32_NONE, trans_a=False, trans_b=True, ou
     return out
 
 
+def split_planes(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [R, C] (row stride allowed) -> bf16 [2, R, C]: hi = bf16(x), lo = bf16(x - hi) -- the operand representation of
+    the exact-mode MFMA kernels (gemm_x3 / attention_x3)."""
+    require_cuda(x, "x")
+    R, Cc = x.shape
+    out = torch.empty(2, R, Cc, dtype=torch.bfloat16, device=x.device)
+    check(lib().wvn_split_planes(ptr(x), x.stride(0), ptr(out[0]), ptr(out[1]), Cc, R, Cc, stream()), "wvn_split_planes")
+    return out
+
+
+def gemm_x3(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epi: int,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Exact-mode GEMM: a [2, M, K] and w [2, N, K] are hi / lo bf16 planes (ops.split_planes / backbone.split_planes);
+    returns bf16 planes [2, M, N] for epi in {EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16}, fp32 [M, N] otherwise."""
+    _, M, K = a.shape
+    N = w.shape[1]
+    planes = epi in (_lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_RELU_BF16)
+    if out is None:
+        out = torch.empty((2, M, N) if planes else (M, N), dtype=torch.bfloat16 if planes else torch.float32, device=a.device)
+    c, c_lo, ldc = (out[0], out[1], out.stride(1)) if planes else (out, None, out.stride(0))
+    check(lib().wvn_gemm_x3(ptr(a[0]), ptr(a[1]), a.stride(1), ptr(w[0]), ptr(w[1]), w.stride(1), ptr(bias), ptr(c), ptr(c_lo),
+                            ldc, M, N, K, epi, stream()), "wvn_gemm_x3")
+    return out
+
+
 def vt_token_order(npad: int, device=None) -> torch.Tensor:
     """Index map of the bf16 attention kernel's V^T layout (include/wvn_hip.h): stored position p of every
     aligned group of 16 tokens holds token p with bits 2 and 3 swapped (an involution).
