@@ -1,41 +1,49 @@
 #!/usr/bin/env python
 """Headline benchmark: frames/s of the WVN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: either launched by torch.distributed.run (RANK / WORLD_SIZE in the environment), or -- when called plainly --
+        bench.py re-executes itself under torch.distributed.run with N ranks on this node (it fails loudly if the node has
+        fewer than N GPUs: it never prints an n_gpus it did not run on).
 
-One "step" = one pass of the hot path over one batch of synthetic frames PER GPU (weak scaling):
-  BASELINE.json configs[2]: 64 frames 448x448 -> ImageNet-normalise + patchify -> DINO ViT-S/8 (12
-  blocks, bf16 MFMA, fp32 accumulate/residual) -> STEGO head (90-d code) -> per-image cosine k-means
-  (20 clusters) segment maps -> fused bilinear-upsample + per-segment mean pooling -> ONE optimisation
-  step of the traversability MLP (forward, loss, backward, Adam) on the batch's segment rows, with the
-  gradient / statistic all-reduce over RCCL when N > 1.
-Inputs are resident in HBM before the timed region; weights are seeded synthetic (no network).
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
-fused attention, HIP-event timed on the launch stream inside the timed region) and `cpu_baseline`
-(the CPU oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+One "step" = one pass of the hot path over one batch of synthetic frames PER GPU (weak scaling; --scaling strong splits
+the 64-frame batch over the ranks):
+  --mode full (default; BASELINE.json configs[2]): 64 frames 448x448 -> ImageNet-normalise + patchify -> DINO ViT-S/8 (12 blocks)
+      -> STEGO head (90-d code) -> per-image cosine k-means (20 clusters, at patch resolution, single pass: no flip TTA)
+      segment maps -> fused bilinear-upsample + per-segment mean pooling -> ONE optimisation step of the traversability MLP
+      (forward, loss, backward, Adam) on the batch's segment rows, with the statistic / gradient all-reduces over RCCL when N > 1.
+  --mode backbone (configs[1]): --batch 32 frames through the ViT only (feature extraction).
+  --precision bf16 : bf16 MFMA operands, fp32 accumulate / residual / statistics (the speed path)
+  --precision exact: hi + lo split bf16 operands, three MFMAs per product -- fp32-class results on the matrix pipe, the
+                     north_star "<= 1e-3" parity mode, timed on the same workload
+Inputs (a pool of distinct batches) are resident in HBM before the timed region; weights are seeded synthetic (no network).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = fused attention, HIP-event timed on the launch stream inside
+the timed region), `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N = 1 only) and `parity`
+(the GPU path against that oracle on the same frames: what BASELINE.md 4.5 asks to be reported with every speed number).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "attention_traffic.json")  # PMC-derived HBM bytes of the dominant kernel
 
 
-def attention_traffic_per_launch(frames_per_launch):
-    """HBM bytes per attention launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, separate passes; profiles/attention_traffic.json says how it was collected).  Traffic of this kernel
-    is proportional to the (frame, head) pairs of a launch, so the profiled figure is rescaled to this run's launch
-    size.  None when no profile is committed."""
+def attention_traffic_per_launch(frames_per_launch, precision):
+    """HBM bytes per attention launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    separate passes; the json says how it was collected).  Traffic of this kernel is proportional to the (frame, head) pairs
+    of a launch, so the profiled figure is rescaled to this run's launch size.  None when no profile is committed."""
     try:
         t = json.load(open(TRAFFIC_FILE))
+        if precision != "bf16":
+            t = t[precision]   # sub-entry of the exact-mode kernel; the top level is the bf16 kernel
         return (t["fetch_bytes_corrected"] + t["write_bytes"]) * frames_per_launch / t["frames_per_launch"]
     except Exception:
         return None
@@ -51,20 +59,44 @@ def vit_flops_per_frame(S=448, P=8, D=384, depth=12):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE configs[2]: 64)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="full", choices=["full", "backbone"])
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (full: 64, backbone: 32 = BASELINE configs[2] / [1])")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch frames per GPU; strong: --batch frames in all, split over the ranks")
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--chunk", type=int, default=64, help="frames pushed through the backbone per launch sequence")
     ap.add_argument("--segmentation", default="stego", choices=["stego", "grid"])
+    ap.add_argument("--pool", type=int, default=4, help="distinct input batches cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (about 15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "exact", "fp32"])
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every step on one stream (default: the backbone of step i+1 runs on a second HIP stream while "
                          "clustering / pooling / the MLP step of step i -- small kernels that do not fill the GPU -- finish)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 64 if args.mode == "full" else 32
+    return args
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without a torchrun environment: become the launcher."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    import torch
+
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but this node exposes {n} GPU(s); refusing to print a line "
+                         "for a configuration that did not run")
+    port = 29500 + (os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def make_pipeline(args, dev):
@@ -72,10 +104,13 @@ def make_pipeline(args, dev):
     from wild_visual_navigation_amd.model import SimpleMLP
     from wild_visual_navigation_amd.traversability_estimator import MlpTrainer
 
-    ftype = "stego" if args.segmentation == "stego" else "dino"
-    fe = FeatureExtractor(dev, segmentation_type=args.segmentation, feature_type=ftype, input_size=args.size,
+    import torch
+
+    ftype = "stego" if (args.segmentation == "stego" and args.mode == "full") else "dino"
+    seg = args.segmentation if args.mode == "full" else "grid"
+    fe = FeatureExtractor(dev, segmentation_type=seg, feature_type=ftype, input_size=args.size,
                           backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
-                          max_chunk=args.chunk)
+                          max_chunk=args.chunk, allow_synthetic=True)
     torch.manual_seed(42)
     model = SimpleMLP(fe.feature_dim, [256, 32, 1], True).to(dev)
     return fe, model, MlpTrainer(model)
@@ -83,6 +118,8 @@ def make_pipeline(args, dev):
 
 def hot_path_step(fe, trainer, img, labels_u, args, backbone_out=None):
     """One pass: frames -> features/segments -> pooled rows -> one MLP optimisation step."""
+    import torch
+
     feat, seg, nseg = fe.extract_batch(img, backbone_out=backbone_out)
     B, S, D = feat.shape
     if args.segmentation == "stego":
@@ -104,12 +141,17 @@ class TwoStreamPipeline:
     one step ahead of B."""
 
     def __init__(self, fe, trainer, args, dev):
+        import torch
+
+        self.torch = torch
         self.fe, self.trainer, self.args = fe, trainer, args
         self.a, self.b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         self.pending = None     # (tokens, event) of a backbone stage already enqueued for the next step
         self.tail_done = None   # event: the previous step's tail has finished
+        self.marks = []         # per-step end events (timing on), recorded on stream B
 
     def _enqueue_backbone(self, img):
+        torch = self.torch
         if self.tail_done is not None:
             self.a.wait_event(self.tail_done)              # A runs at most one step ahead of B (bounded memory)
         with torch.cuda.stream(self.a):
@@ -123,26 +165,30 @@ class TwoStreamPipeline:
         """Runs one step on ``img``; ``next_img`` (the following step's frames, None for the last step) gets its backbone
         stage enqueued FIRST, so that the host-side synchronisation inside this step's tail (boolean-mask row selection)
         does not keep the GPU from starting it."""
+        torch = self.torch
         tok, ready = self.pending if self.pending is not None else self._enqueue_backbone(img)
         self.pending = self._enqueue_backbone(next_img) if next_img is not None else None
         with torch.cuda.stream(self.b):
             self.b.wait_event(ready)
             out = hot_path_step(self.fe, self.trainer, img, labels_u, self.args, backbone_out=tok)
-            self.tail_done = torch.cuda.Event()
+            self.tail_done = torch.cuda.Event(enable_timing=True)
             self.tail_done.record(self.b)
+            self.marks.append(self.tail_done)
         return out
 
     def drain(self):
-        cur = torch.cuda.current_stream()
+        cur = self.torch.cuda.current_stream()
         cur.wait_stream(self.a)
         cur.wait_stream(self.b)
 
 
-def cpu_baseline(args):
-    """CPU oracle (a PORT: PyTorch/numpy restatement of the reference algorithm) on a bounded sample of
-    the same workload: `cpu_frames` frames through backbone + STEGO head + k-means + pooling, then one
-    MLP step on their rows.  Timed on this box's host cores."""
+def cpu_baseline_and_parity(args, fe, dev):
+    """CPU oracle (a PORT: PyTorch/numpy restatement of the reference algorithm, oracle/) on a bounded sample of the same
+    workload -- `cpu_frames` frames through backbone + STEGO head + k-means + pooling, then one MLP step on their rows --
+    timed on this box's host cores; then the SAME frames through the GPU path with the SAME weights, compared stage by stage
+    (the parity figures BASELINE.md 4.5 wants beside every speed number)."""
     import numpy as np
+    import torch
 
     from oracle import interfaces as OI, mlp as OM, segments as OS, vit as OV
 
@@ -150,73 +196,151 @@ def cpu_baseline(args):
     # PyTorch's intra-op pool does not scale to the GPU box's 256 hardware threads for these matrix
     # sizes (256 threads ran ~20x slower than the 8-core survey probe); the thread count used is reported.
     torch.set_num_threads(min(os.cpu_count() or 1, args.cpu_threads))
-    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0)
-    head = OI.make_stego_head_state_dict(384, 90, seed=0)
+    stego = args.segmentation == "stego" and args.mode == "full"
+    bb = fe._extractor._bb if stego else fe._extractor._model
+    sd = {k: v.detach().float().cpu() for k, v in bb._sd.items()}           # the weights the GPU model was built from
+    head = {k: v.detach().float().cpu() for k, v in fe._extractor._head_sd.items()} if stego else None
     img = torch.rand(n, 3, args.size, args.size, generator=torch.Generator().manual_seed(1))
     G = args.size // 8
     t0 = time.perf_counter()
-    rows = []
+    rows, toks, codes, segs = [], [], [], []
     with torch.no_grad():
         for b in range(n):
             tok = OV.vit_tokens(sd, OI.normalize(img[b:b + 1]), 8, 6)[:, 1:]
-            if args.segmentation == "stego":
+            toks.append(tok)
+            if args.mode == "backbone":
+                continue
+            if stego:
                 code = OI.stego_code_tokens(head, tok)
+                codes.append(code)
                 lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), 20))
                 seg = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), args.size)[0, 0].long()
                 fmap = code.reshape(1, G, G, -1).permute(0, 3, 1, 2)
             else:
                 seg = OS.segment_grid(args.size, args.size, 32)[0, 0]
                 fmap = tok.reshape(1, G, G, -1).permute(0, 3, 1, 2)
+            segs.append(seg)
             dense = OI.upsample_bilinear_ac(fmap, args.size)
             rows.append(OS.sparsify_features(dense, seg))
-        x = torch.cat(rows)
-        gsel = torch.Generator().manual_seed(2)
-        yv = torch.rand(x.shape[0], generator=gsel) < 0.16
-        yv[0] = yv[1] = True
-        y = yv.float() * (0.5 + 0.5 * torch.rand(x.shape[0], generator=gsel))
-        st = OM.TrainState(OM.make_mlp_state_dict(x.shape[1]))
-        OM.train_step(st, x, y, yv)
+        if args.mode == "full":
+            x = torch.cat(rows)
+            gsel = torch.Generator().manual_seed(2)
+            yv = torch.rand(x.shape[0], generator=gsel) < 0.16
+            yv[0] = yv[1] = True
+            y = yv.float() * (0.5 + 0.5 * torch.rand(x.shape[0], generator=gsel))
+            st = OM.TrainState(OM.make_mlp_state_dict(x.shape[1]))
+            OM.train_step(st, x, y, yv)
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} frames {args.size}x{args.size} through the CPU oracle (ViT-S/8 12 blocks fp32 + "
-                      f"{args.segmentation} segmentation + pooling + 1 MLP step), {dt:.1f} s wall"}
+    what = (f"ViT-S/8 12 blocks fp32 + {args.segmentation} segmentation + pooling + 1 MLP step" if args.mode == "full"
+            else "ViT-S/8 12 blocks fp32")
+    base = {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frames {args.size}x{args.size} through the CPU oracle ({what}), {dt:.1f} s wall"}
+
+    # ---- parity of the GPU path on the same frames, same weights ----
+    with torch.no_grad():
+        gi = img.to(dev)
+        gtok = bb.forward_tokens(gi).cpu()
+        otok = torch.cat(toks)
+        par = {"mode": args.precision, "frames": n, "against": "oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned)",
+               "max_abs_tokens": float((gtok - otok).abs().max()), "rel_l2_tokens": float((gtok - otok).norm() / otok.norm())}
+        if args.mode == "full":
+            feat, seg, nseg = fe.extract_batch(gi)
+            seg = seg.cpu().long()
+            oseg = torch.stack(segs)
+            same = [bool(torch.equal(seg[b], oseg[b])) for b in range(n)]
+            par["seg_equal_frames"] = f"{sum(same)}/{n}"
+            par["seg_pixel_agreement"] = float((seg == oseg).float().mean())
+            if stego:
+                gcode = fe._extractor.feature_tokens.cpu()
+                par["max_abs_code"] = float((gcode - torch.cat(codes)).abs().max())
+            # pooled features: the oracle's dense features pooled over the GPU's own segment map (so that the figure measures
+            # the features, not a label permutation, when the maps differ)
+            worst = 0.0
+            for b in range(n):
+                fmap = (codes[b] if stego else toks[b]).reshape(1, G, G, -1).permute(0, 3, 1, 2)
+                want = OS.sparsify_features(OI.upsample_bilinear_ac(fmap, args.size), seg[b])
+                got = feat[b, : want.shape[0]].cpu()
+                ok = ~torch.isnan(want).any(1)
+                worst = max(worst, float((got[ok] - want[ok]).abs().max()))
+            par["max_abs_pooled"] = worst
+    return base, par
+
+
+def percentiles(xs):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    pick = lambda q: xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
+    return {"median": round(statistics.median(xs), 3), "p10": round(pick(0.1), 3), "p90": round(pick(0.9), 3)}
 
 
 def main():
     args = parse()
+    maybe_spawn(args)
+    import torch
+
     from wild_visual_navigation_amd import distributed as D, ops
 
     rank, world, local = D.init_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    ranks_seen = world
+    if world > 1:   # prove the process group spans `world` ranks over RCCL before timing anything
+        t = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(t)
+        ranks_seen = int(t.item())
+        assert ranks_seen == world, f"RCCL all-reduce saw {ranks_seen} ranks, expected {world}"
     fe, model, trainer = make_pipeline(args, dev)
-    B = args.batch
+    if args.scaling == "strong":
+        b0, b1 = D.shard_range(args.batch, rank, world)
+        B = b1 - b0
+        if B <= 0:
+            raise SystemExit("--scaling strong: more ranks than frames")
+    else:
+        B = args.batch
     gen = torch.Generator().manual_seed(1000 + rank)
-    img = torch.rand(B, 3, args.size, args.size, generator=gen).to(dev)  # resident in HBM before timing
+    pool = [torch.rand(B, 3, args.size, args.size, generator=gen).to(dev) for _ in range(max(1, args.pool))]  # resident in HBM
     n_lab = 20 if args.segmentation == "stego" else (args.size // 32) ** 2
-    labels_u = torch.rand(B, n_lab, 2, generator=gen).to(dev)
+    labels = [torch.rand(B, n_lab, 2, generator=gen).to(dev) for _ in range(len(pool))]
+    backbone_only = args.mode == "backbone"
+    bb = (fe._extractor._bb if fe.feature_type == "stego" else fe._extractor._model) if backbone_only else None
 
-    pipe = None if args.no_overlap else TwoStreamPipeline(fe, trainer, args, dev)
-    def run_step(last):
-        if pipe is None:
-            return hot_path_step(fe, trainer, img, labels_u, args)
-        return pipe.step(img, labels_u, next_img=None if last else img)
+    pipe = None if (args.no_overlap or backbone_only) else TwoStreamPipeline(fe, trainer, args, dev)
+    marks = []
+
+    def run_step(i, last):
+        img, lab = pool[i % len(pool)], labels[i % len(pool)]
+        if backbone_only:
+            out = (bb.forward_tokens(img), 0)
+        elif pipe is None:
+            out = hot_path_step(fe, trainer, img, lab, args)
+        else:
+            return pipe.step(img, lab, next_img=None if last else pool[(i + 1) % len(pool)])
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
+        return out
 
     for i in range(args.warmup):
-        run_step(i == args.warmup - 1)      # the pipeline is empty again when the timed region starts
+        run_step(i, i == args.warmup - 1)      # the pipeline is empty again when the timed region starts
     if pipe is not None:
         pipe.drain()
+        pipe.marks.clear()
+    marks.clear()
     torch.cuda.synchronize()
     D.barrier()
     ops.prof_enable(True)
+    trainer.comm_events = [] if world > 1 else None
     torch.cuda.synchronize()
+    start = torch.cuda.Event(enable_timing=True)
+    start.record()
     t0 = time.perf_counter()
     rows = 0
     for i in range(args.steps):
-        losses, rows = run_step(i == args.steps - 1)   # exactly `steps` backbone stages and `steps` tails in the timed region
+        losses, rows = run_step(i, i == args.steps - 1)   # exactly `steps` backbone stages and `steps` tails in the timed region
     if pipe is not None:
         pipe.drain()
     torch.cuda.synchronize()
@@ -225,47 +349,74 @@ def main():
     ops.prof_enable(False)
     prof = ops.prof_collect()
     dt = D.max_over_ranks(dt, dev)
-    loss_val = float(losses[0].item())
+    ends = pipe.marks if pipe is not None else marks
+    step_ms, prev = [], start
+    for e in ends:
+        step_ms.append(prev.elapsed_time(e))
+        prev = e
+    comm_ms = None
+    if trainer.comm_events:
+        per = [a.elapsed_time(b) for a, b in trainer.comm_events]
+        comm_ms = {"per_step_total": round(sum(per) / args.steps, 4), "stats_allreduce": percentiles(per[0::2]),
+                   "grad_allreduce": percentiles(per[1::2])}
+        comm_ms["per_step_total"] = D.max_over_ranks(comm_ms["per_step_total"], dev)
+    loss_val = float(losses[0].item()) if not backbone_only else None
 
     if rank == 0:
-        frames = world * B * args.steps
+        total_frames = (args.batch if args.scaling == "strong" else world * B) * args.steps
         total_flops, attn_flops_block = vit_flops_per_frame(args.size)
         att_ms, att_n = prof["attention"]
         chunk = min(args.chunk, B)
-        # every attention launch processes `chunk` frames (the last chunk of a batch may be smaller)
         frames_per_launch = (B * args.steps * 12) / max(att_n, 1)  # 12 attention launches per frame-chunk
         att_avg_ms = att_ms / max(att_n, 1)
         att_tflops = attn_flops_block * frames_per_launch / (att_avg_ms * 1e-3) / 1e12 if att_n else 0.0
         kern = {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in prof.items()}
+        x3 = args.precision == "exact"
+        kernel_name = {"bf16": "attention_bf16_kernel", "exact": "attention_x3_kernel", "fp32": "attention_f32_kernel"}[args.precision]
+        if backbone_only:
+            metric = "frames/sec (448x448 DINO-ViT-S/8 feature extraction)"
+            workload = f"BASELINE configs[1]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU, feature extraction only"
+        else:
+            metric = "frames/sec (448x448 DINO-ViT-S/8 + seg + MLP train-step)"
+            segdesc = ("STEGO head + per-image cosine k-means (20 clusters, at patch resolution, single pass: no flip TTA)"
+                       if args.segmentation == "stego" else "grid segmentation (32-pixel cells)")
+            workload = (f"BASELINE configs[2]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU + {segdesc} + fused segment "
+                        f"pooling + 1 traversability-MLP Adam step on {rows} rows/GPU")
         out = {
-            "metric": "frames/sec (448x448 DINO-ViT-S/8 + seg + MLP train-step)",
-            "value": round(frames / dt, 2),
+            "metric": metric,
+            "value": round(total_frames / dt, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": args.precision,
+            "dtype": {"bf16": "bf16", "exact": "bf16x3 (hi+lo split operands, fp32-class)", "fp32": "f32"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU + STEGO head + "
-                                   f"{args.segmentation} segmentation + fused segment pooling + 1 traversability-MLP "
-                                   f"Adam step on {rows} rows/GPU", "frames_per_gpu_per_step": B,
-                       "backbone_chunk": chunk, "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP grads)",
-                       "schedule": "one stream" if args.no_overlap else
+            "config": {"workload": workload, "frames_per_gpu_per_step": B, "backbone_chunk": chunk, "input_pool": len(pool),
+                       "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP statistics + gradients)",
+                       "ranks_seen": ranks_seen,
+                       "schedule": "one stream" if pipe is None else
                                    "two HIP streams: backbone of step i+1 overlaps clustering / pooling / MLP step of step i"},
-            "backbone_tflops": round(total_flops * frames / dt / 1e12 / world, 1),
+            "step_ms": percentiles(step_ms),
+            "backbone_tflops": round(total_flops * total_frames / dt / 1e12 / world, 1),
             "final_loss": loss_val,
-            "roofline": {"bound": "mfma", "kernel": "attention_bf16_kernel", "achieved": round(att_tflops, 1),
+            "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": round(att_tflops, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tflops / PEAK_BF16_TFLOPS, 4),
-                         "traffic": attention_traffic_per_launch(frames_per_launch), "avg_launch_ms": round(att_avg_ms, 4),
+                         "traffic": attention_traffic_per_launch(frames_per_launch, args.precision),
+                         "avg_launch_ms": round(att_avg_ms, 4),
                          "algorithmic_flops_per_launch": attn_flops_block * frames_per_launch},
             "kernel_ms": kern,
         }
+        if x3:  # three MFMAs per algorithmic product: what the matrix pipe actually issues
+            out["roofline"]["mfma_issued"] = round(3 * att_tflops, 1)
+            out["roofline"]["frac_issued"] = round(3 * att_tflops / PEAK_BF16_TFLOPS, 4)
+        if comm_ms is not None:
+            out["allreduce_ms"] = comm_ms
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(args, fe, dev)
         print(json.dumps(out))
     D.barrier()
 

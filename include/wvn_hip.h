@@ -171,6 +171,9 @@ int wvn_seg_adjacency(const int* seg, long long* edges, int* count, unsigned cha
  * ------------------------------------------------------------------------------------------- */
 /* rows of code [rows, ldc] -> xn [rows, C] = code / max(||code||, 1e-12), sequential fp32 */
 int wvn_normalize_rows(const float* code, int ldc, float* xn, int rows, int C, void* stream);
+/* out[r] = argmax over the cols of row r (lowest index wins ties): label maps of the STEGO cluster probe (cosine similarity
+ * against the checkpoint's learned centroids, run_clustering=False) and linear probe (stego_interface.py:94-100) */
+int wvn_argmax_rows(const float* x, int ld, int rows, int cols, int* out, void* stream);
 /* deterministic cosine k-means per image on xn [B,P,C]; labels [B,P] int32; nseg [B] distinct ids;
  * relabel != 0 compacts ids to 0..K'-1 ascending (feature_extractor.py:245-246). C in {16,64,90}.
  * scratch: wvn_kmeans_scratch_bytes(B,P,C,K) bytes (centroids + per-chunk partial sums). */

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "wvn_seg_centers": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_seg_adjacency": ([_p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_normalize_rows": ([_p, _i, _p, _i, _i, _p], _i),
+    "wvn_argmax_rows": ([_p, _i, _i, _i, _p, _p], _i),
     "wvn_kmeans_scratch_bytes": ([_i, _i, _i, _i], _sz),
     "wvn_kmeans_cosine": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "wvn_mlp_param_count": ([_p], _sz),

@@ -18,9 +18,10 @@ from . import _lib
 ARCH = {"vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}
 
 
-def synthetic_vit_state_dict(arch="vit_small", patch=8, pretrain_grid=28, seed=0, depth=None) -> Dict[str, torch.Tensor]:
+def synthetic_vit_state_dict(arch="vit_small", patch=8, pretrain_grid=28, seed=0, depth=None, dinov2=False) -> Dict[str, torch.Tensor]:
     """Seeded random weights with realistic scales in the upstream DINO layout (no network here to
-    fetch dl.fbaipublicfiles.com/dino checkpoints).  LayerNorm affine and biases are non-trivial."""
+    fetch dl.fbaipublicfiles.com/dino checkpoints).  LayerNorm affine and biases are non-trivial.
+    ``dinov2``: add the LayerScale vectors ``blocks.i.ls{1,2}.gamma`` of the published DINOv2 block."""
     D, dd, _ = ARCH[arch]
     depth = dd if depth is None else depth
     g = torch.Generator().manual_seed(seed)
@@ -50,6 +51,11 @@ def synthetic_vit_state_dict(arch="vit_small", patch=8, pretrain_grid=28, seed=0
         sd[p + "mlp.fc1.bias"] = rn(4 * D, std=0.02)
         sd[p + "mlp.fc2.weight"] = tn(D, 4 * D, std=0.03)
         sd[p + "mlp.fc2.bias"] = rn(D, std=0.02)
+    if dinov2:
+        g2 = torch.Generator().manual_seed(seed + 77)
+        for i in range(depth):
+            sd[f"blocks.{i}.ls1.gamma"] = 0.2 + 0.8 * torch.rand(D, generator=g2)
+            sd[f"blocks.{i}.ls2.gamma"] = 0.2 + 0.8 * torch.rand(D, generator=g2)
     return sd
 
 
@@ -97,6 +103,7 @@ class VitBackbone:
         self.depth = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         self.mlp_dim = state_dict["blocks.0.mlp.fc1.weight"].shape[0]
         self.max_chunk = max_chunk
+        self._sd = state_dict  # kept (host / original tensors) so that .to(device) can re-home the model
         self._keep = []  # device tensors referenced by raw pointers in the C struct
 
         def mat(t, pad_cols=0):
@@ -145,6 +152,14 @@ class VitBackbone:
         self.model = m
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
+
+    def to(self, device) -> "VitBackbone":
+        """A copy of this backbone on another GPU (DinoInterface.change_device, dino_interface.py:61-68); self if unchanged."""
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        return VitBackbone(self._sd, self.img_size, self.patch, self.heads, device=device, precision=self.precision_name,
+                           max_chunk=self.max_chunk)
 
     # ---- workspace (needs no initialisation: wvn_vit_forward resets the padding rows it relies on at every call) ----
     def _workspace(self, batch: int) -> torch.Tensor:

@@ -353,6 +353,9 @@ int wvn_seg_adjacency(const int* seg, long long* edges, int* count, unsigned cha
 int wvn_normalize_rows(const float* code, int ldc, float* xn, int rows, int C, void* stream) {
   return wvn_normalize_rows_launch(code, ldc, xn, rows, C, (hipStream_t)stream);
 }
+int wvn_argmax_rows(const float* x, int ld, int rows, int cols, int* out, void* stream) {
+  return wvn_argmax_rows_launch(x, ld, rows, cols, out, (hipStream_t)stream);
+}
 size_t wvn_kmeans_scratch_bytes(int B, int P, int C, int K) {
   return (B > 0 && P > 0 && C > 0 && K > 0) ? wvn_kmeans_scratch_floats(B, P, C, K) * sizeof(float) : 0;
 }

@@ -28,7 +28,7 @@ constexpr int NS = 3;
 constexpr int W_BYTES = NN * BKS * 2;   // 24 KB
 constexpr int A_BYTES = BM * BKS * 2;   // 16 KB
 constexpr int STAGE_BYTES = W_BYTES + A_BYTES;
-constexpr int RING_BYTES = NS * STAGE_BYTES;               // 122,880
+
 constexpr int STG_PITCH = 132;                             // floats per staged row (128 columns + 4: conflict-light)
 constexpr int STG_BYTES = 32 * STG_PITCH * 4;              // per wave: 16,896
 constexpr int BIAS_OFF = 8 * STG_BYTES;                    // 135,168 (> RING_BYTES: staging and ring share the front)

@@ -220,7 +220,29 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
   return WVN_OK;
 }
 
+// out[r] = argmax_c x[r][c], lowest index wins ties (torch.argmax semantics on finite rows): the label maps of the STEGO
+// cluster probe (cosine similarity against learned centroids) and linear probe (stego_interface.py:94-100)
+__global__ void argmax_rows_kernel(const float* __restrict__ x, int ld, int rows, int cols, int* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* xr = x + (size_t)r * ld;
+  float best = xr[0];
+  int bi = 0;
+  for (int c = 1; c < cols; ++c) {
+    const float v = xr[c];
+    if (v > best) { best = v; bi = c; }
+  }
+  out[r] = bi;
+}
+
 }  // namespace
+
+int wvn_argmax_rows_launch(const float* x, int ld, int rows, int cols, int* out, hipStream_t st) {
+  if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return WVN_ERR_ARG;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, x, ld, rows, cols, out);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
 
 int wvn_normalize_rows_launch(const float* code, int ldc, float* xn, int rows, int C, hipStream_t st) {
   if (!code || !xn) return WVN_ERR_ARG;

@@ -110,6 +110,7 @@ int wvn_centers_launch(const int* seg, float* centers, unsigned long long* scrat
 int wvn_adjacency_launch(const int* seg, long long* edges, int* count, unsigned char* bitmap, int H, int Wd, int S,
                          int max_edges, hipStream_t st);
 int wvn_normalize_rows_launch(const float* code, int ldc, float* xn, int rows, int C, hipStream_t st);
+int wvn_argmax_rows_launch(const float* x, int ld, int rows, int cols, int* out, hipStream_t st);
 size_t wvn_kmeans_scratch_floats(int B, int P, int C, int K);
 int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, float* scratch, int B, int P, int C, int K, int iters,
                       int relabel, hipStream_t st);

@@ -46,6 +46,17 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def all_ranks_ready(ready: bool, device=None) -> bool:
+    """MIN over ranks of a local flag (True for a single process): the collective decision whether a step that contains
+    collectives runs at all."""
+    if not is_parallel():
+        return bool(ready)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([1 if ready else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def barrier():
     if is_parallel():
         dist.barrier()

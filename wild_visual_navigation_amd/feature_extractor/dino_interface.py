@@ -1,5 +1,6 @@
 """DinoInterface -- same constructor / ``inference`` contract as
 wild_visual_navigation/feature_extractor/dino_interface.py:15-108, running on the HIP backbone."""
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -18,7 +19,9 @@ class _Cfg(dict):
         return len(self) == 0
 
 
-def _load_state_dict(pretrained_weights, backbone_type, patch_size, seed=0) -> Dict[str, torch.Tensor]:
+def _load_state_dict(pretrained_weights, backbone_type, patch_size, seed=0, dinov2=False) -> Dict[str, torch.Tensor]:
+    """A DINO / DINOv2 state dict: the given dict, a checkpoint file (released DINO ``*_pretrain.pth`` / ``*_checkpoint.pth``
+    or DINOv2 hub ``dinov2_vit?14_pretrain.pth`` layouts), or -- there is no network here -- seeded synthetic weights."""
     if isinstance(pretrained_weights, dict):
         return pretrained_weights
     if isinstance(pretrained_weights, str):
@@ -28,7 +31,7 @@ def _load_state_dict(pretrained_weights, backbone_type, patch_size, seed=0) -> D
                 sd = sd[key]
         return {k.replace("module.", "").replace("backbone.", ""): v for k, v in sd.items()}
     # The reference lets the external package download DINO weights; no network here.
-    return synthetic_vit_state_dict(backbone_type, patch_size, seed=seed)
+    return synthetic_vit_state_dict(backbone_type, patch_size, pretrain_grid=37 if dinov2 else 28, seed=seed, dinov2=dinov2)
 
 
 class DinoInterface:
@@ -43,8 +46,9 @@ class DinoInterface:
         dropout_p: float = 0,
         pretrained_weights=None,  # path to a DINO checkpoint, or a state dict; None -> seeded synthetic
         cfg=None,
-        precision: str = "bf16",  # extension: "bf16" (MFMA) | "fp32" (exact parity mode)
+        precision: str = "bf16",  # extension: "bf16" (MFMA) | "exact" (<= 1e-3 parity mode on MFMA) | "fp32" (same gate, FMA)
         max_chunk: int = 16,
+        allow_synthetic: bool = False,
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(backbone=backbone, backbone_type=backbone_type, input_size=input_size,
@@ -52,20 +56,29 @@ class DinoInterface:
                              pretrained_weights=pretrained_weights)
         else:
             self._cfg = _Cfg(cfg)
-        if self._cfg.backbone != "dino":
-            raise _lib.WvnError(f"backbone '{self._cfg.backbone}' not supported by the MI355X path (dino only)")
+        if self._cfg.backbone not in ("dino", "dinov2"):
+            raise _lib.WvnError(f"backbone '{self._cfg.backbone}' not supported by the MI355X path (dino, dinov2)")
         c = self._cfg
         _, _, heads = ARCH[c.backbone_type]
-        sd = _load_state_dict(c.pretrained_weights, c.backbone_type, c.patch_size)
+        dinov2 = c.backbone == "dinov2"
+        if dinov2 and c.patch_size != 14:
+            raise _lib.WvnError("backbone 'dinov2' has patch size 14 (dinov2_vit{s,b}14)")
+        if c.pretrained_weights is None and not allow_synthetic:
+            warnings.warn(f"DinoInterface: no pretrained_weights given -- running with seeded SYNTHETIC {c.backbone} "
+                          f"{c.backbone_type}/{c.patch_size} weights (the reference downloads the released checkpoint; there is "
+                          "no network here): shapes and speed are real, the features are meaningless.  Pass "
+                          "pretrained_weights=<path | state dict> or allow_synthetic=True to silence", stacklevel=2)
+        sd = _load_state_dict(c.pretrained_weights, c.backbone_type, c.patch_size, dinov2=dinov2)
         self._precision = precision
         self._device = torch.device(device)
         self._model = VitBackbone(sd, c.input_size, c.patch_size, heads, device=self._device, precision=precision,
                                   max_chunk=max_chunk)
 
     def change_device(self, device):
+        """dino_interface.py:61-68: move the model to another device (another GPU: the HIP path has no CPU form)."""
         device = torch.device(device)
-        if device != self._device:
-            raise _lib.WvnError("change_device: weights are bound to the GPU they were built on")
+        self._model = self._model.to(device)
+        self._device = device
 
     @torch.no_grad()
     def inference_tokens(self, img: torch.Tensor) -> torch.Tensor:

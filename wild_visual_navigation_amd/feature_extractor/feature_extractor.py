@@ -35,19 +35,22 @@ class FeatureExtractor:
                 n_image_clusters=kwargs.get("n_image_clusters", 20),
                 run_clustering=kwargs.get("run_clustering", True),
                 run_crf=kwargs.get("run_crf", False),
-                backbone_type=kwargs.get("backbone_type", "vit_small"),
+                backbone_type=kwargs.get("backbone_type", "vit_small" if kwargs.get("model_path") is None else None),
                 patch_size=kwargs.get("patch_size", 8), precision=precision,
                 backbone_weights=kwargs.get("pretrained_weights"), head_weights=kwargs.get("head_weights"),
-                max_chunk=kwargs.get("max_chunk", 16),
+                probe_weights=kwargs.get("probe_weights"), model_path=kwargs.get("model_path"),
+                max_chunk=kwargs.get("max_chunk", 16), flip_tta=kwargs.get("flip_tta", False),
+                cluster_resolution=kwargs.get("cluster_resolution", "patch"),
+                allow_synthetic=kwargs.get("allow_synthetic", False),
             )
         elif "dino" in self._feature_type:
             self._feature_dim = 384  # the reference hard-codes 384 for any dino type (feature_extractor.py:56)
             self._extractor = DinoInterface(
                 device=device, input_size=input_size, patch_size=kwargs.get("patch_size", 8),
-                backbone=kwargs.get("backbone", self._feature_type),
+                backbone=kwargs.get("backbone", "dinov2" if self._feature_type == "dinov2" else "dino"),
                 backbone_type=kwargs.get("backbone_type", "vit_small"),
                 pretrained_weights=kwargs.get("pretrained_weights"), precision=precision,
-                max_chunk=kwargs.get("max_chunk", 16),
+                max_chunk=kwargs.get("max_chunk", 16), allow_synthetic=kwargs.get("allow_synthetic", False),
             )
             self._feature_dim = self._extractor.feature_dim
         elif self._feature_type == "none":
@@ -80,8 +83,11 @@ class FeatureExtractor:
         return self._segmentation_type
 
     def change_device(self, device):
+        """feature_extractor.py:130-139: move every member to ``device`` (another GPU)."""
         self._device = torch.device(device)
-        self._extractor.change_device(device)
+        self.segment_extractor = self.segment_extractor.to(self._device)
+        if self._extractor is not None:
+            self._extractor.change_device(device)
 
     # ------------------------------------------------------------------------------------------ extract
     @torch.no_grad()
@@ -147,6 +153,8 @@ class FeatureExtractor:
             self._extractor.inference(img, code=backbone_out)
             seg = self._extractor.cluster_segments[0]
             nseg = self._extractor._n_segments
+            if nseg is None:
+                raise _lib.WvnError("extract_batch with stego segmentation needs run_clustering=True (per-image k-means)")
             n_seg = self._extractor._cfg.n_image_clusters
             tokens = self._extractor.feature_tokens
             labels_patch = self._extractor._labels_patch
@@ -263,6 +271,9 @@ class FeatureExtractor:
         """feature_extractor.py:237-249; the ascending relabel is done inside the k-means kernel."""
         self._extractor.inference(img.clone())
         seg = self._extractor.cluster_segments.to(torch.long)  # [1,1,H,H]
+        if self._extractor._n_segments is None:  # cluster-probe ids are not compacted: relabel ascending (:245-246)
+            _, inv = torch.unique(seg, return_inverse=True)
+            seg = inv.reshape(seg.shape)
         self._stego_features_already_computed_in_segmentation = True
         return seg
 

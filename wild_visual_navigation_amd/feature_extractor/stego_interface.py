@@ -1,17 +1,28 @@
 """StegoInterface -- same contract as wild_visual_navigation/feature_extractor/stego_interface.py:18-135.
 
-The STEGO network itself (``stego.stego.Stego``: backbone + segmentation head + cluster / linear
-probes, k-means / CRF post-processing) is an external, absent package; this build implements the
-published STEGO head (1x1-conv linear branch + 1x1-conv/ReLU/1x1-conv branch, summed) on the HIP
-ViT backbone and a deterministic per-image cosine k-means for ``run_clustering=True`` (definition
-in DESIGN.md).  ``run_crf=True`` (pydensecrf, CPU) is not available.
+The STEGO network itself (``stego.stego.Stego``: backbone + segmentation head + cluster / linear probes, k-means / CRF
+post-processing) is an external, absent package (PARITY UNPINNED); this build implements the published
+STEGO head (1x1-conv linear branch + 1x1-conv/ReLU/1x1-conv branch, summed) on the HIP ViT backbone, the cluster probe
+(cosine-similarity argmax against the checkpoint's learned centroids, ``run_clustering=False``), the linear probe, and a
+deterministic per-image cosine k-means for ``run_clustering=True``.  ``model_path`` is honoured: a Lightning checkpoint in
+either the upstream STEGO (``net.model.* / net.cluster1.* / cluster_probe.clusters / linear_probe.*``) or the
+self_supervised_segmentation (``backbone.* / segmentation_head.*``) key layout is loaded (``load_stego_checkpoint``); without
+one, seeded synthetic weights are used and a warning says so.  ``run_crf=True`` (pydensecrf, CPU) is not available.
+
+Two knobs make the definition explicit instead of implicit (both default to the cheap form; bench.py names what it ran):
+  flip_tta            False | True : average the code with the code of the horizontally flipped frame (upstream get_code does;
+                                     doubles the backbone work)
+  cluster_resolution  "patch" | "pixel": k-means over the G x G patch codes (labels then nearest-upsampled: segments are
+                                     patch-aligned) or over the H x H bilinearly up-sampled code pixels
 """
-from typing import Dict, Optional
+import re
+import warnings
+from typing import Dict, Optional, Tuple
 
 import torch
 
 from .. import _lib, ops
-from ..backbone import ARCH, VitBackbone
+from ..backbone import ARCH, VitBackbone, split_planes
 from .dino_interface import _Cfg, _load_state_dict
 from .transforms import resize_nearest_center_crop
 
@@ -33,6 +44,50 @@ def synthetic_stego_head(D: int = 384, Cc: int = STEGO_CODE_DIM, seed: int = 0) 
     }
 
 
+def load_stego_checkpoint(path_or_dict) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+    """Lightning checkpoint of ``Stego.load_from_checkpoint`` (stego_interface.py:43) -> (backbone state dict in the DINO
+    layout, head state dict ``cluster1.0 / cluster2.0 / cluster2.2``, probes ``{clusters [K,C], linear.weight [n,C],
+    linear.bias [n]}``).  Keys are located by suffix, so both the upstream STEGO naming (``net.model.blocks...``,
+    ``net.cluster1.0.weight``) and the ``backbone. / segmentation_head.{linear,nonlinear}`` naming load; 1x1-conv weights
+    [out, in, 1, 1] are flattened to Linear layout.  Pure host code (no GPU needed)."""
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu", weights_only=False)
+    sd = ck.get("state_dict", ck)
+    anchor = [k for k in sd if k.endswith("patch_embed.proj.weight")]
+    if not anchor:
+        raise _lib.WvnError("STEGO checkpoint: no '...patch_embed.proj.weight' key (not a DINO-backbone checkpoint)")
+    prefix = anchor[0][: -len("patch_embed.proj.weight")]
+    backbone = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+    def find(pattern):
+        hits = [k for k in sd if re.search(pattern, k) and not k.startswith(prefix)]
+        return sd[hits[0]] if hits else None
+
+    def lin(t):
+        return None if t is None else t.reshape(t.shape[0], -1).float()
+
+    head = {
+        "cluster1.0.weight": lin(find(r"(cluster1|segmentation_head\.linear)\.0\.weight$")),
+        "cluster1.0.bias": find(r"(cluster1|segmentation_head\.linear)\.0\.bias$"),
+        "cluster2.0.weight": lin(find(r"(cluster2|segmentation_head\.nonlinear)\.0\.weight$")),
+        "cluster2.0.bias": find(r"(cluster2|segmentation_head\.nonlinear)\.0\.bias$"),
+        "cluster2.2.weight": lin(find(r"(cluster2|segmentation_head\.nonlinear)\.2\.weight$")),
+        "cluster2.2.bias": find(r"(cluster2|segmentation_head\.nonlinear)\.2\.bias$"),
+    }
+    missing = [k for k, v in head.items() if v is None]
+    if missing:
+        raise _lib.WvnError(f"STEGO checkpoint: segmentation-head tensors not found: {missing}")
+    probes = {}
+    t = find(r"cluster_probe\.clusters$")
+    if t is not None:
+        probes["clusters"] = t.float()
+    t = find(r"linear_probe\.weight$")
+    if t is not None:
+        probes["linear.weight"] = lin(t)
+        b = find(r"linear_probe\.bias$")
+        probes["linear.bias"] = b.float() if b is not None else torch.zeros(t.shape[0])
+    return backbone, head, probes
+
+
 class StegoInterface:
     def __init__(
         self,
@@ -43,12 +98,16 @@ class StegoInterface:
         run_crf: bool = True,
         run_clustering: bool = False,
         cfg=None,
-        backbone_type: str = "vit_small",  # extension (the reference's released ckpt is ViT-Base)
+        backbone_type: str = None,     # extension: default = what the weights say (the released ckpt is ViT-Base), else vit_small
         patch_size: int = 8,
         precision: str = "bf16",
         backbone_weights=None,
         head_weights: Optional[Dict[str, torch.Tensor]] = None,
+        probe_weights: Optional[Dict[str, torch.Tensor]] = None,
         max_chunk: int = 16,
+        flip_tta: bool = False,
+        cluster_resolution: str = "patch",
+        allow_synthetic: bool = False,
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(model_path=model_path, input_size=input_size, run_crf=run_crf,
@@ -57,30 +116,69 @@ class StegoInterface:
             self._cfg = _Cfg(cfg)
         if self._cfg.run_crf:
             raise _lib.WvnError("run_crf=True needs pydensecrf (CPU, external); FeatureExtractor uses run_crf=False")
+        if cluster_resolution not in ("patch", "pixel"):
+            raise _lib.WvnError("cluster_resolution must be 'patch' or 'pixel'")
         self._device = torch.device(device)
-        D, _, heads = ARCH[backbone_type]
-        sd = _load_state_dict(backbone_weights, backbone_type, patch_size)
+        probes = dict(probe_weights) if probe_weights else {}
+        mp = self._cfg.get("model_path")
+        if mp is not None and backbone_weights is None and head_weights is None:
+            import os
+
+            if os.path.exists(mp):
+                backbone_weights, head_weights, ck_probes = load_stego_checkpoint(mp)
+                probes = {**ck_probes, **probes}
+            else:
+                warnings.warn(f"StegoInterface: model_path '{mp}' does not exist; falling back to SYNTHETIC weights", stacklevel=2)
+        sd = _load_state_dict(backbone_weights, backbone_type or "vit_small", patch_size)
+        D = sd["cls_token"].shape[-1]
+        if backbone_type is None:
+            backbone_type = {v[0]: k for k, v in ARCH.items()}[D]
+        if ARCH[backbone_type][0] != D:
+            raise _lib.WvnError(f"backbone_type {backbone_type} does not match the weights (dim {D})")
+        heads = ARCH[backbone_type][2]
+        patch_size = sd["patch_embed.proj.weight"].shape[-1]
+        if head_weights is None or backbone_weights is None:
+            if not allow_synthetic:
+                warnings.warn("StegoInterface: no STEGO checkpoint given -- running with seeded SYNTHETIC backbone / head weights "
+                              "(shapes and speed are real, the segmentation is meaningless); pass model_path=... or "
+                              "allow_synthetic=True to silence", stacklevel=2)
         self._bb = VitBackbone(sd, self._cfg.input_size, patch_size, heads, device=self._device, precision=precision,
                                max_chunk=max_chunk)
         self._precision = precision
+        self._flip_tta = flip_tta
+        self._cluster_resolution = cluster_resolution
         head = head_weights if head_weights is not None else synthetic_stego_head(D)
         head = {k: v.reshape(v.shape[0], -1) if v.dim() > 2 else v for k, v in head.items()}  # conv1x1 -> linear
+        self._head_sd = head
         dev = self._device
         self._D = D
+        self._C = head["cluster1.0.weight"].shape[0]
         self._b_hid = head["cluster2.0.bias"].float().to(dev).contiguous()
         self._b_code = (head["cluster1.0.bias"] + head["cluster2.2.bias"]).float().to(dev).contiguous()
+        self._b_lin = head["cluster1.0.bias"].float().to(dev).contiguous()
+        self._b_nl = head["cluster2.2.bias"].float().to(dev).contiguous()
         if precision == "bf16":
             self._w_hid = head["cluster2.0.weight"].to(dev, torch.bfloat16).contiguous()
             self._w_code = torch.cat([head["cluster1.0.weight"], head["cluster2.2.weight"]], dim=1).to(
                 dev, torch.bfloat16).contiguous()  # [C, 2D] acting on [tok | hid]
+        elif precision == "exact":  # hi / lo planes for the x3 MFMA GEMMs
+            self._w_hid = split_planes(head["cluster2.0.weight"].float().to(dev))
+            self._w_lin = split_planes(head["cluster1.0.weight"].float().to(dev))
+            self._w_nl = split_planes(head["cluster2.2.weight"].float().to(dev))
         else:
             self._w_hid = head["cluster2.0.weight"].float().to(dev).contiguous()
             self._w_lin = head["cluster1.0.weight"].float().to(dev).contiguous()
             self._w_nl = head["cluster2.2.weight"].float().to(dev).contiguous()
-            self._b_lin = head["cluster1.0.bias"].float().to(dev).contiguous()
-            self._b_nl = head["cluster2.2.bias"].float().to(dev).contiguous()
-        g = torch.Generator().manual_seed(77)
-        self._w_probe = (torch.randn(N_LINEAR_CLASSES, STEGO_CODE_DIM, generator=g) * 0.1).to(dev)
+        # probes (real weights only: nothing is invented for them)
+        self._clusters = None
+        if "clusters" in probes:
+            c = probes["clusters"].float().to(dev)
+            self._clusters = ops.normalize_rows(c.contiguous())          # ClusterLookup: cosine similarity against normalised centroids
+        self._w_probe = probes["linear.weight"].float().to(dev).contiguous() if "linear.weight" in probes else None
+        self._b_probe = probes["linear.bias"].float().to(dev).contiguous() if "linear.bias" in probes else None
+        if not self._cfg.run_clustering and self._clusters is None:
+            raise _lib.WvnError("run_clustering=False uses the checkpoint's learned cluster probe; none was loaded "
+                                "(pass model_path=<STEGO ckpt> or probe_weights={'clusters': ...})")
         self._model = self  # the reference exposes `.model`
         self._cmap = None
         self._code = None
@@ -88,16 +186,23 @@ class StegoInterface:
         self._cluster_pred = None
         self._linear_pred = None
         self._n_segments = None
+        self._labels_patch = None
 
     def change_device(self, device):
-        if torch.device(device) != self._device:
-            raise _lib.WvnError("change_device: weights are bound to the GPU they were built on")
+        """stego_interface.py:60-71: move the model.  Device weights are re-homed (bf16 / plane packs are rebuilt lazily by
+        VitBackbone.to)."""
+        device = torch.device(device)
+        if device == self._device:
+            return
+        self._bb = self._bb.to(device)
+        for name in ("_b_hid", "_b_code", "_b_lin", "_b_nl", "_w_hid", "_w_code", "_w_lin", "_w_nl", "_clusters", "_w_probe", "_b_probe"):
+            t = getattr(self, name, None)
+            if t is not None:
+                setattr(self, name, t.to(device))
+        self._device = device
 
     # ---- code (STEGO head) at patch resolution --------------------------------------------------------
-    @torch.no_grad()
-    def code_tokens(self, img: torch.Tensor) -> torch.Tensor:
-        """[B,3,H,W] in [0,1] -> STEGO code [B, G*G, 90] fp32 (patch resolution)."""
-        img = resize_nearest_center_crop(img.to(self._device), self._cfg.input_size)
+    def _code_once(self, img: torch.Tensor) -> torch.Tensor:
         B = img.shape[0]
         P, D = self._bb.grid ** 2, self._D
         if self._precision == "bf16":
@@ -105,39 +210,70 @@ class StegoInterface:
             self._bb.forward_tokens(img, lowp_out=cat)
             ops.gemm_bf16(cat[:, :D], self._w_hid, self._b_hid, _lib.EPI_RELU_BF16, out=cat[:, D:])
             code = ops.gemm_bf16(cat, self._w_code, self._b_code, _lib.EPI_F32)
+        elif self._precision == "exact":
+            tok = ops.split_planes(self._bb.forward_tokens(img).reshape(B * P, D))
+            hid = ops.gemm_x3(tok, self._w_hid, self._b_hid, _lib.EPI_RELU_BF16)
+            code = ops.gemm_x3(tok, self._w_lin, self._b_lin, _lib.EPI_F32)
+            ops.gemm_x3(hid, self._w_nl, self._b_nl, _lib.EPI_RESID_F32, out=code)
         else:
             tok = self._bb.forward_tokens(img).reshape(B * P, D)
             hid = ops.gemm_f32(tok, self._w_hid, self._b_hid, _lib.F32_RELU)
             code = ops.gemm_f32(tok, self._w_lin, self._b_lin, _lib.F32_NONE)
             ops.gemm_f32(hid, self._w_nl, self._b_nl, _lib.F32_RESID, out=code)
-        return code.reshape(B, P, STEGO_CODE_DIM)
+        return code.reshape(B, P, self._C)
+
+    @torch.no_grad()
+    def code_tokens(self, img: torch.Tensor) -> torch.Tensor:
+        """[B,3,H,W] in [0,1] -> STEGO code [B, G*G, 90] fp32 (patch resolution)."""
+        img = resize_nearest_center_crop(img.to(self._device), self._cfg.input_size)
+        code = self._code_once(img)
+        if self._flip_tta:  # code averaged with the flipped-back code of the mirrored frame
+            G = self._bb.grid
+            c2 = self._code_once(img.flip(-1)).reshape(-1, G, G, self._C).flip(2).reshape(code.shape)
+            code = (code + c2) * 0.5
+        return code
 
     @torch.no_grad()
     def inference(self, img: torch.Tensor, code: torch.Tensor = None):
-        """stego_interface.py:73-111: returns (linear_pred, cluster_pred), both [1,B,H,H] int32, and keeps
-        ``features`` = code [B,90,H,H] (bilinear, align_corners=True).  ``code``: the result of ``code_tokens(img)`` if
-        the caller already ran that stage (e.g. on another stream, FeatureExtractor.backbone_stage)."""
+        """stego_interface.py:73-111: returns (linear_pred, cluster_pred), both [1,B,H,H] int32 (linear_pred is None when no
+        linear probe was loaded), and keeps ``features`` = code [B,90,H,H] (bilinear, align_corners=True).  ``code``: the
+        result of ``code_tokens(img)`` if the caller already ran that stage (e.g. on another stream)."""
         G = self._bb.grid
         H = img.shape[2]
         if code is None:
             code = self.code_tokens(img)
         B = code.shape[0]
         self._code_tokens = code
-        if self._cfg.run_clustering:
-            labels, nseg = ops.kmeans_cosine(code, self._cfg.n_image_clusters, KMEANS_ITERS, relabel=True)
-            self._n_segments = nseg
-        else:
-            # cluster probe: cosine similarity against learned centroids -- not part of the hot path; use
-            # k-means semantics with the probe as fixed centroids is not defined upstream here.
-            raise _lib.WvnError("run_clustering=False (learned cluster probe) needs the STEGO checkpoint's probe")
-        self._labels_patch = labels.reshape(B, G, G)  # patch-resolution cluster ids (before the nearest up-sampling)
-        self._cluster_pred = ops.upsample_nearest_labels(self._labels_patch, H)[None]
-        logits = ops.gemm_f32(code.reshape(B * G * G, -1), self._w_probe)
-        lin = logits.argmax(dim=1).to(torch.int32).reshape(B, G, G)
-        self._linear_pred = ops.upsample_nearest_labels(lin, H)[None]
         self._code = None  # dense code is produced lazily (features property): 72 MB/frame at 448^2
         self._H = H
+        self._labels_patch = None
+        if self._cluster_resolution == "pixel":      # cluster the H x H up-sampled code pixels
+            dense = self.features                                          # [B, C, H, H]
+            pix = dense.permute(0, 2, 3, 1).reshape(B, H * H, self._C)
+            if self._cfg.run_clustering:
+                labels, self._n_segments = ops.kmeans_cosine(pix, self._cfg.n_image_clusters, KMEANS_ITERS, relabel=True)
+            else:
+                labels = self._probe_labels(pix.reshape(B * H * H, self._C), self._clusters, None, cosine=True)
+                self._n_segments = None
+            self._cluster_pred = labels.reshape(1, B, H, H)
+        else:
+            if self._cfg.run_clustering:
+                labels, self._n_segments = ops.kmeans_cosine(code, self._cfg.n_image_clusters, KMEANS_ITERS, relabel=True)
+            else:
+                labels = self._probe_labels(code.reshape(B * G * G, self._C), self._clusters, None, cosine=True)
+                self._n_segments = None
+            self._labels_patch = labels.reshape(B, G, G)  # patch-resolution ids (before the nearest up-sampling)
+            self._cluster_pred = ops.upsample_nearest_labels(self._labels_patch, H)[None]
+        if self._w_probe is not None:
+            lin = self._probe_labels(code.reshape(B * G * G, self._C), self._w_probe, self._b_probe, cosine=False)
+            self._linear_pred = ops.upsample_nearest_labels(lin.reshape(B, G, G), H)[None]
+        else:
+            self._linear_pred = None
         return self._linear_pred, self._cluster_pred
+
+    def _probe_labels(self, rows: torch.Tensor, w: torch.Tensor, b, cosine: bool) -> torch.Tensor:
+        x = ops.normalize_rows(rows) if cosine else (rows if rows.is_contiguous() else rows.contiguous())
+        return ops.argmax_rows(ops.gemm_f32(x, w, b))
 
     @property
     def model(self):

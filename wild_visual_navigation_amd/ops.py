@@ -174,6 +174,26 @@ def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = T
     return labels, nseg
 
 
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """x [R, C] fp32 -> int32 [R] index of the row maximum (lowest index wins ties)."""
+    require_cuda(x, "x")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    R, Cc = x.shape
+    out = torch.empty(R, dtype=torch.int32, device=x.device)
+    check(lib().wvn_argmax_rows(ptr(x), x.stride(0), R, Cc, ptr(out), stream()), "wvn_argmax_rows")
+    return out
+
+
+def normalize_rows(x: torch.Tensor) -> torch.Tensor:
+    """x [R, C] fp32 -> x / max(||x||, 1e-12) (sequential fp32, the k-means kernels' normalisation)."""
+    require_cuda(x, "x")
+    R, Cc = x.shape
+    out = torch.empty(R, Cc, dtype=torch.float32, device=x.device)
+    check(lib().wvn_normalize_rows(ptr(x), x.stride(0), ptr(out), R, Cc, stream()), "wvn_normalize_rows")
+    return out
+
+
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epi: int,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """epilogue(a[M,K] @ w[N,K]^T + bias); a, w bf16 (row strides allowed)."""

@@ -32,6 +32,7 @@ class MlpTrainer:
         self.step = 0
         self._state_dev = None
         self.last_confidence: Optional[torch.Tensor] = None
+        self.comm_events = None   # set to [] to collect (start, end) CUDA-event pairs around the two all-reduces of every step
 
     def _state(self, dev):
         if self._state_dev != dev:
@@ -45,19 +46,27 @@ class MlpTrainer:
 
     # Adam moments in torch.optim.Adam.state_dict() shape, for save/load_checkpoint compatibility
     def optimizer_state_dict(self) -> Dict:
+        """``torch.optim.Adam.state_dict()`` shape: empty ``state`` before the first step (as the reference's optimizer),
+        and every param-group key ``Adam.load_state_dict`` of current and older torch versions expects."""
         ps = self.model._params_in_order()
         st, off = {}, 0
-        for i, p in enumerate(ps):
-            n = p.numel()
-            st[i] = {"step": torch.tensor(float(self.step)), "exp_avg": self.m[off:off + n].view_as(p).clone(),
-                     "exp_avg_sq": self.v[off:off + n].view_as(p).clone()}
-            off += n
-        return {"state": st, "param_groups": [{"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0,
-                                               "amsgrad": False, "params": list(range(len(ps)))}]}
+        if self._state_dev is not None and self.step > 0:
+            for i, p in enumerate(ps):
+                n = p.numel()
+                st[i] = {"step": torch.tensor(float(self.step)), "exp_avg": self.m[off:off + n].view_as(p).clone(),
+                         "exp_avg_sq": self.v[off:off + n].view_as(p).clone()}
+                off += n
+        group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(ps)))}
+        return {"state": st, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, sd: Dict) -> None:
         ps = self.model._params_in_order()
         self._state(ps[0].device)
+        self.m.zero_()
+        self.v.zero_()
+        self.step = 0
         off = 0
         for i, p in enumerate(ps):
             n = p.numel()
@@ -67,6 +76,16 @@ class MlpTrainer:
                 self.step = int(sd["state"][i]["step"])
             off += n
         self.lr = sd["param_groups"][0]["lr"]
+
+    def _timed_allreduce(self, t: torch.Tensor) -> None:
+        if self.comm_events is None:
+            allreduce_sum_(t, self.group)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        allreduce_sum_(t, self.group)   # RCCL runs on its own stream; the current stream waits for it, so b brackets it
+        b.record()
+        self.comm_events.append((a, b))
 
     @torch.no_grad()
     def train_step(self, x: torch.Tensor, y: torch.Tensor, y_valid: torch.Tensor,
@@ -85,18 +104,26 @@ class MlpTrainer:
         R = x.shape[0]
         d = self.model.desc
         flat = self.model.flat_params()
-        ws = self.model._workspace(R)
+        ws = self.model._workspace(max(R, 1))
         st = _lib.stream()
         conf = torch.empty(R, dtype=torch.float32, device=dev) if want_confidence else None
 
-        _lib.check(lib.wvn_mlp_train_phase_a(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), yv.data_ptr(), R,
-                                             self.stats.data_ptr(), ws.data_ptr(), ws.numel(), st), "phase_a")
-        allreduce_sum_(self.stats, self.group)
-        _lib.check(lib.wvn_mlp_train_phase_b(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), y.data_ptr(),
-                                             yv.data_ptr(), R, self.stats.data_ptr(), self.std_factor, self.w_trav,
-                                             self.w_reco, self.grads.data_ptr(), _lib.ptr(conf), ws.data_ptr(),
-                                             ws.numel(), st), "phase_b")
-        allreduce_sum_(self.grads, self.group)
+        # A rank whose shard is empty this step (ragged frame sharding) still takes part in both collectives, contributing
+        # zeros: every rank makes the same sequence of RCCL calls whatever its row count.
+        if R > 0:
+            _lib.check(lib.wvn_mlp_train_phase_a(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), yv.data_ptr(), R,
+                                                 self.stats.data_ptr(), ws.data_ptr(), ws.numel(), st), "phase_a")
+        else:
+            self.stats.zero_()
+        self._timed_allreduce(self.stats)
+        if R > 0:
+            _lib.check(lib.wvn_mlp_train_phase_b(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), y.data_ptr(),
+                                                 yv.data_ptr(), R, self.stats.data_ptr(), self.std_factor, self.w_trav,
+                                                 self.w_reco, self.grads.data_ptr(), _lib.ptr(conf), ws.data_ptr(),
+                                                 ws.numel(), st), "phase_b")
+        else:
+            self.grads.zero_()
+        self._timed_allreduce(self.grads)
         self.step += 1
         _lib.check(lib.wvn_mlp_train_phase_c(C.byref(d), flat.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
                                              self.v.data_ptr(), self.step, self.lr, self.stats.data_ptr(), self.w_trav,

@@ -12,6 +12,7 @@ from threading import Lock
 
 import torch
 
+from ..distributed import all_ranks_ready
 from ..model import get_model
 from ..utils import Batch, TraversabilityLoss
 from .graphs import MissionGraph
@@ -101,11 +102,16 @@ class TraversabilityEstimator:
     def train(self):
         """traversability_estimator.py:449-497: one optimisation step; returns the reference's dict."""
         if self._pause_training:
+            all_ranks_ready(False, self._device)   # a paused replica still answers the others' readiness poll
             return {}
         num_valid_nodes = self._mission_graph.get_num_valid_nodes()
         return_dict = {"mission_graph_num_valid_node": num_valid_nodes}
+        graph = None
         if num_valid_nodes > self._min_samples_for_training:
             graph = self.make_batch(_get(_get(self._params, "ablation_data_module"), "batch_size"))
+        # Data-parallel replicas: the step contains two collectives, so whether it runs is itself decided collectively --
+        # every rank steps iff ALL ranks have a batch (a rank that skipped alone would leave the others hanging in RCCL).
+        if all_ranks_ready(graph is not None, self._device):
             if graph is not None:
                 with self._learning_lock:
                     losses = self.train_on_batch(graph.x, graph.y, graph.y_valid)

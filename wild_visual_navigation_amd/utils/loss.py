@@ -30,6 +30,21 @@ class TraversabilityLoss(torch.nn.Module):
     def reset(self):
         self._confidence_generator.reset()
 
+    # The reference registers the model as a sub-module of the loss (loss.py:75), so its ``traversability_loss_state_dict``
+    # carries ``_model.layers.*`` next to ``_confidence_generator.*``.  Here the model is not a sub-module (one owner for the
+    # flat parameter buffer), so the same keys are emitted as aliases on save and ignored on load: checkpoints are
+    # interchangeable with the reference in both directions.
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        prefix = kwargs.get("prefix", "")
+        for k, v in self._model.state_dict().items():
+            sd[f"{prefix}_model.{k}"] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        own = {k: v for k, v in state_dict.items() if not k.startswith("_model.")}
+        return super().load_state_dict(own, strict=strict, **kwargs)
+
     def forward(self, graph: Optional[Data], res: torch.Tensor, update_generator: bool = True, step: int = 0,
                 log_step: bool = False):
         D = graph.x.shape[1]
