@@ -140,8 +140,9 @@ int wvn_upsample_nearest_i32(const int* labels, int* out, int B, int G, int H, v
 /* FeatureExtractor.sparsify_features (feature_extractor.py:390-396) fused with the bilinear
  * up-sampling that precedes it: feat[b][s][:] = mean over {seg[b]==s} of upsample(tokens[b]).
  * seg [B,H,W] int32 (-1 = ignore), tokens [B,G*G,ld] fp32, feat [B,S,D].
- * scratch_w: B*S*G*G floats, scratch_cnt: B*S ints (receives the pixel count per segment). */
-int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float* feat, float* scratch_w,
+ * scratch_w: B*S*G*G 8-byte words (the tap weights accumulate in 64-bit fixed point: integer atomics are order-independent,
+ * so the result is deterministic), scratch_cnt: B*S ints (receives the pixel count per segment). */
+int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float* feat, void* scratch_w,
                               int* scratch_cnt, int B, int H, int W, int G, int S, int D, void* stream);
 /* Same result as wvn_segpool_bilinear_mean for PATCH-ALIGNED segment maps (a [B,G,G] label grid that
  * the caller would nearest-upsample by exactly the patch size: k-means clusters, grid cells that are a
@@ -151,14 +152,58 @@ int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float
 int wvn_segpool_patch_labels(const int* labels, const float* tokens, int ld, const float* wy, const float* wx,
                              float* feat, int B, int G, int S, int D, void* stream);
 /* FeatureExtractor.sparsify_features on an explicit pixel-resolution map (no resampling):
- * tokens [B,P,D] pixel-major, seg [B,P] -> feat [B,S,D] = per-segment mean (0/0 = NaN). S <= 236. */
-int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, int B, int P, int S, int D,
-                       void* stream);
+ * tokens [B,P,D] pixel-major, seg [B,P] -> feat [B,S,D] = per-segment mean (0/0 = NaN). S <= 236.  Deterministic (fixed
+ * summation order, no atomics); scratch: wvn_segmean_scratch_bytes() bytes; scratch_cnt [B*S] receives the pixel counts. */
+size_t wvn_segmean_scratch_bytes(int B, int P, int S, int D);
+int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, void* scratch, size_t scratch_bytes,
+                       int B, int P, int S, int D, void* stream);
 /* MissionNode.update_supervision_signal (traversability_estimator/nodes.py:400-440).
  * mask [C,H,W] fp32 (NaN = unlabeled), seg [H,W] int32 -> signal [S] fp32, valid [S] uint8.
- * scratch_sum: S floats, scratch_cnt: S ints. */
-int wvn_label_pool(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* scratch_sum,
+ * scratch_sum: S 8-byte words (2^-32 fixed-point sums: deterministic), scratch_cnt: S ints. */
+int wvn_label_pool(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, void* scratch_sum,
                    int* scratch_cnt, int H, int W, int S, void* stream);
+/* The same for n nodes in ONE launch pair (TraversabilityEstimator.add_supervision_node re-pools every mission node in
+ * range, traversability_estimator.py:287-289).  nodes_dev: DEVICE array of n records; scratch_sum: n*Smax 8-byte words,
+ * scratch_cnt: n*Smax ints; all masks [C,H,W], all segment maps [H,W]. */
+typedef struct wvn_label_pool_node {
+  const float* mask;    /* [C][H][W] */
+  const int* seg;       /* [H][W]    */
+  float* signal;        /* [S] out   */
+  unsigned char* valid; /* [S] out   */
+  int S;
+  int reserved;
+} wvn_label_pool_node;
+int wvn_label_pool_batched(const wvn_label_pool_node* nodes_dev, int n, int C, int H, int W, int Smax, void* scratch_sum,
+                           int* scratch_cnt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Supervision masks: ImageProjector.project_and_render (image_projector.py:126-197: pinhole projection +
+ * kornia draw_convex_polygon) fused with the torch.fmin merge of traversability_estimator.py:281-286, for n mission nodes in
+ * one launch.  Per node: K [4][4] (the projector's scaled camera matrix), pose [4][4] = pose_cam_in_world, mask [C][H][W]
+ * updated IN PLACE (inside the projected polygon: fmin(old, value); elsewhere untouched = fmin(old, NaN)), projected [npts][2]
+ * (optional out; NaN for points behind the camera).  points: [npts][3] world coordinates shared by all nodes, or
+ * [n][npts][3] when points_batched.  value = colour * traversability, read from value_dev[0] if non-NULL (no host sync when
+ * the traversability lives on the GPU).  npts <= 256.  Arithmetic order: csrc/supervision.hip header.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct wvn_render_node {
+  const float* K;
+  const float* pose;
+  float* mask;
+  float* projected;
+} wvn_render_node;
+int wvn_project_render_fmin(const wvn_render_node* nodes_dev, int n, const float* points, int points_batched, int npts, int C,
+                            int H, int W, const float* value_dev, float value, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SLIC superpixels (FeatureExtractor default segmentation_type, feature_extractor.py:84-90,221-225: fast_slic on the CPU in
+ * the reference).  Integer-arithmetic SLIC (csrc/slic.hip): img [3][H][W] uint8 or float in [0,1]; labels [H][W] int32 in
+ * [0, wvn_slic_num_clusters()).  lut_lin [256], lut_f [4096]: sRGB->linear and CIELAB f(t) tables (device, int32; built by the
+ * caller in double precision: wild_visual_navigation_amd/ops.py slic_tables).  Parity with fast_slic is unpinned.
+ * ------------------------------------------------------------------------------------------- */
+int wvn_slic_num_clusters(int H, int W, int num_components);
+size_t wvn_slic_scratch_bytes(int H, int W, int num_components);
+int wvn_slic(const void* img, int img_is_u8, int H, int W, int num_components, float compactness, int iters, const int* lut_lin,
+             const int* lut_f, int* labels, void* scratch, size_t scratch_bytes, void* stream);
 /* SegmentExtractor.centers (segment_extractor.py:70-92): centers [S,2] fp32 (x,y). scratch: 3*S u64. */
 int wvn_seg_centers(const int* seg, float* centers, void* scratch, int H, int W, int S, void* stream);
 /* SegmentExtractor.adjacency_list (segment_extractor.py:39-67): edges [max_edges,2] int64 sorted by

@@ -227,6 +227,122 @@ def pin_confidence():
     return out
 
 
+def _kornia_transform_points(trans_01, points_1):
+    """Restatement of kornia.geometry.linalg.transform_points (kornia is absent; the reference's meshes.py calls it)."""
+    ones = torch.ones_like(points_1[..., :1])
+    ph = torch.cat([points_1, ones], dim=-1)
+    out = torch.matmul(ph, trans_01.transpose(-1, -2))
+    z = out[..., -1:]
+    scale = torch.where(z.abs() > 1e-8, 1.0 / (z + 1e-8), torch.ones_like(z))
+    return scale * out[..., :-1]
+
+
+def _pose(x, y, yaw, z=0.0):
+    import math
+
+    T = torch.eye(4)
+    T[0, 0], T[0, 1], T[1, 0], T[1, 1] = math.cos(yaw), -math.sin(yaw), math.sin(yaw), math.cos(yaw)
+    T[0, 3], T[1, 3], T[2, 3] = x, y, z
+    return T
+
+
+def pin_geometry():
+    """First-party geometry / bookkeeping of the supervision path, executed from the reference:
+    meshes.make_plane / make_polygon_from_points / make_dense_plane, SupervisionNode.make_footprint_with_node,
+    ImageProjector's scaled camera matrix, BaseGraph / DistanceWindowGraph / MaxElementsGraph eviction and radius queries
+    (real networkx).  Third-party pieces they touch are stubbed by restatements: kornia transform_points (above) and the
+    liegroups SE(3) distance (translation norm; the pin cases use planar poses whose relative rotation is about z, for which
+    |log(T)[:3]| is computed by the product's own se3 helper and cross-checked against the closed form below)."""
+    import wild_visual_navigation.utils.meshes as RM
+
+    RM.transform_points = _kornia_transform_points
+    from wild_visual_navigation.traversability_estimator import nodes as RN, graphs as RG
+
+    RN.make_plane, RN.make_polygon_from_points, RN.make_dense_plane = RM.make_plane, RM.make_polygon_from_points, RM.make_dense_plane
+    out = {"planes": [], "footprints": [], "graphs": {}, "projector": []}
+    for kw in (dict(x=0.0, y=0.6, grid_size=2), dict(x=1.0, y=0.6, grid_size=25), dict(y=0.4, z=0.3, grid_size=3)):
+        pose = _pose(1.0, -2.0, 0.7, 0.2)
+        full = {k: v for k, v in kw.items()}
+        out["planes"].append({"kw": full, "pose": pose, "points": RM.make_plane(pose=pose, **full)})
+    sq = torch.tensor([[0.0, 0, 0], [1, 0, 0], [1, 2, 0.5], [0, 2, 0.5]])
+    out["polygon"] = {"points": sq, "grid_size": 10, "out": RM.make_polygon_from_points(sq, grid_size=10)}
+    out["dense"] = {"pose": _pose(0.3, 0.1, -0.4), "out": RM.make_dense_plane(y=0.4, z=0.3, pose=_pose(0.3, 0.1, -0.4), grid_size=5)}
+
+    def sup(t, x, y, yaw):
+        return RN.SupervisionNode(timestamp=t, pose_base_in_world=_pose(x, y, yaw), pose_footprint_in_base=_pose(0, 0, 0, -0.3),
+                                  width=0.6, length=1.0, height=0.4, supervision=torch.ones(1),
+                                  traversability=torch.tensor([0.7]), traversability_var=torch.tensor([0.1]))
+
+    a, b = sup(1.0, 0.0, 0.0, 0.0), sup(2.0, 0.9, 0.2, 0.3)
+    out["footprints"].append({"prev": (1.0, 0.0, 0.0, 0.0), "cur": (2.0, 0.9, 0.2, 0.3), "side_prev": a.get_side_points(),
+                              "side_cur": b.get_side_points(), "footprint": b.make_footprint_with_node(a)})
+
+    # graphs: distance = translation norm (valid for the planar, small-rotation pin poses to 1e-3; stated in the fixture)
+    def dist(self, other):
+        return torch.linalg.norm(self.pose_base_in_world[:3, 3] - other.pose_base_in_world[:3, 3])
+
+    RN.BaseNode.distance_to = dist
+    xs = [0.0, 0.05, 0.5, 1.1, 1.15, 2.0, 3.5, 3.6, 5.2, 6.0]
+    def run(graph):
+        acc = []
+        for i, x in enumerate(xs):
+            acc.append(bool(graph.add_node(RN.BaseNode(float(i), _pose(x, 0.0, 0.0)))))
+        return acc, [n.timestamp for n in graph.get_nodes()]
+    g = RG.BaseGraph(edge_distance=0.2)
+    acc, kept = run(g)
+    q = [n.timestamp for n in g.get_nodes_within_radius_range(g.get_last_node(), 0, 2.6)]
+    out["graphs"]["base"] = {"xs": xs, "edge_distance": 0.2, "accepted": acc, "kept": kept, "radius": 2.6, "within": q}
+    g = RG.DistanceWindowGraph(edge_distance=0.2, max_distance=2.0)
+    acc, kept = run(g)
+    out["graphs"]["distance_window"] = {"xs": xs, "edge_distance": 0.2, "max_distance": 2.0, "accepted": acc, "kept": kept}
+    g = RG.MaxElementsGraph(edge_distance=0.2, max_elements=4)
+    acc, kept = run(g)
+    out["graphs"]["max_elements"] = {"xs": xs, "edge_distance": 0.2, "max_elements": 4, "accepted": acc, "kept": kept}
+
+    # ImageProjector: scaled camera matrix (kornia.PinholeCamera is a mock here: read its call arguments)
+    import wild_visual_navigation.image_projector.image_projector as RI
+
+    for (h, w, nh, nw) in ((1080, 1440, 448, None), (540, 720, 224, 224), (1080, 1440, 448, 600)):
+        K = torch.eye(4)[None].clone()
+        K[0, 0, 0], K[0, 1, 1], K[0, 0, 2], K[0, 1, 2] = 1000.0, 1100.0, 700.0, 500.0
+        RI.PinholeCamera.reset_mock()
+        RI.ImageProjector(K, torch.tensor(h), torch.tensor(w), new_h=nh, new_w=nw)
+        sK = RI.PinholeCamera.call_args[0][0]
+        out["projector"].append({"h": h, "w": w, "new_h": nh, "new_w": nw, "K": K, "sK": sK.clone(),
+                                 "sh": int(RI.PinholeCamera.call_args[0][2]), "sw": int(RI.PinholeCamera.call_args[0][3])})
+    return out
+
+
+def pin_checkpoint():
+    """Key layout of the reference's checkpoint pieces (traversability_estimator.py:377-429): SimpleMLP.state_dict,
+    TraversabilityLoss.state_dict (which carries ``_model.*`` because the loss registers the model as a sub-module) and
+    torch.optim.Adam.state_dict after three steps -- a small D = 16 instance."""
+    from wild_visual_navigation.model.simple_mlp import SimpleMLP
+    from wild_visual_navigation.utils.loss import TraversabilityLoss
+    from wild_visual_navigation.utils.data import Data
+
+    torch.manual_seed(42)
+    D = 16
+    model = SimpleMLP(input_size=D, hidden_sizes=[256, 32, 1], reconstruction=True)
+    loss_fn = TraversabilityLoss(w_trav=0.03, w_reco=0.5, w_temp=0.0, anomaly_balanced=True, model=model,
+                                 method="latest_measurement", confidence_std_factor=0.5, log_enabled=False, log_folder="/tmp")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    empty_opt = opt.state_dict()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(40, D, generator=g)
+    yv = torch.rand(40, generator=g) < 0.3
+    y = yv.float() * 0.8
+    for step in range(3):
+        b = Data(x=x, y=y, y_valid=yv)
+        loss, _, _ = loss_fn(b, model(b), step=step, log_step=False)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return {"step": 3, "model_state_dict": model.state_dict(), "optimizer_state_dict": opt.state_dict(),
+            "traversability_loss_state_dict": loss_fn.state_dict(), "loss": float(loss.item()),
+            "_empty_optimizer_state_dict": empty_opt, "_D": D}
+
+
 def main():
     import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -239,6 +355,9 @@ def main():
     torch.save(pin_confidence(), os.path.join(GOLDEN, "confidence.pt"))
     print("pinning MLP / loss / Adam ...")
     torch.save(pin_mlp(), os.path.join(GOLDEN, "mlp_train.pt"))
+    print("pinning supervision geometry / graphs / checkpoint layout ...")
+    torch.save(pin_checkpoint(), os.path.join(GOLDEN, "ref_checkpoint.pt"))
+    torch.save(pin_geometry(), os.path.join(GOLDEN, "geometry.pt"))
     print("oracle pinned; fixtures in", GOLDEN)
 
 

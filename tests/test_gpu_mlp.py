@@ -118,8 +118,9 @@ def test_traversability_estimator_train_loop_and_checkpoint(dev, tmp_path):
         n.feature_segments = (torch.arange(H * H).reshape(H, H) * S // (H * H)).to(dev)
         mask = torch.full((3, H, H), float("nan"))
         mask[:, : H // 2] = 0.5 + 0.5 * torch.rand(3, H // 2, H, generator=g)
-        n.supervision_mask = mask.to(dev)
-        assert te.add_mission_node(n)
+        assert te.add_mission_node(n)                       # fresh all-NaN mask + first pooling (nothing labelled yet)
+        assert not n.is_valid() and torch.isnan(n.supervision_mask).all()
+        te.update_supervision(n, mask.to(dev))              # fmin merge of a rendered mask + re-pooling
         assert n.supervision_signal.shape == (S,) and n.supervision_signal_valid.any() and n.is_valid()
     first = te.train()
     assert set(first) == {"mission_graph_num_valid_node", "loss_total", "loss_trav", "loss_reco"}

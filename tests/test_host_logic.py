@@ -102,3 +102,20 @@ def test_resize_crop_commutes_with_uint8_to_float():
         a = resize_nearest_center_crop(u8, size).float() / 255
         b = resize_nearest_center_crop(u8.float() / 255, size)
         assert a.shape == (2, 3, size, size) and torch.equal(a, b)
+
+
+def test_gelu_polynomial_is_within_a_quarter_bf16_ulp_of_erf_gelu():
+    """The bf16 fc1 epilogue evaluates GELU as x * sigmoid(g(x)), g an odd degree-7 polynomial (csrc/gemm_a384.hip).  This
+    pins the claim in its comment: at most 0.25 ulp of the bf16 result away from the exact erf GELU of torch.nn.GELU."""
+    import numpy as np
+    from scipy.special import erf
+
+    k = np.array([-2.296416554e+00, -1.096917929e-01, 1.435476415e-03, -1.285982656e-05])   # coefficients * -log2(e)
+    x = np.linspace(-9, 9, 72001)
+    x2 = x * x
+    y = x * (k[0] + x2 * (k[1] + x2 * (k[2] + x2 * k[3])))
+    got = x / (1 + np.exp2(y))
+    want = 0.5 * x * (1 + erf(x / np.sqrt(2)))
+    ulp = np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-300))) - 7), 2.0 ** -20)   # bf16 ulp, floored at 1e-6 absolute
+    assert (np.abs(got - want) / ulp).max() < 0.26
+    assert np.abs(got - want).max() < 2.5e-4

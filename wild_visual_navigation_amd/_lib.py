@@ -71,8 +71,14 @@ _SIGNATURES = {
     "wvn_upsample_nearest_i32": ([_p, _p, _i, _i, _i, _p], _i),
     "wvn_segpool_bilinear_mean": ([_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "wvn_segpool_patch_labels": ([_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p], _i),
-    "wvn_segmean_tokens": ([_p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
+    "wvn_segmean_scratch_bytes": ([_i, _i, _i, _i], _sz),
+    "wvn_segmean_tokens": ([_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _p], _i),
     "wvn_label_pool": ([_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "wvn_label_pool_batched": ([_p, _i, _i, _i, _i, _i, _p, _p, _p], _i),
+    "wvn_project_render_fmin": ([_p, _i, _p, _i, _i, _i, _i, _i, _p, _f, _p], _i),
+    "wvn_slic_num_clusters": ([_i, _i, _i], _i),
+    "wvn_slic_scratch_bytes": ([_i, _i, _i], _sz),
+    "wvn_slic": ([_p, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p], _i),
     "wvn_seg_centers": ([_p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_seg_adjacency": ([_p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_normalize_rows": ([_p, _i, _p, _i, _i, _p], _i),

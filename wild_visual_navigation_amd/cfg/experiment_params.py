@@ -58,10 +58,26 @@ class SimpleMlpCfgParams(_Node):
 
 
 @dataclass
+class OtherModelCfgParams(_Node):
+    """Config slots of the non-default models (DoubleMLP / SimpleGCN / LinearRnvp, experiment_params.py:113-139): callers write
+    ``input_size`` into all four unconditionally (quick_start.py:131-134); the models themselves are outside this build."""
+    input_size: int = 384
+
+
+@dataclass
 class ModelParams(_Node):
     name: str = "SimpleMLP"
     load_ckpt: Optional[str] = None
     simple_mlp_cfg: SimpleMlpCfgParams = field(default_factory=SimpleMlpCfgParams)
+    double_mlp_cfg: OtherModelCfgParams = field(default_factory=OtherModelCfgParams)
+    simple_gcn_cfg: OtherModelCfgParams = field(default_factory=OtherModelCfgParams)
+    linear_rnvp_cfg: OtherModelCfgParams = field(default_factory=OtherModelCfgParams)
+
+
+@dataclass
+class LossAnomalyParams(_Node):
+    method: str = "latest_measurement"
+    confidence_std_factor: float = 0.5
 
 
 @dataclass
@@ -69,5 +85,6 @@ class ExperimentParams(_Node):
     general: GeneralParams = field(default_factory=GeneralParams)
     optimizer: OptimizerParams = field(default_factory=OptimizerParams)
     loss: LossParams = field(default_factory=LossParams)
+    loss_anomaly: LossAnomalyParams = field(default_factory=LossAnomalyParams)
     ablation_data_module: AblationDataModuleParams = field(default_factory=AblationDataModuleParams)
     model: ModelParams = field(default_factory=ModelParams)

@@ -327,7 +327,7 @@ int wvn_upsample_nearest_i32(const int* labels, int* out, int B, int G, int H, v
   if (!labels || !out) return WVN_ERR_ARG;
   return wvn_upsample_nearest_i32_launch(labels, out, B, G, H, (hipStream_t)stream);
 }
-int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float* feat, float* scratch_w,
+int wvn_segpool_bilinear_mean(const int* seg, const float* tokens, int ld, float* feat, void* scratch_w,
                               int* scratch_cnt, int B, int H, int W, int G, int S, int D, void* stream) {
   return wvn_segpool_launch(seg, tokens, ld, feat, scratch_w, scratch_cnt, B, H, W, G, S, D, (hipStream_t)stream);
 }
@@ -335,13 +335,35 @@ int wvn_segpool_patch_labels(const int* labels, const float* tokens, int ld, con
                              float* feat, int B, int G, int S, int D, void* stream) {
   return wvn_segpool_patch_launch(labels, tokens, ld, wy, wx, feat, B, G, S, D, (hipStream_t)stream);
 }
-int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, int B, int P, int S, int D,
-                       void* stream) {
-  return wvn_segmean_tokens_launch(seg, tokens, feat, scratch_cnt, B, P, S, D, (hipStream_t)stream);
+size_t wvn_segmean_scratch_bytes(int B, int P, int S, int D) {
+  return (B > 0 && P > 0 && S > 0 && D > 0) ? wvn_segmean_scratch_bytes_impl(B, P, S, D) : 0;
 }
-int wvn_label_pool(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* scratch_sum,
+int wvn_segmean_tokens(const int* seg, const float* tokens, float* feat, int* scratch_cnt, void* scratch, size_t scratch_bytes,
+                       int B, int P, int S, int D, void* stream) {
+  return wvn_segmean_tokens_launch(seg, tokens, feat, scratch_cnt, scratch, scratch_bytes, B, P, S, D, (hipStream_t)stream);
+}
+int wvn_label_pool(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, void* scratch_sum,
                    int* scratch_cnt, int H, int W, int S, void* stream) {
   return wvn_label_pool_launch(mask, C, seg, signal, valid, scratch_sum, scratch_cnt, H, W, S, (hipStream_t)stream);
+}
+int wvn_label_pool_batched(const wvn_label_pool_node* nodes_dev, int n, int C, int H, int W, int Smax, void* scratch_sum,
+                           int* scratch_cnt, void* stream) {
+  return wvn_label_pool_batched_launch(nodes_dev, n, C, H, W, Smax, (long long*)scratch_sum, scratch_cnt, (hipStream_t)stream);
+}
+int wvn_project_render_fmin(const wvn_render_node* nodes_dev, int n, const float* points, int points_batched, int npts, int C,
+                            int H, int W, const float* value_dev, float value, void* stream) {
+  return wvn_project_render_fmin_launch(nodes_dev, n, points, points_batched, npts, C, H, W, value_dev, value, (hipStream_t)stream);
+}
+int wvn_slic_num_clusters(int H, int W, int num_components) {
+  return (H > 0 && W > 0 && num_components > 0) ? wvn_slic_num_clusters_impl(H, W, num_components) : 0;
+}
+size_t wvn_slic_scratch_bytes(int H, int W, int num_components) {
+  return (H > 0 && W > 0 && num_components > 0) ? wvn_slic_scratch_bytes_impl(H, W, num_components) : 0;
+}
+int wvn_slic(const void* img, int img_is_u8, int H, int W, int num_components, float compactness, int iters, const int* lut_lin,
+             const int* lut_f, int* labels, void* scratch, size_t scratch_bytes, void* stream) {
+  return wvn_slic_launch(img, img_is_u8, H, W, num_components, compactness, iters, lut_lin, lut_f, labels, scratch, scratch_bytes,
+                         (hipStream_t)stream);
 }
 int wvn_seg_centers(const int* seg, float* centers, void* scratch, int H, int W, int S, void* stream) {
   return wvn_centers_launch(seg, centers, (unsigned long long*)scratch, H, W, S, (hipStream_t)stream);

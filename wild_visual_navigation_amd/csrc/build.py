@@ -20,13 +20,13 @@ LIB = os.path.join(PKG, "lib", "libwvn_hip.so")
 SOURCES = [
     "api.hip", "gemm_bf16.hip", "gemm_a384.hip", "gemm_n384.hip", "gemm_x3.hip", "gemm_f32.hip", "elementwise.hip", "attention_bf16.hip",
     "attention_x3.hip", "attention_f32.hip",
-    "segments.hip", "stego.hip", "mlp.hip", "pixel_mlp.hip",
+    "segments.hip", "stego.hip", "mlp.hip", "pixel_mlp.hip", "supervision.hip", "slic.hip",
 ]
 HEADERS = ["common.h", "wvn_internal.h", os.path.join("..", "..", "include", "wvn_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall",
          "-Wno-unused-function"]
 # bit-exact integer outputs need un-fused multiply/add in the k-means kernels (see stego.hip)
-EXTRA = {"stego.hip": ["-ffp-contract=off"], "attention_bf16.hip": ["-fno-honor-nans"],
+EXTRA = {"stego.hip": ["-ffp-contract=off"], "supervision.hip": ["-ffp-contract=off"], "attention_bf16.hip": ["-fno-honor-nans"],
          "attention_x3.hip": ["-fno-honor-nans"]}
 
 

@@ -14,7 +14,7 @@
 //   loop is unrolled by two so register slots and LDS stages are compile-time.
 //
 // Outputs that feed another MFMA (LayerNorm'd activations, q/k/v, the GELU'd hidden layer) leave the epilogue as hi/lo
-// planes; the residual stream stays fp32.  GELU is the exact erf form (torch.nn.GELU default, as the oracle).
+// planes; the residual stream stays fp32.  GELU is the exact erf form (torch.nn.GELU default, as the oracle), erf to 1.5e-7.
 #include "common.h"
 #include "wvn_internal.h"
 
@@ -38,9 +38,22 @@ __device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   lo = pack_bf16x2(a - ah, b - bh);
 }
 
+// exact erf GELU with erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7: fp32-class, like everything else in this mode)
+// instead of libm's erff, whose ~40 VALU per element doubled the fc1 kernel's time
+__device__ inline float gelu_as(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 template <int EPI>
 __device__ inline float activate(float v) {
-  if constexpr (EPI == EPI_GELU_BF16) return gelu_exact(v);
+  if constexpr (EPI == EPI_GELU_BF16) return gelu_as(v);
   if constexpr (EPI == EPI_RELU_BF16) return fmaxf(v, 0.f);
   return v;
 }

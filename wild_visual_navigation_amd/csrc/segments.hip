@@ -1,4 +1,5 @@
-// Segment kernels (HBM-bound integer / scatter work; wave-level reductions, no GEMM reshaping):
+// Segment kernels (HBM-bound integer / scatter work; wave-level reductions, no GEMM reshaping).  Every float result here is
+// deterministic: sums either run in a fixed order or accumulate in 64-bit fixed point (integer atomics are order-independent).
 //   segpool_weights + segpool_reduce : FeatureExtractor.sparsify_features fused with the bilinear
 //        up-sampling of DinoInterface.inference -- the [B,D,H,H] dense map (308 MB/frame) is never
 //        materialised.  mean_{pixels in s} bilinear(F)(pixel) = sum_p W[s,p] F[p] / |s| with
@@ -20,10 +21,18 @@ __device__ inline float wave_incl_scan(float v, int lane) {
   return v;
 }
 
+// Weights accumulate as 2^-40 fixed point in 64-bit integers: integer addition is associative, so the result does not
+// depend on the order in which the atomics land (fp32 atomics made the general pooling run-to-run different in the last
+// bits).  Tap weights are in [0, 64] per run and a segment has < 2^18 pixels: no overflow; quantisation 1e-12.
+constexpr double WFIX = 1099511627776.0;  // 2^40
+__device__ inline void wfix_add(unsigned long long* p, float v) {
+  atomicAdd(p, (unsigned long long)__double2ll_rn((double)v * WFIX));
+}
+
 // One lane per pixel, a wave covers 64 consecutive pixels of the flattened frame.  Runs of lanes
-// with the same (segment, row, left tap) are reduced in-wave (prefix-sum differences) so that one
+// with the same (segment, row, left tap) are reduced in-wave (prefix-sum differences, fixed lane order) so that one
 // lane per run issues the 4 weight atomics + 1 count atomic (~8x fewer L2 atomics at P=8).
-__global__ __launch_bounds__(256) void segpool_weights_kernel(const int* __restrict__ seg, float* __restrict__ W,
+__global__ __launch_bounds__(256) void segpool_weights_kernel(const int* __restrict__ seg, unsigned long long* __restrict__ W,
                                                               int* __restrict__ cnt, int H, int Wd, int G, int S) {
   const int b = blockIdx.y;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,12 +67,12 @@ __global__ __launch_bounds__(256) void segpool_weights_kernel(const int* __restr
   const float b0 = __shfl_up(p0, 1, 64), b1 = __shfl_up(p1, 1, 64);
   if (head && s >= 0) {
     const float r0 = e0 - (lane ? b0 : 0.f), r1 = e1 - (lane ? b1 : 0.f);
-    float* Wr = W + ((size_t)b * S + s) * (size_t)(G * G);
-    atomicAdd(Wr + y0 * G + x0, wy0 * r0);
-    if (r1 != 0.f) atomicAdd(Wr + y0 * G + x1, wy0 * r1);
+    unsigned long long* Wr = W + ((size_t)b * S + s) * (size_t)(G * G);
+    wfix_add(Wr + y0 * G + x0, wy0 * r0);
+    if (r1 != 0.f) wfix_add(Wr + y0 * G + x1, wy0 * r1);
     if (wy1 != 0.f) {
-      atomicAdd(Wr + y1 * G + x0, wy1 * r0);
-      if (r1 != 0.f) atomicAdd(Wr + y1 * G + x1, wy1 * r1);
+      wfix_add(Wr + y1 * G + x0, wy1 * r0);
+      if (r1 != 0.f) wfix_add(Wr + y1 * G + x1, wy1 * r1);
     }
     atomicAdd(cnt + (size_t)b * S + s, last - lane + 1);
   }
@@ -72,18 +81,18 @@ __global__ __launch_bounds__(256) void segpool_weights_kernel(const int* __restr
 // feat[b][s][:] = (sum_p W[b][s][p] * F[b][p][:]) / cnt[b][s]   (0/0 -> NaN like the reference's empty mean)
 // One workgroup per (s, b); thread = channel.  W rows are sparse: chunks are staged in LDS and
 // zero entries skipped (wave-uniform branch).  Accumulation order is ascending p: deterministic.
-__global__ void segpool_reduce_kernel(const float* __restrict__ W, const int* __restrict__ cnt,
+__global__ void segpool_reduce_kernel(const unsigned long long* __restrict__ W, const int* __restrict__ cnt,
                                       const float* __restrict__ F, int ldf, float* __restrict__ feat, int P, int S,
                                       int D) {
   __shared__ float wch[256];
   const int s = blockIdx.x, b = blockIdx.y;
   const int d = threadIdx.x;
-  const float* Wr = W + ((size_t)b * S + s) * P;
+  const unsigned long long* Wr = W + ((size_t)b * S + s) * P;
   const float* Fb = F + (size_t)b * P * ldf;
   float acc = 0.f;
   for (int p0 = 0; p0 < P; p0 += 256) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) wch[i] = (p0 + i < P) ? Wr[p0 + i] : 0.f;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) wch[i] = (p0 + i < P) ? (float)((double)Wr[p0 + i] * (1.0 / WFIX)) : 0.f;
     __syncthreads();
     const int n = min(256, P - p0);
     for (int i = 0; i < n; ++i) {
@@ -95,29 +104,54 @@ __global__ void segpool_reduce_kernel(const float* __restrict__ W, const int* __
 }
 
 // ---- label pooling --------------------------------------------------------------------------
-__global__ void label_pool_accum_kernel(const float* __restrict__ mask, int C, const int* __restrict__ seg,
-                                        float* __restrict__ sum, int* __restrict__ cnt, int npix, int S) {
+// Per-pixel label = nanmean over the mask channels; per-segment sum in 2^-32 fixed point (64-bit integer atomics:
+// order-independent, deterministic; labels are traversability scores in [0, 1]).  Batched over nodes through pointer
+// tables so that add_supervision_node re-pools every mission node in range with ONE launch pair.
+constexpr double LFIX = 4294967296.0;  // 2^32
+struct LabelPoolNode {
+  const float* mask;        // [C][H][W]
+  const int* seg;           // [H][W]
+  float* signal;            // [S]
+  unsigned char* valid;     // [S]
+  int S;
+  int pad;
+};
+__device__ inline void lp_accum(const LabelPoolNode& nd, int C, long long* sum, int* cnt, int npix) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   float t = 0.f;
   int c = 0;
   for (int ch = 0; ch < C; ++ch) {
-    float v = mask[(size_t)ch * npix + i];
+    float v = nd.mask[(size_t)ch * npix + i];
     if (!isnan(v)) { t += v; ++c; }
   }
-  int s = seg[i];
-  if (c == 0 || s < 0 || s >= S) return;
-  atomicAdd(sum + s, t / (float)c);
+  int s = nd.seg[i];
+  if (c == 0 || s < 0 || s >= nd.S) return;
+  atomicAdd((unsigned long long*)(sum + s), (unsigned long long)__double2ll_rn((double)(t / (float)c) * LFIX));
   atomicAdd(cnt + s, 1);
 }
-__global__ void label_pool_final_kernel(const float* __restrict__ sum, const int* __restrict__ cnt,
-                                        float* __restrict__ signal, unsigned char* __restrict__ valid, int S) {
+__device__ inline void lp_final(const LabelPoolNode& nd, const long long* sum, const int* cnt) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  float m = (cnt[s] > 0) ? sum[s] / (float)cnt[s] : 0.f;  // nan_to_num(0/0) = 0
+  if (s >= nd.S) return;
+  const int n = cnt[s];
+  float m = (n > 0) ? (float)((double)sum[s] * (1.0 / LFIX) / (double)n) : 0.f;  // nan_to_num(0/0) = 0
   if (isnan(m)) m = 0.f;
-  signal[s] = m;
-  valid[s] = m > 0.f;
+  nd.signal[s] = m;
+  nd.valid[s] = m > 0.f;
+}
+__global__ void label_pool_accum_batched_kernel(const LabelPoolNode* __restrict__ nodes, int C, long long* __restrict__ sum,
+                                                int* __restrict__ cnt, int npix, int Smax) {
+  lp_accum(nodes[blockIdx.y], C, sum + (size_t)blockIdx.y * Smax, cnt + (size_t)blockIdx.y * Smax, npix);
+}
+__global__ void label_pool_final_batched_kernel(const LabelPoolNode* __restrict__ nodes, const long long* __restrict__ sum,
+                                                const int* __restrict__ cnt, int Smax) {
+  lp_final(nodes[blockIdx.y], sum + (size_t)blockIdx.y * Smax, cnt + (size_t)blockIdx.y * Smax);
+}
+__global__ void label_pool_accum_kernel(LabelPoolNode nd, int C, long long* __restrict__ sum, int* __restrict__ cnt, int npix) {
+  lp_accum(nd, C, sum, cnt, npix);
+}
+__global__ void label_pool_final_kernel(LabelPoolNode nd, const long long* __restrict__ sum, const int* __restrict__ cnt) {
+  lp_final(nd, sum, cnt);
 }
 
 // ---- centers ----------------------------------------------------------------------------------
@@ -185,39 +219,49 @@ __global__ __launch_bounds__(1024) void adjacency_compact_kernel(const unsigned 
 
 
 // ---- plain per-segment mean of an explicit pixel-resolution map (sparsify_features on a dense tensor) ----
-// tokens [B,P,D] (pixel-major), seg [B,P]; workgroup = (pixel chunk, 64-channel slab, b): LDS partial sums,
-// then one global atomic per touched (segment, channel).  sums must be zero-filled, S*64*4 B <= 60 KB.
-constexpr int SM_PIX = 4096;
-__global__ __launch_bounds__(256) void segmean_accum_kernel(const int* __restrict__ seg, const float* __restrict__ tok,
-                                                            float* __restrict__ sums, int* __restrict__ cnt, int P,
-                                                            int S, int D) {
+// tokens [B,P,D] (pixel-major), seg [B,P].  Deterministic, no atomics: ONE wave per (pixel chunk, 64-channel slab, frame)
+// walks its chunk in ascending pixel order (lane = channel) into an LDS table [S][64], writes the table as a partial to
+// scratch; a second kernel adds the chunk partials in ascending chunk order and divides by the pixel count.
+constexpr int SM_PIX = 2048;
+__global__ __launch_bounds__(64) void segmean_partial_kernel(const int* __restrict__ seg, const float* __restrict__ tok,
+                                                             float* __restrict__ part_out, int* __restrict__ cnt_out, int P,
+                                                             int S, int D, int nchunk) {
   extern __shared__ float part[];  // [S][64] + int cnt[S]
   int* pc = (int*)(part + (size_t)S * 64);
-  const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * SM_PIX;
-  const int ch = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < S * 64; i += 256) part[i] = 0.f;
-  for (int i = threadIdx.x; i < S; i += 256) pc[i] = 0;
-  __syncthreads();
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, chunk = blockIdx.x, p0 = chunk * SM_PIX;
+  const int ch = threadIdx.x;
+  for (int i = ch; i < S * 64; i += 64) part[i] = 0.f;
+  for (int i = ch; i < S; i += 64) pc[i] = 0;
   const int pend = min(P, p0 + SM_PIX);
-  for (int p = p0 + pl; p < pend; p += 4) {
-    const int s = seg[(size_t)b * P + p];
+  const bool live = c0 + ch < D;
+  for (int p = p0; p < pend; ++p) {
+    const int s = seg[(size_t)b * P + p];   // wave-uniform
     if (s < 0 || s >= S) continue;
-    if (c0 + ch < D) atomicAdd(&part[s * 64 + ch], tok[((size_t)b * P + p) * D + c0 + ch]);
-    if (ch == 0 && blockIdx.y == 0) atomicAdd(&pc[s], 1);
+    if (live) part[s * 64 + ch] += tok[((size_t)b * P + p) * D + c0 + ch];
+    if (ch == 0) pc[s] += 1;
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < S * 64; i += 256) {
-    const int s = i >> 6, c = i & 63;
-    if (part[i] != 0.f && c0 + c < D) atomicAdd(&sums[((size_t)b * S + s) * D + c0 + c], part[i]);
-  }
+  // (single wave: its own LDS writes are visible to its later reads in program order)
+  float* dst = part_out + (((size_t)b * nchunk + chunk) * S) * D + c0;
+  for (int s = 0; s < S; ++s)
+    if (live) dst[(size_t)s * D + ch] = part[s * 64 + ch];
   if (blockIdx.y == 0)
-    for (int i = threadIdx.x; i < S; i += 256)
-      if (pc[i]) atomicAdd(&cnt[(size_t)b * S + i], pc[i]);
+    for (int i = ch; i < S; i += 64) cnt_out[((size_t)b * nchunk + chunk) * S + i] = pc[i];
 }
-__global__ void segmean_final_kernel(float* __restrict__ sums, const int* __restrict__ cnt, long long n, int D) {
+__global__ void segmean_final_kernel(const float* __restrict__ part, const int* __restrict__ pcnt, float* __restrict__ out,
+                                     int* __restrict__ cnt, int B, int S, int D, int nchunk) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  sums[i] = sums[i] / (float)cnt[i / D];
+  if (i >= (long long)B * S * D) return;
+  const int d = (int)(i % D);
+  const int s = (int)((i / D) % S);
+  const int b = (int)(i / ((long long)D * S));
+  float t = 0.f;
+  int n = 0;
+  for (int c = 0; c < nchunk; ++c) {   // ascending chunk order
+    t += part[(((size_t)b * nchunk + c) * S + s) * D + d];
+    n += pcnt[((size_t)b * nchunk + c) * S + s];
+  }
+  out[i] = t / (float)n;   // 0/0 = NaN for an id without pixels, like the reference's empty mean
+  if (d == 0) cnt[(size_t)b * S + s] = n;
 }
 
 // ---- fused up-sample + segment mean for PATCH-ALIGNED label maps (k-means clusters, grid cells) ---------
@@ -320,11 +364,12 @@ int wvn_segpool_patch_launch(const int* labels, const float* tok, int ldf, const
   return WVN_OK;
 }
 
-int wvn_segpool_launch(const int* seg, const float* tok, int ldf, float* feat, float* W, int* cnt, int B, int H,
+int wvn_segpool_launch(const int* seg, const float* tok, int ldf, float* feat, void* Wv, int* cnt, int B, int H,
                        int Wd, int G, int S, int D, hipStream_t st) {
-  if (!seg || !tok || !feat || !W || !cnt || S <= 0 || D <= 0 || D > 1024) return WVN_ERR_ARG;
+  unsigned long long* W = (unsigned long long*)Wv;
+  if (!seg || !tok || !feat || !W || !cnt || S <= 0 || D <= 0 || D > 1024 || ((uintptr_t)W & 7)) return WVN_ERR_ARG;
   const int P = G * G;
-  hipError_t e = hipMemsetAsync(W, 0, (size_t)B * S * P * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(W, 0, (size_t)B * S * P * sizeof(unsigned long long), st);
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(cnt, 0, (size_t)B * S * sizeof(int), st);
   if (e != hipSuccess) return (int)e;
@@ -336,17 +381,35 @@ int wvn_segpool_launch(const int* seg, const float* tok, int ldf, float* feat, f
   return WVN_OK;
 }
 
-int wvn_label_pool_launch(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* sum,
+// nodes: DEVICE array of n LabelPoolNode-shaped records (include/wvn_hip.h: wvn_label_pool_node); sum / cnt: n * Smax words
+int wvn_label_pool_batched_launch(const void* nodes, int n, int C, int H, int Wd, int Smax, long long* sum, int* cnt,
+                                  hipStream_t st) {
+  if (!nodes || !sum || !cnt || n <= 0 || Smax <= 0 || C <= 0) return WVN_ERR_ARG;
+  hipError_t e = hipMemsetAsync(sum, 0, (size_t)n * Smax * sizeof(long long), st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(cnt, 0, (size_t)n * Smax * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(label_pool_accum_batched_kernel, dim3(ceil_div(H * Wd, 256), n), dim3(256), 0, st,
+                     (const LabelPoolNode*)nodes, C, sum, cnt, H * Wd, Smax);
+  WVN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(label_pool_final_batched_kernel, dim3(ceil_div(Smax, 256), n), dim3(256), 0, st,
+                     (const LabelPoolNode*)nodes, sum, cnt, Smax);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+// single node; sum: S 8-byte words, cnt: S ints
+int wvn_label_pool_launch(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, void* sum,
                           int* cnt, int H, int Wd, int S, hipStream_t st) {
-  if (!mask || !seg || !signal || !valid || !sum || !cnt) return WVN_ERR_ARG;
-  hipError_t e = hipMemsetAsync(sum, 0, S * sizeof(float), st);
+  if (!mask || !seg || !signal || !valid || !sum || !cnt || ((uintptr_t)sum & 7)) return WVN_ERR_ARG;
+  hipError_t e = hipMemsetAsync(sum, 0, (size_t)S * sizeof(long long), st);
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(cnt, 0, S * sizeof(int), st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(label_pool_accum_kernel, dim3(ceil_div(H * Wd, 256)), dim3(256), 0, st, mask, C, seg, sum, cnt,
-                     H * Wd, S);
+  LabelPoolNode nd{mask, seg, signal, valid, S, 0};
+  hipLaunchKernelGGL(label_pool_accum_kernel, dim3(ceil_div(H * Wd, 256)), dim3(256), 0, st, nd, C, (long long*)sum, cnt, H * Wd);
   WVN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(label_pool_final_kernel, dim3(ceil_div(S, 256)), dim3(256), 0, st, sum, cnt, signal, valid, S);
+  hipLaunchKernelGGL(label_pool_final_kernel, dim3(ceil_div(S, 256)), dim3(256), 0, st, nd, (const long long*)sum, (const int*)cnt);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -375,19 +438,25 @@ int wvn_adjacency_launch(const int* seg, long long* edges, int* count, unsigned 
   return WVN_OK;
 }
 
-int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, int B, int P, int S, int D,
-                              hipStream_t st) {
-  if (!seg || !tok || !out || !cnt || S <= 0 || (size_t)S * 65 * 4 > 60 * 1024) return WVN_ERR_ARG;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)B * S * D * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(cnt, 0, (size_t)B * S * sizeof(int), st);
-  if (e != hipSuccess) return (int)e;
+size_t wvn_segmean_scratch_bytes_impl(int B, int P, int S, int D) {
+  const size_t nchunk = (size_t)ceil_div(P, SM_PIX);
+  return (size_t)B * nchunk * S * D * sizeof(float) + (size_t)B * nchunk * S * sizeof(int);
+}
+
+int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, void* scratch, size_t scratch_bytes, int B,
+                              int P, int S, int D, hipStream_t st) {
+  if (!seg || !tok || !out || !cnt || !scratch || S <= 0 || (size_t)S * 65 * 4 > 60 * 1024) return WVN_ERR_ARG;
+  if (scratch_bytes < wvn_segmean_scratch_bytes_impl(B, P, S, D)) return WVN_ERR_WORKSPACE;
+  const int nchunk = ceil_div(P, SM_PIX);
+  float* part = (float*)scratch;
+  int* pcnt = (int*)(part + (size_t)B * nchunk * S * D);
   size_t shm = (size_t)S * 65 * 4;
-  hipLaunchKernelGGL(segmean_accum_kernel, dim3(ceil_div(P, SM_PIX), ceil_div(D, 64), B), dim3(256), shm, st, seg, tok,
-                     out, cnt, P, S, D);
+  hipLaunchKernelGGL(segmean_partial_kernel, dim3(nchunk, ceil_div(D, 64), B), dim3(64), shm, st, seg, tok, part, pcnt, P, S,
+                     D, nchunk);
   WVN_LAUNCH_CHECK();
   long long n = (long long)B * S * D;
-  hipLaunchKernelGGL(segmean_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, cnt, n, D);
+  hipLaunchKernelGGL(segmean_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, pcnt, out, cnt, B, S, D,
+                     nchunk);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

@@ -101,9 +101,11 @@ int wvn_splitk_reduce_launch(const float* part, int splitk, size_t n, const floa
                              hipStream_t st);
 int wvn_upsample_bilinear_launch(const float* tok, float* out, int B, int G, int D, int H, hipStream_t st);
 int wvn_upsample_nearest_i32_launch(const int* lab, int* out, int B, int G, int H, hipStream_t st);
-int wvn_segpool_launch(const int* seg, const float* tok, int ldf, float* feat, float* W, int* cnt, int B, int H,
+int wvn_segpool_launch(const int* seg, const float* tok, int ldf, float* feat, void* W, int* cnt, int B, int H,
                        int Wd, int G, int S, int D, hipStream_t st);
-int wvn_label_pool_launch(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, float* sum,
+int wvn_label_pool_batched_launch(const void* nodes, int n, int C, int H, int Wd, int Smax, long long* sum, int* cnt,
+                                  hipStream_t st);
+int wvn_label_pool_launch(const float* mask, int C, const int* seg, float* signal, unsigned char* valid, void* sum,
                           int* cnt, int H, int Wd, int S, hipStream_t st);
 int wvn_centers_launch(const int* seg, float* centers, unsigned long long* scratch, int H, int Wd, int S,
                        hipStream_t st);
@@ -129,7 +131,8 @@ int wvn_mlp_confidence_launch(const float* out, int ldo, const float* x, int ldx
                               float std_factor, float* trav, float* conf, int R, int D, hipStream_t st);
 int wvn_segpool_patch_launch(const int* labels, const float* tok, int ldf, const float* wy, const float* wx,
                              float* feat, int B, int G, int S, int D, hipStream_t st);
-int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, int B, int P, int S, int D,
+size_t wvn_segmean_scratch_bytes_impl(int B, int P, int S, int D);
+int wvn_segmean_tokens_launch(const int* seg, const float* tok, float* out, int* cnt, void* scratch, size_t scratch_bytes, int B, int P, int S, int D,
                               hipStream_t st);
 
 // ---- fused per-pixel traversability inference (pixel_mlp.hip) ------------------------------------
@@ -147,3 +150,11 @@ int wvn_pixel_mlp_infer_exact_launch(int D, int h1, int h2, const float* params,
                                      int ldt, int B, int G, int out_h, int out_w, float mean, float std, float std_factor,
                                      const float* conf_state, float* trav, float* conf, float* loss, void* workspace,
                                      size_t workspace_bytes, hipStream_t st);
+
+// ---- supervision path (supervision.hip) and SLIC (slic.hip) -------------------------------------------------------------
+int wvn_project_render_fmin_launch(const void* nodes, int n, const float* points, int points_batched, int npts, int C, int H,
+                                   int W, const float* value_dev, float value, hipStream_t st);
+int wvn_slic_num_clusters_impl(int H, int W, int num_components);
+size_t wvn_slic_scratch_bytes_impl(int H, int W, int num_components);
+int wvn_slic_launch(const void* img, int img_u8, int H, int W, int num_components, float compactness, int iters,
+                    const int* lut_lin, const int* lut_f, int* labels, void* scratch, size_t scratch_bytes, hipStream_t st);

@@ -60,12 +60,10 @@ class FeatureExtractor:
             raise TypeError(f"Extractor[{self._feature_type}] not supported!")
 
         if self.segmentation_type == "slic":
-            try:
-                from fast_slic import Slic  # CPU SLIC, external; identical to the reference's dependency
-            except ImportError as e:
-                raise _lib.WvnError("segmentation_type='slic' needs the external CPU package fast_slic") from e
-            self.slic = Slic(num_components=kwargs.get("slic_num_components", 100),
-                             compactness=kwargs.get("slic_compactness", 10))
+            # The reference round-trips through the CPU package fast_slic (feature_extractor.py:84-90, 221-225); here SLIC runs on
+            # the GPU in integer arithmetic (csrc/slic.hip; parity with fast_slic's own variant is unpinned)
+            self._slic_num_components = kwargs.get("slic_num_components", 100)
+            self._slic_compactness = kwargs.get("slic_compactness", 10)
         elif self.segmentation_type == "stego" and self._feature_type != "stego":
             raise TypeError("segmentation_type 'stego' requires feature_type 'stego' (as in the reference)")
 
@@ -158,6 +156,11 @@ class FeatureExtractor:
             n_seg = self._extractor._cfg.n_image_clusters
             tokens = self._extractor.feature_tokens
             labels_patch = self._extractor._labels_patch
+        elif self._segmentation_type == "slic":
+            seg = torch.stack([ops.slic(img[b], self._slic_num_components, self._slic_compactness) for b in range(B)])
+            n_seg = ops.slic_num_clusters(H, W, self._slic_num_components)
+            nseg = torch.full((B,), n_seg, dtype=torch.int32, device=self._device)
+            tokens = backbone_out if backbone_out is not None else self._feature_tokens(img)
         else:
             raise TypeError(f"extract_batch: segmentation_type [{self._segmentation_type}] not supported")
         feat = None
@@ -252,12 +255,10 @@ class FeatureExtractor:
         return (gy[:, None] * (W // cell) + gx[None, :])[None, None].to(torch.int64)
 
     def segment_slic(self, img, **kwargs):
-        import numpy as np
-
-        img_np = img[0].permute(1, 2, 0).cpu().numpy()
-        u8 = img_np if img_np.dtype == np.uint8 else np.uint8(np.ascontiguousarray(img_np) * 255)
-        seg = self.slic.iterate(np.ascontiguousarray(u8))[None, None]
-        return torch.from_numpy(seg).to(self._device).type(torch.long)
+        """feature_extractor.py:221-225 without the host round trip: [1,3,H,W] (float in [0,1], truncated to 8 bits like the
+        reference's np.uint8(img * 255), or uint8) -> [1,1,H,W] int64 ids in [0, number of SLIC clusters)."""
+        seg = ops.slic(img[0].to(self._device), self._slic_num_components, self._slic_compactness)
+        return seg[None, None].to(torch.long)
 
     def segment_random(self, img, **kwargs):
         H, W = img.shape[2:]

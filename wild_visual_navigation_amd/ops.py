@@ -44,7 +44,7 @@ def segpool_bilinear_mean(seg: torch.Tensor, tokens: torch.Tensor, grid: int, n_
     D = tokens.shape[-1]
     dev = tokens.device
     feat = torch.empty(B, n_seg, D, dtype=torch.float32, device=dev)
-    wbuf = torch.empty(B * n_seg * grid * grid, dtype=torch.float32, device=dev)
+    wbuf = torch.empty(B * n_seg * grid * grid, dtype=torch.int64, device=dev)  # 2^-40 fixed-point tap weights
     cnt = torch.empty(B * n_seg, dtype=torch.int32, device=dev)
     check(lib().wvn_segpool_bilinear_mean(ptr(seg), ptr(tokens), D, ptr(feat), ptr(wbuf), ptr(cnt), B, H, W, grid,
                                           n_seg, D, stream()), "wvn_segpool_bilinear_mean")
@@ -110,8 +110,9 @@ def segmean_tokens(seg: torch.Tensor, tokens: torch.Tensor, n_seg: int) -> torch
     seg = _i32(seg).reshape(B, P).contiguous()
     out = torch.empty(B, n_seg, D, dtype=torch.float32, device=tokens.device)
     cnt = torch.empty(B * n_seg, dtype=torch.int32, device=tokens.device)
-    check(lib().wvn_segmean_tokens(ptr(seg), ptr(tokens), ptr(out), ptr(cnt), B, P, n_seg, D, stream()),
-          "wvn_segmean_tokens")
+    scratch = torch.empty(lib().wvn_segmean_scratch_bytes(B, P, n_seg, D), dtype=torch.uint8, device=tokens.device)
+    check(lib().wvn_segmean_tokens(ptr(seg), ptr(tokens), ptr(out), ptr(cnt), ptr(scratch), scratch.numel(), B, P, n_seg, D,
+                                   stream()), "wvn_segmean_tokens")
     return out
 
 
@@ -126,11 +127,104 @@ def label_pool(mask: torch.Tensor, seg: torch.Tensor, n_seg: int) -> Tuple[torch
     dev = mask.device
     signal = torch.empty(n_seg, dtype=torch.float32, device=dev)
     valid = torch.empty(n_seg, dtype=torch.uint8, device=dev)
-    ssum = torch.empty(n_seg, dtype=torch.float32, device=dev)
+    ssum = torch.empty(n_seg, dtype=torch.int64, device=dev)   # 2^-32 fixed-point sums (deterministic integer atomics)
     scnt = torch.empty(n_seg, dtype=torch.int32, device=dev)
     check(lib().wvn_label_pool(ptr(mask), Cc, ptr(seg), ptr(signal), ptr(valid), ptr(ssum), ptr(scnt), H, W, n_seg,
                                stream()), "wvn_label_pool")
     return signal, valid.bool()
+
+
+def _record_table(rows, dev) -> torch.Tensor:
+    """Device array of C records whose fields are 8-byte words (pointers / int pairs), built from Python ints."""
+    return torch.tensor(rows, dtype=torch.int64).to(dev)
+
+
+def label_pool_batched(masks, segs, n_segs):
+    """``label_pool`` for a list of nodes in ONE launch pair.  masks: list of [C,H,W] fp32 CUDA tensors (same shape), segs:
+    list of [H,W] int32 CUDA tensors, n_segs: list of ints -> list of (signal [S_i] fp32, valid [S_i] bool)."""
+    n = len(masks)
+    dev = masks[0].device
+    Cc, H, W = masks[0].shape
+    smax = max(n_segs)
+    sig = [torch.empty(s, dtype=torch.float32, device=dev) for s in n_segs]
+    val = [torch.empty(s, dtype=torch.uint8, device=dev) for s in n_segs]
+    for m, sg in zip(masks, segs):
+        require_cuda(m, "mask")
+        if m.dtype != torch.float32 or not m.is_contiguous() or sg.dtype != torch.int32 or not sg.is_contiguous():
+            raise _lib.WvnError("label_pool_batched: masks must be contiguous fp32 [C,H,W], segment maps contiguous int32 [H,W]")
+    table = _record_table([[ptr(m), ptr(sg), ptr(a), ptr(b), s] for m, sg, a, b, s in zip(masks, segs, sig, val, n_segs)], dev)
+    ssum = torch.empty(n * smax, dtype=torch.int64, device=dev)
+    scnt = torch.empty(n * smax, dtype=torch.int32, device=dev)
+    check(lib().wvn_label_pool_batched(ptr(table), n, Cc, H, W, smax, ptr(ssum), ptr(scnt), stream()), "wvn_label_pool_batched")
+    return [(a, b.bool()) for a, b in zip(sig, val)]
+
+
+def project_render_fmin(Ks, poses, masks, points: torch.Tensor, value, want_projected: bool = False):
+    """ImageProjector.project_and_render + torch.fmin merge for n nodes in one launch (csrc/supervision.hip).
+    Ks / poses: lists of [4,4] fp32 CUDA tensors (scaled camera matrix, pose_cam_in_world); masks: list of contiguous
+    [C,H,W] fp32 CUDA tensors, UPDATED IN PLACE; points [N,3] (shared) or [n,N,3]; value: float or 1-element CUDA tensor
+    (colour * traversability).  Returns the projected points [n,N,2] if asked."""
+    n = len(masks)
+    dev = masks[0].device
+    Cc, H, W = masks[0].shape
+    points = points.to(dev, torch.float32).contiguous()
+    batched = points.dim() == 3
+    N = points.shape[-2]
+    proj = torch.empty(n, N, 2, dtype=torch.float32, device=dev) if want_projected else None
+    keep = []
+    rows = []
+    for i in range(n):
+        K = Ks[i].to(dev, torch.float32).contiguous()
+        T = poses[i].to(dev, torch.float32).contiguous()
+        keep += [K, T]
+        m = masks[i]
+        if m.dtype != torch.float32 or not m.is_contiguous() or tuple(m.shape) != (Cc, H, W):
+            raise _lib.WvnError("project_render_fmin: masks must be contiguous fp32 [C,H,W] of one shape")
+        rows.append([ptr(K), ptr(T), ptr(m), ptr(proj[i]) if proj is not None else 0])
+    table = _record_table(rows, dev)
+    vdev = value if isinstance(value, torch.Tensor) else None
+    if vdev is not None:
+        vdev = vdev.to(dev, torch.float32).reshape(-1).contiguous()
+    check(lib().wvn_project_render_fmin(ptr(table), n, ptr(points), int(batched), N, Cc, H, W, ptr(vdev),
+                                        0.0 if vdev is not None else float(value), stream()), "wvn_project_render_fmin")
+    return proj
+
+
+_SLIC_TABLES = {}
+
+
+def slic_tables(device):
+    """sRGB -> linear (x 4095) and CIELAB f(t) (x 4096) lookup tables of the integer SLIC (csrc/slic.hip), built in double
+    precision on the host."""
+    key = str(device)
+    if key not in _SLIC_TABLES:
+        import numpy as np
+
+        c = np.arange(256, dtype=np.float64) / 255.0
+        lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+        t = np.arange(4096, dtype=np.float64) / 4095.0
+        f = np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16.0 / 116.0)
+        _SLIC_TABLES[key] = (torch.from_numpy(np.rint(lin * 4095.0).astype(np.int32)).to(device),
+                             torch.from_numpy(np.rint(f * 4096.0).astype(np.int32)).to(device))
+    return _SLIC_TABLES[key]
+
+
+def slic(img: torch.Tensor, num_components: int = 100, compactness: float = 10.0, iters: int = 10) -> torch.Tensor:
+    """img [3,H,W] uint8 or float in [0,1] (CUDA) -> SLIC label map [H,W] int32 in [0, slic_num_clusters)."""
+    require_cuda(img, "img")
+    u8 = img.dtype == torch.uint8
+    img = img.contiguous() if u8 else img.contiguous().float()
+    _, H, W = img.shape
+    lin, f = slic_tables(img.device)
+    labels = torch.empty(H, W, dtype=torch.int32, device=img.device)
+    scratch = torch.empty(lib().wvn_slic_scratch_bytes(H, W, num_components), dtype=torch.uint8, device=img.device)
+    check(lib().wvn_slic(ptr(img), int(u8), H, W, num_components, float(compactness), iters, ptr(lin), ptr(f), ptr(labels),
+                         ptr(scratch), scratch.numel(), stream()), "wvn_slic")
+    return labels
+
+
+def slic_num_clusters(H: int, W: int, num_components: int) -> int:
+    return int(lib().wvn_slic_num_clusters(H, W, num_components))
 
 
 def seg_centers(seg: torch.Tensor, n_seg: int) -> torch.Tensor:

@@ -68,3 +68,13 @@ class TraversabilityLoss(torch.nn.Module):
     def update_node_confidence(self, node):
         reco_loss = F.mse_loss(node.prediction[:, 1:], node.features, reduction="none").mean(dim=1)
         node.confidence = self._confidence_generator.inference_without_update(reco_loss)
+
+
+class AnomalyLoss(torch.nn.Module):
+    """wild_visual_navigation/utils/loss.py:16-54 belongs to the LinearRnvp anomaly-detection ablation (non-default model,
+    SURVEY.md section 2: out of scope).  The name exists because callers import it unconditionally (quick_start.py:12,
+    wvn_feature_extractor_node.py:12); constructing it is refused."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise ValueError("AnomalyLoss (LinearRnvp anomaly detection) is outside the MI355X hot path")
