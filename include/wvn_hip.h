@@ -309,6 +309,19 @@ int wvn_pixel_mlp_infer_exact(const wvn_mlp_desc* d, const float* params, const 
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A -> B wire format: the per-frame wild_visual_navigation_msgs/ImageFeatures message built at
+ * wvn_feature_extractor_node.py:373-393 (seg.cpu().numpy().astype(np.int32) + feat.cpu().numpy().flatten().tolist()) and
+ * decoded at wvn_learning_node.py:651-656.  wvn_wire_pack lays the frame out on the device as the message carries it:
+ *   [ 64-byte header {magic "WVNF", version, H, W, S, D, seg_offset, feat_offset} | int32 seg[H*W] | float32 feat[S*D] ]
+ * (the two payload sections are the byte arrays of Image.data, step 4*W, and Float32MultiArray.data): one contiguous
+ * device->host copy per frame instead of two copies, a host cast and a Python list.  wvn_wire_unpack is the inverse on the
+ * learner's GPU (segments as int64, what MissionNode stores, and/or int32).  out / in: 16-byte aligned, wvn_wire_bytes() bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t wvn_wire_bytes(int H, int W, int S, int D);
+int wvn_wire_pack(const void* seg, int seg_is_i64, const float* feat, int ldf, void* out, int H, int W, int S, int D, void* stream);
+int wvn_wire_unpack(const void* in, long long* seg_i64, int* seg_i32, float* feat, int H, int W, int S, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instrumentation (scripts/a384_timing.py, scripts/attn_timing.py): in-kernel s_memtime phase timings of
  * the two MFMA kernels.  Not part of the drop-in surface.
  * ------------------------------------------------------------------------------------------- */

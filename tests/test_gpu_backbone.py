@@ -179,9 +179,76 @@ def test_stego_interface_contract(dev):
     si = StegoInterface(dev, input_size=64, n_image_clusters=6, run_crf=False, run_clustering=True,
                         backbone_weights=sd, precision="fp32")
     lin, clu = si.inference(torch.rand(2, 3, 64, 64, generator=g(1)).to(dev))
-    assert lin.shape == clu.shape == (1, 2, 64, 64) and clu.dtype == torch.int32
-    assert si.features.shape == (2, 90, 64, 64) and si.cluster_segments is clu and si.linear_segments is lin
+    assert lin is None                                      # no linear probe was given: nothing is invented for it
+    assert clu.shape == (1, 2, 64, 64) and clu.dtype == torch.int32
+    assert si.features.shape == (2, 90, 64, 64) and si.cluster_segments is clu and si.linear_segments is None
     assert int(clu.min()) == 0 and int(clu.max()) < 6
+
+
+def _lightning_ckpt(sd, head, clusters, lin_w, lin_b, layout):
+    """A Stego.load_from_checkpoint-style file (stego_interface.py:43) in the upstream STEGO key layout (``net.model.*``,
+    ``net.cluster1/2.*`` as 1x1 convolutions, ``cluster_probe.clusters``, ``linear_probe.*``) or the
+    self_supervised_segmentation one (``backbone.*``, ``segmentation_head.linear/nonlinear.*``)."""
+    out = {}
+    bb, c1, c2 = ("net.model.", "net.cluster1.", "net.cluster2.") if layout == "stego" else \
+                 ("backbone.model.", "segmentation_head.linear.", "segmentation_head.nonlinear.")
+    for k, v in sd.items():
+        out[bb + k] = v
+    conv = lambda w: w[:, :, None, None]
+    out[c1 + "0.weight"], out[c1 + "0.bias"] = conv(head["cluster1.0.weight"]), head["cluster1.0.bias"]
+    out[c2 + "0.weight"], out[c2 + "0.bias"] = conv(head["cluster2.0.weight"]), head["cluster2.0.bias"]
+    out[c2 + "2.weight"], out[c2 + "2.bias"] = conv(head["cluster2.2.weight"]), head["cluster2.2.bias"]
+    out["cluster_probe.clusters"] = clusters
+    out["linear_probe.weight"], out["linear_probe.bias"] = conv(lin_w), lin_b
+    return {"state_dict": out, "hyper_parameters": {"n_classes": lin_w.shape[0]}}
+
+
+@pytest.mark.parametrize("layout,prec", [("stego", "fp32"), ("sss", "exact"), ("stego", "bf16")])
+def test_stego_checkpoint_probes_flip_tta_and_pixel_clustering(dev, tmp_path, layout, prec):
+    """StegoInterface(model_path=...) (stego_interface.py:23,43): backbone + head + cluster probe + linear probe come from the
+    Lightning checkpoint; run_clustering=False labels with the learned cluster probe (cosine argmax), the linear probe gives
+    linear_pred; flip_tta averages the mirrored pass; cluster_resolution="pixel" clusters the up-sampled code."""
+    S, P = 64, 8
+    G = S // P
+    sd = OV.make_vit_state_dict("vit_small", P, pretrain_grid=28, seed=21, depth=1)
+    head = OI.make_stego_head_state_dict(384, 90, seed=4)
+    gg = g(31)
+    clusters, lin_w, lin_b = torch.randn(27, 90, generator=gg), torch.randn(27, 90, generator=gg) * 0.3, torch.randn(27, generator=gg) * 0.1
+    path = str(tmp_path / "stego_ckpt.ckpt")
+    torch.save(_lightning_ckpt(sd, head, clusters, lin_w, lin_b, layout), path)
+    img = torch.rand(2, 3, S, S, generator=g(32))
+    tok = OV.vit_tokens(sd, OI.normalize(img), P, 6)[:, 1:]
+    code = OI.stego_code_tokens(head, tok)                                      # [2, G*G, 90]
+    tol = {"fp32": 1e-4, "exact": 1e-4, "bf16": 0.15}[prec]
+
+    si = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=False, precision=prec)
+    lin, clu = si.inference(img.to(dev))
+    assert (si.feature_tokens.cpu() - code).abs().max().item() < tol
+    assert lin.shape == clu.shape == (1, 2, S, S) and lin.dtype == torch.int32
+    want_clu = (torch.nn.functional.normalize(code, dim=-1) @ torch.nn.functional.normalize(clusters, dim=1).T).argmax(-1)
+    want_lin = (code @ lin_w.T + lin_b).argmax(-1)
+    agree = lambda got, want: (got[0].cpu()[:, ::P, ::P].reshape(2, -1) == want).float().mean().item()
+    thr = 0.999 if prec != "bf16" else 0.9
+    assert agree(clu, want_clu) >= thr and agree(lin, want_lin) >= thr
+
+    flip = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=True, precision=prec,
+                          flip_tta=True)
+    tok_f = OV.vit_tokens(sd, OI.normalize(img.flip(-1)), P, 6)[:, 1:]
+    code_f = OI.stego_code_tokens(head, tok_f).reshape(2, G, G, 90).flip(2).reshape(2, G * G, 90)
+    assert (flip.code_tokens(img.to(dev)).cpu() - 0.5 * (code + code_f)).abs().max().item() < tol
+
+    if prec == "fp32":
+        pix = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=True,
+                             precision=prec, cluster_resolution="pixel")
+        _, clu_p = pix.inference(img.to(dev))
+        dense = pix.features                                                     # [2, 90, S, S] on the GPU
+        for b in range(2):
+            want = OI.relabel_ascending(OI.kmeans_cosine_labels(dense[b].permute(1, 2, 0).reshape(S * S, 90).cpu().numpy(), 5))
+            assert np.array_equal(clu_p[0, b].cpu().numpy().reshape(-1), want)   # bit-exact on identical fp32 input
+        fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=S, model_path=path,
+                              n_image_clusters=5, precision=prec, cluster_resolution="pixel")
+        edges, feat, seg, center, _ = fe.extract(img[:1].to(dev))
+        assert feat.shape == (int(seg.max()) + 1, 90) and torch.isfinite(feat).all()
 
 
 def test_extract_batch_equals_per_frame(dev):
@@ -195,8 +262,8 @@ def test_extract_batch_equals_per_frame(dev):
     assert feat.shape == (4, 16, 384) and seg.shape == (4, S, S) and nseg.tolist() == [16] * 4
     for b in range(4):
         _, f1, s1, _, _ = fe.extract(img[b:b + 1], cell_size=16)
-        # tokens are bit-identical (batch invariance); the pooling weights are accumulated with fp32
-        # atomics whose order is not fixed, hence round-off-level differences only
+        # tokens are bit-identical (batch invariance); the patch-aligned and the general pooling kernels associate the same
+        # sums differently, hence round-off-level differences only
         assert torch.allclose(f1, feat[b], atol=1e-5, rtol=0) and torch.equal(s1.int(), seg[b])
 
 

@@ -76,6 +76,9 @@ _SIGNATURES = {
     "wvn_label_pool": ([_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_label_pool_batched": ([_p, _i, _i, _i, _i, _i, _p, _p, _p], _i),
     "wvn_project_render_fmin": ([_p, _i, _p, _i, _i, _i, _i, _i, _p, _f, _p], _i),
+    "wvn_wire_bytes": ([_i, _i, _i, _i], _sz),
+    "wvn_wire_pack": ([_p, _i, _p, _i, _p, _i, _i, _i, _i, _p], _i),
+    "wvn_wire_unpack": ([_p, _p, _p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_slic_num_clusters": ([_i, _i, _i], _i),
     "wvn_slic_scratch_bytes": ([_i, _i, _i], _sz),
     "wvn_slic": ([_p, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p], _i),

@@ -354,6 +354,13 @@ int wvn_project_render_fmin(const wvn_render_node* nodes_dev, int n, const float
                             int H, int W, const float* value_dev, float value, void* stream) {
   return wvn_project_render_fmin_launch(nodes_dev, n, points, points_batched, npts, C, H, W, value_dev, value, (hipStream_t)stream);
 }
+size_t wvn_wire_bytes(int H, int W, int S, int D) { return (H > 0 && W > 0 && S > 0 && D > 0) ? wvn_wire_bytes_impl(H, W, S, D) : 0; }
+int wvn_wire_pack(const void* seg, int seg_is_i64, const float* feat, int ldf, void* out, int H, int W, int S, int D, void* stream) {
+  return wvn_wire_pack_launch(seg, seg_is_i64, feat, ldf, out, H, W, S, D, (hipStream_t)stream);
+}
+int wvn_wire_unpack(const void* in, long long* seg_i64, int* seg_i32, float* feat, int H, int W, int S, int D, void* stream) {
+  return wvn_wire_unpack_launch(in, seg_i64, seg_i32, feat, H, W, S, D, (hipStream_t)stream);
+}
 int wvn_slic_num_clusters(int H, int W, int num_components) {
   return (H > 0 && W > 0 && num_components > 0) ? wvn_slic_num_clusters_impl(H, W, num_components) : 0;
 }

@@ -20,7 +20,7 @@ LIB = os.path.join(PKG, "lib", "libwvn_hip.so")
 SOURCES = [
     "api.hip", "gemm_bf16.hip", "gemm_a384.hip", "gemm_n384.hip", "gemm_x3.hip", "gemm_f32.hip", "elementwise.hip", "attention_bf16.hip",
     "attention_x3.hip", "attention_f32.hip",
-    "segments.hip", "stego.hip", "mlp.hip", "pixel_mlp.hip", "supervision.hip", "slic.hip",
+    "segments.hip", "stego.hip", "mlp.hip", "pixel_mlp.hip", "supervision.hip", "slic.hip", "wire.hip",
 ]
 HEADERS = ["common.h", "wvn_internal.h", os.path.join("..", "..", "include", "wvn_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall",

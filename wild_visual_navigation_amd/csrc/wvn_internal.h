@@ -158,3 +158,10 @@ int wvn_slic_num_clusters_impl(int H, int W, int num_components);
 size_t wvn_slic_scratch_bytes_impl(int H, int W, int num_components);
 int wvn_slic_launch(const void* img, int img_u8, int H, int W, int num_components, float compactness, int iters,
                     const int* lut_lin, const int* lut_f, int* labels, void* scratch, size_t scratch_bytes, hipStream_t st);
+
+// ---- A -> B wire format (wire.hip) ---------------------------------------------------------------------------------------
+size_t wvn_wire_bytes_impl(int H, int W, int S, int D);
+int wvn_wire_pack_launch(const void* seg, int seg_is_i64, const float* feat, int ldf, void* out, int H, int W, int S, int D,
+                         hipStream_t st);
+int wvn_wire_unpack_launch(const void* in, long long* seg_i64, int* seg_i32, float* feat, int H, int W, int S, int D,
+                           hipStream_t st);
