@@ -29,7 +29,7 @@ def _cam_looking_forward_down(x, y, yaw, pitch=0.5, h=0.8):
     base = _pose(x, y, yaw, h)
     R = torch.tensor([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])         # camera axes in the base frame
     cp, sp = math.cos(pitch), math.sin(pitch)
-    Rp = torch.tensor([[1.0, 0, 0], [0, cp, -sp], [0, sp, cp]])                       # pitch about the camera's x axis
+    Rp = torch.tensor([[1.0, 0, 0], [0, cp, sp], [0, -sp, cp]])                       # tilt the optical axis DOWN (camera y points down)
     T = torch.eye(4)
     T[:3, :3] = R @ Rp
     return base @ T
