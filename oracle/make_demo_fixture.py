@@ -31,6 +31,13 @@ def main():
     torch.save({"names": names, "frames_u8": torch.stack(frames),
                 "source": "leggedrobotics/wild_visual_navigation assets/demo_data, quick_start.py:156-174 preprocessing"}, OUT)
     print("wrote", OUT, names, torch.stack(frames).shape)
+    # the one real 448 x 448 frame the reference ships (assets/graph/img.png, the visualiser demo's input): BASELINE's full size
+    p448 = "/root/reference/assets/graph/img.png"
+    img = torch.from_numpy(np.array(Image.open(p448).convert("RGB"))).permute(2, 0, 1).contiguous()
+    assert img.shape == (3, 448, 448) and img.dtype == torch.uint8
+    out448 = os.path.join(os.path.dirname(OUT), "graph_img_448.pt")
+    torch.save({"name": "assets/graph/img.png", "frame_u8": img}, out448)
+    print("wrote", out448, tuple(img.shape))
 
 
 if __name__ == "__main__":

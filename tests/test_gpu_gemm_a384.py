@@ -59,7 +59,8 @@ def test_a384_gelu_is_the_erf_gelu_to_one_bf16_ulp(dev):
     ulp = torch.ldexp(torch.ones_like(want), torch.floor(torch.log2(want.abs().clamp_min(1e-300))).int() - 7).clamp_min(2.0 ** -20)
     err = (out[:, 0].double() - want).abs() / ulp
     assert err.max().item() <= 1.0, err.max().item()
-    assert (out[:, 0] == exact_bf16).float().mean().item() > 0.9         # and nearly always the correctly rounded value itself
+    # a deviation of up to 0.25 ulp before the rounding moves at most ~1/4 of the values to the neighbouring bf16
+    assert (out[:, 0] == exact_bf16).float().mean().item() > 0.7
     assert torch.equal(out, out[:, :1].expand(M, N))
 
 

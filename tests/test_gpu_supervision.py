@@ -47,7 +47,7 @@ def test_project_render_fmin_matches_oracle_bit_for_bit(dev):
     H, W, n = 120, 160, 5
     Ks = [_K(110.0 + 7 * i, 80.0 + i, 60.0 - i) for i in range(n)]
     poses = [_cam_looking_forward_down(0.2 * i, -0.1 * i, 0.1 * i - 0.2, 0.45 + 0.03 * i) for i in range(n)]
-    poses[4] = _cam_looking_forward_down(5.0, 0.0, math.pi, 0.5)        # looks away: every point behind the camera -> untouched
+    poses[4] = _cam_looking_forward_down(5.0, 0.0, 0.0, 0.5)            # beyond the footprint, looking away: every point behind the camera -> untouched
     quad = torch.tensor([[1.2, 0.35, 0.0], [1.2, -0.35, 0.0], [2.4, -0.45, 0.0], [2.4, 0.45, 0.0]])
     from wild_visual_navigation_amd.utils import make_polygon_from_points
 

@@ -143,3 +143,44 @@ def test_dinov2_layerscale_patch14(dev, arch, heads, S, depth, B):
         assert err < tol, (prec, err)
     got = VitBackbone(sd, S, 14, heads, device=dev, precision="bf16", max_chunk=2).forward_tokens(img.to(dev)).cpu()
     assert ((got - want).norm() / want.norm()).item() < 2.5e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# "Test what you bench": the instantiations bench.py actually launches, against the oracle
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_reference_448_frame_through_the_full_backbone(dev, golden):
+    """assets/graph/img.png -- the one real 448 x 448 frame the reference ships -- through all 12 blocks in every precision."""
+    u8 = golden("graph_img_448.pt")["frame_u8"]
+    img = (u8.float() / 255)[None]
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0)
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    got = VitBackbone(sd, 448, 8, 6, device=dev, precision="exact").forward_tokens(img.to(dev)).cpu()
+    err = (got - want).abs().max().item()
+    print(f"img.png 448^2 exact: max|err| = {err:.3e}")
+    assert err < 1e-3
+    bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16")
+    got = bb.forward_tokens(img.to(dev)).cpu()
+    rel = ((got - want).norm() / want.norm()).item()
+    print(f"img.png 448^2 bf16: rel-L2 = {rel:.3e}, max|err| = {(got - want).abs().max().item():.3e}")
+    assert rel < 2.5e-2
+    assert torch.equal(bb.forward_tokens(u8[None].to(dev)).cpu(), got)          # uint8 ingest: bit-identical
+
+
+def test_bf16_shipped_instantiations_at_448(dev):
+    """bf16 path exactly as bench.py drives it, scaled down in depth only: 448^2 (25 query blocks, 50 key tiles, masked tail),
+    B = 16 frames in ONE launch sequence -> (frame, head) count 96 = XCD-ordered attention, pre-scaled-q kernel; 50,432 token
+    rows = 197 row blocks -> the fc2 row-panel kernel WITH its thin-last-round hand-over to the tiled kernel (the dispatcher's
+    threshold is 192 row blocks); A-stationary K = 384 kernels with the persistent unit-balanced schedule."""
+    B = 16
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=2, depth=2)
+    img = torch.rand(B, 3, 448, 448, generator=g(11))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=B)
+    got = bb.forward_tokens(img.to(dev)).cpu()
+    rel = ((got - want).norm() / want.norm()).item()
+    print(f"bf16 448^2 B=16 (XCD attention, row-panel fc2): rel-L2 = {rel:.3e}, max|err| = {(got - want).abs().max().item():.3e}")
+    assert rel < 1e-2 and (got - want).abs().max().item() < 0.15
+    # the same frames one at a time take the non-XCD attention instantiation and the tiled fc2 kernel: same bits
+    one = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=1)
+    for b in (0, 7, 15):
+        assert torch.equal(one.forward_tokens(img[b:b + 1].to(dev)).cpu()[0], got[b]), b
