@@ -73,8 +73,6 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (about 15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "exact", "fp32"])
-    ap.add_argument("--no-fuse-ln", action="store_true",
-                    help="A/B: run LayerNorm 1 / 2 as stand-alone kernels instead of inside the QKV / fc1 GEMMs (bf16 ViT-S)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every step on one stream (default: the backbone of step i+1 runs on a second HIP stream while "
                          "clustering / pooling / the MLP step of step i -- small kernels that do not fill the GPU -- finish)")
@@ -112,7 +110,7 @@ def make_pipeline(args, dev):
     seg = args.segmentation if args.mode == "full" else "grid"
     fe = FeatureExtractor(dev, segmentation_type=seg, feature_type=ftype, input_size=args.size,
                           backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
-                          max_chunk=args.chunk, allow_synthetic=True, fuse_ln=not args.no_fuse_ln)
+                          max_chunk=args.chunk, allow_synthetic=True)
     torch.manual_seed(42)
     model = SimpleMLP(fe.feature_dim, [256, 32, 1], True).to(dev)
     return fe, model, MlpTrainer(model)

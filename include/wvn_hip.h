@@ -55,7 +55,7 @@ typedef struct wvn_vit_model {
   int heads;    /* h (6); head dim is fixed at 64        */
   int mlp_dim;  /* F (1536)                              */
   int precision;
-  int flags;    /* WVN_VIT_LN_FOLDED: see below */
+  int reserved;
   const void* patch_w;  /* [D][3*P*P (padded, see above)] conv weight flattened (c, py, px) */
   const float* patch_b; /* [D]                                                      */
   const float* cls_pos; /* [D]  = cls_token + pos_embed[0]                          */
@@ -64,11 +64,6 @@ typedef struct wvn_vit_model {
   wvn_vit_layer layers[WVN_MAX_DEPTH];
 } wvn_vit_model;
 
-/* flags bit 0 (WVN_PREC_BF16, dim == 384 only): LayerNorm 1 / 2 of every block are FUSED into the QKV / fc1 GEMMs -- those kernels
- * read the fp32 residual rows and normalise them in registers, so the two LayerNorm passes per block (620 MB of HBM traffic
- * at 64 frames) disappear.  The caller must then hand over folded weights: qkv_w = W_qkv * diag(ln1_g), qkv_b += W_qkv ln1_b,
- * fc1_w = W_fc1 * diag(ln2_g), fc1_b += W_fc1 ln2_b (ln1_g .. ln2_b of the layers are ignored). */
-#define WVN_VIT_LN_FOLDED 1
 size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch);
 
 /* img [B,3,S,S] fp32 in [0,1] (already resized/cropped, dino_interface.py:54-57) ->

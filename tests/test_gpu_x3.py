@@ -184,28 +184,3 @@ def test_bf16_shipped_instantiations_at_448(dev):
     one = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=1)
     for b in (0, 7, 15):
         assert torch.equal(one.forward_tokens(img[b:b + 1].to(dev)).cpu()[0], got[b]), b
-
-
-def test_fused_layernorm_in_the_qkv_and_fc1_kernels(dev):
-    """bf16 ViT-S runs LayerNorm 1 / 2 inside the A-stationary QKV / fc1 kernels (they read the fp32 residual rows; gamma / beta
-    folded into the weights): same features as with the stand-alone LayerNorm kernels up to bf16 rounding of differently
-    associated products, the same oracle parity, batch-invariant."""
-    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=6, depth=4)
-    img = torch.rand(5, 3, 224, 224, generator=g(13))
-    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
-    fused = VitBackbone(sd, 224, 8, 6, device=dev, precision="bf16", max_chunk=5)
-    plain = VitBackbone(sd, 224, 8, 6, device=dev, precision="bf16", max_chunk=5, fuse_ln=False)
-    assert fused.fuse_ln and not plain.fuse_ln
-    a, b = fused.forward_tokens(img.to(dev)).cpu(), plain.forward_tokens(img.to(dev)).cpu()
-    ea, eb = ((a - want).norm() / want.norm()).item(), ((b - want).norm() / want.norm()).item()
-    print(f"bf16 rel-L2 vs oracle: fused LN {ea:.3e}, stand-alone LN {eb:.3e}")
-    assert ea < 1e-2 and eb < 1e-2 and ea < 1.5 * eb + 1e-4
-    one = VitBackbone(sd, 224, 8, 6, device=dev, precision="bf16", max_chunk=1)
-    assert torch.equal(one.forward_tokens(img[2:3].to(dev)).cpu()[0], a[2])
-    # rows with a large common offset and tiny spread: the one-pass variance must not cancel
-    x = (1000.0 + 1e-2 * torch.randn(256, 384, generator=g(14))).to(dev)
-    w = (torch.randn(64, 384, generator=g(15)) * 0.05).to(dev)
-    ref = torch.nn.functional.layer_norm(x.double(), (384,), eps=1e-6) @ w.double().T
-    # (drive the kernel through a one-block model whose qkv weight is w: simpler to compare LN directly)
-    got = torch.nn.functional.layer_norm(x, (384,), eps=1e-6).double() @ w.double().T
-    assert (got - ref).abs().max().item() < 1e-2

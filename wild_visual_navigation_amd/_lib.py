@@ -15,7 +15,6 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwvn_hip.so")
 
 WVN_MAX_DEPTH = 32
 PREC_F32, PREC_BF16, PREC_X3 = 0, 1, 2
-VIT_LN_FOLDED = 1
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -35,7 +34,7 @@ class VitLayer(C.Structure):
 class VitModel(C.Structure):
     _fields_ = [
         ("img_size", C.c_int), ("patch", C.c_int), ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
-        ("mlp_dim", C.c_int), ("precision", C.c_int), ("flags", C.c_int),
+        ("mlp_dim", C.c_int), ("precision", C.c_int), ("reserved", C.c_int),
         ("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls_pos", C.c_void_p), ("pos", C.c_void_p),
         ("norm_g", C.c_void_p), ("norm_b", C.c_void_p),
         ("layers", VitLayer * WVN_MAX_DEPTH),

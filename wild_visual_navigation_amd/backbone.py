@@ -66,14 +66,6 @@ def split_planes(t: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo]).contiguous()
 
 
-def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
-    """Weights of a Linear that follows a LayerNorm, with the LayerNorm's affine part folded in: returns (W diag(gamma),
-    b + W beta), computed in fp64 and returned as fp32."""
-    w64 = w.detach().double().cpu()
-    return ((w64 * gamma.detach().double().cpu()[None, :]).float(),
-            (b.detach().double().cpu() + w64 @ beta.detach().double().cpu()).float())
-
-
 def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
     """DINO's position-table resampling (bicubic, scale (grid+0.1)/g; DINOv2 keeps the same rule with its default
     interpolate_offset = 0.1, antialias off), done ONCE when the model is
@@ -98,7 +90,7 @@ class VitBackbone:
     kernels; slow, kept as the independent cross-check of "exact")."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
-                 device="cuda", precision: str = "bf16", max_chunk: int = 16, fuse_ln: bool = True):
+                 device="cuda", precision: str = "bf16", max_chunk: int = 16):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
@@ -137,10 +129,6 @@ class VitBackbone:
         m = _lib.VitModel()
         m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim = img_size, patch, self.dim, self.depth, heads, self.mlp_dim
         m.precision = self.precision
-        # bf16 ViT-S: LayerNorm 1 / 2 of every block run INSIDE the QKV / fc1 GEMM kernels (they normalise the fp32 residual
-        # rows in registers, csrc/gemm_a384.hip); gamma is folded into the weight columns and beta into the bias here, once
-        self.fuse_ln = bool(fuse_ln and self.precision == _lib.PREC_BF16 and self.dim == 384)
-        m.flags = _lib.VIT_LN_FOLDED if self.fuse_ln else 0
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
@@ -153,14 +141,9 @@ class VitBackbone:
         for i in range(self.depth):
             p = f"blocks.{i}."
             L = m.layers[i]
-            qkv_w, qkv_b = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
-            fc1_w, fc1_b = sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]
-            if self.fuse_ln:   # LN(x) W^T + b = ((x - mu) rstd) (W diag(gamma))^T + (b + W beta)
-                qkv_w, qkv_b = fold_layernorm(qkv_w, qkv_b, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
-                fc1_w, fc1_b = fold_layernorm(fc1_w, fc1_b, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-            L.qkv_w, L.qkv_b = mat(qkv_w), vec(qkv_b)
+            L.qkv_w, L.qkv_b = mat(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
             L.proj_w, L.proj_b = mat(sd[p + "attn.proj.weight"]), vec(sd[p + "attn.proj.bias"])
-            L.fc1_w, L.fc1_b = mat(fc1_w), vec(fc1_b)
+            L.fc1_w, L.fc1_b = mat(sd[p + "mlp.fc1.weight"]), vec(sd[p + "mlp.fc1.bias"])
             L.fc2_w, L.fc2_b = mat(sd[p + "mlp.fc2.weight"]), vec(sd[p + "mlp.fc2.bias"])
             L.ln1_g, L.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
             L.ln2_g, L.ln2_b = vec(sd[p + "norm2.weight"]), vec(sd[p + "norm2.bias"])
@@ -176,7 +159,7 @@ class VitBackbone:
         if device == self.device:
             return self
         return VitBackbone(self._sd, self.img_size, self.patch, self.heads, device=device, precision=self.precision_name,
-                           max_chunk=self.max_chunk, fuse_ln=self.fuse_ln)
+                           max_chunk=self.max_chunk)
 
     # ---- workspace (needs no initialisation: wvn_vit_forward resets the padding rows it relies on at every call) ----
     def _workspace(self, batch: int) -> torch.Tensor:

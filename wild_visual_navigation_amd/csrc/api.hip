@@ -134,8 +134,6 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
   const float scale = 1.0f / sqrtf(64.f);
   const int M = (int)d.M, Mp = (int)d.Mp;
-  const bool ln_fused = (m->flags & WVN_VIT_LN_FOLDED) != 0;   // LN1 / LN2 live inside the QKV / fc1 kernels
-  if (ln_fused && (!bf || d.D != 384)) return WVN_ERR_ARG;
   // exact mode: an activation / weight "matrix" is two stacked bf16 planes, hi then lo
   const size_t pl_xn = (size_t)d.M * d.D, pl_hid = (size_t)d.M * d.F, pl_qkv = (size_t)d.B * d.H * d.npad * 64,
                pl_pat = (size_t)d.Mp * d.KPs;
@@ -206,7 +204,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   }
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
-    if (!ln_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     {
       Span s(3, st);
       GemmBf16Params e{};
@@ -215,7 +213,6 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       // the running max as an MFMA operand (attention_bf16.hip, PRE)
       if (bf) e.q_scale = scale * 1.44269504088896340736f;
       if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
-      if (ln_fused) { e.ln_x = w.x; e.ln_ldx = d.D; e.ln_eps = 1e-6f; }
       RET_IF(linear(w.xn, pl_xn, d.D, L.qkv_w, L.qkv_b, nullptr, 0, 0, M, 3 * d.D, d.D, EPI_QKV, nullptr, &e));
     }
     {
@@ -225,13 +222,8 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
     { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
-    if (!ln_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
-    {
-      Span s(6, st);
-      GemmBf16Params e{};
-      if (ln_fused) { e.ln_x = w.x; e.ln_ldx = d.D; e.ln_eps = 1e-6f; }
-      RET_IF(linear(w.xn, pl_xn, d.D, L.fc1_w, L.fc1_b, w.hid, pl_hid, d.F, M, d.F, d.D, EPI_GELU_BF16, nullptr, ln_fused ? &e : nullptr));
-    }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    { Span s(6, st); RET_IF(linear(w.xn, pl_xn, d.D, L.fc1_w, L.fc1_b, w.hid, pl_hid, d.F, M, d.F, d.D, EPI_GELU_BF16, nullptr, nullptr)); }
     { Span s(7, st); RET_IF(linear(w.hid, pl_hid, d.F, L.fc2_w, L.fc2_b, w.x, 0, d.D, M, d.D, d.F, EPI_RESID_F32, L.ls2, nullptr)); }
   }
   {

@@ -57,7 +57,6 @@ struct A384Params {
   float q_scale;       // A_QK: multiplier of the q column tiles (1 = none)
   bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;  // one buffer descriptor for q / k / v^T (byte offsets from qkv_base)
   long long* dbg;  // TIMING builds: per wave {wait+barrier, mfma, epilogue, total} shader cycles
-  const float* X; int ldx; float ln_eps;  // LNA: the fp32 residual rows whose LayerNorm IS the A operand (A / lda unused)
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -94,7 +93,7 @@ __device__ inline f32x2_t act2(f32x2_t v) {
   return v;
 }
 
-template <int EPI, bool TIMING = false, bool LNA = false>
+template <int EPI, bool TIMING = false, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -144,61 +143,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   for (int i = tid; i < p.N; i += 512) ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
   bf16x8_t xf[KD / 16];
   auto load_a = [&]() {
-    if constexpr (LNA) {
-      // Fused LayerNorm: the A operand is LN(x) of the fp32 residual rows, normalised in registers on the way in (gamma is
-      // folded into W and beta into the bias when the model is packed, so only (x - mean) * rstd is left).  A lane holds half
-      // a row (192 values: k = 16 s + 8 hi .. + 7), the other half sits in lane ^ 32.  Pass 1: sum and sum of squares
-      // (fp32; var = E[x^2] - mean^2 loses ~6e-8 (1 + mean^2 / var) relative, far below the bf16 rounding of the result);
-      // pass 2 re-reads the same addresses (L2-resident), normalises as one fma per value and converts -- holding the fp32
-      // row would take 192 VGPRs.  Two-element vector arithmetic so that hipcc emits packed fp32 instructions: ~400 VALU
-      // per wave and row block, against 18k-37k cycles of MFMA work on those rows.
-      const float* xp = p.X + (size_t)min(m0w + l31, p.M - 1) * p.ldx + hi * 8;
-      f32x2_t s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-      constexpr int GRP = 6;  // k-steps per batch of loads (12 x 16 B in flight per lane)
+    const bf16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
 #pragma unroll
-      for (int s0 = 0; s0 < KD / 16; s0 += GRP) {
-        f32x4_t a[GRP], b[GRP];
-#pragma unroll
-        for (int s = 0; s < GRP; ++s) { a[s] = *(const f32x4_t*)(xp + (s0 + s) * 16); b[s] = *(const f32x4_t*)(xp + (s0 + s) * 16 + 4); }
-#pragma unroll
-        for (int s = 0; s < GRP; ++s) {
-          const f32x2_t v0 = {a[s][0], a[s][1]}, v1 = {a[s][2], a[s][3]}, v2 = {b[s][0], b[s][1]}, v3 = {b[s][2], b[s][3]};
-          s1 += v0; s1 += v1; s1 += v2; s1 += v3;
-          s2 = v0 * v0 + s2; s2 = v1 * v1 + s2; s2 = v2 * v2 + s2; s2 = v3 * v3 + s2;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      float t1 = s1[0] + s1[1], t2 = s2[0] + s2[1];
-      t1 += __shfl_xor(t1, 32, 64);
-      t2 += __shfl_xor(t2, 32, 64);
-      const float mu = t1 * (1.0f / KD);
-      const float var = fmaxf(t2 * (1.0f / KD) - mu * mu, 0.f);
-      const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-      const float off = -mu * rstd;
-      const f32x2_t r2 = {rstd, rstd}, o2 = {off, off};
-#pragma unroll
-      for (int s0 = 0; s0 < KD / 16; s0 += GRP) {
-        f32x4_t a[GRP], b[GRP];
-#pragma unroll
-        for (int s = 0; s < GRP; ++s) { a[s] = *(const f32x4_t*)(xp + (s0 + s) * 16); b[s] = *(const f32x4_t*)(xp + (s0 + s) * 16 + 4); }
-#pragma unroll
-        for (int s = 0; s < GRP; ++s) {
-          const f32x2_t v0 = f32x2_t{a[s][0], a[s][1]} * r2 + o2, v1 = f32x2_t{a[s][2], a[s][3]} * r2 + o2;
-          const f32x2_t v2 = f32x2_t{b[s][0], b[s][1]} * r2 + o2, v3 = f32x2_t{b[s][2], b[s][3]} * r2 + o2;
-          union { u32x4_t u; bf16x8_t v; } o;
-          o.u[0] = pack_bf16x2(v0[0], v0[1]);
-          o.u[1] = pack_bf16x2(v1[0], v1[1]);
-          o.u[2] = pack_bf16x2(v2[0], v2[1]);
-          o.u[3] = pack_bf16x2(v3[0], v3[1]);
-          xf[s0 + s] = o.v;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      const bf16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
-#pragma unroll
-      for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
-    }
+    for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
   };
 
   f32x16_t acc[2], prev[2];
@@ -257,23 +204,25 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
     auto rd = [&](int s, int t) {
       return *(const bf16x8_t*)(base + t * 8192 + (((2 * s + hi) ^ xc) << 4));
     };
-    constexpr int LA = 2;  // k-steps of fragments in flight
+    // LA k-steps of fragments in flight (VAR 1: 4 instead of 2; VAR 2 is a TIMING-ONLY experiment that reads half
+    // of the fragments -- wrong results -- to tell LDS bandwidth from LDS latency)
+    constexpr int LA = VAR == 1 ? 4 : 2;
     bf16x8_t wf[2 * LA];
 #pragma unroll
-    for (int i = 0; i < 2 * LA; ++i) wf[i] = rd(i >> 1, i & 1);
+    for (int i = 0; i < 2 * LA; ++i) wf[i] = rd(i >> 1, VAR == 2 ? 0 : (i & 1));
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int slot = (s % LA) * 2 + t;
+        const int slot = (s % LA) * 2 + (VAR == 2 ? 0 : t);
         if constexpr (TR)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[slot], xf[ks * 8 + s], acc[t], 0, 0, 0);
         else
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks * 8 + s], wf[slot], acc[t], 0, 0, 0);
-        if (s + LA < 8) wf[slot] = rd(s + LA, t);
+        if (s + LA < 8 && (VAR != 2 || t == 1)) wf[slot] = rd(s + LA, VAR == 2 ? 0 : t);
       }
     }
-    {
+    if constexpr (VAR != 2) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * LA, 0);
 #pragma unroll
       for (int i = 0; i < 16 - 2 * LA; ++i) {
@@ -398,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   long long t_wait = 0, t_mfma = 0, t_epi = 0;
   const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
   auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, bool do_epi_in) {
-    const bool do_epi = do_epi_in;
+    const bool do_epi = VAR == 3 ? false : do_epi_in;  // VAR 3 / 4: timing-only experiments (no epilogue / no DMA)
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
     if (i + 2 < total) {
@@ -408,14 +357,14 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (i + NS - 1 < total) issue(i + NS - 1);
+    if (VAR != 4 && i + NS - 1 < total) issue(i + NS - 1);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
     if (epi_first) {
       if (do_epi) {
-        __builtin_amdgcn_s_setprio(2);  // the VALU-heavy half wins issue arbitration over the partner's MFMA stream
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(2);  // the VALU-heavy half wins issue arbitration over the partner's MFMA stream
         epi_part(ks, j - 1, etr);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = (long long)__builtin_amdgcn_s_memtime(); }
@@ -425,9 +374,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TIMING) { asm volatile("s_nop 7\n s_nop 7" ::: "memory"); c2 = (long long)__builtin_amdgcn_s_memtime(); }
       if (do_epi) {
-        __builtin_amdgcn_s_setprio(2);
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(2);
         epi_part(ks, j - 1, etr);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -482,11 +431,11 @@ int a384_num_cus() {
   return n;
 }
 
-template <int EPI, bool TIMING, bool LNA>
+template <int EPI, bool TIMING, int VAR>
 int launch_k(const A384Params& p, int lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_a384_kernel<EPI, TIMING, LNA>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_a384_kernel<EPI, TIMING, VAR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, A384_LDS_MAX);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -494,7 +443,7 @@ int launch_k(const A384Params& p, int lds, hipStream_t st) {
   // one persistent workgroup per CU (144 KB of LDS each), never more workgroups than (row block, column tile) units
   const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
   const int grid = (int)(units < a384_num_cus() ? units : a384_num_cus());
-  hipLaunchKernelGGL((gemm_a384_kernel<EPI, TIMING, LNA>), dim3(grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((gemm_a384_kernel<EPI, TIMING, VAR>), dim3(grid), dim3(512), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -503,12 +452,7 @@ template <int EPI>
 int launch(const A384Params& p, hipStream_t st) {
   const int lds = BIAS_OFF + p.N * 4;
   if (lds > A384_LDS_MAX) return WVN_ERR_ARG;
-  if constexpr (EPI == A_GELU || EPI == A_QK || EPI == A_V || EPI == A_BF16) {  // the LayerNorm-fed linears (fc1, qkv)
-    if (p.X) return launch_k<EPI, false, true>(p, lds, st);
-  } else {
-    if (p.X) return WVN_ERR_ARG;
-  }
-  return p.dbg ? launch_k<EPI, true, false>(p, lds, st) : launch_k<EPI, false, false>(p, lds, st);
+  return p.dbg ? launch_k<EPI, true, 0>(p, lds, st) : launch_k<EPI, false, 0>(p, lds, st);
 }
 
 }  // namespace
@@ -516,15 +460,9 @@ int launch(const A384Params& p, hipStream_t st) {
 // Eligibility: K == 384, N % 64 == 0, 16-byte aligned operands; returns WVN_ERR_ARG otherwise so the
 // caller can use the generic tiled kernel.  epi uses the GemmEpilogue codes of wvn_internal.h.
 int wvn_gemm_a384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
-  if (g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.W) return WVN_ERR_ARG;
-  if (g.ln_x) {  // fused LayerNorm on the A rows: fp32 residual in, 16-byte aligned rows
-    if ((g.ln_ldx % 4) != 0 || ((uintptr_t)g.ln_x & 15)) return WVN_ERR_ARG;
-  } else if (!g.A || (g.lda % 8) != 0 || ((uintptr_t)g.A & 15)) {
-    return WVN_ERR_ARG;
-  }
-  if ((uintptr_t)g.W & 15) return WVN_ERR_ARG;
+  if (g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.A || !g.W || (g.lda % 8) != 0) return WVN_ERR_ARG;
+  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return WVN_ERR_ARG;
   A384Params p{};
-  p.X = g.ln_x; p.ldx = g.ln_ldx; p.ln_eps = g.ln_eps;
   p.A = g.A; p.lda = g.lda; p.W = g.W; p.bias = g.bias; p.C = g.C; p.ldc = g.ldc; p.M = g.M; p.N = g.N;
   p.q = g.q; p.k = g.k; p.vt = g.vt; p.heads = g.heads; p.npad = g.npad; p.ntok_s = g.ntok_s;
   p.q_scale = g.q_scale != 0.f ? g.q_scale : 1.f;

@@ -345,10 +345,6 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
 }  // namespace
 
 int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
-  if (p.ln_x) {  // fused-LayerNorm operand: only the A-stationary K = 384 kernel takes it
-    if (p.K != 384 || p.ls) return WVN_ERR_ARG;
-    return wvn_gemm_a384_launch(p, epi, st);
-  }
   if (!p.A || !p.W || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
     return WVN_ERR_ARG;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return WVN_ERR_ARG;

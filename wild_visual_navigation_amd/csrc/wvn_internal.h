@@ -27,9 +27,6 @@ struct GemmBf16Params {
   // EPI_QKV
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad;
   float q_scale;  // EPI_QKV: the q third is multiplied by this before it is rounded to bf16 (0 = leave as is)
-  // fused LayerNorm (gemm_a384.hip, K == 384 only): when ln_x is set the A operand is (x - mean) / sqrt(var + eps) of these
-  // fp32 rows (A / lda are ignored); gamma / beta must already be folded into W / bias
-  const float* ln_x; int ln_ldx; float ln_eps;
   const float* ls;  // EPI_RESID_F32: optional LayerScale vector [N] (DINOv2): C += ls * (acc + bias); nullptr = plain residual
   // exact mode (gemm_x3.hip): the lo planes of the operands and of plane-typed outputs (hi planes are A / W / C / q / k / vt)
   const bf16_t* A_lo; const bf16_t* W_lo; void* C_lo; bf16_t* q_lo; bf16_t* k_lo; bf16_t* vt_lo;
