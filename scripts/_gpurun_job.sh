@@ -1,10 +1,9 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 5 > gpurun_out/r02a_bench_bf16.json 2> gpurun_out/r02a_bench_bf16.err
-python bench.py --precision exact --steps 20 --warmup 5 > gpurun_out/r02a_bench_exact.json 2> gpurun_out/r02a_bench_exact.err
-python bench.py --mode backbone --steps 20 --warmup 5 > gpurun_out/r02a_bench_backbone.json 2> gpurun_out/r02a_bench_backbone.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r02a_exact -o r02a -- python bench.py --precision exact --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r02a_prof_exact.log 2>&1
-python scripts/summarize_profile.py db $(find gpurun_out/prof_r02a_exact -name "*.db" | head -1) > gpurun_out/r02a_exact_kernel_stats.md 2>> gpurun_out/r02a_prof_exact.log
-rm -rf gpurun_out/prof_r02a_exact
-tail -3 gpurun_out/*.err; cat gpurun_out/r02a_bench_*.json; cat gpurun_out/r02a_exact_kernel_stats.md
+python -m pytest tests/test_gpu_x3.py tests/test_gpu_supervision.py tests/test_gpu_gemm_a384.py tests/test_gpu_backbone.py tests/test_gpu_distributed.py tests/test_gpu_bridge.py tests/test_gpu_slic.py -m gpu -q -s 2>&1 | tail -120 > gpurun_out/r02c_tests.log
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r02c_bench_fused.json 2> gpurun_out/r02c_bench_fused.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fuse-ln > gpurun_out/r02c_bench_unfused.json 2> gpurun_out/r02c_bench_unfused.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r02c_bench_fused2.json 2>> gpurun_out/r02c_bench_fused.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --precision exact > gpurun_out/r02c_bench_exact.json 2> gpurun_out/r02c_bench_exact.err
+tail -30 gpurun_out/r02c_tests.log; tail -3 gpurun_out/*.err; cat gpurun_out/r02c_bench_*.json

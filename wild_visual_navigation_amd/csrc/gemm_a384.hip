@@ -77,9 +77,9 @@ __device__ inline f32x2_t gelu_fast2(f32x2_t x) {
   t = t * x2 + k1;
   t = t * x2 + k0;
   f32x2_t y = t * x;
-  // the polynomial is only fitted (and monotone) on |x| <= 9: beyond that the result is x or -0 to every bit of a bf16 anyway
-  y[0] = fminf(fmaxf(y[0], -126.f), 126.f);
-  y[1] = fminf(fmaxf(y[1], -126.f), 126.f);
+  // (fitted on |x| <= 9; beyond that the polynomial factor stays negative -- -1.286e-5 x^2 + 1.435e-3 < 0 from x^2 = 112 on and
+  // the outer terms only add negative amounts -- so y -> -inf / +inf, exp2 -> 0 / inf, and the result saturates to x / -0
+  // for every finite x without a clamp)
   f32x2_t e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};  // exp(-g)
   e = e + one;
   const f32x2_t r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
@@ -93,7 +93,7 @@ __device__ inline f32x2_t act2(f32x2_t v) {
   return v;
 }
 
-template <int EPI, bool TIMING = false, int VAR = 0>
+template <int EPI, bool TIMING = false>
 __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -204,25 +204,23 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
     auto rd = [&](int s, int t) {
       return *(const bf16x8_t*)(base + t * 8192 + (((2 * s + hi) ^ xc) << 4));
     };
-    // LA k-steps of fragments in flight (VAR 1: 4 instead of 2; VAR 2 is a TIMING-ONLY experiment that reads half
-    // of the fragments -- wrong results -- to tell LDS bandwidth from LDS latency)
-    constexpr int LA = VAR == 1 ? 4 : 2;
+    constexpr int LA = 2;  // k-steps of fragments in flight
     bf16x8_t wf[2 * LA];
 #pragma unroll
-    for (int i = 0; i < 2 * LA; ++i) wf[i] = rd(i >> 1, VAR == 2 ? 0 : (i & 1));
+    for (int i = 0; i < 2 * LA; ++i) wf[i] = rd(i >> 1, i & 1);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int slot = (s % LA) * 2 + (VAR == 2 ? 0 : t);
+        const int slot = (s % LA) * 2 + t;
         if constexpr (TR)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[slot], xf[ks * 8 + s], acc[t], 0, 0, 0);
         else
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks * 8 + s], wf[slot], acc[t], 0, 0, 0);
-        if (s + LA < 8 && (VAR != 2 || t == 1)) wf[slot] = rd(s + LA, VAR == 2 ? 0 : t);
+        if (s + LA < 8) wf[slot] = rd(s + LA, t);
       }
     }
-    if constexpr (VAR != 2) {
+    {
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * LA, 0);
 #pragma unroll
       for (int i = 0; i < 16 - 2 * LA; ++i) {
@@ -347,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
   long long t_wait = 0, t_mfma = 0, t_epi = 0;
   const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
   auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, bool do_epi_in) {
-    const bool do_epi = VAR == 3 ? false : do_epi_in;  // VAR 3 / 4: timing-only experiments (no epilogue / no DMA)
+    const bool do_epi = do_epi_in;
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
     if (i + 2 < total) {
@@ -357,14 +355,14 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (VAR != 4 && i + NS - 1 < total) issue(i + NS - 1);
+    if (i + NS - 1 < total) issue(i + NS - 1);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
     if (epi_first) {
       if (do_epi) {
-        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(2);  // the VALU-heavy half wins issue arbitration over the partner's MFMA stream
+        __builtin_amdgcn_s_setprio(2);  // the VALU-heavy half wins issue arbitration over the partner's MFMA stream
         epi_part(ks, j - 1, etr);
-        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = (long long)__builtin_amdgcn_s_memtime(); }
@@ -374,9 +372,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TIMING) { asm volatile("s_nop 7\n s_nop 7" ::: "memory"); c2 = (long long)__builtin_amdgcn_s_memtime(); }
       if (do_epi) {
-        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(2);
         epi_part(ks, j - 1, etr);
-        if constexpr (VAR != 2) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -431,11 +429,11 @@ int a384_num_cus() {
   return n;
 }
 
-template <int EPI, bool TIMING, int VAR>
+template <int EPI, bool TIMING>
 int launch_k(const A384Params& p, int lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_a384_kernel<EPI, TIMING, VAR>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_a384_kernel<EPI, TIMING>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, A384_LDS_MAX);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -443,7 +441,7 @@ int launch_k(const A384Params& p, int lds, hipStream_t st) {
   // one persistent workgroup per CU (144 KB of LDS each), never more workgroups than (row block, column tile) units
   const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
   const int grid = (int)(units < a384_num_cus() ? units : a384_num_cus());
-  hipLaunchKernelGGL((gemm_a384_kernel<EPI, TIMING, VAR>), dim3(grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((gemm_a384_kernel<EPI, TIMING>), dim3(grid), dim3(512), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -452,7 +450,7 @@ template <int EPI>
 int launch(const A384Params& p, hipStream_t st) {
   const int lds = BIAS_OFF + p.N * 4;
   if (lds > A384_LDS_MAX) return WVN_ERR_ARG;
-  return p.dbg ? launch_k<EPI, true, 0>(p, lds, st) : launch_k<EPI, false, 0>(p, lds, st);
+  return p.dbg ? launch_k<EPI, true>(p, lds, st) : launch_k<EPI, false>(p, lds, st);
 }
 
 }  // namespace
