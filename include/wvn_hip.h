@@ -26,6 +26,10 @@ extern "C" {
 #define WVN_PREC_X3 2   /* exact mode ON THE MATRIX PIPE: every MFMA operand is two bf16 planes (hi + lo, 16 significant bits),  \
                            every product hi*hi + hi*lo + lo*hi in fp32 accumulators (fp32-class results, <= 1e-3 gate), erf GELU, \
                            fp32 residual / LayerNorm / softmax */
+#define WVN_PREC_FP8 3  /* BASELINE configs[4]: the four linears of every block on fp8 (OCP e4m3) MFMA at twice the bf16 rate --    \
+                           per-token scales of the activations (computed by the LayerNorm / row-quantise kernels), per-output-channel \
+                           scales of the weights, fp32 accumulate; attention, patch embedding, LayerNorm and the residual stream as   \
+                           in WVN_PREC_BF16 */
 
 int wvn_version(void);
 
@@ -33,8 +37,9 @@ int wvn_version(void);
  * DINO ViT backbone  (replaces stego.backbones.backbone.get_backbone(cfg)(img), called from
  * wild_visual_navigation/feature_extractor/dino_interface.py:45,84, plus the T.Normalize of :52).
  * Weights: matrices in torch.nn.Linear layout [out][in]; bf16 bits (uint16) when precision == WVN_PREC_BF16, float for
- * WVN_PREC_F32, and for WVN_PREC_X3 TWO stacked bf16 planes [2][out][in]: hi = bf16(w), lo = bf16(w - hi).  For the two MFMA
- * precisions the patch weight rows are zero-padded to a multiple of 64 columns (588 -> 640 for patch 14).
+ * WVN_PREC_F32, for WVN_PREC_X3 TWO stacked bf16 planes [2][out][in]: hi = bf16(w), lo = bf16(w - hi), and for WVN_PREC_FP8
+ * e4m3 bytes with the row scales in qkv_s .. fc2_s (the patch weight stays bf16).  For the MFMA precisions the patch weight
+ * rows are zero-padded to a multiple of 64 columns (588 -> 640 for patch 14).
  * Biases, LayerNorm affine, LayerScale and the position table are always fp32.
  * ------------------------------------------------------------------------------------------- */
 typedef struct wvn_vit_layer {
@@ -45,6 +50,7 @@ typedef struct wvn_vit_layer {
   const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const float *ls1, *ls2; /* [D] LayerScale of the attention / MLP branch (DINOv2 blocks.i.ls{1,2}.gamma); NULL = none (DINO) */
+  const float *qkv_s, *proj_s, *fc1_s, *fc2_s; /* WVN_PREC_FP8: per-output-channel scale of each e4m3 weight row (w = q * s) */
 } wvn_vit_layer;
 
 typedef struct wvn_vit_model {
@@ -98,6 +104,13 @@ int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
  * (C_lo ignored). */
 int wvn_gemm_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,
                 void* C, void* C_lo, int ldc, int M, int N, int K, int epi, void* stream);
+/* The fp8 building blocks (WVN_PREC_FP8): rows of src (fp32, or bf16 when src_is_bf16) -> e4m3 rows q [rows, ldq] + scale[rows]
+ * (= amax / 448, 1 for a zero row);  C = epilogue((A_q W_q^T) sa[m] sw[n] + bias) on v_mfma_scale_f32_32x32x64_f8f6f4 with
+ * epi 0 (bf16 out), 1 (gelu -> bf16), 3 (fp32 out), 4 (fp32 +=).  K % 128 == 0, lda / ldw % 16 == 0. */
+int wvn_quantize_rows_fp8(const void* src, int src_is_bf16, int lds, void* q, int ldq, float* scale, int rows, int cols,
+                          void* stream);
+int wvn_gemm_fp8(const void* A_q, int lda, const void* W_q, int ldw, const float* sa, const float* sw, const float* bias,
+                 void* C, int ldc, int M, int N, int K, int epi, void* stream);
 /* fp32 [rows, lds] -> hi = bf16(x), lo = bf16(x - hi), both [rows, ldd] */
 int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream);
 /* exact-mode attention: q / k planes [B,h,npad,64], V^T planes [B,h,64,npad] (token permutation of the bf16 path),

@@ -1,0 +1,85 @@
+"""fp8 (OCP e4m3) path of BASELINE configs[4] (DINOv2 ViT-B/14, 518 x 518, fp8 MFMA backbone): row quantisers, the scaled-MFMA
+GEMM against fp64 math ON THE QUANTISED OPERANDS (exact up to fp32 accumulation: pins the 32x32x64 fragment layout), and the
+whole backbone against the CPU oracle with the accuracy gate stated per test (e4m3 carries 3 mantissa bits: this is the
+throughput mode of configs[4], gated against the bf16 mode; the <= 1e-3 gate belongs to precision "exact")."""
+import pytest
+import torch
+
+from oracle import interfaces as OI, vit as OV
+from wild_visual_navigation_amd import _lib, ops
+from wild_visual_navigation_amd.backbone import VitBackbone
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C", [(37, 384), (130, 768), (9, 3072), (5, 1536)])
+def test_quantize_rows(dev, dtype, R, C):
+    x = (torch.randn(R, C, generator=g(1)) * torch.logspace(-2, 2, R)[:, None]).to(dtype)
+    x[3] = 0
+    q, sc = ops.quantize_rows_fp8(x.to(dev))
+    amax = x.float().abs().amax(1)
+    want_sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(sc.cpu(), want_sc, rtol=1e-6)
+    want_q = (x.float() / want_sc[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    got, ref = q.cpu().float(), want_q.float()
+    # the hardware converter and torch's cast are both round-to-nearest-even e4m3fn: identical codes (ties included) except
+    # where x / scale itself differs in the last fp32 bit (multiply by the reciprocal here, a division there)
+    assert (got == ref).float().mean().item() > 0.999
+    assert ((got - ref).abs() <= 0.0626 * ref.abs() + 2.0 ** -9).all()
+    assert (q.cpu().float()[3] == 0).all() and float(sc[3]) == 1.0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 2304, 768), (515, 768, 3072), (130, 200, 128)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "f32", "resid"])
+def test_gemm_fp8_against_fp64_on_the_quantised_operands(dev, M, N, K, epi):
+    a = torch.randn(M, K, generator=g(2)) * torch.logspace(-1, 1, M)[:, None]
+    w = torch.randn(N, K, generator=g(3)) * 0.05 * torch.logspace(-1, 0.5, N)[:, None]
+    bias = (torch.randn(N, generator=g(4)) * 0.1).to(dev)
+    aq, sa = ops.quantize_rows_fp8(a.to(dev))
+    wq, sw = ops.quantize_rows_fp8(w.to(dev))
+    ref = (aq.double() * sa.double()[:, None]) @ (wq.double() * sw.double()[:, None]).T + bias.double()
+    if epi == "bf16":
+        got = ops.gemm_fp8(aq, sa, wq, sw, bias, _lib.EPI_BF16).double()
+        tol = 2.0 ** -8
+    elif epi == "gelu":
+        got = ops.gemm_fp8(aq, sa, wq, sw, bias, _lib.EPI_GELU_BF16).double()
+        ref = torch.nn.functional.gelu(ref)
+        tol = 2.0 ** -8
+    elif epi == "f32":
+        got = ops.gemm_fp8(aq, sa, wq, sw, bias, _lib.EPI_F32).double()
+        tol = 2e-6
+    else:
+        c0 = torch.randn(M, N, generator=g(5)).to(dev)
+        got = ops.gemm_fp8(aq, sa, wq, sw, bias, _lib.EPI_RESID_F32, out=c0.clone()).double()
+        ref = ref + c0.double()
+        tol = 2e-6
+    mag = (aq.double().abs() * sa.double()[:, None]) @ (wq.double().abs() * sw.double()[:, None]).T + 1.0
+    err = ((got - ref).abs() / mag).max().item()
+    assert err < tol, err
+    # against the UNQUANTISED product: the price of e4m3 itself (3 mantissa bits per operand, random over K)
+    full = a.double().to(dev) @ w.double().to(dev).T + bias.double()
+    if epi == "f32":
+        rel = ((got - full).norm() / full.norm()).item()
+        assert rel < 0.06, rel
+
+
+@pytest.mark.parametrize("arch,patch,heads,S,depth,B", [("vit_small", 8, 6, 224, 4, 2), ("vit_base", 14, 12, 518, 12, 1)])
+def test_backbone_fp8_accuracy_gate(dev, arch, patch, heads, S, depth, B):
+    """configs[4]: DINOv2 ViT-B/14 at 518^2 (and ViT-S/8) with the block linears on e4m3.  Gate: relative L2 error of the final
+    tokens against the fp32 oracle below 8 %, and within 6x of the bf16 mode's own error + 3 % (the two numbers are printed)."""
+    sd = (OV.make_dinov2_state_dict(arch, patch, pretrain_grid=37, seed=3, depth=depth) if patch == 14
+          else OV.make_vit_state_dict(arch, patch, pretrain_grid=28, seed=3, depth=depth))
+    img = torch.rand(B, 3, S, S, generator=g(9))
+    want = OV.vit_tokens(sd, OI.normalize(img), patch, heads)[:, 1:]
+    e = {}
+    for prec in ("bf16", "fp8"):
+        got = VitBackbone(sd, S, patch, heads, device=dev, precision=prec, max_chunk=2).forward_tokens(img.to(dev)).cpu()
+        assert torch.isfinite(got).all()
+        e[prec] = ((got - want).norm() / want.norm()).item()
+    print(f"{arch}/{patch} S={S} depth={depth}: rel-L2 vs oracle  bf16 {e['bf16']:.3e}  fp8 {e['fp8']:.3e}")
+    assert e["fp8"] < 0.08 and e["fp8"] < 6 * e["bf16"] + 0.03

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwvn_hip.so")
 
 WVN_MAX_DEPTH = 32
-PREC_F32, PREC_BF16, PREC_X3 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_X3, PREC_FP8 = 0, 1, 2, 3
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -28,7 +28,7 @@ class WvnError(RuntimeError):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2")]
+        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s")]
 
 
 class VitModel(C.Structure):
@@ -58,6 +58,8 @@ _SIGNATURES = {
     "wvn_prof_collect": ([_p, _p], _i),
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_gemm_x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_quantize_rows_fp8": ([_p, _i, _i, _p, _i, _p, _i, _i, _p], _i),
+    "wvn_gemm_fp8": ([_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_split_planes": ([_p, _i, _p, _p, _i, _i, _i, _p], _i),
     "wvn_attention_x3": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "wvn_gemm_f32": ([_p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p], _i),

@@ -87,7 +87,8 @@ def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
 class VitBackbone:
     """Device-resident DINO / DINOv2 ViT.  ``precision``: "bf16" (MFMA fast path), "exact" (hi + lo split bf16 operands, three
     MFMAs per product: fp32-class results on the matrix pipe, the <= 1e-3 parity mode) or "fp32" (the same gate on fp32 FMA
-    kernels; slow, kept as the independent cross-check of "exact")."""
+    kernels; slow, kept as the independent cross-check of "exact") or "fp8" (BASELINE configs[4]: the four linears of every block on
+    e4m3 MFMA at twice the bf16 rate, per-token / per-channel scales; everything else as "bf16")."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
                  device="cuda", precision: str = "bf16", max_chunk: int = 16):
@@ -95,7 +96,7 @@ class VitBackbone:
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
         self.lib = _lib.lib()
-        self.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_F32, "exact": _lib.PREC_X3}[precision]
+        self.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_F32, "exact": _lib.PREC_X3, "fp8": _lib.PREC_FP8}[precision]
         self.precision_name = precision
         self.img_size, self.patch, self.heads = img_size, patch, heads
         self.grid = img_size // patch
@@ -111,7 +112,7 @@ class VitBackbone:
             if pad_cols:
                 t = F.pad(t, (0, pad_cols))
             t = t.to(self.device)
-            if self.precision == _lib.PREC_BF16:
+            if self.precision in (_lib.PREC_BF16, _lib.PREC_FP8):
                 t = t.to(torch.bfloat16).contiguous()
             elif self.precision == _lib.PREC_X3:  # two stacked bf16 planes: hi = bf16(w), lo = bf16(w - hi)
                 t = split_planes(t)
@@ -119,6 +120,15 @@ class VitBackbone:
                 t = t.contiguous()
             self._keep.append(t)
             return t.data_ptr()
+
+        def mat8(t):
+            """fp8 (OCP e4m3) weight with one scale per output channel: w ~ q * s, s = amax(row) / 448."""
+            t = t.detach().float().cpu()
+            s = t.abs().amax(dim=1).clamp_min(1e-30) / 448.0
+            qw = (t / s[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(self.device).contiguous()
+            s = s.to(self.device).contiguous()
+            self._keep += [qw, s]
+            return qw.data_ptr(), s.data_ptr()
 
         def vec(t):
             t = t.detach().to(self.device, dtype=torch.float32).contiguous()
@@ -141,10 +151,16 @@ class VitBackbone:
         for i in range(self.depth):
             p = f"blocks.{i}."
             L = m.layers[i]
-            L.qkv_w, L.qkv_b = mat(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
-            L.proj_w, L.proj_b = mat(sd[p + "attn.proj.weight"]), vec(sd[p + "attn.proj.bias"])
-            L.fc1_w, L.fc1_b = mat(sd[p + "mlp.fc1.weight"]), vec(sd[p + "mlp.fc1.bias"])
-            L.fc2_w, L.fc2_b = mat(sd[p + "mlp.fc2.weight"]), vec(sd[p + "mlp.fc2.bias"])
+            if self.precision == _lib.PREC_FP8:
+                L.qkv_w, L.qkv_s = mat8(sd[p + "attn.qkv.weight"])
+                L.proj_w, L.proj_s = mat8(sd[p + "attn.proj.weight"])
+                L.fc1_w, L.fc1_s = mat8(sd[p + "mlp.fc1.weight"])
+                L.fc2_w, L.fc2_s = mat8(sd[p + "mlp.fc2.weight"])
+            else:
+                L.qkv_w, L.proj_w = mat(sd[p + "attn.qkv.weight"]), mat(sd[p + "attn.proj.weight"])
+                L.fc1_w, L.fc2_w = mat(sd[p + "mlp.fc1.weight"]), mat(sd[p + "mlp.fc2.weight"])
+            L.qkv_b, L.proj_b = vec(sd[p + "attn.qkv.bias"]), vec(sd[p + "attn.proj.bias"])
+            L.fc1_b, L.fc2_b = vec(sd[p + "mlp.fc1.bias"]), vec(sd[p + "mlp.fc2.bias"])
             L.ln1_g, L.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
             L.ln2_g, L.ln2_b = vec(sd[p + "norm2.weight"]), vec(sd[p + "norm2.bias"])
             if p + "ls1.gamma" in sd:  # DINOv2 LayerScale
@@ -172,7 +188,7 @@ class VitBackbone:
     @property
     def lowp_dtype(self):
         """dtype of ``lowp_out`` rows (None: the exact mode hands out fp32 tokens only)."""
-        return {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_F32: torch.float32}.get(self.precision)
+        return {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_FP8: torch.bfloat16, _lib.PREC_F32: torch.float32}.get(self.precision)
 
     def forward_tokens(self, img: torch.Tensor, out: Optional[torch.Tensor] = None,
                        lowp_out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -187,7 +203,7 @@ class VitBackbone:
             raise _lib.WvnError(f"expected [B,3,{self.img_size},{self.img_size}], got {tuple(img.shape)}")
         if lowp_out is not None and self.precision == _lib.PREC_X3:
             raise _lib.WvnError("precision 'exact' returns fp32 tokens only (split them with ops.split_planes)")
-        u8 = img.dtype == torch.uint8 and self.precision == _lib.PREC_BF16 and self.patch == 8
+        u8 = img.dtype == torch.uint8 and self.precision in (_lib.PREC_BF16, _lib.PREC_FP8) and self.patch == 8
         if u8:
             img = img.contiguous()
         elif img.dtype == torch.uint8:
@@ -201,7 +217,7 @@ class VitBackbone:
         chunk = min(self.max_chunk, B)
         ws = self._workspace(chunk)
         st = _lib.stream()
-        esz = 2 if self.precision == _lib.PREC_BF16 else 4
+        esz = 2 if self.precision in (_lib.PREC_BF16, _lib.PREC_FP8) else 4
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             lp, ld = 0, 0

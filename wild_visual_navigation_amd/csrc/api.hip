@@ -44,6 +44,7 @@ struct Span {
 
 struct VitDims {
   int B, S, P, G, D, H, F, KP, KPs, ntok, ntok_s, npad, npatch;
+  bool fp8;
   size_t esz;
   long long M, Mp;
 };
@@ -54,13 +55,14 @@ VitDims vit_dims(const wvn_vit_model* m, int batch) {
   // patch rows as the MFMA GEMMs read them: K padded to a multiple of 64 (588 -> 640 for patch 14; 192 and 768 unchanged);
   // the fp32 FMA path reads the unpadded rows
   d.KPs = m->precision == WVN_PREC_F32 ? d.KP : (d.KP + 63) / 64 * 64;
+  d.fp8 = m->precision == WVN_PREC_FP8;
   d.ntok_s = (d.ntok + 15) / 16 * 16;  // rows per frame: 8-token (16 B) chunks and the 16-token V^T permutation groups never straddle frames
   d.npad = (d.ntok + 127) / 128 * 128;
-  d.esz = m->precision == WVN_PREC_BF16 ? 2 : 4;  // exact mode (X3): two bf16 planes = 4 bytes per element
+  d.esz = (m->precision == WVN_PREC_BF16 || m->precision == WVN_PREC_FP8) ? 2 : 4;  // exact mode (X3): two bf16 planes = 4 bytes per element
   d.M = (long long)batch * d.ntok_s; d.Mp = (long long)batch * d.npatch;
   return d;
 }
-struct VitWs { float* x; void* xn; void* q; void* k; void* v; void* hid; void* patches; size_t total; };
+struct VitWs { float* x; void* xn; void* q; void* k; void* v; void* hid; void* patches; unsigned char* xq; unsigned char* hq; float* sa; size_t total; };
 VitWs vit_carve(const VitDims& d, void* base) {
   VitWs w;
   size_t off = 0;
@@ -71,6 +73,12 @@ VitWs vit_carve(const VitDims& d, void* base) {
   w.q = take(qkv); w.k = take(qkv); w.v = take(qkv);
   w.hid = take((size_t)d.M * d.F * d.esz);
   w.patches = take((size_t)d.Mp * d.KPs * d.esz);
+  w.xq = nullptr; w.hq = nullptr; w.sa = nullptr;
+  if (d.fp8) {  // e4m3 images of the GEMM inputs + their per-row scales
+    w.xq = (unsigned char*)take((size_t)d.M * d.D);
+    w.hq = (unsigned char*)take((size_t)d.M * d.F);
+    w.sa = (float*)take((size_t)d.M * 4);
+  }
   w.total = off;
   return w;
 }
@@ -114,7 +122,7 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
 
 int wvn_vit_forward_u8(const wvn_vit_model* m, const unsigned char* img, int batch, float* tokens_f32, void* tokens_lowp,
                        int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
-  if (m && (m->precision != WVN_PREC_BF16 || m->patch != 8)) return WVN_ERR_ARG;
+  if (m && ((m->precision != WVN_PREC_BF16 && m->precision != WVN_PREC_FP8) || m->patch != 8)) return WVN_ERR_ARG;
   return vit_forward_impl(m, img, 1, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
 }
 
@@ -125,12 +133,15 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (!m || !img || !workspace || batch <= 0) return WVN_ERR_ARG;
   if (m->dim != m->heads * 64 || m->depth <= 0 || m->depth > WVN_MAX_DEPTH || m->img_size % m->patch) return WVN_ERR_ARG;
   if (m->dim % 128 || m->mlp_dim % 128) return WVN_ERR_ARG;
-  if (m->precision != WVN_PREC_F32 && m->precision != WVN_PREC_BF16 && m->precision != WVN_PREC_X3) return WVN_ERR_ARG;
+  if (m->precision < WVN_PREC_F32 || m->precision > WVN_PREC_FP8) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const VitDims d = vit_dims(m, batch);
   const VitWs w = vit_carve(d, workspace);
   if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
-  const bool bf = m->precision == WVN_PREC_BF16, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
+  const bool fp8 = m->precision == WVN_PREC_FP8;
+  if (fp8 && ((d.D % 128) || (d.F % 128))) return WVN_ERR_ARG;
+  // fp8: everything that is not one of the four block linears runs exactly as in the bf16 mode
+  const bool bf = m->precision == WVN_PREC_BF16 || fp8, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
   if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
   const float scale = 1.0f / sqrtf(64.f);
   const int M = (int)d.M, Mp = (int)d.Mp;
@@ -202,8 +213,43 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     e.pos = m->pos; e.npatch = d.npatch; e.ntok = d.ntok; e.ntok_s = d.ntok_s;
     RET_IF(linear(w.patches, pl_pat, d.KPs, m->patch_w, m->patch_b, w.x, 0, d.D, Mp, d.D, d.KPs, EPI_PATCH, nullptr, &e));
   }
+  // fp8: quantise-then-GEMM for the four linears of a block (A rows -> e4m3 + per-token scale in ws.xq / ws.hq / ws.sa)
+  auto linear_fp8 = [&](const unsigned char* Aq, int K, const void* W, const float* sw, const float* bias, void* C, int ldc, int N,
+                        int epi, const float* ls, const GemmBf16Params* extra) -> int {
+    GemmFp8Params p{};
+    p.A = Aq; p.lda = K; p.W = (const unsigned char*)W; p.ldw = K; p.sa = w.sa; p.sw = sw; p.bias = bias; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.ls = ls;
+    if (extra) { p.q = extra->q; p.k = extra->k; p.vt = extra->vt; p.heads = extra->heads; p.npad = extra->npad; p.ntok = extra->ntok;
+                 p.ntok_s = extra->ntok_s; p.q_scale = extra->q_scale; }
+    return wvn_gemm_fp8_launch(p, epi, st);
+  };
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
+    if (fp8) {
+      if (!L.qkv_s || !L.proj_s || !L.fc1_s || !L.fc2_s) return WVN_ERR_ARG;
+      { Span s(2, st); RET_IF(wvn_layernorm_fp8_launch(w.x, L.ln1_g, L.ln1_b, w.xq, d.D, w.sa, M, d.D, 1e-6f, st)); }
+      {
+        Span s(3, st);
+        GemmBf16Params e{};
+        e.q = (bf16_t*)w.q; e.k = (bf16_t*)w.k; e.vt = (bf16_t*)w.v; e.heads = d.H; e.npad = d.npad; e.ntok = d.ntok; e.ntok_s = d.ntok_s;
+        e.q_scale = scale * 1.44269504088896340736f;
+        RET_IF(linear_fp8(w.xq, d.D, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, 0, 3 * d.D, EPI_QKV, nullptr, &e));
+      }
+      { Span s(4, st); RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st)); }
+      {
+        Span s(5, st);
+        RET_IF(wvn_quantize_rows_fp8_launch(w.xn, 1, d.D, w.xq, d.D, w.sa, M, d.D, st));
+        RET_IF(linear_fp8(w.xq, d.D, L.proj_w, L.proj_s, L.proj_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr));
+      }
+      { Span s(2, st); RET_IF(wvn_layernorm_fp8_launch(w.x, L.ln2_g, L.ln2_b, w.xq, d.D, w.sa, M, d.D, 1e-6f, st)); }
+      { Span s(6, st); RET_IF(linear_fp8(w.xq, d.D, L.fc1_w, L.fc1_s, L.fc1_b, w.hid, d.F, d.F, EPI_GELU_BF16, nullptr, nullptr)); }
+      {
+        Span s(7, st);
+        RET_IF(wvn_quantize_rows_fp8_launch(w.hid, 1, d.F, w.hq, d.F, w.sa, M, d.F, st));
+        RET_IF(linear_fp8(w.hq, d.F, L.fc2_w, L.fc2_s, L.fc2_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls2, nullptr));
+      }
+      continue;
+    }
     { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     {
       Span s(3, st);
@@ -254,6 +300,18 @@ int wvn_gemm_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, c
   p.A = (const bf16_t*)A_hi; p.A_lo = (const bf16_t*)A_lo; p.lda = lda; p.W = (const bf16_t*)W_hi; p.W_lo = (const bf16_t*)W_lo;
   p.ldw = ldw; p.bias = bias; p.C = C; p.C_lo = C_lo; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   return wvn_gemm_x3_launch(p, epi, (hipStream_t)stream);
+}
+int wvn_quantize_rows_fp8(const void* src, int src_is_bf16, int lds, void* q, int ldq, float* scale, int rows, int cols,
+                          void* stream) {
+  return wvn_quantize_rows_fp8_launch(src, src_is_bf16, lds, (unsigned char*)q, ldq, scale, rows, cols, (hipStream_t)stream);
+}
+int wvn_gemm_fp8(const void* A_q, int lda, const void* W_q, int ldw, const float* sa, const float* sw, const float* bias,
+                 void* C, int ldc, int M, int N, int K, int epi, void* stream) {
+  if (epi != EPI_BF16 && epi != EPI_GELU_BF16 && epi != EPI_F32 && epi != EPI_RESID_F32) return WVN_ERR_ARG;
+  GemmFp8Params p{};
+  p.A = (const unsigned char*)A_q; p.lda = lda; p.W = (const unsigned char*)W_q; p.ldw = ldw; p.sa = sa; p.sw = sw; p.bias = bias;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  return wvn_gemm_fp8_launch(p, epi, (hipStream_t)stream);
 }
 int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream) {
   return wvn_split_planes_launch(src, lds, (bf16_t*)hi, (bf16_t*)lo, ldd, rows, cols, (hipStream_t)stream);

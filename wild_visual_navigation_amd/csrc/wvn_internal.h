@@ -41,6 +41,27 @@ int wvn_gemm_n384_launch(const GemmBf16Params& p, int epi, hipStream_t st, int* 
 // "bf16" ones
 int wvn_gemm_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 
+// ---- fp8 (e4m3) MFMA GEMM with per-row scales of both operands (gemm_fp8.hip) + the row quantisers (fp8.hip) -----------
+struct GemmFp8Params {
+  const unsigned char* A; int lda;   // [M,K] e4m3, lda in elements (= bytes)
+  const unsigned char* W; int ldw;   // [N,K] e4m3
+  const float* sa;                   // [M] scale of every A row  (value = q * sa)
+  const float* sw;                   // [N] scale of every W row
+  const float* bias;                 // [N] or nullptr
+  void* C; int ldc;
+  int M, N, K;
+  const float* pos; int npatch; int ntok; int ntok_s;                         // (EPI_PATCH is not instantiated for fp8)
+  bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad; float q_scale;      // EPI_QKV (bf16 outputs for attention_bf16.hip)
+  const float* ls;                                                            // EPI_RESID_F32: optional LayerScale
+};
+int wvn_gemm_fp8_launch(const GemmFp8Params& p, int epi, hipStream_t st);
+// rows of src (fp32 or bf16, leading dimension lds_) -> e4m3 rows (leading dimension ldq, bytes) + scale[rows] = amax / 448
+int wvn_quantize_rows_fp8_launch(const void* src, int src_bf16, int lds_, unsigned char* q, int ldq, float* scale, int rows,
+                                 int cols, hipStream_t st);
+// LayerNorm (fp32 rows of x, D = 64 * {6, 12}) fused with the row quantiser
+int wvn_layernorm_fp8_launch(const float* x, const float* gamma, const float* beta, unsigned char* q, int ldq, float* scale,
+                             int rows, int D, float eps, hipStream_t st);
+
 // ---- fp32 GEMM (gemm_f32.hip): exact-mode linears + the traversability MLP ---------------------
 enum GemmF32Epilogue {
   F32_EPI_NONE = 0,       // C = acc + bias

@@ -157,7 +157,7 @@ class StegoInterface:
         self._b_code = (head["cluster1.0.bias"] + head["cluster2.2.bias"]).float().to(dev).contiguous()
         self._b_lin = head["cluster1.0.bias"].float().to(dev).contiguous()
         self._b_nl = head["cluster2.2.bias"].float().to(dev).contiguous()
-        if precision == "bf16":
+        if precision in ("bf16", "fp8"):   # the (tiny) head stays on the bf16 kernels in the fp8 mode
             self._w_hid = head["cluster2.0.weight"].to(dev, torch.bfloat16).contiguous()
             self._w_code = torch.cat([head["cluster1.0.weight"], head["cluster2.2.weight"]], dim=1).to(
                 dev, torch.bfloat16).contiguous()  # [C, 2D] acting on [tok | hid]
@@ -205,7 +205,7 @@ class StegoInterface:
     def _code_once(self, img: torch.Tensor) -> torch.Tensor:
         B = img.shape[0]
         P, D = self._bb.grid ** 2, self._D
-        if self._precision == "bf16":
+        if self._precision in ("bf16", "fp8"):
             cat = torch.empty(B * P, 2 * D, dtype=torch.bfloat16, device=self._device)  # [tok | hid]
             self._bb.forward_tokens(img, lowp_out=cat)
             ops.gemm_bf16(cat[:, :D], self._w_hid, self._b_hid, _lib.EPI_RELU_BF16, out=cat[:, D:])

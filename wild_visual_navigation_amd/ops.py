@@ -314,6 +314,30 @@ def gemm_f32(a, b, bias=None, epi=_lib.F32_NONE, trans_a=False, trans_b=True, ou
     return out
 
 
+def quantize_rows_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [R, C] fp32 or bf16 (row stride allowed) -> (q [R, C] float8_e4m3fn, scale [R] fp32): x ~ q * scale, scale = amax / 448."""
+    require_cuda(x, "x")
+    R, Cc = x.shape
+    q = torch.empty(R, Cc, dtype=torch.float8_e4m3fn, device=x.device)
+    sc = torch.empty(R, dtype=torch.float32, device=x.device)
+    check(lib().wvn_quantize_rows_fp8(ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), ptr(q), Cc, ptr(sc), R, Cc, stream()),
+          "wvn_quantize_rows_fp8")
+    return q, sc
+
+
+def gemm_fp8(a_q: torch.Tensor, sa: torch.Tensor, w_q: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor], epi: int,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue((a_q @ w_q^T) * sa[:, None] * sw[None, :] + bias); a_q [M,K], w_q [N,K] float8_e4m3fn, K % 128 == 0."""
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    if out is None:
+        dt = torch.bfloat16 if epi in (_lib.EPI_BF16, _lib.EPI_GELU_BF16) else torch.float32
+        out = torch.empty(M, N, dtype=dt, device=a_q.device)
+    check(lib().wvn_gemm_fp8(ptr(a_q), a_q.stride(0), ptr(w_q), w_q.stride(0), ptr(sa), ptr(sw), ptr(bias), ptr(out), out.stride(0),
+                             M, N, K, epi, stream()), "wvn_gemm_fp8")
+    return out
+
+
 def split_planes(x: torch.Tensor) -> torch.Tensor:
     """fp32 [R, C] (row stride allowed) -> bf16 [2, R, C]: hi = bf16(x), lo = bf16(x - hi) -- the operand representation of
     the exact-mode MFMA kernels (gemm_x3 / attention_x3)."""
