@@ -13,6 +13,8 @@ the 64-frame batch over the ranks):
       segment maps -> fused bilinear-upsample + per-segment mean pooling -> ONE optimisation step of the traversability MLP
       (forward, loss, backward, Adam) on the batch's segment rows, with the statistic / gradient all-reduces over RCCL when N > 1.
   --mode backbone (configs[1]): --batch 32 frames through the ViT only (feature extraction).
+  --mode dinov2   (configs[4]): DINOv2 ViT-B/14 at 518x518 (1370 tokens, LayerScale) + STEGO head, --batch 16 frames per GPU
+                  (128 over 8 GPUs); meant for --precision fp8 (block linears on e4m3 MFMA), also runs in bf16 / exact.
   --precision bf16 : bf16 MFMA operands, fp32 accumulate / residual / statistics (the speed path)
   --precision exact: hi + lo split bf16 operands, three MFMAs per product -- fp32-class results on the matrix pipe, the
                      north_star "<= 1e-3" parity mode, timed on the same workload
@@ -61,7 +63,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", default="full", choices=["full", "backbone"])
+    ap.add_argument("--mode", default="full", choices=["full", "backbone", "dinov2"])
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (full: 64, backbone: 32 = BASELINE configs[2] / [1])")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch frames per GPU; strong: --batch frames in all, split over the ranks")
@@ -72,13 +74,20 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (about 15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "exact", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "exact", "fp32", "fp8"],
+                    help="default: bf16 (fp8 for --mode dinov2)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every step on one stream (default: the backbone of step i+1 runs on a second HIP stream while "
                          "clustering / pooling / the MLP step of step i -- small kernels that do not fill the GPU -- finish)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 64 if args.mode == "full" else 32
+        args.batch = {"full": 64, "backbone": 32, "dinov2": 16}[args.mode]
+    if args.precision is None:
+        args.precision = "fp8" if args.mode == "dinov2" else "bf16"
+    if args.mode == "dinov2":
+        args.size, args.chunk = 518, min(args.chunk, args.batch)
+    if args.precision == "fp8" and args.mode == "full":
+        raise SystemExit("--precision fp8 is the configs[4] mode (--mode dinov2 / backbone); configs[2] is quoted in bf16")
     return args
 
 
@@ -106,11 +115,20 @@ def make_pipeline(args, dev):
 
     import torch
 
-    ftype = "stego" if (args.segmentation == "stego" and args.mode == "full") else "dino"
-    seg = args.segmentation if args.mode == "full" else "grid"
-    fe = FeatureExtractor(dev, segmentation_type=seg, feature_type=ftype, input_size=args.size,
-                          backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
-                          max_chunk=args.chunk, allow_synthetic=True)
+    if args.mode == "dinov2":
+        from wild_visual_navigation_amd.backbone import synthetic_vit_state_dict
+        from wild_visual_navigation_amd.feature_extractor.stego_interface import synthetic_stego_head
+
+        fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=518, n_image_clusters=20,
+                              precision=args.precision, max_chunk=args.chunk, backbone_type="vit_base", patch_size=14,
+                              pretrained_weights=synthetic_vit_state_dict("vit_base", 14, pretrain_grid=37, seed=0, dinov2=True),
+                              head_weights=synthetic_stego_head(768), allow_synthetic=True)
+    else:
+        ftype = "stego" if (args.segmentation == "stego" and args.mode == "full") else "dino"
+        seg = args.segmentation if args.mode == "full" else "grid"
+        fe = FeatureExtractor(dev, segmentation_type=seg, feature_type=ftype, input_size=args.size,
+                              backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
+                              max_chunk=args.chunk, allow_synthetic=True)
     torch.manual_seed(42)
     model = SimpleMLP(fe.feature_dim, [256, 32, 1], True).to(dev)
     return fe, model, MlpTrainer(model)
@@ -196,23 +214,26 @@ def cpu_baseline_and_parity(args, fe, dev):
     # PyTorch's intra-op pool does not scale to the GPU box's 256 hardware threads for these matrix
     # sizes (256 threads ran ~20x slower than the 8-core survey probe); the thread count used is reported.
     torch.set_num_threads(min(os.cpu_count() or 1, args.cpu_threads))
-    stego = args.segmentation == "stego" and args.mode == "full"
+    stego = fe.feature_type == "stego"
     bb = fe._extractor._bb if stego else fe._extractor._model
+    P, heads = bb.patch, bb.heads
     sd = {k: v.detach().float().cpu() for k, v in bb._sd.items()}           # the weights the GPU model was built from
     head = {k: v.detach().float().cpu() for k, v in fe._extractor._head_sd.items()} if stego else None
     img = torch.rand(n, 3, args.size, args.size, generator=torch.Generator().manual_seed(1))
-    G = args.size // 8
+    G = args.size // P
     t0 = time.perf_counter()
     rows, toks, codes, segs = [], [], [], []
     with torch.no_grad():
         for b in range(n):
-            tok = OV.vit_tokens(sd, OI.normalize(img[b:b + 1]), 8, 6)[:, 1:]
+            tok = OV.vit_tokens(sd, OI.normalize(img[b:b + 1]), P, heads)[:, 1:]
             toks.append(tok)
             if args.mode == "backbone":
                 continue
             if stego:
                 code = OI.stego_code_tokens(head, tok)
                 codes.append(code)
+                if args.mode == "dinov2":
+                    continue
                 lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), 20))
                 seg = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), args.size)[0, 0].long()
                 fmap = code.reshape(1, G, G, -1).permute(0, 3, 1, 2)
@@ -231,8 +252,8 @@ def cpu_baseline_and_parity(args, fe, dev):
             st = OM.TrainState(OM.make_mlp_state_dict(x.shape[1]))
             OM.train_step(st, x, y, yv)
     dt = time.perf_counter() - t0
-    what = (f"ViT-S/8 12 blocks fp32 + {args.segmentation} segmentation + pooling + 1 MLP step" if args.mode == "full"
-            else "ViT-S/8 12 blocks fp32")
+    what = {"full": f"ViT-S/8 12 blocks fp32 + {args.segmentation} segmentation + pooling + 1 MLP step",
+            "backbone": "ViT-S/8 12 blocks fp32", "dinov2": "DINOv2 ViT-B/14 12 blocks fp32 + STEGO head"}[args.mode]
     base = {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} frames {args.size}x{args.size} through the CPU oracle ({what}), {dt:.1f} s wall"}
 
@@ -243,6 +264,11 @@ def cpu_baseline_and_parity(args, fe, dev):
         otok = torch.cat(toks)
         par = {"mode": args.precision, "frames": n, "against": "oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned)",
                "max_abs_tokens": float((gtok - otok).abs().max()), "rel_l2_tokens": float((gtok - otok).norm() / otok.norm())}
+        if args.mode == "dinov2":
+            gcode = fe.backbone_stage(gi).cpu()
+            ocode = torch.cat(codes)
+            par["max_abs_code"] = float((gcode - ocode).abs().max())
+            par["rel_l2_code"] = float((gcode - ocode).norm() / ocode.norm())
         if args.mode == "full":
             feat, seg, nseg = fe.extract_batch(gi)
             seg = seg.cpu().long()
@@ -305,7 +331,7 @@ def main():
     pool = [torch.rand(B, 3, args.size, args.size, generator=gen).to(dev) for _ in range(max(1, args.pool))]  # resident in HBM
     n_lab = 20 if args.segmentation == "stego" else (args.size // 32) ** 2
     labels = [torch.rand(B, n_lab, 2, generator=gen).to(dev) for _ in range(len(pool))]
-    backbone_only = args.mode == "backbone"
+    backbone_only = args.mode in ("backbone", "dinov2")
     bb = (fe._extractor._bb if fe.feature_type == "stego" else fe._extractor._model) if backbone_only else None
 
     pipe = None if (args.no_overlap or backbone_only) else TwoStreamPipeline(fe, trainer, args, dev)
@@ -313,7 +339,9 @@ def main():
 
     def run_step(i, last):
         img, lab = pool[i % len(pool)], labels[i % len(pool)]
-        if backbone_only:
+        if args.mode == "dinov2":
+            out = (fe.backbone_stage(img), 0)          # ViT-B/14 + STEGO head -> 90-d code tokens
+        elif backbone_only:
             out = (bb.forward_tokens(img), 0)
         elif pipe is None:
             out = hot_path_step(fe, trainer, img, lab, args)
@@ -364,7 +392,7 @@ def main():
 
     if rank == 0:
         total_frames = (args.batch if args.scaling == "strong" else world * B) * args.steps
-        total_flops, attn_flops_block = vit_flops_per_frame(args.size)
+        total_flops, attn_flops_block = (vit_flops_per_frame(518, 14, 768) if args.mode == "dinov2" else vit_flops_per_frame(args.size))
         att_ms, att_n = prof["attention"]
         chunk = min(args.chunk, B)
         frames_per_launch = (B * args.steps * 12) / max(att_n, 1)  # 12 attention launches per frame-chunk
@@ -372,8 +400,13 @@ def main():
         att_tflops = attn_flops_block * frames_per_launch / (att_avg_ms * 1e-3) / 1e12 if att_n else 0.0
         kern = {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in prof.items()}
         x3 = args.precision == "exact"
-        kernel_name = {"bf16": "attention_bf16_kernel", "exact": "attention_x3_kernel", "fp32": "attention_f32_kernel"}[args.precision]
-        if backbone_only:
+        kernel_name = {"bf16": "attention_bf16_kernel", "exact": "attention_x3_kernel", "fp32": "attention_f32_kernel",
+                       "fp8": "attention_bf16_kernel"}[args.precision]
+        if args.mode == "dinov2":
+            metric = "frames/sec (518x518 DINOv2 ViT-B/14 + STEGO head)"
+            workload = (f"BASELINE configs[4]: DINOv2 ViT-B/14 518x518 batch={B}/GPU (1370 tokens, LayerScale) + STEGO head -> 90-d "
+                        f"code; block linears in {args.precision}")
+        elif backbone_only:
             metric = "frames/sec (448x448 DINO-ViT-S/8 feature extraction)"
             workload = f"BASELINE configs[1]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU, feature extraction only"
         else:
@@ -393,7 +426,8 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "exact": "bf16x3 (hi+lo split operands, fp32-class)", "fp32": "f32"}[args.precision],
+            "dtype": {"bf16": "bf16", "exact": "bf16x3 (hi+lo split operands, fp32-class)", "fp32": "f32",
+                      "fp8": "fp8-e4m3 linears (per-token / per-channel scales), bf16 attention, fp32 residual"}[args.precision],
             "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu_per_step": B, "backbone_chunk": chunk, "input_pool": len(pool),
                        "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP statistics + gradients)",

@@ -31,8 +31,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.VitLayer) == 14 * 8
-    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 14 * 8
+    assert C.sizeof(_lib.VitLayer) == 18 * 8
+    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 18 * 8
     assert C.sizeof(_lib.MlpDesc) == 16
 
 
@@ -92,6 +92,21 @@ def test_argument_validation_without_gpu():
     assert h.wvn_gemm_x3(None, None, 0, None, None, 0, None, None, None, 0, 1, 1, 64, 0, None) == 1001
     assert h.wvn_attention_x3(None, None, None, None, None, None, None, None, 1, 6, 100, 128, 0.125, None) == 1001
     assert h.wvn_split_planes(None, 0, None, None, 0, 1, 1, None) == 1001
+    assert h.wvn_gemm_fp8(None, 0, None, 0, None, None, None, None, 0, 1, 1, 128, 0, None) == 1001
+    assert h.wvn_quantize_rows_fp8(None, 0, 0, None, 0, None, 1, 4, None) == 1001
+    assert h.wvn_project_render_fmin(None, 1, None, 0, 4, 3, 8, 8, None, 1.0, None) == 1001
+    assert h.wvn_label_pool_batched(None, 1, 3, 8, 8, 4, None, None, None) == 1001
+    assert h.wvn_slic(None, 1, 8, 8, 4, 10.0, 10, None, None, None, None, 0, None) == 1001
+    assert h.wvn_wire_pack(None, 1, None, 4, None, 8, 8, 2, 4, None) == 1001
+    assert h.wvn_slic_num_clusters(448, 448, 100) == 100 and h.wvn_slic_num_clusters(224, 224, 100) == 100
+    assert h.wvn_wire_bytes(224, 224, 100, 384) == 64 + 224 * 224 * 4 + 100 * 384 * 4
+    m = _lib.VitModel()
+    m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim, m.precision = 518, 14, 768, 12, 12, 3072, _lib.PREC_FP8
+    bf = _lib.VitModel()
+    bf.img_size, bf.patch, bf.dim, bf.depth, bf.heads, bf.mlp_dim, bf.precision = 518, 14, 768, 12, 12, 3072, _lib.PREC_BF16
+    # fp8 workspace = the bf16 one + e4m3 images of the GEMM inputs (M x 768, M x 3072) + per-token scales
+    extra = h.wvn_vit_workspace_bytes(C.byref(m), 2) - h.wvn_vit_workspace_bytes(C.byref(bf), 2)
+    assert 2 * 1376 * (768 + 3072 + 4) <= extra <= 2 * 1376 * (768 + 3072 + 4) + 3 * 256
     assert h.wvn_vit_forward(None, None, 1, None, None, 0, None, 0, None) == 1001
     with pytest.raises(_lib.WvnError):
         _lib.check(1002, "x")
