@@ -1,9 +1,8 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-python -m pytest tests/test_gpu_x3.py tests/test_gpu_supervision.py tests/test_gpu_gemm_a384.py tests/test_gpu_backbone.py tests/test_gpu_distributed.py tests/test_gpu_bridge.py tests/test_gpu_slic.py -m gpu -q -s 2>&1 | tail -120 > gpurun_out/r02c_tests.log
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r02c_bench_fused.json 2> gpurun_out/r02c_bench_fused.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fuse-ln > gpurun_out/r02c_bench_unfused.json 2> gpurun_out/r02c_bench_unfused.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r02c_bench_fused2.json 2>> gpurun_out/r02c_bench_fused.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --precision exact > gpurun_out/r02c_bench_exact.json 2> gpurun_out/r02c_bench_exact.err
-tail -30 gpurun_out/r02c_tests.log; tail -3 gpurun_out/*.err; cat gpurun_out/r02c_bench_*.json
+python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/r02e_tests.log
+python bench.py --mode dinov2 --steps 20 --warmup 5 > gpurun_out/r02e_bench_dinov2_fp8.json 2> gpurun_out/r02e_a.err
+python bench.py --mode dinov2 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r02e_bench_dinov2_bf16.json 2> gpurun_out/r02e_b.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r02e_bench_bf16.json 2> gpurun_out/r02e_c.err
+tail -15 gpurun_out/r02e_tests.log; tail -n 3 gpurun_out/r02e_*.err; cat gpurun_out/r02e_bench_*.json | cut -c1-1800

@@ -52,7 +52,7 @@ constexpr bool out_is_bf16() {
 
 // TR = true : accumulators hold C^T (lane = row m, regs = cols n)  -> LDS image [m][n]
 // TR = false: accumulators hold C   (lane = col n, regs = rows m)  -> LDS image [n][m]   (V^T tiles)
-template <int EPI, bool TR, int PD, int NK>
+template <int EPI, bool TR>
 __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, unsigned char* smem) {
   unsigned char* lds = smem;
   const int tid = threadIdx.x;
@@ -61,17 +61,11 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
   const int l31 = lane & 31, hi = lane >> 5;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // Staging: 4 A chunks + 4 W chunks of 16 B per thread per K-tile, held in one of PD register sets.
-  // The memory system needs ~2-3k cycles to return a K-tile while its MFMAs take ~0.5k, so PD K-tiles are
-  // kept in flight per workgroup (register prefetch depth PD; slot of tile t = t % PD).  LDS stays
-  // double-buffered: tile t+1 moves registers -> LDS right after the MFMAs of tile t, and the freed
-  // register slot is immediately re-issued for tile t+1+PD.  All slot indices are compile-time (the K
-  // loop is unrolled by PD) so nothing spills to scratch.
-  // Loads are branch-free: rows past M / N are clamped to the last valid row (their results are never
-  // stored; an output element depends only on its own A row and its own W row).  With no control flow
-  // around the loads and a fully unrolled K loop (NK > 0) hipcc counts its vmcnt waits exactly, i.e. it
-  // waits only for the tile it is about to move to LDS while PD-1 younger tiles stay in flight.
-  u32x4_t ra[PD][4], rb[PD][4];
+  // Staging: 4 A chunks + 4 W chunks of 16 B per thread per K-tile, held in one of two register sets (two K-tiles in
+  // flight per workgroup); LDS is double-buffered: tile t+1 moves registers -> LDS right after the MFMAs of tile t.
+  // Loads are branch-free: rows past M / N are clamped to the last valid row (their results are never stored; an output
+  // element depends only on its own A row and its own W row).
+  u32x4_t ra[2][4], rb[2][4];
   const int srow = tid >> 3, skc = tid & 7;
   const unsigned char* pa[4];
   const unsigned char* pb[4];
@@ -137,36 +131,25 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
     }
   };
 
-  if constexpr (NK > 0) {
-    // straight-line software pipeline: every index and every condition below folds at compile time
-#pragma unroll
-    for (int u = 0; u < PD; ++u)
-      if (u < NK) load_regs(u, ra[u], rb[u]);
-    store_regs(0, ra[0], rb[0]);
-    if (PD < NK) load_regs(PD, ra[0], rb[0]);
+  // register prefetch two K-tiles deep, branch-free (the K-tile index is clamped, so hipcc counts vmcnt exactly: it waits
+  // only for the tile it is about to move to LDS); the loop is unrolled by two so register slots and LDS stages are
+  // compile-time.  (Fully unrolled K pipelines as in gemm_bf16.hip spilled 176 VGPRs here: the 8-VGPR fragments.)
+  const int nk = p.K / BK;
+  auto load_c = [&](int kt, u32x4_t (&a)[4], u32x4_t (&b)[4]) { load_regs(min(kt, nk - 1), a, b); };
+  load_c(0, ra[0], rb[0]);
+  load_c(1, ra[1], rb[1]);
+  store_regs(0, ra[0], rb[0]);
+  load_c(2, ra[0], rb[0]);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    compute(0);                              // tile kt
+    store_regs(1, ra[1], rb[1]);             // tile kt + 1 (or a clamped re-load of the last tile: then never read)
+    load_c(kt + 3, ra[1], rb[1]);
     __syncthreads();
-#pragma unroll
-    for (int kt = 0; kt < NK; ++kt) {
-      compute(kt & 1);
-      if (kt + 1 < NK) {
-        store_regs((kt + 1) & 1, ra[(kt + 1) % PD], rb[(kt + 1) % PD]);  // tile kt+1: issued PD tiles ago
-        if (kt + 1 + PD < NK) load_regs(kt + 1 + PD, ra[(kt + 1) % PD], rb[(kt + 1) % PD]);
-      }
-      __syncthreads();  // also: after the last K-tile every wave is done with the operand LDS
-    }
-  } else {
-    // generic K (any multiple of 64): runtime loop, one tile in flight
-    const int nk = p.K / BK;
-    load_regs(0, ra[0], rb[0]);
-    store_regs(0, ra[0], rb[0]);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = (kt + 1 < nk);
-      if (more) load_regs(kt + 1, ra[0], rb[0]);
-      compute(kt & 1);
-      if (more) store_regs((kt + 1) & 1, ra[0], rb[0]);
-      __syncthreads();
-    }
+    if (kt + 1 < nk) compute(1);             // tile kt + 1 (block-uniform)
+    store_regs(0, ra[0], rb[0]);             // tile kt + 2
+    load_c(kt + 4, ra[0], rb[0]);
+    __syncthreads();                         // also: after the last K-tile every wave is done with the operand LDS
   }
 
   // ---------------- epilogue, part 1: registers -> LDS tile image (bias + activation applied) ----------
@@ -293,7 +276,7 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
   }
 }
 
-template <int EPI, int PD, int NK>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmFp8Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -302,34 +285,25 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmFp8Params p) {
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   if constexpr (EPI == EPI_QKV) {
     if (tn * BN >= 2 * (p.N / 3)) {  // block-uniform: the V third is produced as V^T
-      gemm_fp8_tile<EPI, false, PD, NK>(p, tm, tn, smem);
+      gemm_fp8_tile<EPI, false>(p, tm, tn, smem);
       return;
     }
   }
-  gemm_fp8_tile<EPI, true, PD, NK>(p, tm, tn, smem);
-}
-
-template <int EPI, int NK>
-int launch(const GemmFp8Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI, 3, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL((gemm_fp8_kernel<EPI, 3, NK>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
-  WVN_LAUNCH_CHECK();
-  return WVN_OK;
+  gemm_fp8_tile<EPI, true>(p, tm, tn, smem);
 }
 
 template <int EPI>
 int launch_epi(const GemmFp8Params& p, hipStream_t st) {
-  switch (p.K / BK) {   // K of the ViT linears: 384 / 768 (qkv, proj, fc1), 1536 / 3072 (fc2); anything else: runtime loop
-    case 3: return launch<EPI, 3>(p, st);
-    case 6: return launch<EPI, 6>(p, st);
-    default: return launch<EPI, 0>(p, st);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
   }
+  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  hipLaunchKernelGGL((gemm_fp8_kernel<EPI>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
 }
 
 }  // namespace
