@@ -31,7 +31,7 @@ def test_quantize_rows(dev, dtype, R, C):
     # where x / scale itself differs in the last fp32 bit (multiply by the reciprocal here, a division there)
     # (bf16 inputs carry 8 mantissa bits, so x / scale lands on e4m3 rounding ties far more often than fp32 inputs do)
     assert (got == ref).float().mean().item() > (0.999 if dtype == torch.float32 else 0.97)
-    assert ((got - ref).abs() <= 0.0626 * ref.abs() + 2.0 ** -9).all()
+    assert ((got - ref).abs() <= 0.126 * ref.abs() + 2.0 ** -9).all()       # a differing code is the neighbouring e4m3 value (step <= 1/8 of the value)
     assert (q.cpu().float()[3] == 0).all() and float(sc[3]) == 1.0
 
 

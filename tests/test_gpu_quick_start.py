@@ -65,3 +65,67 @@ def test_quick_start_sequence_on_reference_demo_frames(dev, setup, prec, tol, to
             confidence = cg.inference_without_update(x=loss_reco).reshape(224, 224)
             assert (confidence.cpu().reshape(-1) - conf_o).abs().max().item() < tol_conf, name
             assert out_trav.shape == (224, 224) and 0.0 < float(out_trav.min()) and float(out_trav.max()) < 1.0
+
+
+def test_quick_start_body_through_the_reference_import_paths(dev, setup):
+    """The caller's own lines -- quick_start.py:6-18 (imports), :111-128 (ConfidenceGenerator, FeatureExtractor with the
+    quick_start keyword set), :131-143 (get_model, load_state_dict(strict=False) with the extra "confidence_generator" key),
+    :165-181 (ImageProjector.resize_image, extract), :183-210 -- executed against ``wild_visual_navigation`` as aliased by
+    ``wild_visual_navigation_amd.dropin.install()``, with precision "exact" (the <= 1e-3 mode on the matrix pipe) and the
+    reference's default segmentation ("slic"); every float output against the CPU oracle."""
+    import wild_visual_navigation_amd.dropin as dropin
+
+    dropin.install(force_synthetic=True)
+    from wild_visual_navigation import WVN_ROOT_DIR                                   # noqa: F401  quick_start.py:6
+    from wild_visual_navigation.feature_extractor import FeatureExtractor as FE        # :7
+    from wild_visual_navigation.cfg import ExperimentParams as EP                      # :8
+    from wild_visual_navigation.image_projector import ImageProjector                  # :9
+    from wild_visual_navigation.model import get_model as gm                           # :10
+    from wild_visual_navigation.utils import ConfidenceGenerator as CG, AnomalyLoss    # noqa: F401  :11-12
+    from wild_visual_navigation.utils import Data as D2                                # :18
+    from oracle import slic as OSL
+
+    frames, sd, mlp_sd = setup
+    params = EP()
+    confidence_generator = CG(method=params.loss.method, std_factor=params.loss.confidence_std_factor)
+    feature_extractor = FE(device=dev, segmentation_type="slic", feature_type="dino", patch_size=8, backbone_type="vit_small",
+                           input_size=224, slic_num_components=100, pretrained_weights=sd, precision="exact")
+    params.model.simple_mlp_cfg.input_size = feature_extractor.feature_dim
+    params.model.double_mlp_cfg.input_size = feature_extractor.feature_dim
+    params.model.simple_gcn_cfg.input_size = feature_extractor.feature_dim
+    params.model.linear_rnvp_cfg.input_size = feature_extractor.feature_dim
+    model = gm(params.model).to(dev)
+    model.eval()
+    state = {**mlp_sd, "confidence_generator": {"mean": torch.tensor([0.9]), "var": torch.tensor([[0.06]]), "std": torch.tensor([0.25])}}
+    model.load_state_dict(state, strict=False)
+    cg = state["confidence_generator"]
+    confidence_generator.var, confidence_generator.mean, confidence_generator.std = (
+        torch.nn.Parameter(cg["var"], requires_grad=False), torch.nn.Parameter(cg["mean"], requires_grad=False),
+        torch.nn.Parameter(cg["std"], requires_grad=False))                          # quick_start.py:146-150 assigns the fields
+    confidence_generator = confidence_generator.to(dev)
+    raw = torch.zeros(3, 224, 299, dtype=torch.uint8)
+    raw[:, :, 37:261] = frames["frames_u8"][0]                                        # a 299 x 224 frame like assets/demo_data
+    torch_image = raw.to(dev).float() / 255.0
+    image_projector = ImageProjector(K=torch.eye(4, device=dev)[None], h=224, w=299, new_h=224, new_w=224)
+    torch_image = image_projector.resize_image(torch_image)
+    assert torch_image.shape == (3, 224, 224)
+    _, feat, seg, center, dense_feat = feature_extractor.extract(img=torch_image[None], return_centers=False,
+                                                                 return_dense_features=True, n_random_pixels=100)
+    img_cpu = torch_image.cpu()
+    dense_o = OI.dino_inference(sd, img_cpu[None], 224, 8, 6)
+    seg_o = torch.from_numpy(OSL.slic(img_cpu.numpy(), 100, 10.0)).long()
+    assert torch.equal(seg.cpu(), seg_o)                                               # bit-exact segment-index map
+    assert (dense_feat.cpu() - dense_o).abs().max().item() < 1e-3
+    feat_o = OS.sparsify_features(dense_o, seg_o)
+    ok = ~torch.isnan(feat_o).any(1)
+    assert (feat.cpu()[ok] - feat_o[ok]).abs().max().item() < 1e-3
+    input_feat = torch.nan_to_num(feat)[seg.reshape(-1)]
+    data = D2(x=input_feat)
+    prediction = model.forward(data)
+    out_trav = prediction.reshape(224, 224, -1)[:, :, 0]
+    pred_o = OM.mlp_forward(mlp_sd, torch.nan_to_num(feat_o)[seg_o.reshape(-1)])
+    assert (prediction.cpu() - pred_o).abs().max().item() < 1e-3
+    loss_reco = torch.nn.functional.mse_loss(prediction[:, 1:], data.x, reduction="none").mean(dim=1)
+    confidence = confidence_generator.inference_without_update(x=loss_reco)
+    conf_o = OM.confidence_from_stats(((pred_o[:, 1:] - torch.nan_to_num(feat_o)[seg_o.reshape(-1)]) ** 2).mean(1), 0.9, 0.25, 0.5)
+    assert (confidence.cpu() - conf_o).abs().max().item() < 1e-3 and out_trav.shape == (224, 224)
