@@ -77,3 +77,44 @@ def test_transform_identity_and_crop():
     assert out.shape[-2:] == (224, 224) and torch.equal(out, img[..., :, 38:262])
     sq = torch.rand(1, 3, 224, 224)
     assert OI.resize_nearest_center_crop(sq, 224) is sq
+
+
+@pytest.mark.parametrize("arch,heads,img,depth", [("vit_small", 6, 70, 2), ("vit_base", 12, 56, 2)])
+def test_dinov2_matches_huggingface(arch, heads, img, depth):
+    """The DINOv2 restatement (LayerScale on both branch outputs, patch 14) against HuggingFace's Dinov2Model with the same
+    synthetic weights copied in, at the pre-training grid (identity position table)."""
+    transformers = pytest.importorskip("transformers")
+    patch = 14
+    sd = OV.make_dinov2_state_dict(arch, patch, pretrain_grid=img // patch, seed=5, depth=depth)
+    D = sd["cls_token"].shape[-1]
+    cfg = transformers.Dinov2Config(hidden_size=D, num_hidden_layers=depth, num_attention_heads=heads, mlp_ratio=4, hidden_act="gelu",
+                                    layer_norm_eps=1e-6, image_size=img, patch_size=patch, qkv_bias=True, layerscale_value=1.0,
+                                    use_swiglu_ffn=False, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = transformers.Dinov2Model(cfg).eval()
+    hs = {"embeddings.cls_token": sd["cls_token"], "embeddings.position_embeddings": sd["pos_embed"],
+          "embeddings.mask_token": torch.zeros(1, D),
+          "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+          "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
+          "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+    for i in range(depth):
+        p, q = f"blocks.{i}.", f"encoder.layer.{i}."
+        w, b = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
+        for j, n in enumerate(("query", "key", "value")):
+            hs[q + f"attention.attention.{n}.weight"], hs[q + f"attention.attention.{n}.bias"] = w[j * D:(j + 1) * D], b[j * D:(j + 1) * D]
+        hs[q + "attention.output.dense.weight"], hs[q + "attention.output.dense.bias"] = sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]
+        for n in ("norm1", "norm2"):
+            hs[q + n + ".weight"], hs[q + n + ".bias"] = sd[p + n + ".weight"], sd[p + n + ".bias"]
+        for n in ("fc1", "fc2"):
+            hs[q + f"mlp.{n}.weight"], hs[q + f"mlp.{n}.bias"] = sd[p + f"mlp.{n}.weight"], sd[p + f"mlp.{n}.bias"]
+        hs[q + "layer_scale1.lambda1"], hs[q + "layer_scale2.lambda1"] = sd[p + "ls1.gamma"], sd[p + "ls2.gamma"]
+    have = set(m.state_dict())
+    if not set(hs) <= have:
+        pytest.skip(f"this transformers version names the Dinov2 parameters differently: {sorted(set(hs) - have)[:4]}")
+    missing, unexpected = m.load_state_dict(hs, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    x = OI.normalize(torch.rand(2, 3, img, img, generator=torch.Generator().manual_seed(2)))
+    with torch.no_grad():
+        ours = OV.vit_tokens(sd, x, patch, heads)
+        hf = m(pixel_values=x).last_hidden_state
+    assert ours.shape == hf.shape and (ours - hf).abs().max().item() < 2e-4
+    assert sum(v.numel() for v in OV.make_dinov2_state_dict("vit_base", 14, 37).values()) == 86_580_480 - 768   # SURVEY.md 8 (minus mask_token)
