@@ -42,6 +42,11 @@ int wvn_version(void);
  * rows are zero-padded to a multiple of 64 columns (588 -> 640 for patch 14).
  * Biases, LayerNorm affine, LayerScale and the position table are always fp32.
  * ------------------------------------------------------------------------------------------- */
+/* wvn_vit_model.flags.  WVN_VIT_MLP_FUSED (WVN_PREC_BF16, D = 384, F % 64 == 0): every fc2_w is stored with the hidden (input)
+ * index permuted -- bits 2 and 3 swapped inside each aligned group of 16, fc2_w_stored[n][k] = fc2.weight[n][swap23(k)] -- and
+ * the block MLP, including its LayerNorm (blocks.i.norm2), runs as ONE kernel that keeps the normalised rows and the hidden
+ * activation in registers (csrc/mlp_fused.hip). */
+#define WVN_VIT_MLP_FUSED 1
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
@@ -61,7 +66,7 @@ typedef struct wvn_vit_model {
   int heads;    /* h (6); head dim is fixed at 64        */
   int mlp_dim;  /* F (1536)                              */
   int precision;
-  int reserved;
+  int flags;    /* WVN_VIT_* bits */
   const void* patch_w;  /* [D][3*P*P (padded, see above)] conv weight flattened (c, py, px) */
   const float* patch_b; /* [D]                                                      */
   const float* cls_pos; /* [D]  = cls_token + pos_embed[0]                          */
@@ -95,6 +100,13 @@ int wvn_prof_collect(double* ms_by_cat_host, long long* launches_by_cat_host); /
 /* ---------------------------------------------------------------------------------------------
  * Building blocks, exported so tests/ can check each kernel against the oracle.
  * ------------------------------------------------------------------------------------------- */
+/* Block MLP in one launch: x [M,ldx] fp32 += gelu(xn [M,lda] bf16 * W1[F,384]^T + b1) * W2[384,F]^T + b2  (optionally
+ * times LayerScale ls [384]).  W2p = W2 with the hidden index permuted as WVN_VIT_MLP_FUSED describes.  xn == NULL: the kernel
+ * computes xn = LayerNorm(x; ln_g, ln_b, ln_eps) itself (what wvn_vit_forward uses: blocks.i.norm2 never touches memory).
+ * D is fixed at 384, F % 64 == 0, F <= 1536.  Same arithmetic as wvn_gemm_bf16(epi 1) followed by wvn_gemm_bf16(epi 4) except
+ * the summation order inside an MFMA (and inside the LayerNorm statistics). */
+int wvn_mlp_fused(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
+                  const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream);
 /* C = epilogue(A[M,K] * W[N,K]^T + bias).  epi: 0 bf16 out, 1 gelu->bf16, 2 relu->bf16, 3 f32 out,
  * 4 f32 out += (residual), 5 same as 4.  A/W bf16, K % 64 == 0. */
 int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,

@@ -1,0 +1,45 @@
+"""Micro-benchmark of the fused block MLP against the un-fused pair at the shipped shape (64 frames of 3152 rows)."""
+import sys
+import torch
+from wild_visual_navigation_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+M, F = 64 * 3152, 1536
+g = torch.Generator().manual_seed(0)
+xn = torch.randn(M, 384, generator=g).to(torch.bfloat16).to(dev)
+w1 = (torch.randn(F, 384, generator=g) * 0.06).to(torch.bfloat16).to(dev)
+w2 = (torch.randn(384, F, generator=g) * 0.03).to(torch.bfloat16).to(dev)
+b1 = torch.randn(F, generator=g).to(dev)
+b2 = torch.randn(384, generator=g).to(dev)
+x = torch.randn(M, 384, generator=g).to(dev)
+hid = torch.empty(M, F, dtype=torch.bfloat16, device=dev)
+w2p = w2[:, ops.vt_token_order(F, device=dev)].contiguous()
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def unfused():
+    ops.gemm_bf16(xn, w1, b1, _lib.EPI_GELU_BF16, out=hid)
+    ops.gemm_bf16(hid, w2, b2, _lib.EPI_RESID_F32, out=x)
+
+
+print("unfused pair: %.1f us" % timeit(unfused))
+fl = 2.0 * M * 384 * F * 2
+t = timeit(lambda: ops.mlp_fused(xn, w1, b1, w2p, b2, x))
+print("fused (xn given): %.1f us  (%.0f TFLOP/s)" % (t, fl / t / 1e6))
+gam, bet = torch.ones(384, device=dev), torch.zeros(384, device=dev)
+x.normal_()
+t = timeit(lambda: ops.mlp_fused(None, w1, b1, w2p * 0, b2 * 0, x, ln=(gam, bet, 1e-6)))
+print("fused (LayerNorm inside): %.1f us  (%.0f TFLOP/s)" % (t, fl / t / 1e6))
+xnb = torch.empty(M, 384, dtype=torch.bfloat16, device=dev)

@@ -1,0 +1,155 @@
+// Micro-benchmark: issue rate of v_mfma_f32_32x32x16_bf16 from one wave per SIMD, as a function of the number of independent
+// accumulator chains, in shader cycles (s_memtime) and wall time.  Build: hipcc --offload-arch=gfx950 -O3 -o mfma_rate mfma_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int NCHAIN, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256 * WAVES_PER_SIMD, 1) void k(const bf16x8_t* in, float* out, long long* cyc, int iters) {
+  bf16x8_t a[NCHAIN], b = in[threadIdx.x & 63];
+  f32x16_t acc[NCHAIN];
+#pragma unroll
+  for (int c = 0; c < NCHAIN; ++c) {
+    a[c] = in[64 + c * 64 + (threadIdx.x & 63)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  }
+  __syncthreads();
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 32 / NCHAIN; ++u)
+#pragma unroll
+      for (int c = 0; c < NCHAIN; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c], b, acc[c], 0, 0, 0);
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCHAIN; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[c][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+// FILL: 1 = one s_nop after every MFMA, 2 = the fused-MLP pattern: every MFMA's A operand comes from a ds_read_b128 issued 4 MFMAs
+// earlier (ring of 4 fragments), 3 = same + 4 VALU ops per MFMA
+template <int NCHAIN, int FILL>
+__global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, long long* cyc, int iters) {
+  __shared__ bf16x8_t lds[64 * 32];
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) lds[i] = in[i];
+  bf16x8_t b = in[threadIdx.x & 63];
+  f32x16_t acc[NCHAIN];
+  float v[4] = {1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+  for (int c = 0; c < NCHAIN; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  __syncthreads();
+  const bf16x8_t* base = lds + (threadIdx.x & 63);
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+    if constexpr (FILL == 1) {
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        acc[u % NCHAIN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, acc[u % NCHAIN], 0, 0, 0);
+        asm volatile("s_nop 0");
+      }
+    } else {
+      bf16x8_t wf[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wf[q] = base[q * 64];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        acc[u % NCHAIN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u & 3], b, acc[u % NCHAIN], 0, 0, 0);
+        if (u + 4 < 32) wf[u & 3] = base[((u + 4) & 31) * 64];
+        if constexpr (FILL == 3) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaf(v[q], 1.0001f, 0.5f);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int u = 0; u < 28; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (FILL == 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float s = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+  for (int c = 0; c < NCHAIN; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[c][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int NCHAIN, int FILL>
+void runf(int grid, const bf16x8_t* in, float* out, long long* cyc, const char* tag) {
+  const int iters = 2000;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL((kf<NCHAIN, FILL>), dim3(grid), dim3(256), 0, 0, in, out, cyc, iters);
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((kf<NCHAIN, FILL>), dim3(grid), dim3(256), 0, 0, in, out, cyc, iters);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<long long> h(grid * 4);
+  (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+  double mean = 0; for (auto v : h) mean += v; mean /= h.size();
+  const double n = (double)iters * 32;
+  printf("%-36s grid %4d: %.1f ticks/MFMA/wave, wall %.3f ms -> %.2f ns/MFMA/wave, %.0f TFLOP/s\n", tag, grid, mean / n, ms, ms * 1e6 / n,
+         n * grid * 4 * 32768.0 / (ms * 1e-3) / 1e12);
+}
+
+template <int NCHAIN, int W>
+void run(int grid, const bf16x8_t* in, float* out, long long* cyc, const char* tag) {
+  const int iters = 2000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k<NCHAIN, W>), dim3(grid), dim3(256 * W), 0, 0, in, out, cyc, iters);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((k<NCHAIN, W>), dim3(grid), dim3(256 * W), 0, 0, in, out, cyc, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  std::vector<long long> h(grid * 4 * W);
+  hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+  double mean = 0; for (auto v : h) mean += v; mean /= h.size();
+  const double n = (double)iters * 32;
+  printf("%-28s grid %4d: %.1f ticks/MFMA/wave, wall %.3f ms -> %.2f ns/MFMA/wave, %.0f TFLOP/s\n", tag, grid, mean / n, ms, ms * 1e6 / n,
+         n * grid * 4 * W * 32768.0 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+  bf16x8_t* in; float* out; long long* cyc;
+  (void)hipMalloc(&in, 64 * 64 * sizeof(bf16x8_t)); (void)hipMalloc(&out, 1024 * 512 * 4); (void)hipMalloc(&cyc, 1024 * 8 * 8);
+  std::vector<unsigned short> h(64 * 64 * 8);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 2654435761u) >> 20 & 0x3ff);  // random-ish bf16 near 1
+  hipMemcpy(in, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  for (int grid : {1, 256}) {
+    runf<2, 1>(grid, in, out, cyc, "2 chains + s_nop");
+    runf<4, 1>(grid, in, out, cyc, "4 chains + s_nop");
+    runf<2, 2>(grid, in, out, cyc, "2 chains + ds_read ring");
+    runf<4, 2>(grid, in, out, cyc, "4 chains + ds_read ring");
+    runf<8, 2>(grid, in, out, cyc, "8 chains + ds_read ring");
+    runf<2, 3>(grid, in, out, cyc, "2 chains + ds_read ring + 4 VALU");
+    runf<4, 3>(grid, in, out, cyc, "4 chains + ds_read ring + 4 VALU");
+    runf<8, 3>(grid, in, out, cyc, "8 chains + ds_read ring + 4 VALU");
+    run<1, 1>(grid, in, out, cyc, "1 chain, 1 wave/SIMD");
+    run<2, 1>(grid, in, out, cyc, "2 chains, 1 wave/SIMD");
+    run<4, 1>(grid, in, out, cyc, "4 chains, 1 wave/SIMD");
+    run<8, 1>(grid, in, out, cyc, "8 chains, 1 wave/SIMD");
+    run<2, 2>(grid, in, out, cyc, "2 chains, 2 waves/SIMD");
+    run<4, 2>(grid, in, out, cyc, "4 chains, 2 waves/SIMD");
+  }
+  return 0;
+}

@@ -1,0 +1,113 @@
+"""The fused block MLP (csrc/mlp_fused.hip: fc1 -> GELU -> fc2 with the hidden activation kept in registers, W1 / W2 through one
+direct-to-LDS ring), called through the C-ABI, against (a) the un-fused kernel pair it replaces -- same bf16 rounding points,
+so the two agree to fp32 summation-order noise -- and (b) fp32 math on the bf16-rounded inputs.  Shapes cover partial row
+blocks, fewer row blocks than CUs, several row blocks per workgroup (the ring streams across them) and LayerScale; the repeat
+test screens for pipeline races (ring reuse, counted vmcnt): a race shows up as run-to-run differences."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from wild_visual_navigation_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def make(M, Fh, dev, ls=False):
+    xn = torch.randn(M, 384, generator=g(1)).to(torch.bfloat16)
+    w1 = (torch.randn(Fh, 384, generator=g(2)) * 0.06).to(torch.bfloat16)
+    b1 = torch.randn(Fh, generator=g(3)) * 0.5
+    w2 = (torch.randn(384, Fh, generator=g(4)) * 0.03).to(torch.bfloat16)
+    b2 = torch.randn(384, generator=g(5)) * 0.5
+    x = torch.randn(M, 384, generator=g(6))
+    gam = (torch.rand(384, generator=g(7)) + 0.5) if ls else None
+    t = [xn, w1, b1, w2, b2, x] + ([gam] if ls else [])
+    return [a.to(dev) for a in t] + ([] if ls else [None])
+
+
+def unfused(xn, w1, b1, w2, b2, x):
+    hid = ops.gemm_bf16(xn, w1, b1, _lib.EPI_GELU_BF16)
+    out = x.clone()
+    ops.gemm_bf16(hid, w2, b2, _lib.EPI_RESID_F32, out=out)
+    return out
+
+
+@pytest.mark.parametrize("M", [1, 31, 128, 300, 1000, 128 * 300 + 17])
+@pytest.mark.parametrize("Fh", [1536, 64, 704])
+def test_fused_matches_unfused_pair(dev, M, Fh):
+    if M > 1000 and Fh != 1536:
+        pytest.skip("large M only at the shipped width")
+    xn, w1, b1, w2, b2, x, _ = make(M, Fh, dev)
+    want = unfused(xn, w1, b1, w2, b2, x)
+    w2p = w2[:, ops.vt_token_order(Fh, device=dev)].contiguous()
+    got = ops.mlp_fused(xn, w1, b1, w2p, b2, x.clone())
+    torch.cuda.synchronize()
+    # identical bf16 rounding of the hidden activation except where fp32 summation order flips a rounding (rare); the output
+    # sums 1536 products of magnitude ~0.03: allow a few bf16 flips of single hidden units
+    err = (got - want).abs().max().item()
+    assert err <= 2e-3, err
+    assert (got - want).abs().mean().item() <= 2e-5
+    # fp32 math on the same inputs
+    ref = x.cpu() + F.gelu(xn.float().cpu() @ w1.float().cpu().T + b1.cpu()).to(torch.bfloat16).float() @ w2.float().cpu().T + b2.cpu()
+    assert (got.cpu() - ref).abs().max().item() <= 2e-2
+    assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("M", [5, 128, 777, 128 * 300 + 17])
+def test_fused_with_layernorm(dev, M):
+    """xn=None: the kernel normalises the rows of x itself (blocks.i.norm2 folded in) -- against the LayerNorm kernel + un-fused pair"""
+    Fh = 1536
+    _, w1, b1, w2, b2, x, _ = make(M, Fh, dev)
+    x = x * 3.0 + 0.7                                   # rows with a mean and a spread
+    gam = (torch.rand(384, generator=g(8)) + 0.5).to(dev)
+    bet = (torch.randn(384, generator=g(9)) * 0.2).to(dev)
+    xn = F.layer_norm(x, (384,), gam, bet, 1e-6).to(torch.bfloat16)
+    want = unfused(xn, w1, b1, w2, b2, x)
+    w2p = w2[:, ops.vt_token_order(Fh, device=dev)].contiguous()
+    got = ops.mlp_fused(None, w1, b1, w2p, b2, x.clone(), ln=(gam, bet, 1e-6))
+    torch.cuda.synchronize()
+    # the LayerNorm statistics are summed in another order than torch's: a few normalised values land on the other side of a bf16
+    # rounding boundary (1 ulp = 2^-8 relative on values ~1, times |w1| ~0.06 through GELU and |w2| ~0.03): 1e-2 covers it
+    assert (got - want).abs().max().item() <= 1e-2
+    assert (got - want).abs().mean().item() <= 1e-4
+    assert torch.isfinite(got).all()
+    again = ops.mlp_fused(None, w1, b1, w2p, b2, x.clone(), ln=(gam, bet, 1e-6))
+    assert torch.equal(got, again)
+
+
+def test_fused_layerscale(dev):
+    M, Fh = 515, 1536
+    xn, w1, b1, w2, b2, x, gam = make(M, Fh, dev, ls=True)
+    w2p = w2[:, ops.vt_token_order(Fh, device=dev)].contiguous()
+    got = ops.mlp_fused(xn, w1, b1, w2p, b2, x.clone(), ls=gam).cpu()
+    hid = F.gelu(xn.float().cpu() @ w1.float().cpu().T + b1.cpu()).to(torch.bfloat16).float()
+    ref = x.cpu() + gam.cpu() * (hid @ w2.float().cpu().T + b2.cpu())
+    assert (got - ref).abs().max().item() <= 3e-2
+
+
+def test_fused_rows_past_m_untouched_and_repeatable(dev):
+    M, Fh = 128 * 520 + 77, 1536   # > 2 row blocks per workgroup on 256 CUs, ragged tail
+    xn, w1, b1, w2, b2, x, _ = make(M, Fh, dev)
+    w2p = w2[:, ops.vt_token_order(Fh, device=dev)].contiguous()
+    guard = torch.full((M + 256, 384), 7.0, device=dev)
+    guard[:M] = x
+    outs = []
+    for _ in range(4):
+        buf = guard.clone()
+        ops.mlp_fused(xn, w1, b1, w2p, b2, buf[:M])
+        torch.cuda.synchronize()
+        assert (buf[M:] == 7.0).all(), "rows past M were written"
+        outs.append(buf[:M].clone())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "run-to-run difference (pipeline race)"
+    want = unfused(xn, w1, b1, w2, b2, x)
+    assert (outs[0] - want).abs().max().item() <= 2e-3
+
+
+def test_fused_argument_checks(dev):
+    xn, w1, b1, w2, b2, x, _ = make(64, 1536, dev)
+    with pytest.raises(_lib.WvnError):
+        ops.mlp_fused(xn, w1[:100], b1[:100], w2[:, :100].contiguous(), b2, x)   # F % 64 != 0

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwvn_hip.so")
 
 WVN_MAX_DEPTH = 32
 PREC_F32, PREC_BF16, PREC_X3, PREC_FP8 = 0, 1, 2, 3
+VIT_MLP_FUSED = 1
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -34,7 +35,7 @@ class VitLayer(C.Structure):
 class VitModel(C.Structure):
     _fields_ = [
         ("img_size", C.c_int), ("patch", C.c_int), ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
-        ("mlp_dim", C.c_int), ("precision", C.c_int), ("reserved", C.c_int),
+        ("mlp_dim", C.c_int), ("precision", C.c_int), ("flags", C.c_int),
         ("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls_pos", C.c_void_p), ("pos", C.c_void_p),
         ("norm_g", C.c_void_p), ("norm_b", C.c_void_p),
         ("layers", VitLayer * WVN_MAX_DEPTH),
@@ -57,6 +58,7 @@ _SIGNATURES = {
     "wvn_prof_enable": ([_i], _i),
     "wvn_prof_collect": ([_p, _p], _i),
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_mlp_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_gemm_x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_quantize_rows_fp8": ([_p, _i, _i, _p, _i, _p, _i, _i, _p], _i),
     "wvn_gemm_fp8": ([_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),

@@ -91,7 +91,7 @@ class VitBackbone:
     e4m3 MFMA at twice the bf16 rate, per-token / per-channel scales; everything else as "bf16")."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
-                 device="cuda", precision: str = "bf16", max_chunk: int = 16):
+                 device="cuda", precision: str = "bf16", max_chunk: int = 16, fuse_mlp: Optional[bool] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
@@ -104,6 +104,11 @@ class VitBackbone:
         self.depth = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         self.mlp_dim = state_dict["blocks.0.mlp.fc1.weight"].shape[0]
         self.max_chunk = max_chunk
+        # block MLP as one kernel with the hidden activation kept on chip (csrc/mlp_fused.hip): bf16, D = 384
+        can_fuse = self.precision == _lib.PREC_BF16 and self.dim == 384 and self.mlp_dim % 64 == 0 and self.mlp_dim <= 2176
+        if fuse_mlp and not can_fuse:
+            raise _lib.WvnError("fuse_mlp needs precision 'bf16', dim 384 and mlp_dim % 64 == 0")
+        self.fuse_mlp = can_fuse if fuse_mlp is None else bool(fuse_mlp)
         self._sd = state_dict  # kept (host / original tensors) so that .to(device) can re-home the model
         self._keep = []  # device tensors referenced by raw pointers in the C struct
 
@@ -139,6 +144,7 @@ class VitBackbone:
         m = _lib.VitModel()
         m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim = img_size, patch, self.dim, self.depth, heads, self.mlp_dim
         m.precision = self.precision
+        m.flags = _lib.VIT_MLP_FUSED if self.fuse_mlp else 0
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
@@ -158,7 +164,11 @@ class VitBackbone:
                 L.fc2_w, L.fc2_s = mat8(sd[p + "mlp.fc2.weight"])
             else:
                 L.qkv_w, L.proj_w = mat(sd[p + "attn.qkv.weight"]), mat(sd[p + "attn.proj.weight"])
-                L.fc1_w, L.fc2_w = mat(sd[p + "mlp.fc1.weight"]), mat(sd[p + "mlp.fc2.weight"])
+                w2 = sd[p + "mlp.fc2.weight"]
+                if self.fuse_mlp:  # hidden index in the order the fc1 accumulators hand it over (wvn_hip.h WVN_VIT_MLP_FUSED)
+                    k = torch.arange(self.mlp_dim)
+                    w2 = w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)]
+                L.fc1_w, L.fc2_w = mat(sd[p + "mlp.fc1.weight"]), mat(w2)
             L.qkv_b, L.proj_b = vec(sd[p + "attn.qkv.bias"]), vec(sd[p + "attn.proj.bias"])
             L.fc1_b, L.fc2_b = vec(sd[p + "mlp.fc1.bias"]), vec(sd[p + "mlp.fc2.bias"])
             L.ln1_g, L.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
@@ -175,7 +185,7 @@ class VitBackbone:
         if device == self.device:
             return self
         return VitBackbone(self._sd, self.img_size, self.patch, self.heads, device=device, precision=self.precision_name,
-                           max_chunk=self.max_chunk)
+                           max_chunk=self.max_chunk, fuse_mlp=self.fuse_mlp)
 
     # ---- workspace (needs no initialisation: wvn_vit_forward resets the padding rows it relies on at every call) ----
     def _workspace(self, batch: int) -> torch.Tensor:

@@ -142,6 +142,8 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (fp8 && ((d.D % 128) || (d.F % 128))) return WVN_ERR_ARG;
   // fp8: everything that is not one of the four block linears runs exactly as in the bf16 mode
   const bool bf = m->precision == WVN_PREC_BF16 || fp8, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
+  const bool mlp_fused = (m->flags & WVN_VIT_MLP_FUSED) != 0;
+  if (mlp_fused && (m->precision != WVN_PREC_BF16 || d.D != 384 || (d.F % 64) != 0)) return WVN_ERR_ARG;
   if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
   const float scale = 1.0f / sqrtf(64.f);
   const int M = (int)d.M, Mp = (int)d.Mp;
@@ -268,7 +270,13 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
     { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
-    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    if (!mlp_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    if (mlp_fused) {  // LayerNorm 2 + fc1 + GELU + fc2 + residual: one launch, no xn / hid round trip
+      Span s(6, st);
+      RET_IF(wvn_mlp_fused_launch(nullptr, 0, L.ln2_g, L.ln2_b, 1e-6f, (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w, L.fc2_b,
+                                  L.ls2, w.x, d.D, M, d.F, st));
+      continue;
+    }
     { Span s(6, st); RET_IF(linear(w.xn, pl_xn, d.D, L.fc1_w, L.fc1_b, w.hid, pl_hid, d.F, M, d.F, d.D, EPI_GELU_BF16, nullptr, nullptr)); }
     { Span s(7, st); RET_IF(linear(w.hid, pl_hid, d.F, L.fc2_w, L.fc2_b, w.x, 0, d.D, M, d.D, d.F, EPI_RESID_F32, L.ls2, nullptr)); }
   }
@@ -291,6 +299,12 @@ int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
+}
+
+int wvn_mlp_fused(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
+                  const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream) {
+  return wvn_mlp_fused_launch((const bf16_t*)xn, lda, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1, (const bf16_t*)W2p, b2, ls, x, ldx,
+                              M, F, (hipStream_t)stream);
 }
 
 int wvn_gemm_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,

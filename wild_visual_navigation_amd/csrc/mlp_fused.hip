@@ -1,0 +1,386 @@
+// Fused ViT MLP for D = 384 on gfx950:   x[M,384] (fp32, in place) += gelu(xn[M,384] W1^T + b1) W2^T + b2
+//
+// The un-fused pair (gemm_a384 fc1 -> 620 MB of bf16 hidden activations written and read back per 64 frames -> gemm_n384
+// fc2) moves 1.24 GB per block that this kernel never creates: the hidden activation lives in registers for the few hundred
+// cycles between being produced and being consumed.
+//
+//   * a workgroup is 4 waves = ONE wave per SIMD with the whole 512-entry register file; a wave owns 32 token rows for the
+//     whole MLP: its xn rows as MFMA operands (96 VGPRs, loaded once), the 32 x 384 fp32 output accumulator (192), and one
+//     32 x 64 tile of hidden pre-activations (32);
+//   * W1 ([F][384]) and W2 ([384][F], hidden index permuted, see below) stream through ONE LDS ring of 16 KB slices written by
+//     direct-to-LDS DMA: per 64 hidden units three W1 slices [64 h][128 k] and three W2 slices [128 n][64 h]; one s_barrier
+//     and a counted vmcnt per slice, 16 MFMAs per wave per slice, the ring never drains (it keeps streaming across row blocks);
+//   * fc1 runs in the "transposed" orientation mfma(W1 frag, xn frag): lane = token row, registers = 4 consecutive hidden
+//     units -- after bias (accumulator init) and GELU those registers, packed to bf16, ARE the B operand of the fc2 MFMA
+//     mfma(W2 frag, h frag): an MFMA sums over its k-slots in a fixed but arbitrary order, so operands only have to agree on
+//     which hidden unit sits in which slot.  The accumulator hands lane half hi the units {4 hi .. 4 hi + 3} and
+//     {8 + 4 hi .. 8 + 4 hi + 3} of every group of 16; W2 is therefore stored with bits 2 and 3 of the hidden index swapped
+//     inside every aligned group of 16 (the V^T trick of attention_bf16.hip), done once when the model is packed;
+//   * epilogue once per row block: accumulators -> wave-private LDS image -> (+ b2) + residual read-modify-write of whole
+//     512-byte rows, exactly the association of the un-fused kernels ((acc + bias) + x).
+//
+// GELU: the 0.25-bf16-ulp polynomial form of gemm_a384.hip (same code, same bits as the un-fused fc1 epilogue).
+#include <type_traits>
+#include "common.h"
+#include "wvn_internal.h"
+
+namespace {
+
+constexpr int KD = 384;            // model dim (K of fc1, N of fc2)
+constexpr int HT = 64;             // hidden units per tile
+constexpr int SLICE = 16384;       // ring slice bytes
+constexpr int NS = 5;              // ring depth
+constexpr int RING = NS * SLICE;   // 81,920
+constexpr int BM = 128;            // rows per workgroup (4 waves x 32)
+constexpr int STG_PITCH = 132;                        // floats per staged row (128 columns + 4)
+constexpr int STG_BYTES = 32 * STG_PITCH * 4;         // 16,896 per wave
+constexpr int STG_OFF = RING;
+constexpr int B2_OFF = STG_OFF + 4 * STG_BYTES;       // 149,504
+constexpr int B1_OFF = B2_OFF + KD * 4;               // 151,040
+// + F * 4 bytes of b1 (6 KB at F = 1536): 157,184 <= 163,840
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// the fc1 epilogue GELU of gemm_a384.hip (x * sigmoid(g(x)), g fitted to logit Phi(x): within 0.25 bf16 ulp of erf GELU)
+__device__ inline f32x2_t gelu_fast2(f32x2_t x) {
+  const f32x2_t k3 = {-1.285982656e-05f, -1.285982656e-05f}, k2 = {1.435476415e-03f, 1.435476415e-03f},
+                k1 = {-1.096917929e-01f, -1.096917929e-01f}, k0 = {-2.296416554e+00f, -2.296416554e+00f}, one = {1.f, 1.f};
+  const f32x2_t x2 = x * x;
+  f32x2_t t = x2 * k3 + k2;
+  t = t * x2 + k1;
+  t = t * x2 + k0;
+  const f32x2_t y = t * x;
+  f32x2_t e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+  e = e + one;
+  const f32x2_t r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  return x * r;
+}
+
+struct MlpFusedParams {
+  const bf16_t* A; int lda;      // xn [M][384] bf16 (LNF = false)
+  const float *ln_g, *ln_b;      // LayerNorm affine (LNF = true: the kernel normalises X's rows itself)
+  float ln_eps;
+  const bf16_t* W1;              // [F][384]
+  const bf16_t* W2;              // [384][F], hidden index permuted (bits 2 <-> 3 inside groups of 16)
+  const float* b1;               // [F]
+  const float* b2;               // [384]
+  const float* ls;               // optional LayerScale [384] (nullptr = none)
+  float* X; int ldx;             // residual stream [M][384] fp32, updated in place
+  int M, F;
+};
+
+// One 16-byte store of a row piece.  gfx950: a buffer_store_dwordx4 with an SGPR soffset is still reading its data registers for a
+// few cycles after issue, and a VALU write to them in the next two issue slots corrupts some lanes of the stored data; LLVM's
+// hazard recognizer covers only the immediate-soffset form (scripts/check_store_hazard.py screens the whole library for the
+// pattern).  The nop keeps the register allocator's favourite move -- recycling the result registers at once -- out of the window.
+__device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 1");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool LNF>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int NTL = p.F / HT;                         // hidden tiles (24)
+  const int nrb = (p.M + BM - 1) / BM;
+  const int my_rb = (nrb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // row blocks of this workgroup
+  const int total = my_rb * NTL * 6;               // ring slices this workgroup consumes
+  float* b1_l = (float*)(smem + B1_OFF);
+  float* b2_l = (float*)(smem + B2_OFF);
+  float* lng_l = (float*)(smem + B1_OFF + p.F * 4);   // LNF: gamma [384], beta [384]
+  for (int i = tid; i < p.F; i += 256) b1_l[i] = p.b1 ? p.b1[i] : 0.f;
+  for (int i = tid; i < KD; i += 256) b2_l[i] = p.b2 ? p.b2[i] : 0.f;
+  if constexpr (LNF)
+    for (int i = tid; i < KD; i += 256) { lng_l[i] = p.ln_g[i]; lng_l[KD + i] = p.ln_b[i]; }
+
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, (unsigned)((size_t)p.F * KD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, (unsigned)((size_t)KD * p.F * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((size_t)p.M * p.ldx * 4), 0x00020000);
+  // ---- DMA lane offsets: 16 wave-instructions of 1 KB per slice, 4 per wave ------------------------------------------------
+  // W1 slice [64 h][128 k]: LDS rows of 256 B, instruction = 4 rows; chunk XOR (row & 15)            (gemm_a384.hip)
+  // W2 slice [128 n][64 h]: LDS rows of 128 B, instruction = 8 rows; chunk XOR ((row >> 1) & 7)      (attention_bf16.hip K tile)
+  unsigned w1off[4], w2off[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int inst = wave * 4 + u;
+    const int r1 = inst * 4 + (lane >> 4);
+    w1off[u] = (unsigned)((r1 * KD + (((lane & 15) ^ (r1 & 15)) * 8)) * 2);
+    const int r2 = inst * 8 + (lane >> 3);
+    w2off[u] = (unsigned)(((size_t)r2 * p.F + (((lane & 7) ^ ((r2 >> 1) & 7)) * 8)) * 2);
+  }
+  // Slice sequence of one hidden tile j: positions 0, 1, 2 = W1 k-slices, 3, 4, 5 = W2 n-thirds; the same for every row block.
+  // The kind of every slice is static at its issue and read sites (separate code paths: one buffer resource each).
+  auto issue = [&](auto Qc, int slot, int jj) {
+    constexpr int Q = decltype(Qc)::value;
+    unsigned char* dst = smem + slot * SLICE + wave * 4096;
+    if constexpr (Q < 3) {
+      const unsigned soff = __builtin_amdgcn_readfirstlane((jj * HT * KD + Q * 128) * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, w1off[u], soff, 0, 0);
+    } else {
+      const unsigned soff = __builtin_amdgcn_readfirstlane((((Q - 3) * 128) * p.F + jj * HT) * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, w2off[u], soff, 0, 0);
+    }
+  };
+  static_assert(NS == 5, "the issue schedule below is written for a ring of 5");
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+  // prologue: slices 0, 1, 2 in flight (every workgroup owns at least one row block = 6 NTL slices)
+  issue(I0{}, 0, 0); issue(I1{}, 1, 0); issue(I2{}, 2, 0);
+
+  // fragment addressing: fragment i of a slice at position Q (the i-th of its 16 MFMAs) in ring slot `slot`
+  // (12 precomputed swizzled lane offsets: a read costs one v_add of the slot base)
+  unsigned off1[8], off2[4];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) off1[s] = l31 * 256 + (((2 * s + hi) ^ (l31 & 15)) << 4);          // W1 slice: row l31, k-step s
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg) off2[sg] = l31 * 128 + (((2 * sg + hi) ^ ((l31 >> 1) & 7)) << 4);  // W2 slice: row l31, k-step sg
+  auto frag = [&](auto Qc, int slot, int i) -> bf16x8_t {
+    constexpr int Q = decltype(Qc)::value;
+    if constexpr (Q < 3) return *(const bf16x8_t*)(smem + slot * SLICE + off1[i >> 1] + (i & 1) * 8192);   // sub-tile t = i & 1
+    else return *(const bf16x8_t*)(smem + slot * SLICE + off2[i >> 2] + (i & 3) * 4096);                    // column tile T = i & 3
+  };
+  const unsigned cvoff = (unsigned)(((lane >> 5) * p.ldx + (lane & 31) * 4) * 4);
+  float* stg = (float*)(smem + STG_OFF + wave * STG_BYTES);
+
+  int si = 0;      // workgroup-local index of the slice being multiplied
+  int rslot = 0;   // its ring slot
+  // "slice n = si + 1 is readable": it has landed for this wave when at most the two younger slices (4 DMAs each) are outstanding
+  // -- loads complete in order among themselves, and whatever else is in flight (epilogue loads / stores, A rows) only adds to the
+  // counter -- and for everybody after the barrier, which also says that every wave is done with slice si - 1: its slot takes
+  // slice si + 4 (position (Q + 4) % 6 of this tile or the next).  Runs in the MIDDLE of slice si, so that the tail of si can
+  // already fetch the first fragments of si + 1.
+  auto open_next = [&](auto Qc, int j, int jn) {
+    constexpr int Q = decltype(Qc)::value;        // position of slice si
+    __builtin_amdgcn_sched_barrier(0);
+    if (si + 1 < total) {
+      if (si + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (si + 4 < total) {
+        const int islot = rslot == 0 ? NS - 1 : rslot - 1;
+        issue(std::integral_constant<int, (Q + 4) % 6>{}, islot, Q < 2 ? j : jn);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // scheduling shape of half a slice: 8 x (one MFMA, one fragment read)
+  auto shape8 = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  __syncthreads();   // bias / LayerNorm tables visible
+  // open slice 0 and fetch its first four fragments; from here on wf[] always holds the fragments of the next four MFMAs
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  issue(I3{}, 3, 0);
+  bf16x8_t wf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wf[i] = frag(I0{}, 0, i);
+
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int m0w = rb * BM + wave * 32;
+    // ---- A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7); rows past M are clamped ----
+    bf16x8_t xf[KD / 16];
+    if constexpr (LNF) {
+      // LayerNorm of the wave's 32 residual rows, once per row block: a lane holds half a row (the k-slots it feeds the MFMAs),
+      // its partner lane ^ 32 the other half
+      const float* xp = p.X + (size_t)min(m0w + l31, p.M - 1) * p.ldx + hi * 8;
+      f32x4_t xq[KD / 8];
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) { xq[2 * s] = *(const f32x4_t*)(xp + 16 * s); xq[2 * s + 1] = *(const f32x4_t*)(xp + 16 * s + 4); }
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < KD / 8; ++i) sm += (xq[i][0] + xq[i][1]) + (xq[i][2] + xq[i][3]);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm / 384.f;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < KD / 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xq[i][e] - mean; q += d * d; }
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = 1.0f / sqrtf(q / 384.f + p.ln_eps);
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) {
+        union { u32x4_t u; bf16x8_t v; } o;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x4_t g4 = *(const f32x4_t*)(lng_l + 16 * s + 8 * hi + 4 * h2);
+          const f32x4_t b4 = *(const f32x4_t*)(lng_l + KD + 16 * s + 8 * hi + 4 * h2);
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (xq[2 * s + h2][e] - mean) * rstd * g4[e] + b4[e];
+          o.u[2 * h2] = pack_bf16x2(y[0], y[1]);
+          o.u[2 * h2 + 1] = pack_bf16x2(y[2], y[3]);
+        }
+        xf[s] = o.v;
+      }
+    } else {
+      const bf16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
+    }
+    f32x16_t out[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+
+    for (int j = 0; j < NTL; ++j) {
+      const int jn = j + 1 == NTL ? 0 : j + 1;
+      // ---- fc1: h[32 rows][64 hidden] = xn W1_j^T + b1_j  (accumulators start at the bias) ----
+      f32x16_t hacc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t b4 = *(const f32x4_t*)(b1_l + j * HT + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hacc[t][4 * g + e] = b4[e];
+        }
+      bf16x8_t hf[4];
+      // one slice = 16 MFMAs; MFMA i takes wf[i & 3], which is then refilled with fragment i + 4 -- of this slice, or (i >= 12) of
+      // the next one, opened half-way through
+      auto slice = [&](auto Qc) {
+        constexpr int Q = decltype(Qc)::value;
+        constexpr int QN = (Q + 1) % 6;
+        const int nslot = rslot == NS - 1 ? 0 : rslot + 1;
+        auto step = [&](int i) {
+          if constexpr (Q < 3) hacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 3], xf[Q * 8 + (i >> 1)], hacc[i & 1], 0, 0, 0);
+          else out[4 * (Q - 3) + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 3], hf[i >> 2], out[4 * (Q - 3) + (i & 3)], 0, 0, 0);
+          if (i + 4 < 16) wf[i & 3] = frag(Qc, rslot, i + 4);
+          else wf[i & 3] = frag(std::integral_constant<int, QN>{}, nslot, i + 4 - 16);
+        };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) step(i);
+        shape8();
+        open_next(Qc, j, jn);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) step(i);
+        shape8();
+        ++si;
+        rslot = nslot;
+      };
+      slice(I0{}); slice(I1{}); slice(I2{});
+      // ---- GELU, pack: the accumulator registers become the fc2 B-operand fragments (k-step sigma = 2 t + (g >> 1)) ----
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          union { u32x4_t u; bf16x8_t v; } o;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {   // g = 2 gp + q: slots j = 4 q + e
+            const int g = 2 * gp + q;
+            const f32x2_t a = gelu_fast2(f32x2_t{hacc[t][4 * g + 0], hacc[t][4 * g + 1]});
+            const f32x2_t b = gelu_fast2(f32x2_t{hacc[t][4 * g + 2], hacc[t][4 * g + 3]});
+            o.u[2 * q] = pack_bf16x2(a[0], a[1]);
+            o.u[2 * q + 1] = pack_bf16x2(b[0], b[1]);
+          }
+          hf[2 * t + gp] = o.v;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- fc2: out[32 rows][384] += h W2_j^T, 128 output columns per slice ----
+      slice(I3{}); slice(I4{}); slice(I5{});
+    }
+
+    // ---- epilogue: x[rows of this wave][384] += out + b2, 128 columns at a time through the wave's LDS image ----
+    // (the staging area does not overlap the ring: the W stream of the next row block keeps flowing meanwhile).  The residual
+    // rows are fetched one 128-column chunk ahead: a wave alone on its SIMD has nothing else to hide a load behind.
+    u32x4_t xr0[16], xr1[16];
+    auto load_x = [&](int c, u32x4_t (&dst)[16]) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldx + 128 * c) * 4);
+        dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, cvoff, so, 0);
+      }
+    };
+    load_x(0, xr0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (c == 0) load_x(1, xr1);
+      if (c == 1) load_x(2, xr0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x16_t& a = out[4 * c + tt];
+          const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+          *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
+        }
+      const f32x4_t b4 = *(const f32x4_t*)(b2_l + 128 * c + (lane & 31) * 4);
+      f32x4_t l4 = {1.f, 1.f, 1.f, 1.f};
+      if (p.ls) l4 = *(const f32x4_t*)(p.ls + 128 * c + (lane & 31) * 4);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldx + 128 * c) * 4);
+        const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
+        const u32x4_t r = (c & 1) ? xr1[it] : xr0[it];
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[e]));
+        store_b128_guarded(o, rs_x, cvoff, so);  // rows >= M fall outside num_records: dropped
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+int mlp_fused_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+}  // namespace
+
+// Eligibility: D == 384, F % 64 == 0 (F * 4 + 154,112 bytes of LDS), 16-byte aligned operands, 32-bit byte offsets.
+// W2 must be stored with the hidden index permuted (wvn_hip.h: WVN_VIT_MLP_FUSED).  xn == nullptr: the kernel applies
+// LayerNorm(ln_g, ln_b, ln_eps) to the rows of x itself (once per row block).  WVN_ERR_ARG otherwise.
+int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,
+                         const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
+                         hipStream_t st) {
+  const bool lnf = xn == nullptr;
+  if (!W1 || !W2p || !x || M <= 0 || F <= 0 || (F % HT) != 0 || (ldx % 4) != 0) return WVN_ERR_ARG;
+  if (lnf ? (!ln_g || !ln_b) : ((lda % 8) != 0 || ((uintptr_t)xn & 15) != 0)) return WVN_ERR_ARG;
+  if ((((uintptr_t)W1 | (uintptr_t)W2p | (uintptr_t)x) & 15) != 0) return WVN_ERR_ARG;
+  const int lds = B1_OFF + F * 4 + 2 * KD * 4;
+  if (lds > 160 * 1024) return WVN_ERR_ARG;
+  if ((size_t)M * ldx * 4 >= (1ull << 32) || (size_t)F * KD * 2 >= (1ull << 32)) return WVN_ERR_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  MlpFusedParams p{};
+  p.A = xn; p.lda = lda; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.W1 = W1; p.W2 = W2p; p.b1 = b1; p.b2 = b2; p.ls = ls;
+  p.X = x; p.ldx = ldx; p.M = M; p.F = F;
+  const int nrb = ceil_div(M, BM), ncu = mlp_fused_num_cus();
+  const dim3 grid(nrb < ncu ? nrb : ncu);
+  if (lnf) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(256), lds, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}

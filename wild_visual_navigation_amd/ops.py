@@ -363,6 +363,20 @@ def gemm_x3(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epi:
     return out
 
 
+def mlp_fused(xn: Optional[torch.Tensor], w1: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor],
+              x: torch.Tensor, ls: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
+    """x [M,384] fp32 += gelu(xn [M,384] bf16 @ w1[F,384]^T + b1) @ w2^T + b2 in ONE launch, in place.  ``w2p`` is fc2.weight
+    [384, F] with its hidden index in the fused order: ``w2[:, vt_token_order(F)]`` (include/wvn_hip.h WVN_VIT_MLP_FUSED).
+    ``xn=None, ln=(gamma, beta, eps)``: the kernel normalises the rows of ``x`` itself."""
+    M, F = x.shape[0], w1.shape[0]
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    if (xn is None) == (ln is None):
+        raise _lib.WvnError("mlp_fused takes either xn or ln=(gamma, beta, eps)")
+    check(lib().wvn_mlp_fused(ptr(xn), xn.stride(0) if xn is not None else 0, ptr(g), ptr(b), float(eps), ptr(w1), ptr(b1), ptr(w2p),
+                              ptr(b2), ptr(ls), ptr(x), x.stride(0), M, F, stream()), "wvn_mlp_fused")
+    return x
+
+
 def vt_token_order(npad: int, device=None) -> torch.Tensor:
     """Index map of the bf16 attention kernel's V^T layout (include/wvn_hip.h): stored position p of every
     aligned group of 16 tokens holds token p with bits 2 and 3 swapped (an involution).
