@@ -357,6 +357,10 @@ int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, co
 /* subsequent wvn_attention_bf16 launches write dbg[(workgroup * 4 + wave) * 5 + {0 wait, 1 QK^T, 2 softmax, 3 PV,
  * 4 total}]; NULL switches the instrumented build off again. */
 int wvn_debug_attention_timing(long long* dbg);
+/* which form of the pre-scaled (scale == 0) attention kernel subsequent launches use: 0 = exact per-tile row max, 1 = lazy (no
+ * per-tile max; the row sums raise the alarm and the tile is redone exactly -- the default), < 0 = back to the default.  Same
+ * results within the kernel's tolerance; tests/test_gpu_attention_lazy.py runs both, bench.py --attn-variant A/Bs them. */
+int wvn_debug_attention_variant(int variant);
 /* the row-panel N = 384 residual GEMM on every row block, whatever M (the dispatcher of wvn_gemm_bf16 only uses it from about
  * 0.75 x #CU row blocks of 256 on); tests */
 int wvn_debug_gemm_n384(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int K,

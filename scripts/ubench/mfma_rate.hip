@@ -69,13 +69,32 @@ __global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, lon
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaf(v[q], 1.0001f, 0.5f);
         }
+        if constexpr (FILL == 4) {   // 4 transcendentals per MFMA
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_exp2f(v[q]);
+        }
+        if constexpr (FILL == 5) {   // the attention mix per MFMA: 2 exp2, 1 max3, 1 cvt_pk, 1 dot2c
+          v[0] = __builtin_amdgcn_exp2f(v[0]);
+          v[1] = __builtin_amdgcn_exp2f(v[1]);
+          v[2] = __builtin_fmaxf(__builtin_fmaxf(v[2], v[0]), v[1]);
+          unsigned pk;
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[0]), "v"(v[1]));
+          typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+          v[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, pk), __builtin_bit_cast(b2, 0x3f803f80u), v[3], false);
+        }
+        if constexpr (FILL == 6) {   // 2 exp2 only
+          v[0] = __builtin_amdgcn_exp2f(v[0]);
+          v[1] = __builtin_amdgcn_exp2f(v[1]);
+        }
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
       for (int u = 0; u < 28; ++u) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if constexpr (FILL == 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if constexpr (FILL == 3 || FILL == 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if constexpr (FILL == 5) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        if constexpr (FILL == 6) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -144,6 +163,9 @@ int main() {
     runf<2, 3>(grid, in, out, cyc, "2 chains + ds_read ring + 4 VALU");
     runf<4, 3>(grid, in, out, cyc, "4 chains + ds_read ring + 4 VALU");
     runf<8, 3>(grid, in, out, cyc, "8 chains + ds_read ring + 4 VALU");
+    runf<4, 4>(grid, in, out, cyc, "4 chains + ds_read + 4 exp2");
+    runf<4, 6>(grid, in, out, cyc, "4 chains + ds_read + 2 exp2");
+    runf<4, 5>(grid, in, out, cyc, "4 chains + ds_read + attn mix (5)");
     run<1, 1>(grid, in, out, cyc, "1 chain, 1 wave/SIMD");
     run<2, 1>(grid, in, out, cyc, "2 chains, 1 wave/SIMD");
     run<4, 1>(grid, in, out, cyc, "4 chains, 1 wave/SIMD");

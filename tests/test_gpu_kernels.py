@@ -136,12 +136,14 @@ def test_attention_f32(dev, ntok):
     assert (out.cpu().double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("prescaled", [False, True])
+@pytest.mark.parametrize("prescaled", [False, "exact-max", "lazy"])
 @pytest.mark.parametrize("ntok", [65, 197, 785, 130, 3137])
 def test_attention_bf16(dev, ntok, prescaled):
     """prescaled: q carries softmax_scale * log2(e) (what wvn_vit_forward's QKV epilogue writes) and the kernel is called
-    with scale = 0 -- the variant with the running max as the S^T MFMA's C operand.  The reference is computed from the
-    q the kernel actually sees."""
+    with scale = 0 -- the variant with the running max as the S^T MFMA's C operand, in its two forms: a row max per tile
+    ("exact-max") and the shipped default without it ("lazy": the row sums raise the alarm, tests/test_gpu_attention_lazy.py).
+    The reference is computed from the q the kernel actually sees."""
+    lib().wvn_debug_attention_variant({"exact-max": 0, "lazy": 1}.get(prescaled, -1))
     B, h, scale = (1, 2, 0.125) if ntok > 1000 else (2, 3, 0.125)
     q, k, v = (bf(torch.randn(B, h, ntok, 64, generator=g(s))) for s in (1, 2, 3))
     if ntok == 197:
@@ -162,13 +164,17 @@ def test_attention_bf16(dev, ntok, prescaled):
     check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(vt), ptr(out), B, h, ntok, npad, kscale, stream()))
     ref = _attn_ref(q.float(), k.float(), v.float(), scale).permute(0, 2, 1, 3).reshape(B * ntok, h * 64)
     err = (out.float().cpu().double() - ref).abs().max().item()
-    # P is rounded to bf16 before PV (rel 2^-9 per term, averaging down) and O to bf16 on store
-    assert err < 2e-2, err
+    # P is rounded to bf16 before PV (rel 2^-9 per term, averaging down) and O to bf16 on store.  With a row max per tile the
+    # dominant key of a row gets P = 1 exactly after the rescale; the lazy form carries it at an arbitrary power of two times a
+    # mantissa, i.e. WITH the 2^-9 rounding: where two keys with very different values share a row (this test plants 5x / 6x key
+    # spikes) that is worth another 2^-9 * |v_i - v_j| ~ 5e-3
+    assert err < (2.5e-2 if prescaled == "lazy" else 2e-2), err
     # uniform V => output must be exactly that constant row (softmax weights sum to 1 within rounding)
     v1 = torch.ones(B, h, npad, 64, dtype=torch.bfloat16)
     v1[:, :, ntok:] = 0
     v1t = v1.transpose(-1, -2)[..., perm].contiguous().to(dev)
     check(lib().wvn_attention_bf16(ptr(qd), ptr(kd), ptr(v1t), ptr(out), B, h, ntok, npad, kscale, stream()))
+    lib().wvn_debug_attention_variant(-1)
     assert (out.float().cpu() - 1.0).abs().max().item() < 1e-2
 
 

@@ -339,6 +339,7 @@ int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const
 }
 
 int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
+int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); return WVN_OK; }
 
 int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                               int N, int K, int epi, long long* dbg, void* stream) {

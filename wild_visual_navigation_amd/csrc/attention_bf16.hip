@@ -68,7 +68,7 @@ __device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a,
 // rounding) and the running max enters the S^T MFMA chain as its C operand (a 16-register block holding -M, rewritten
 // only when the max moves): the accumulators come out as exp2 arguments and the 16 v_pk_fma per tile disappear.
 // SUM: how the row sums are formed.  0: v_dot2c_f32_bf16 on the packed P (16 per tile); 1: plain adds on the fp32 P.
-template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false, int SUM = 0>
+template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false, int SUM = 0, bool LAZY = false>
 __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* __restrict__ q,
                                                                   const bf16_t* __restrict__ k,
                                                                   const bf16_t* __restrict__ vt,
@@ -297,6 +297,112 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     }
   };
 
+  // LAZY (pre-scaled q only): the same online softmax WITHOUT the per-tile row max.  The kernel is bound by VALU issue
+  // (scripts/ubench/mfma_rate.hip: the 2 exp2 + max3 + cvt_pk + dot2c that go with every MFMA cost 60 cycles per MFMA in one wave
+  // against 36 without), and the 16 v_max3 + lane swap per tile only serve a decision that is almost always "no".  So: exponentiate
+  // against the running max as it stands, pack, sum -- the row sums are needed anyway -- and let the SUMS raise the alarm: a
+  // probability above 2^16 (a score 16 exp2-units above the running max) makes its lane's partial sum exceed 2^16, overflow to inf
+  // included.  Only then (and on the first tile) the tile is redone the exact way: S^T again from the K tile still in LDS, exact row
+  // max, rescale of O / l / the C operand, exponentials again.  Undetected probabilities are <= 2^16 instead of <= 2^6: harmless in
+  // fp32 / bf16 floating point, P and l carry the same factor.
+  auto compute_tile_lazy = [&](int kv0, int stage, int t_issue, auto tail_tag) {
+    constexpr bool MAYBE_TAIL = decltype(tail_tag)::value;
+    unsigned fa[4];
+    unsigned so = (unsigned)(stage * 2 * TILE_BYTES);
+    asm volatile("" : "+s"(so));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fa[s] = rdo[s] + so;
+      asm volatile("" : "+v"(fa[s]));
+    }
+    f32x16_t st[2];
+    auto qk = [&]() {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8_t kf = *(const bf16x8_t*)(lds + fa[s] + t * 4096);
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? cneg : st[t], 0, 0, 0);
+        }
+      if (MAYBE_TAIL && kv0 + KVB > ntok) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= ntok) st[t][r] = -1e30f;
+          }
+      }
+    };
+    u32x4_t pfu[4];
+    float s0, s1;
+    auto expsum = [&]() {   // P = exp2(st) packed to bf16 (the PV operand fragments) and the lane's partial row sums of the rounded P
+      s0 = 0.f; s1 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int t = ks >> 1, h8 = (ks & 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t pk = pack_bf16x2(__builtin_amdgcn_exp2f(st[t][h8 + 2 * e]), __builtin_amdgcn_exp2f(st[t][h8 + 2 * e + 1]));
+          pfu[ks][e] = pk;
+          const bf16x2v_t pp = __builtin_bit_cast(bf16x2v_t, pk), one2 = __builtin_bit_cast(bf16x2v_t, 0x3f803f80u);
+          if (e & 1) s1 = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, s1, false);
+          else s0 = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, s0, false);
+        }
+      }
+    };
+    qk();
+    __builtin_amdgcn_sched_barrier(0);
+    if (t_issue >= 0) issue(t_issue);
+    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr float ALARM = 65536.f;
+    if (!fresh) expsum();
+    if (fresh || __any(s0 + s1 > ALARM)) {
+      if (!fresh) qk();   // the exponentials overwrote the scores
+      float ma = max3f(st[0][0], st[0][1], st[0][2]), mb = max3f(st[1][0], st[1][1], st[1][2]);
+      ma = max3f(ma, st[0][3], st[0][4]); mb = max3f(mb, st[1][3], st[1][4]);
+#pragma unroll
+      for (int r = 5; r < 15; r += 2) { ma = max3f(ma, st[0][r], st[0][r + 1]); mb = max3f(mb, st[1][r], st[1][r + 1]); }
+      float mt = max3f(ma, mb, st[0][15]);
+      mt = fmaxf(mt, st[1][15]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = max3f(mt, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      const float delta = fresh ? mt : fmaxf(mt, 0.f);
+      const float alpha = fresh ? 1.f : __builtin_amdgcn_exp2f(-delta);
+      fresh = false;
+      m_run += delta;
+      l_run *= alpha;
+      l_run1 *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] -= delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cneg[r] = -m_run;
+      expsum();
+    }
+    l_run += s0;
+    l_run1 += s1;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      union { u32x4_t u; bf16x8_t v; } pf;
+      pf.u = pfu[ks];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8_t vf = *(const bf16x8_t*)(lds + fa[ks] + TILE_BYTES + dt * 4096);
+        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, ot[dt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
   // tile loop: wait for tile t (NST - 2 younger tiles may stay in flight), barrier (everyone has the tile and
   // has finished reading tile t - 1, whose slot the next DMA overwrites), issue tile t + NST - 1, compute
   // The last tile (the only one that may need masking) is peeled: with both instantiations of compute_tile inside one
@@ -310,14 +416,16 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     if constexpr (TIMING) tm[0] += now() - w0;
     // (the next tile's DMA is requested inside compute_tile, after the QK^T MFMAs have been issued: the four DMA
     // instructions cost the wave a few hundred cycles of issue time, which then overlap the matrix pipe's work)
-    compute_tile(t * KVB, t % NST, t + NST - 1 < nt ? t + NST - 1 : -1, std::false_type{});
+    if constexpr (LAZY) compute_tile_lazy(t * KVB, t % NST, t + NST - 1 < nt ? t + NST - 1 : -1, std::false_type{});
+    else compute_tile(t * KVB, t % NST, t + NST - 1 < nt ? t + NST - 1 : -1, std::false_type{});
   }
   {
     const long long w0 = now();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (TIMING) tm[0] += now() - w0;
-    compute_tile((nt - 1) * KVB, (nt - 1) % NST, -1, std::true_type{});
+    if constexpr (LAZY) compute_tile_lazy((nt - 1) * KVB, (nt - 1) % NST, -1, std::true_type{});
+    else compute_tile((nt - 1) * KVB, (nt - 1) % NST, -1, std::true_type{});
   }
 
   if constexpr (TIMING) {
@@ -347,12 +455,24 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
 
 long long* g_attn_dbg = nullptr;  // set by wvn_debug_attention_timing (scripts/attn_timing.py)
 
+constexpr int ATTN_DEFAULT = 1;
+int g_attn_variant = ATTN_DEFAULT;   // 0: exact per-tile row max, 1: lazy (alarm on the row sums; what ships: -4 % attention time)
+
 void launch_pre(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
                 int heads, int nbh, int nqb, int ntok, int ntok_s, int npad) {
   // 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for 3 stages /
   // 3 workgroups and 13.2 for 4 stages / 2); row sums by v_dot2c_f32_bf16 on the packed P (plain fp32 adds, which hipcc packs
   // into v_pk_add_f32, measured 12.0 ms per step against 11.7).  The same arithmetic with and without the XCD block order:
   // results must not depend on the batch size (tests/test_gpu_attention_xcd.py).
+  if (g_attn_variant == 1) {
+    if (xcd)
+      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+    else
+      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+    return;
+  }
   if (xcd)
     hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
                        nqb, ntok, ntok_s, npad, 1.f, nullptr);
@@ -380,6 +500,7 @@ void launch_v(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t
 }  // namespace
 
 void wvn_attention_bf16_set_debug(long long* dbg) { g_attn_dbg = dbg; }
+void wvn_attention_bf16_set_variant(int v) { g_attn_variant = v < 0 ? ATTN_DEFAULT : v; }  // < 0: back to the default
 
 // scale > 0: q holds the raw projections.  scale == 0: q is pre-multiplied by softmax_scale * log2(e) (EPI_QKV with
 // q_scale set), the kernel with the running max folded into the S^T MFMA chain runs.

@@ -113,7 +113,8 @@ int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, i
 // ---- attention (attention_bf16.hip / attention_f32.hip) ---------------------------------------
 int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
                               int ntok, int ntok_s, int npad, float scale, hipStream_t st);
-void wvn_attention_bf16_set_debug(long long* dbg);  // per-wave phase timings (TIMING build), nullptr = off
+void wvn_attention_bf16_set_debug(long long* dbg);
+void wvn_attention_bf16_set_variant(int v);  // per-wave phase timings (TIMING build), nullptr = off
 int wvn_attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok,
                              int ntok_s, int npad, float scale, hipStream_t st);
 // exact mode on the matrix pipe (attention_x3.hip): hi / lo planes of q, k [B,h,npad,64], v^T [B,h,64,npad] (token-permuted),
