@@ -47,6 +47,9 @@ int wvn_version(void);
  * the block MLP, including its LayerNorm (blocks.i.norm2), runs as ONE kernel that keeps the normalised rows and the hidden
  * activation in registers (csrc/mlp_fused.hip). */
 #define WVN_VIT_MLP_FUSED 1
+/* WVN_VIT_QKV_FUSED (WVN_PREC_BF16, D = 384, heads = 6): blocks.i.norm1 and the QKV projection run as ONE kernel that normalises the
+ * residual rows in registers (csrc/qkv_fused.hip); no weight re-layout. */
+#define WVN_VIT_QKV_FUSED 2
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
@@ -100,6 +103,11 @@ int wvn_prof_collect(double* ms_by_cat_host, long long* launches_by_cat_host); /
 /* ---------------------------------------------------------------------------------------------
  * Building blocks, exported so tests/ can check each kernel against the oracle.
  * ------------------------------------------------------------------------------------------- */
+/* LayerNorm + QKV projection in one launch: x [M,ldx] fp32 (rows b * ntok_s + t) -> q, k [B*heads][npad][64] and
+ * v^T [B*heads][64][npad] (token order of wvn_attention_bf16) in bf16; W [3*heads*64][384] bf16 in qkv.weight row order, q rows
+ * multiplied by q_scale before rounding (0 = 1).  heads == 6, ntok_s % 16 == 0, M % 16 == 0, npad % 16 == 0. */
+int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
+                  void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream);
 /* Block MLP in one launch: x [M,ldx] fp32 += gelu(xn [M,lda] bf16 * W1[F,384]^T + b1) * W2[384,F]^T + b2  (optionally
  * times LayerScale ls [384]).  W2p = W2 with the hidden index permuted as WVN_VIT_MLP_FUSED describes.  xn == NULL: the kernel
  * computes xn = LayerNorm(x; ln_g, ln_b, ln_eps) itself (what wvn_vit_forward uses: blocks.i.norm2 never touches memory).
@@ -361,6 +369,9 @@ int wvn_debug_attention_timing(long long* dbg);
  * per-tile max; the row sums raise the alarm and the tile is redone exactly -- the default), < 0 = back to the default.  Same
  * results within the kernel's tolerance; tests/test_gpu_attention_lazy.py runs both, bench.py --attn-variant A/Bs them. */
 int wvn_debug_attention_variant(int variant);
+/* subsequent wvn_qkv_fused launches write dbg[(workgroup * 4 + wave) * 4 + {0 LayerNorm prologue, 1 MFMA slices, 2 tile epilogues,
+ * 3 total}] in shader cycles (scripts/bench_qkv_fused.py); NULL switches the instrumented build off again. */
+int wvn_debug_qkv_fused_timing(long long* dbg);
 /* the row-panel N = 384 residual GEMM on every row block, whatever M (the dispatcher of wvn_gemm_bf16 only uses it from about
  * 0.75 x #CU row blocks of 256 on); tests */
 int wvn_debug_gemm_n384(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int K,

@@ -42,4 +42,3 @@ gam, bet = torch.ones(384, device=dev), torch.zeros(384, device=dev)
 x.normal_()
 t = timeit(lambda: ops.mlp_fused(None, w1, b1, w2p * 0, b2 * 0, x, ln=(gam, bet, 1e-6)))
 print("fused (LayerNorm inside): %.1f us  (%.0f TFLOP/s)" % (t, fl / t / 1e6))
-xnb = torch.empty(M, 384, dtype=torch.bfloat16, device=dev)

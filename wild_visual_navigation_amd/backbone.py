@@ -91,7 +91,8 @@ class VitBackbone:
     e4m3 MFMA at twice the bf16 rate, per-token / per-channel scales; everything else as "bf16")."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
-                 device="cuda", precision: str = "bf16", max_chunk: int = 16, fuse_mlp: Optional[bool] = None):
+                 device="cuda", precision: str = "bf16", max_chunk: int = 16, fuse_mlp: Optional[bool] = None,
+                 fuse_qkv: Optional[bool] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
@@ -109,6 +110,11 @@ class VitBackbone:
         if fuse_mlp and not can_fuse:
             raise _lib.WvnError("fuse_mlp needs precision 'bf16', dim 384 and mlp_dim % 64 == 0")
         self.fuse_mlp = can_fuse if fuse_mlp is None else bool(fuse_mlp)
+        # LayerNorm 1 + QKV projection as one kernel (csrc/qkv_fused.hip): bf16, D = 384 with 6 heads
+        can_fuse_qkv = self.precision == _lib.PREC_BF16 and self.dim == 384 and heads == 6
+        if fuse_qkv and not can_fuse_qkv:
+            raise _lib.WvnError("fuse_qkv needs precision 'bf16', dim 384 and 6 heads")
+        self.fuse_qkv = can_fuse_qkv if fuse_qkv is None else bool(fuse_qkv)
         self._sd = state_dict  # kept (host / original tensors) so that .to(device) can re-home the model
         self._keep = []  # device tensors referenced by raw pointers in the C struct
 
@@ -144,7 +150,7 @@ class VitBackbone:
         m = _lib.VitModel()
         m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim = img_size, patch, self.dim, self.depth, heads, self.mlp_dim
         m.precision = self.precision
-        m.flags = _lib.VIT_MLP_FUSED if self.fuse_mlp else 0
+        m.flags = (_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
@@ -185,7 +191,7 @@ class VitBackbone:
         if device == self.device:
             return self
         return VitBackbone(self._sd, self.img_size, self.patch, self.heads, device=device, precision=self.precision_name,
-                           max_chunk=self.max_chunk, fuse_mlp=self.fuse_mlp)
+                           max_chunk=self.max_chunk, fuse_mlp=self.fuse_mlp, fuse_qkv=self.fuse_qkv)
 
     # ---- workspace (needs no initialisation: wvn_vit_forward resets the padding rows it relies on at every call) ----
     def _workspace(self, batch: int) -> torch.Tensor:

@@ -142,7 +142,8 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (fp8 && ((d.D % 128) || (d.F % 128))) return WVN_ERR_ARG;
   // fp8: everything that is not one of the four block linears runs exactly as in the bf16 mode
   const bool bf = m->precision == WVN_PREC_BF16 || fp8, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
-  const bool mlp_fused = (m->flags & WVN_VIT_MLP_FUSED) != 0;
+  const bool mlp_fused = (m->flags & WVN_VIT_MLP_FUSED) != 0, qkv_fused = (m->flags & WVN_VIT_QKV_FUSED) != 0;
+  if (qkv_fused && (m->precision != WVN_PREC_BF16 || d.D != 384 || d.H != 6 || (d.ntok_s % 16) != 0)) return WVN_ERR_ARG;
   if (mlp_fused && (m->precision != WVN_PREC_BF16 || d.D != 384 || (d.F % 64) != 0)) return WVN_ERR_ARG;
   if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
   const float scale = 1.0f / sqrtf(64.f);
@@ -200,6 +201,10 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     // their V^T / K bytes still enter MFMAs and must be finite.
     RET_IF(wvn_pad_zero_launch(w.x, d.B, (long long)d.ntok_s * d.D * 4, (long long)d.ntok * d.D * 4,
                                (long long)(d.ntok_s - d.ntok) * d.D * 4, st));
+    // with the fused LayerNorm + QKV kernel nothing writes the padding rows of xn (the attention output buffer the projection
+    // GEMM reads whole): they used to hold LayerNorm 1's output
+    if (qkv_fused)
+      RET_IF(wvn_pad_zero_launch(w.xn, d.B, (long long)d.ntok_s * d.D * 2, (long long)d.ntok * d.D * 2, (long long)(d.ntok_s - d.ntok) * d.D * 2, st));
     const long long nbh = (long long)d.B * d.H;
     const long long tokb = f32 ? 256 : 128, npl = x3 ? 2 : 1;  // bytes per token row of q / k; planes per tensor
     RET_IF(wvn_pad_zero_launch(w.q, nbh * npl, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
@@ -252,6 +257,11 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       }
       continue;
     }
+    if (qkv_fused) {  // LayerNorm 1 + QKV projection: one launch, no xn round trip
+      Span s(3, st);
+      RET_IF(wvn_qkv_fused_launch(w.x, d.D, L.ln1_g, L.ln1_b, 1e-6f, (const bf16_t*)L.qkv_w, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
+                                  (bf16_t*)w.v, d.H, d.npad, d.ntok_s, scale * 1.44269504088896340736f, M, st));
+    } else {
     { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     {
       Span s(3, st);
@@ -262,6 +272,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       if (bf) e.q_scale = scale * 1.44269504088896340736f;
       if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
       RET_IF(linear(w.xn, pl_xn, d.D, L.qkv_w, L.qkv_b, nullptr, 0, 0, M, 3 * d.D, d.D, EPI_QKV, nullptr, &e));
+    }
     }
     {
       Span s(4, st);
@@ -299,6 +310,12 @@ int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
+}
+
+int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
+                  void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream) {
+  return wvn_qkv_fused_launch(x, ldx, ln_g, ln_b, ln_eps, (const bf16_t*)W, bias, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, heads, npad, ntok_s,
+                              q_scale, M, (hipStream_t)stream);
 }
 
 int wvn_mlp_fused(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
@@ -339,6 +356,8 @@ int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const
 }
 
 int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
+extern long long* g_qkv_fused_dbg;
+int wvn_debug_qkv_fused_timing(long long* dbg) { g_qkv_fused_dbg = dbg; return WVN_OK; }
 int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); return WVN_OK; }
 
 int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,

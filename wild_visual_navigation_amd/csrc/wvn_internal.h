@@ -35,12 +35,15 @@ struct GemmBf16Params {
 int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 // A-stationary kernel for K == 384 (gemm_a384.hip); WVN_ERR_ARG when the shape is not eligible
 int wvn_gemm_a384_launch(const GemmBf16Params& p, int epi, hipStream_t st);
-// row-panel kernel for N == 384 residual updates with long K (gemm_n384.hip); WVN_ERR_ARG when not eligible
 // mlp_fused.hip: x += gelu(xn W1^T + b1) W2p^T + b2 with the hidden activation kept in registers (D = 384 only);
 // xn == nullptr: xn = LayerNorm(x; ln_g, ln_b, ln_eps) computed in the kernel, once per row block
 int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,
                          const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
                          hipStream_t st);
+// qkv_fused.hip: LayerNorm(x) -> q | k | v^T in the layouts of attention_bf16.hip (D = 384, heads = 6), one launch
+int wvn_qkv_fused_launch(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W, const float* bias,
+                         bf16_t* q, bf16_t* k, bf16_t* vt, int heads, int npad, int ntok_s, float q_scale, int M, hipStream_t st);
+// row-panel kernel for N == 384 residual updates with long K (gemm_n384.hip); WVN_ERR_ARG when not eligible
 int wvn_gemm_n384_launch(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done, int force = 0);
 // exact mode: hi/lo bf16 planes, three MFMAs per product (gemm_x3.hip); same epilogue codes, plane-typed outputs for the
 // "bf16" ones

@@ -363,6 +363,21 @@ def gemm_x3(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epi:
     return out
 
 
+def qkv_fused(x: torch.Tensor, ln: Tuple[torch.Tensor, torch.Tensor, float], w: torch.Tensor, bias: Optional[torch.Tensor],
+              frames: int, ntok_s: int, npad: int, q_scale: float = 0.0):
+    """LayerNorm + QKV projection in one launch (csrc/qkv_fused.hip).  x [frames * ntok_s, 384] fp32, w [1152, 384] bf16 ->
+    q, k [frames * 6, npad, 64] bf16 and v^T [frames * 6, 64, npad] bf16 in the attention kernel's layouts.  Slots of tokens
+    >= ntok_s and the padding are left untouched (returned zero-initialised)."""
+    M, heads = x.shape[0], 6
+    n = frames * heads * npad * 64   # the three outputs are carved from ONE allocation: the kernel addresses them through one
+    buf = torch.zeros(3 * n, dtype=torch.bfloat16, device=x.device)   # 32-bit buffer descriptor (they must lie within 2 GB)
+    q, k, vt = buf[:n].view(frames * heads, npad, 64), buf[n:2 * n].view(frames * heads, npad, 64), buf[2 * n:].view(frames * heads, 64, npad)
+    g, b, eps = ln
+    check(lib().wvn_qkv_fused(ptr(x), x.stride(0), ptr(g), ptr(b), float(eps), ptr(w), ptr(bias), ptr(q), ptr(k), ptr(vt), heads, npad,
+                              ntok_s, float(q_scale), M, stream()), "wvn_qkv_fused")
+    return q, k, vt
+
+
 def mlp_fused(xn: Optional[torch.Tensor], w1: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor],
               x: torch.Tensor, ls: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
     """x [M,384] fp32 += gelu(xn [M,384] bf16 @ w1[F,384]^T + b1) @ w2^T + b2 in ONE launch, in place.  ``w2p`` is fc2.weight
