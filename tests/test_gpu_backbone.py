@@ -51,6 +51,26 @@ def test_vit_bf16_mode(dev, S, depth, B):
     assert cos.min().item() > 0.995
 
 
+@pytest.mark.parametrize("fuse_mlp,fuse_qkv", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("S,B", [(64, 3), (224, 2)])
+def test_fused_block_kernels_agree_with_separate_kernels(dev, S, B, fuse_mlp, fuse_qkv):
+    """The shipped bf16 ViT-S path runs LayerNorm + QKV and LayerNorm + fc1 + GELU + fc2 as single kernels (csrc/qkv_fused.hip,
+    csrc/mlp_fused.hip); with the switches off it runs the LayerNorm kernel and the GEMM kernels.  Same rounding points, other
+    summation orders: both must sit inside the oracle tolerance and within bf16 noise of each other."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=12)
+    img = torch.rand(B, 3, S, S, generator=g(7))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    default = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16")
+    assert default.fuse_mlp and default.fuse_qkv
+    a = default.forward_tokens(img.to(dev)).cpu()
+    b = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16", fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv).forward_tokens(img.to(dev)).cpu()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert rel_l2(a, want) < 2.5e-2 and rel_l2(b, want) < 2.5e-2
+    assert rel_l2(a, b) < 1.5e-2   # two bf16 paths differ from each other by about what each differs from fp32
+    with pytest.raises(Exception):
+        VitBackbone(sd, S, 8, 6, device=dev, precision="fp32", fuse_mlp=True)
+
+
 def test_batch_invariance_and_chunking(dev):
     """A frame's features must not depend on its batch neighbours or on the chunking (bit-exact)."""
     sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=3)
