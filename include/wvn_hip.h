@@ -372,6 +372,9 @@ int wvn_debug_attention_variant(int variant);
 /* subsequent wvn_qkv_fused launches write dbg[(workgroup * 4 + wave) * 4 + {0 LayerNorm prologue, 1 MFMA slices, 2 tile epilogues,
  * 3 total}] in shader cycles (scripts/bench_qkv_fused.py); NULL switches the instrumented build off again. */
 int wvn_debug_qkv_fused_timing(long long* dbg);
+/* the same for wvn_mlp_fused with the LayerNorm inside: dbg[(workgroup * 4 + wave) * 6 + {0 row prologue (LayerNorm), 1 fc1 slices,
+ * 2 GELU + pack, 3 fc2 slices, 4 epilogue, 5 total}] (scripts/bench_mlp_fused.py) */
+int wvn_debug_mlp_fused_timing(long long* dbg);
 /* the row-panel N = 384 residual GEMM on every row block, whatever M (the dispatcher of wvn_gemm_bf16 only uses it from about
  * 0.75 x #CU row blocks of 256 on); tests */
 int wvn_debug_gemm_n384(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int K,

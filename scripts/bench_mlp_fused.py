@@ -42,3 +42,15 @@ gam, bet = torch.ones(384, device=dev), torch.zeros(384, device=dev)
 x.normal_()
 t = timeit(lambda: ops.mlp_fused(None, w1, b1, w2p * 0, b2 * 0, x, ln=(gam, bet, 1e-6)))
 print("fused (LayerNorm inside): %.1f us  (%.0f TFLOP/s)" % (t, fl / t / 1e6))
+import ctypes
+dbg = torch.zeros(256 * 4 * 6, dtype=torch.int64, device=dev)
+_lib.lib().wvn_debug_mlp_fused_timing(ctypes.c_void_p(dbg.data_ptr()))
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record(); ops.mlp_fused(None, w1, b1, w2p * 0, b2 * 0, x, ln=(gam, bet, 1e-6)); b.record(); torch.cuda.synchronize()
+_lib.lib().wvn_debug_mlp_fused_timing(ctypes.c_void_p(0))
+d = dbg.cpu().view(256, 4, 6).double()
+tot = d[..., 5].mean()
+names = ["LayerNorm prologue", "fc1 slices", "GELU + pack", "fc2 slices", "epilogue"]
+print("instrumented launch %.1f us; per wave cycles: total %.0f (max %.0f); " % (a.elapsed_time(b) * 1e3, tot, d[..., 5].max()) +
+      " | ".join("%s %.0f (%.1f%%)" % (n, d[..., i].mean(), 100 * d[..., i].mean() / tot) for i, n in enumerate(names)))
+print("MFMA floor per wave: %.0f cycles" % (M / 128 / 256 * 24 * 96 * 32))

@@ -82,6 +82,43 @@ __global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, lon
           typedef __attribute__((ext_vector_type(2))) __bf16 b2;
           v[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, pk), __builtin_bit_cast(b2, 0x3f803f80u), v[3], false);
         }
+        if constexpr (FILL == 7) {   // lazy-max attention mix: 2 exp2, cvt_pk, dot2c
+          v[0] = __builtin_amdgcn_exp2f(v[0]);
+          v[1] = __builtin_amdgcn_exp2f(v[1]);
+          unsigned pk;
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[0]), "v"(v[1]));
+          typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+          v[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, pk), __builtin_bit_cast(b2, 0x3f803f80u), v[3], false);
+        }
+        if constexpr (FILL == 8 || FILL == 9) {   // one of the two exp2 (8) / every fourth (9: only when u & 1) as a VALU polynomial: fract, sub, 3 fma, cvt, ldexp
+          const bool poly = FILL == 8 || (u & 1);
+          if (poly) {
+            const float f = __builtin_amdgcn_fractf(v[0]);
+            const float n = v[0] - f;
+            float pz = __builtin_fmaf(f, 0.0555f, 0.2402f);
+            pz = __builtin_fmaf(pz, f, 0.6931f);
+            pz = __builtin_fmaf(pz, f, 1.0f);
+            v[0] = __builtin_amdgcn_ldexpf(pz, (int)n);
+          } else {
+            v[0] = __builtin_amdgcn_exp2f(v[0]);
+          }
+          v[1] = __builtin_amdgcn_exp2f(v[1]);
+          unsigned pk;
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[0]), "v"(v[1]));
+          typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+          v[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, pk), __builtin_bit_cast(b2, 0x3f803f80u), v[3], false);
+        }
+        if constexpr (FILL >= 10 && FILL <= 13) {   // cost of the pieces: 10: 2 exp + cvt_pk; 11: 2 exp + dot2c; 12: 2 exp + cvt_pk + 2 v_add_f32; 13: 2 exp + cvt_pk + 1 v_add (sum of the pair by one 3-op add? no: v_add3 is integer) -> v_fma(p0, 1, p1) style
+          v[0] = __builtin_amdgcn_exp2f(v[0]);
+          v[1] = __builtin_amdgcn_exp2f(v[1]);
+          unsigned pk = 0x3f803f80u;
+          if constexpr (FILL != 11) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[0]), "v"(v[1]));
+          typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+          if constexpr (FILL == 11) { pk = __builtin_bit_cast(unsigned, v[0]); v[3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, pk), __builtin_bit_cast(b2, 0x3f803f80u), v[3], false); }
+          if constexpr (FILL == 12) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[3]) : "v"(v[0])); asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[2]) : "v"(v[1])); }
+          if constexpr (FILL == 13) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[3]) : "v"(v[0])); }
+          if constexpr (FILL != 11) asm volatile("" :: "v"(pk));
+        }
         if constexpr (FILL == 6) {   // 2 exp2 only
           v[0] = __builtin_amdgcn_exp2f(v[0]);
           v[1] = __builtin_amdgcn_exp2f(v[1]);
@@ -94,6 +131,12 @@ __global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, lon
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if constexpr (FILL == 3 || FILL == 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         if constexpr (FILL == 5) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        if constexpr (FILL == 7) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if constexpr (FILL == 10 || FILL == 11) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if constexpr (FILL == 12) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        if constexpr (FILL == 13) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if constexpr (FILL == 8) __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+        if constexpr (FILL == 9) { if (u & 1) __builtin_amdgcn_sched_group_barrier(0x002, 10, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
         if constexpr (FILL == 6) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -166,6 +209,13 @@ int main() {
     runf<4, 4>(grid, in, out, cyc, "4 chains + ds_read + 4 exp2");
     runf<4, 6>(grid, in, out, cyc, "4 chains + ds_read + 2 exp2");
     runf<4, 5>(grid, in, out, cyc, "4 chains + ds_read + attn mix (5)");
+    runf<4, 7>(grid, in, out, cyc, "lazy attn mix: 2 exp, cvt, dot2c");
+    runf<4, 10>(grid, in, out, cyc, "2 exp + cvt_pk");
+    runf<4, 11>(grid, in, out, cyc, "2 exp + dot2c");
+    runf<4, 12>(grid, in, out, cyc, "2 exp + cvt_pk + 2 v_add_f32");
+    runf<4, 13>(grid, in, out, cyc, "2 exp + cvt_pk + 1 v_add_f32");
+    runf<4, 8>(grid, in, out, cyc, "1 exp + 1 poly exp2, cvt, dot2c");
+    runf<4, 9>(grid, in, out, cyc, "1.5 exp + 0.5 poly exp2, cvt, dot2c");
     run<1, 1>(grid, in, out, cyc, "1 chain, 1 wave/SIMD");
     run<2, 1>(grid, in, out, cyc, "2 chains, 1 wave/SIMD");
     run<4, 1>(grid, in, out, cyc, "4 chains, 1 wave/SIMD");

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_debug_attention_variant": ([_i], _i),
     "wvn_debug_qkv_fused_timing": ([_p], _i),
+    "wvn_debug_mlp_fused_timing": ([_p], _i),
     "wvn_qkv_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),
     "wvn_mlp_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_gemm_x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),

@@ -356,6 +356,8 @@ int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const
 }
 
 int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
+extern long long* g_mlp_fused_dbg;
+int wvn_debug_mlp_fused_timing(long long* dbg) { g_mlp_fused_dbg = dbg; return WVN_OK; }
 extern long long* g_qkv_fused_dbg;
 int wvn_debug_qkv_fused_timing(long long* dbg) { g_qkv_fused_dbg = dbg; return WVN_OK; }
 int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); return WVN_OK; }

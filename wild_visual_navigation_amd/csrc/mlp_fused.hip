@@ -67,6 +67,7 @@ struct MlpFusedParams {
   const float* ls;               // optional LayerScale [384] (nullptr = none)
   float* X; int ldx;             // residual stream [M][384] fp32, updated in place
   int M, F;
+  long long* dbg;   // TIMING: per wave {prologue (rows / LayerNorm), fc1 slices, GELU + pack, fc2 slices, epilogue, total} in shader cycles
 };
 
 // One 16-byte store of a row piece.  gfx950: a buffer_store_dwordx4 with an SGPR soffset is still reading its data registers for a
@@ -80,7 +81,7 @@ __device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool LNF>
+template <bool LNF, bool TIMING = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -191,8 +192,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) wf[i] = frag(I0{}, 0, i);
 
+  long long tm[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> long long {
+    if constexpr (TIMING) { __builtin_amdgcn_sched_barrier(0); return (long long)__builtin_amdgcn_s_memtime(); }
+    return 0;
+  };
+  const long long t_begin = now();
   for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     const int m0w = rb * BM + wave * 32;
+    const long long c_p0 = now();
     // ---- A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7); rows past M are clamped ----
     bf16x8_t xf[KD / 16];
     if constexpr (LNF) {
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
 #pragma unroll
       for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
     }
+    if constexpr (TIMING) tm[0] += now() - c_p0;
     f32x16_t out[12];
 #pragma unroll
     for (int t = 0; t < 12; ++t)
@@ -275,7 +284,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
         ++si;
         rslot = nslot;
       };
+      const long long c0 = now();
       slice(I0{}); slice(I1{}); slice(I2{});
+      const long long c1 = now();
       // ---- GELU, pack: the accumulator registers become the fc2 B-operand fragments (k-step sigma = 2 t + (g >> 1)) ----
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -294,8 +305,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
         }
       __builtin_amdgcn_sched_barrier(0);
       // ---- fc2: out[32 rows][384] += h W2_j^T, 128 output columns per slice ----
+      const long long c2 = now();
       slice(I3{}); slice(I4{}); slice(I5{});
+      if constexpr (TIMING) { tm[1] += c1 - c0; tm[2] += c2 - c1; tm[3] += now() - c2; }
     }
+    const long long c_e0 = now();
 
     // ---- epilogue: x[rows of this wave][384] += out + b2, 128 columns at a time through the wave's LDS image ----
     // (the staging area does not overlap the ring: the W stream of the next row block keeps flowing meanwhile).  The residual
@@ -338,6 +352,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (TIMING) tm[4] += now() - c_e0;
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 6;
+      for (int i = 0; i < 5; ++i) d[i] = tm[i];
+      d[5] = now() - t_begin;
+    }
   }
 }
 
@@ -357,6 +379,8 @@ int mlp_fused_num_cus() {
 // Eligibility: D == 384, F % 64 == 0 (F * 4 + 154,112 bytes of LDS), 16-byte aligned operands, 32-bit byte offsets.
 // W2 must be stored with the hidden index permuted (wvn_hip.h: WVN_VIT_MLP_FUSED).  xn == nullptr: the kernel applies
 // LayerNorm(ln_g, ln_b, ln_eps) to the rows of x itself (once per row block).  WVN_ERR_ARG otherwise.
+long long* g_mlp_fused_dbg = nullptr;   // wvn_debug_mlp_fused_timing (scripts/bench_mlp_fused.py)
+
 int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,
                          const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
                          hipStream_t st) {
@@ -371,6 +395,7 @@ int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const flo
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -379,7 +404,9 @@ int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const flo
   p.X = x; p.ldx = ldx; p.M = M; p.F = F;
   const int nrb = ceil_div(M, BM), ncu = mlp_fused_num_cus();
   const dim3 grid(nrb < ncu ? nrb : ncu);
-  if (lnf) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(256), lds, st, p);
+  p.dbg = g_mlp_fused_dbg;
+  if (lnf && g_mlp_fused_dbg) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
+  else if (lnf) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
