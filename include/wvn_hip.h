@@ -42,14 +42,19 @@ int wvn_version(void);
  * rows are zero-padded to a multiple of 64 columns (588 -> 640 for patch 14).
  * Biases, LayerNorm affine, LayerScale and the position table are always fp32.
  * ------------------------------------------------------------------------------------------- */
-/* wvn_vit_model.flags.  WVN_VIT_MLP_FUSED (WVN_PREC_BF16, D = 384, F % 64 == 0): every fc2_w is stored with the hidden (input)
- * index permuted -- bits 2 and 3 swapped inside each aligned group of 16, fc2_w_stored[n][k] = fc2.weight[n][swap23(k)] -- and
- * the block MLP, including its LayerNorm (blocks.i.norm2), runs as ONE kernel that keeps the normalised rows and the hidden
- * activation in registers (csrc/mlp_fused.hip). */
+/* wvn_vit_model.flags: which single-kernel forms of the block stages wvn_vit_forward MAY use (WVN_PREC_BF16, D = 384).  They are
+ * persistent one-workgroup-per-CU kernels and pay off once the token matrix fills the chip; below that (a single live frame)
+ * wvn_vit_forward runs the separate LayerNorm / GEMM kernels whatever the flags say (thresholds: csrc/api.hip).
+ * WVN_VIT_MLP_FUSED (F % 64 == 0): every layer also carries fc2_w_fused = fc2.weight with the hidden (input) index permuted --
+ * bits 2 and 3 swapped inside each aligned group of 16, fc2_w_fused[n][k] = fc2.weight[n][swap23(k)] -- and the block MLP,
+ * including its LayerNorm (blocks.i.norm2), runs as ONE kernel that keeps the normalised rows and the hidden activation in
+ * registers (csrc/mlp_fused.hip). */
 #define WVN_VIT_MLP_FUSED 1
 /* WVN_VIT_QKV_FUSED (WVN_PREC_BF16, D = 384, heads = 6): blocks.i.norm1 and the QKV projection run as ONE kernel that normalises the
  * residual rows in registers (csrc/qkv_fused.hip); no weight re-layout. */
 #define WVN_VIT_QKV_FUSED 2
+/* use the allowed single-kernel forms at every size (tests, A/B runs), not only where they pay */
+#define WVN_VIT_FUSE_ANY_SIZE 4
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
@@ -59,6 +64,7 @@ typedef struct wvn_vit_layer {
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const float *ls1, *ls2; /* [D] LayerScale of the attention / MLP branch (DINOv2 blocks.i.ls{1,2}.gamma); NULL = none (DINO) */
   const float *qkv_s, *proj_s, *fc1_s, *fc2_s; /* WVN_PREC_FP8: per-output-channel scale of each e4m3 weight row (w = q * s) */
+  const void* fc2_w_fused;                     /* WVN_VIT_MLP_FUSED: fc2.weight with the permuted hidden index (see above); else NULL */
 } wvn_vit_layer;
 
 typedef struct wvn_vit_model {

@@ -61,14 +61,32 @@ def test_fused_block_kernels_agree_with_separate_kernels(dev, S, B, fuse_mlp, fu
     img = torch.rand(B, 3, S, S, generator=g(7))
     want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
     default = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16")
-    assert default.fuse_mlp and default.fuse_qkv
-    a = default.forward_tokens(img.to(dev)).cpu()
-    b = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16", fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv).forward_tokens(img.to(dev)).cpu()
+    assert default.fuse_mlp and default.fuse_qkv          # allowed; used from about half a chip of row blocks on (csrc/api.hip)
+    fused = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16", fuse_mlp=True, fuse_qkv=True)   # explicit True: at every size
+    a = fused.forward_tokens(img.to(dev)).cpu()
+    if not (fuse_mlp or fuse_qkv):   # at these sizes the default takes the separate kernels: bit-identical to asking for them
+        assert torch.equal(default.forward_tokens(img.to(dev)).cpu(),
+                           VitBackbone(sd, S, 8, 6, device=dev, precision="bf16", fuse_mlp=False, fuse_qkv=False).forward_tokens(img.to(dev)).cpu())
+    b = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16", fuse_mlp=fuse_mlp or False, fuse_qkv=fuse_qkv or False).forward_tokens(img.to(dev)).cpu()
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert rel_l2(a, want) < 2.5e-2 and rel_l2(b, want) < 2.5e-2
     assert rel_l2(a, b) < 1.5e-2   # two bf16 paths differ from each other by about what each differs from fp32
     with pytest.raises(Exception):
         VitBackbone(sd, S, 8, 6, device=dev, precision="fp32", fuse_mlp=True)
+
+
+def test_fused_kernels_take_over_at_batch_size(dev):
+    """From about half a chip of row blocks on wvn_vit_forward switches to the single-kernel block stages by itself: a 12-frame
+    448^2 batch runs them (same tokens as forcing them), a 2-frame batch does not (same tokens as forbidding them)."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=2)
+    img = torch.rand(12, 3, 448, 448, generator=g(9)).to(dev)
+    auto = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=12)
+    forced = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=12, fuse_mlp=True, fuse_qkv=True)
+    never = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=12, fuse_mlp=False, fuse_qkv=False)
+    t_auto, t_forced, t_never = auto.forward_tokens(img), forced.forward_tokens(img), never.forward_tokens(img)
+    assert torch.equal(t_auto, t_forced) and not torch.equal(t_auto, t_never)
+    assert rel_l2(t_auto.float().cpu(), t_never.float().cpu()) < 1.5e-2
+    assert torch.equal(auto.forward_tokens(img[:2]), never.forward_tokens(img[:2]))
 
 
 def test_batch_invariance_and_chunking(dev):

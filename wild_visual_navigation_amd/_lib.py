@@ -17,6 +17,7 @@ WVN_MAX_DEPTH = 32
 PREC_F32, PREC_BF16, PREC_X3, PREC_FP8 = 0, 1, 2, 3
 VIT_MLP_FUSED = 1
 VIT_QKV_FUSED = 2
+VIT_FUSE_ANY_SIZE = 4
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -30,7 +31,7 @@ class WvnError(RuntimeError):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s")]
+        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s", "fc2_w_fused")]
 
 
 class VitModel(C.Structure):

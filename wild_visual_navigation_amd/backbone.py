@@ -150,7 +150,9 @@ class VitBackbone:
         m = _lib.VitModel()
         m.img_size, m.patch, m.dim, m.depth, m.heads, m.mlp_dim = img_size, patch, self.dim, self.depth, heads, self.mlp_dim
         m.precision = self.precision
-        m.flags = (_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
+        # None: the library decides by size (the fused kernels pay from about half a chip of row blocks on); True: always
+        m.flags = ((_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
+                   | (_lib.VIT_FUSE_ANY_SIZE if (fuse_mlp is True or fuse_qkv is True) else 0))
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
@@ -171,10 +173,10 @@ class VitBackbone:
             else:
                 L.qkv_w, L.proj_w = mat(sd[p + "attn.qkv.weight"]), mat(sd[p + "attn.proj.weight"])
                 w2 = sd[p + "mlp.fc2.weight"]
-                if self.fuse_mlp:  # hidden index in the order the fc1 accumulators hand it over (wvn_hip.h WVN_VIT_MLP_FUSED)
-                    k = torch.arange(self.mlp_dim)
-                    w2 = w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)]
                 L.fc1_w, L.fc2_w = mat(sd[p + "mlp.fc1.weight"]), mat(w2)
+                if self.fuse_mlp:  # a second copy with the hidden index in the order the fc1 accumulators hand it over (wvn_hip.h)
+                    k = torch.arange(self.mlp_dim)
+                    L.fc2_w_fused = mat(w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)])
             L.qkv_b, L.proj_b = vec(sd[p + "attn.qkv.bias"]), vec(sd[p + "attn.proj.bias"])
             L.fc1_b, L.fc2_b = vec(sd[p + "mlp.fc1.bias"]), vec(sd[p + "mlp.fc2.bias"])
             L.ln1_g, L.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])

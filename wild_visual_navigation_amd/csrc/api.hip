@@ -142,9 +142,14 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (fp8 && ((d.D % 128) || (d.F % 128))) return WVN_ERR_ARG;
   // fp8: everything that is not one of the four block linears runs exactly as in the bf16 mode
   const bool bf = m->precision == WVN_PREC_BF16 || fp8, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
-  const bool mlp_fused = (m->flags & WVN_VIT_MLP_FUSED) != 0, qkv_fused = (m->flags & WVN_VIT_QKV_FUSED) != 0;
-  if (qkv_fused && (m->precision != WVN_PREC_BF16 || d.D != 384 || d.H != 6 || (d.ntok_s % 16) != 0)) return WVN_ERR_ARG;
-  if (mlp_fused && (m->precision != WVN_PREC_BF16 || d.D != 384 || (d.F % 64) != 0)) return WVN_ERR_ARG;
+  // The single-kernel block stages are persistent one-workgroup-per-CU kernels (128 / 256 rows per workgroup): measured against the
+  // separate kernels (scripts/small_batch_latency.py, 448^2 and 224^2 frames) they win from about half a chip of row blocks on and
+  // lose below -- a single live frame is 25 / 13 row blocks on 256 CUs, 2.5 ms against 1.7.
+  const bool mlp_ok = (m->flags & WVN_VIT_MLP_FUSED) != 0, qkv_ok = (m->flags & WVN_VIT_QKV_FUSED) != 0;
+  if (qkv_ok && (m->precision != WVN_PREC_BF16 || d.D != 384 || d.H != 6 || (d.ntok_s % 16) != 0)) return WVN_ERR_ARG;
+  const bool any_size = (m->flags & WVN_VIT_FUSE_ANY_SIZE) != 0;
+  const bool mlp_fused = mlp_ok && (any_size || d.M >= 128 * 128), qkv_fused = qkv_ok && (any_size || d.M >= 144 * 256);
+  if (mlp_ok && (m->precision != WVN_PREC_BF16 || d.D != 384 || (d.F % 64) != 0)) return WVN_ERR_ARG;
   if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
   const float scale = 1.0f / sqrtf(64.f);
   const int M = (int)d.M, Mp = (int)d.Mp;
@@ -284,7 +289,8 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     if (!mlp_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     if (mlp_fused) {  // LayerNorm 2 + fc1 + GELU + fc2 + residual: one launch, no xn / hid round trip
       Span s(6, st);
-      RET_IF(wvn_mlp_fused_launch(nullptr, 0, L.ln2_g, L.ln2_b, 1e-6f, (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w, L.fc2_b,
+      if (!L.fc2_w_fused) return WVN_ERR_ARG;
+      RET_IF(wvn_mlp_fused_launch(nullptr, 0, L.ln2_g, L.ln2_b, 1e-6f, (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b,
                                   L.ls2, w.x, d.D, M, d.F, st));
       continue;
     }
