@@ -175,12 +175,18 @@ def test_bf16_shipped_instantiations_at_448(dev):
     sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=2, depth=2)
     img = torch.rand(B, 3, 448, 448, generator=g(11))
     want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
-    bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=B)
+    # (a) as shipped: at this size wvn_vit_forward takes the single-kernel LayerNorm + QKV / LayerNorm + MLP stages
+    auto = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=B).forward_tokens(img.to(dev)).cpu()
+    rel = ((auto - want).norm() / want.norm()).item()
+    print(f"bf16 448^2 B=16 (XCD attention, fused block stages): rel-L2 = {rel:.3e}, max|err| = {(auto - want).abs().max().item():.3e}")
+    assert rel < 1e-2 and (auto - want).abs().max().item() < 0.15
+    # (b) the separate kernels at the same size: A-stationary QKV / fc1, row-panel fc2 with its hand-over
+    bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=B, fuse_mlp=False, fuse_qkv=False)
     got = bb.forward_tokens(img.to(dev)).cpu()
     rel = ((got - want).norm() / want.norm()).item()
     print(f"bf16 448^2 B=16 (XCD attention, row-panel fc2): rel-L2 = {rel:.3e}, max|err| = {(got - want).abs().max().item():.3e}")
     assert rel < 1e-2 and (got - want).abs().max().item() < 0.15
-    # the same frames one at a time take the non-XCD attention instantiation and the tiled fc2 kernel: same bits
+    # the same frames one at a time take the non-XCD attention instantiation and the tiled fc2 kernel: same bits as (b)
     one = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=1)
     for b in (0, 7, 15):
         assert torch.equal(one.forward_tokens(img[b:b + 1].to(dev)).cpu()[0], got[b]), b
