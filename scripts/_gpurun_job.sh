@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_x3.py -x -q 2>&1 | tail -3
+timeout 120 scripts/ubench/mfma_rate 2>&1 | grep "grid  256" | grep "2 exp"

@@ -119,6 +119,16 @@ __global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, lon
           if constexpr (FILL == 13) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[3]) : "v"(v[0])); }
           if constexpr (FILL != 11) asm volatile("" :: "v"(pk));
         }
+        if constexpr (FILL >= 14 && FILL <= 17) {   // 2 exp + a pack: 14 v_cvt_pkrtz_f16_f32, 15 v_perm_b32 (bf16 truncation), 16 v_cvt_pk_f16_f32, 17 v_and_or (bf16 truncation in 1 VOP3)
+          v[0] = __builtin_amdgcn_exp2f(v[0]);
+          v[1] = __builtin_amdgcn_exp2f(v[1]);
+          unsigned pk;
+          if constexpr (FILL == 14) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[0]), "v"(v[1]));
+          if constexpr (FILL == 15) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(pk) : "v"(v[1]), "v"(v[0]), "s"(0x07060302u));
+          if constexpr (FILL == 16) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(v[0]), "v"(v[1]));
+          if constexpr (FILL == 17) asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(pk) : "v"(v[1]), "s"(0xffff0000u), "v"(v[0]));
+          asm volatile("" :: "v"(pk));
+        }
         if constexpr (FILL == 6) {   // 2 exp2 only
           v[0] = __builtin_amdgcn_exp2f(v[0]);
           v[1] = __builtin_amdgcn_exp2f(v[1]);
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, lon
         if constexpr (FILL == 3 || FILL == 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         if constexpr (FILL == 5) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         if constexpr (FILL == 7) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        if constexpr (FILL == 10 || FILL == 11) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if constexpr (FILL == 10 || FILL == 11 || (FILL >= 14 && FILL <= 17)) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         if constexpr (FILL == 12) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         if constexpr (FILL == 13) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         if constexpr (FILL == 8) __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
@@ -211,6 +221,10 @@ int main() {
     runf<4, 5>(grid, in, out, cyc, "4 chains + ds_read + attn mix (5)");
     runf<4, 7>(grid, in, out, cyc, "lazy attn mix: 2 exp, cvt, dot2c");
     runf<4, 10>(grid, in, out, cyc, "2 exp + cvt_pk");
+    runf<4, 14>(grid, in, out, cyc, "2 exp + v_cvt_pkrtz_f16_f32");
+    runf<4, 15>(grid, in, out, cyc, "2 exp + v_perm_b32 (trunc bf16)");
+    runf<4, 16>(grid, in, out, cyc, "2 exp + v_cvt_pk_f16_f32");
+    runf<4, 17>(grid, in, out, cyc, "2 exp + v_and_or_b32");
     runf<4, 11>(grid, in, out, cyc, "2 exp + dot2c");
     runf<4, 12>(grid, in, out, cyc, "2 exp + cvt_pk + 2 v_add_f32");
     runf<4, 13>(grid, in, out, cyc, "2 exp + cvt_pk + 1 v_add_f32");
