@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 120 scripts/ubench/mfma_rate 2>&1 | grep "grid  256" | grep "2 exp"
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
+for i in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['step_ms']['median'], {k:round(v['ms_total']/10,2) for k,v in d['kernel_ms'].items()})"; done

@@ -348,6 +348,11 @@ int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
   if (!p.A || !p.W || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
     return WVN_ERR_ARG;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return WVN_ERR_ARG;
+  // attention projection + residual at sizes that fill the chip: W resident in LDS, built for HBM throughput (gemm_proj.hip)
+  if (epi == EPI_RESID_F32 && p.N == 384 && p.K == 384 && p.ldw == 384 && p.M >= 32768 && !p.dbg) {
+    const int rc = wvn_proj_resid_launch(p.A, p.lda, p.W, p.bias, p.ls, (float*)p.C, p.ldc, p.M, st);
+    if (rc != WVN_ERR_ARG) return rc;
+  }
   if (p.K == 384 && !p.ls) {  // A-stationary kernel for the K = 384 linears
     const int rc = wvn_gemm_a384_launch(p, epi, st);
     if (rc != WVN_ERR_ARG) return rc;
