@@ -206,10 +206,31 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
     if constexpr (LNF) {
       // LayerNorm of the wave's 32 residual rows, once per row block: a lane holds half a row (the k-slots it feeds the MFMAs),
       // its partner lane ^ 32 the other half
-      const float* xp = p.X + (size_t)min(m0w + l31, p.M - 1) * p.ldx + hi * 8;
+      // The rows come in coalesced (an instruction = 4 rows x 256 contiguous bytes = 8 whole lines; the fragment layout would
+      // touch 32 lines for the same 1 KB, and the L1 takes lines, not bytes) and reach the fragment layout through the wave's LDS
+      // image, 64 columns at a time.
       f32x4_t xq[KD / 8];
+      {
+        const int lr = lane >> 4, lc = (lane & 15) * 4;            // loader: row 4 i + lr, columns lc .. lc + 3 of the chunk
+        f32x4_t buf[2][8];
+        auto load_chunk = [&](int c, f32x4_t (&b)[8]) {
 #pragma unroll
-      for (int s = 0; s < KD / 16; ++s) { xq[2 * s] = *(const f32x4_t*)(xp + 16 * s); xq[2 * s + 1] = *(const f32x4_t*)(xp + 16 * s + 4); }
+          for (int i = 0; i < 8; ++i) b[i] = *(const f32x4_t*)(p.X + (size_t)min(m0w + 4 * i + lr, p.M - 1) * p.ldx + 64 * c + lc);
+        };
+        load_chunk(0, buf[0]);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          if (c + 1 < 6) load_chunk(c + 1, buf[(c + 1) & 1]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) *(f32x4_t*)(stg + (4 * i + lr) * 68 + lc) = buf[c & 1][i];   // [32][68] fp32
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            xq[2 * (4 * c + kk)] = *(const f32x4_t*)(stg + l31 * 68 + 16 * kk + 8 * hi);
+            xq[2 * (4 * c + kk) + 1] = *(const f32x4_t*)(stg + l31 * 68 + 16 * kk + 8 * hi + 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       float sm = 0.f;
 #pragma unroll
       for (int i = 0; i < KD / 8; ++i) sm += (xq[i][0] + xq[i][1]) + (xq[i][2] + xq[i][3]);

@@ -178,10 +178,35 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
     int dep = 0;   // serialises the two 32-row passes (384 fp32 values in flight at once would not fit the register file)
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) {
-      const float* xp = p.X + (size_t)min(m0w + rs * 32 + l31, p.M - 1) * p.ldx + hi * 8 + dep;   // rows past M: clamped, never stored
+      // The rows come in COALESCED (an instruction = 4 rows x 256 contiguous bytes = 8 whole lines) and are turned into the fragment
+      // layout (lane = row) through the wave's LDS image, 32 rows x 64 columns at a time.  Loading them in the fragment layout
+      // directly (32 rows x 32 bytes per instruction: 32 lines touched for 1 KB) made this prologue 38 % of the kernel: the L1
+      // takes lines, not bytes (gemm_proj.hip measured the same thing on the residual).
       f32x4_t xq[KD / 8];
+      {
+        const int lr = lane >> 4, lc = (lane & 15) * 4;            // loader: row 4 i + lr, columns lc .. lc + 3 of the chunk
+        const float* xg = p.X + (size_t)dep + lc;
+        float* stgf = (float*)stg;                                  // [32][68] fp32 (8,704 B of the 9,216)
+        f32x4_t buf[2][8];
+        auto load_chunk = [&](int c, f32x4_t (&b)[8]) {
 #pragma unroll
-      for (int k = 0; k < KD / 16; ++k) { xq[2 * k] = *(const f32x4_t*)(xp + 16 * k); xq[2 * k + 1] = *(const f32x4_t*)(xp + 16 * k + 4); }
+          for (int i = 0; i < 8; ++i)
+            b[i] = *(const f32x4_t*)(xg + (size_t)min(m0w + rs * 32 + 4 * i + lr, p.M - 1) * p.ldx + 64 * c);   // rows past M: clamped, never stored
+        };
+        load_chunk(0, buf[0]);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          if (c + 1 < 6) load_chunk(c + 1, buf[(c + 1) & 1]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) *(f32x4_t*)(stgf + (4 * i + lr) * 68 + lc) = buf[c & 1][i];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            xq[2 * (4 * c + kk)] = *(const f32x4_t*)(stgf + l31 * 68 + 16 * kk + 8 * hi);
+            xq[2 * (4 * c + kk) + 1] = *(const f32x4_t*)(stgf + l31 * 68 + 16 * kk + 8 * hi + 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       float sm = 0.f;
 #pragma unroll
       for (int i = 0; i < KD / 8; ++i) sm += (xq[i][0] + xq[i][1]) + (xq[i][2] + xq[i][3]);
