@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct input batches cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B: 0 exact per-tile row max, 1 lazy (alarm on the row sums)")
+    ap.add_argument("--no-fuse-proj", action="store_true", help="A/B: the attention projection as its own kernel instead of the fused MLP kernel's prologue")
     ap.add_argument("--no-fuse-qkv", action="store_true", help="A/B: LayerNorm kernel + QKV GEMM instead of the fused kernel")
     ap.add_argument("--no-fuse-mlp", action="store_true", help="A/B: run the block MLP as the un-fused fc1 / fc2 kernel pair")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (about 15 s of CPU work)")
@@ -132,7 +133,7 @@ def make_pipeline(args, dev):
         fe = FeatureExtractor(dev, segmentation_type=seg, feature_type=ftype, input_size=args.size,
                               backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
                               max_chunk=args.chunk, allow_synthetic=True, fuse_mlp=False if args.no_fuse_mlp else None,
-                              fuse_qkv=False if args.no_fuse_qkv else None)
+                              fuse_qkv=False if args.no_fuse_qkv else None, fuse_proj=not args.no_fuse_proj)
     if args.attn_variant is not None:
         from wild_visual_navigation_amd import _lib
         _lib.lib().wvn_debug_attention_variant(args.attn_variant)

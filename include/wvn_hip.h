@@ -55,6 +55,8 @@ int wvn_version(void);
 #define WVN_VIT_QKV_FUSED 2
 /* use the allowed single-kernel forms at every size (tests, A/B runs), not only where they pay */
 #define WVN_VIT_FUSE_ANY_SIZE 4
+/* keep the attention projection a separate kernel where the fused MLP kernel runs (A/B runs; default: it is folded into that kernel) */
+#define WVN_VIT_NO_PROJ_IN_MLP 8
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
@@ -114,6 +116,13 @@ int wvn_prof_collect(double* ms_by_cat_host, long long* launches_by_cat_host); /
  * multiplied by q_scale before rounding (0 = 1).  heads == 6, ntok_s % 16 == 0, M % 16 == 0, npad % 16 == 0. */
 int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
                   void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream);
+/* Attention projection + block MLP in one launch: x += (attn [M,lda] bf16 * Wp[384,384]^T + bp) (* ls1), then the block MLP of
+ * wvn_mlp_fused with the LayerNorm inside on the updated rows.  What wvn_vit_forward uses where WVN_VIT_MLP_FUSED applies: the
+ * projection's separate pass over the residual stream disappears (the rows are re-read from the L2 they were just written to).
+ * Wp, W1 and W2p must lie within 4 GB of each other (one buffer descriptor). */
+int wvn_proj_mlp_fused(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
+                       const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
+                       const float* ls2, float* x, int ldx, int M, int F, void* stream);
 /* Block MLP in one launch: x [M,ldx] fp32 += gelu(xn [M,lda] bf16 * W1[F,384]^T + b1) * W2[384,F]^T + b2  (optionally
  * times LayerScale ls [384]).  W2p = W2 with the hidden index permuted as WVN_VIT_MLP_FUSED describes.  xn == NULL: the kernel
  * computes xn = LayerNorm(x; ln_g, ln_b, ln_eps) itself (what wvn_vit_forward uses: blocks.i.norm2 never touches memory).

@@ -78,6 +78,43 @@ def test_fused_with_layernorm(dev, M):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("M", [5, 128, 777, 128 * 300 + 17])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_projection_in_the_prologue(dev, M, scaled):
+    """attention projection + residual, then LayerNorm + MLP + residual, as ONE launch -- against the two kernels it replaces
+    (projection GEMM with residual epilogue, then the fused MLP kernel): same rounding points, the LayerNorm sees a residual
+    stream that differs by fp32 summation order only"""
+    Fh = 1536
+    _, w1, b1, w2, b2, x, _ = make(M, Fh, dev)
+    x = x * 2.0 + 0.4
+    attn = (torch.randn(M, 384, generator=g(11)) * 1.5).to(torch.bfloat16).to(dev)
+    wp = (torch.randn(384, 384, generator=g(12)) * 0.05).to(torch.bfloat16).to(dev)
+    bp = (torch.randn(384, generator=g(13)) * 0.3).to(dev)
+    gam = (torch.rand(384, generator=g(8)) + 0.5).to(dev)
+    bet = (torch.randn(384, generator=g(9)) * 0.2).to(dev)
+    ls1 = (torch.rand(384, generator=g(14)) + 0.5).to(dev) if scaled else None
+    ls2 = (torch.rand(384, generator=g(15)) + 0.5).to(dev) if scaled else None
+    w2p = w2[:, ops.vt_token_order(Fh, device=dev)]
+    pack = torch.cat([wp.reshape(-1), w1.reshape(-1), w2p.reshape(-1)]).contiguous()   # one allocation: one buffer descriptor
+    n0, n1 = wp.numel(), w1.numel()
+    wp_v, w1_v, w2p_v = pack[:n0].view(384, 384), pack[n0:n0 + n1].view(Fh, 384), pack[n0 + n1:].view(384, Fh)
+    # reference: the two kernels
+    want = x.clone()
+    if scaled:   # the projection GEMM has no LayerScale operand at this level: fold it into weights / bias of the reference
+        y = attn.float() @ wp.float().T + bp
+        want = want + ls1 * y
+    else:
+        ops.gemm_bf16(attn, wp, bp, _lib.EPI_RESID_F32, out=want)
+    ops.mlp_fused(None, w1_v, b1, w2p_v, b2, want, ls=ls2, ln=(gam, bet, 1e-6))
+    got = ops.proj_mlp_fused(attn, wp_v, bp, (gam, bet, 1e-6), w1_v, b1, w2p_v, b2, x.clone(), ls1=ls1, ls2=ls2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 1e-2
+    assert (got - want).abs().mean().item() <= 1e-4
+    again = ops.proj_mlp_fused(attn, wp_v, bp, (gam, bet, 1e-6), w1_v, b1, w2p_v, b2, x.clone(), ls1=ls1, ls2=ls2)
+    assert torch.equal(got, again), "run-to-run difference (pipeline race)"
+
+
 def test_fused_layerscale(dev):
     M, Fh = 515, 1536
     xn, w1, b1, w2, b2, x, gam = make(M, Fh, dev, ls=True)

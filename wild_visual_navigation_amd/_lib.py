@@ -18,6 +18,7 @@ PREC_F32, PREC_BF16, PREC_X3, PREC_FP8 = 0, 1, 2, 3
 VIT_MLP_FUSED = 1
 VIT_QKV_FUSED = 2
 VIT_FUSE_ANY_SIZE = 4
+VIT_NO_PROJ_IN_MLP = 8
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -64,6 +65,7 @@ _SIGNATURES = {
     "wvn_debug_qkv_fused_timing": ([_p], _i),
     "wvn_debug_mlp_fused_timing": ([_p], _i),
     "wvn_qkv_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),
+    "wvn_proj_mlp_fused": ([_p, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_mlp_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_gemm_x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_quantize_rows_fp8": ([_p, _i, _i, _p, _i, _p, _i, _i, _p], _i),

@@ -92,7 +92,7 @@ class VitBackbone:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
                  device="cuda", precision: str = "bf16", max_chunk: int = 16, fuse_mlp: Optional[bool] = None,
-                 fuse_qkv: Optional[bool] = None):
+                 fuse_qkv: Optional[bool] = None, fuse_proj: bool = True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
@@ -115,6 +115,7 @@ class VitBackbone:
         if fuse_qkv and not can_fuse_qkv:
             raise _lib.WvnError("fuse_qkv needs precision 'bf16', dim 384 and 6 heads")
         self.fuse_qkv = can_fuse_qkv if fuse_qkv is None else bool(fuse_qkv)
+        self._fuse_args = (fuse_mlp, fuse_qkv, fuse_proj)
         self._sd = state_dict  # kept (host / original tensors) so that .to(device) can re-home the model
         self._keep = []  # device tensors referenced by raw pointers in the C struct
 
@@ -152,7 +153,8 @@ class VitBackbone:
         m.precision = self.precision
         # None: the library decides by size (the fused kernels pay from about half a chip of row blocks on); True: always
         m.flags = ((_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
-                   | (_lib.VIT_FUSE_ANY_SIZE if (fuse_mlp is True or fuse_qkv is True) else 0))
+                   | (_lib.VIT_FUSE_ANY_SIZE if (fuse_mlp is True or fuse_qkv is True) else 0)
+                   | (0 if fuse_proj else _lib.VIT_NO_PROJ_IN_MLP))
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
@@ -171,12 +173,22 @@ class VitBackbone:
                 L.fc1_w, L.fc1_s = mat8(sd[p + "mlp.fc1.weight"])
                 L.fc2_w, L.fc2_s = mat8(sd[p + "mlp.fc2.weight"])
             else:
-                L.qkv_w, L.proj_w = mat(sd[p + "attn.qkv.weight"]), mat(sd[p + "attn.proj.weight"])
+                L.qkv_w = mat(sd[p + "attn.qkv.weight"])
+                if not self.fuse_mlp:
+                    L.proj_w = mat(sd[p + "attn.proj.weight"])
                 w2 = sd[p + "mlp.fc2.weight"]
-                L.fc1_w, L.fc2_w = mat(sd[p + "mlp.fc1.weight"]), mat(w2)
-                if self.fuse_mlp:  # a second copy with the hidden index in the order the fc1 accumulators hand it over (wvn_hip.h)
+                L.fc2_w = mat(w2)
+                if self.fuse_mlp:
+                    # the fused kernel addresses proj.weight, fc1.weight and its own copy of fc2.weight (hidden index in the order the
+                    # fc1 accumulators hand it over, wvn_hip.h) through ONE buffer descriptor: one allocation per layer
                     k = torch.arange(self.mlp_dim)
-                    L.fc2_w_fused = mat(w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)])
+                    parts = [sd[p + "attn.proj.weight"], sd[p + "mlp.fc1.weight"], w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)]]
+                    pack = torch.cat([t.detach().float().reshape(-1) for t in parts]).to(self.device).to(torch.bfloat16).contiguous()
+                    self._keep.append(pack)
+                    n0, n1 = parts[0].numel(), parts[1].numel()
+                    L.proj_w, L.fc1_w, L.fc2_w_fused = pack.data_ptr(), pack.data_ptr() + 2 * n0, pack.data_ptr() + 2 * (n0 + n1)
+                else:
+                    L.fc1_w = mat(sd[p + "mlp.fc1.weight"])
             L.qkv_b, L.proj_b = vec(sd[p + "attn.qkv.bias"]), vec(sd[p + "attn.proj.bias"])
             L.fc1_b, L.fc2_b = vec(sd[p + "mlp.fc1.bias"]), vec(sd[p + "mlp.fc2.bias"])
             L.ln1_g, L.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
@@ -193,7 +205,7 @@ class VitBackbone:
         if device == self.device:
             return self
         return VitBackbone(self._sd, self.img_size, self.patch, self.heads, device=device, precision=self.precision_name,
-                           max_chunk=self.max_chunk, fuse_mlp=self.fuse_mlp, fuse_qkv=self.fuse_qkv)
+                           max_chunk=self.max_chunk, fuse_mlp=self._fuse_args[0], fuse_qkv=self._fuse_args[1], fuse_proj=self._fuse_args[2])
 
     # ---- workspace (needs no initialisation: wvn_vit_forward resets the padding rows it relies on at every call) ----
     def _workspace(self, batch: int) -> torch.Tensor:

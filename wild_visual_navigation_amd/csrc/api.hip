@@ -147,7 +147,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   // lose below -- a single live frame is 25 / 13 row blocks on 256 CUs, 2.5 ms against 1.7.
   const bool mlp_ok = (m->flags & WVN_VIT_MLP_FUSED) != 0, qkv_ok = (m->flags & WVN_VIT_QKV_FUSED) != 0;
   if (qkv_ok && (m->precision != WVN_PREC_BF16 || d.D != 384 || d.H != 6 || (d.ntok_s % 16) != 0)) return WVN_ERR_ARG;
-  const bool any_size = (m->flags & WVN_VIT_FUSE_ANY_SIZE) != 0;
+  const bool any_size = (m->flags & WVN_VIT_FUSE_ANY_SIZE) != 0, proj_in_mlp = (m->flags & WVN_VIT_NO_PROJ_IN_MLP) == 0;
   const bool mlp_fused = mlp_ok && (any_size || d.M >= 128 * 128), qkv_fused = qkv_ok && (any_size || d.M >= 144 * 256);
   if (mlp_ok && (m->precision != WVN_PREC_BF16 || d.D != 384 || (d.F % 64) != 0)) return WVN_ERR_ARG;
   if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
@@ -285,6 +285,15 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
+    if (mlp_fused && proj_in_mlp) {  // attention projection + LayerNorm 2 + fc1 + GELU + fc2 + both residual updates: one launch
+      Span s(6, st);
+      if (!L.fc2_w_fused) return WVN_ERR_ARG;
+      const int rc = wvn_proj_mlp_fused_launch((const bf16_t*)w.xn, d.D, (const bf16_t*)L.proj_w, L.proj_b, L.ls1, L.ln2_g, L.ln2_b, 1e-6f,
+                                               (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b, L.ls2, w.x, d.D, M,
+                                               d.F, st);
+      if (rc == WVN_OK) continue;
+      if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: the three weight matrices are not within 4 GB of each other -- separate kernels)
+    }
     { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
     if (!mlp_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     if (mlp_fused) {  // LayerNorm 2 + fc1 + GELU + fc2 + residual: one launch, no xn / hid round trip
@@ -322,6 +331,13 @@ int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b,
                   void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream) {
   return wvn_qkv_fused_launch(x, ldx, ln_g, ln_b, ln_eps, (const bf16_t*)W, bias, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, heads, npad, ntok_s,
                               q_scale, M, (hipStream_t)stream);
+}
+
+int wvn_proj_mlp_fused(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
+                       const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
+                       const float* ls2, float* x, int ldx, int M, int F, void* stream) {
+  return wvn_proj_mlp_fused_launch((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, ls1, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1,
+                                   (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream);
 }
 
 int wvn_mlp_fused(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,

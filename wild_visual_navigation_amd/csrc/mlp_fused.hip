@@ -67,6 +67,11 @@ struct MlpFusedParams {
   const float* ls;               // optional LayerScale [384] (nullptr = none)
   float* X; int ldx;             // residual stream [M][384] fp32, updated in place
   int M, F;
+  // PROJ: the attention output projection of the same block runs in this kernel's prologue: x += (attn Wp^T + bp) (* ls1) first
+  const bf16_t* attn; int lda_attn;   // attention output rows [M][384] bf16
+  const float* bp;               // [384]
+  const float* ls1;              // optional LayerScale of the attention branch
+  const bf16_t* wbase; unsigned off_wp, off_w1, off_w2, wbytes;   // one buffer descriptor over Wp [384][384] / W1 / W2 (byte offsets)
   long long* dbg;   // TIMING: per wave {prologue (rows / LayerNorm), fc1 slices, GELU + pack, fc2 slices, epilogue, total} in shader cycles
 };
 
@@ -81,7 +86,7 @@ __device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool LNF, bool TIMING = false>
+template <bool LNF, bool TIMING = false, bool PROJ = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,20 +95,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   const int NTL = p.F / HT;                         // hidden tiles (24)
   const int nrb = (p.M + BM - 1) / BM;
   const int my_rb = (nrb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // row blocks of this workgroup
-  const int total = my_rb * NTL * 6;               // ring slices this workgroup consumes
+  constexpr int PS = PROJ ? 18 : 0;                 // projection slices per row block: 6 column pairs x 3 k-slices of Wp
+  const int per_rb = PS + NTL * 6;
+  const int total = my_rb * per_rb;                // ring slices this workgroup consumes
   float* b1_l = (float*)(smem + B1_OFF);
   float* b2_l = (float*)(smem + B2_OFF);
   float* lng_l = (float*)(smem + B1_OFF + p.F * 4);   // LNF: gamma [384], beta [384]
+  float* bp_l = lng_l + 2 * KD;                        // PROJ: projection bias [384]
   for (int i = tid; i < p.F; i += 256) b1_l[i] = p.b1 ? p.b1[i] : 0.f;
   for (int i = tid; i < KD; i += 256) b2_l[i] = p.b2 ? p.b2[i] : 0.f;
   if constexpr (LNF)
     for (int i = tid; i < KD; i += 256) { lng_l[i] = p.ln_g[i]; lng_l[KD + i] = p.ln_b[i]; }
+  if constexpr (PROJ)
+    for (int i = tid; i < KD; i += 256) bp_l[i] = p.bp ? p.bp[i] : 0.f;
 
-  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, (unsigned)((size_t)p.F * KD * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, (unsigned)((size_t)KD * p.F * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wbase, 0, p.wbytes, 0x00020000);   // Wp | W1 | W2
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((size_t)p.M * p.ldx * 4), 0x00020000);
   // ---- DMA lane offsets: 16 wave-instructions of 1 KB per slice, 4 per wave ------------------------------------------------
-  // W1 slice [64 h][128 k]: LDS rows of 256 B, instruction = 4 rows; chunk XOR (row & 15)            (gemm_a384.hip)
+  // W1 / Wp slice [64 rows][128 k]: LDS rows of 256 B, instruction = 4 rows; chunk XOR (row & 15)    (gemm_a384.hip)
   // W2 slice [128 n][64 h]: LDS rows of 128 B, instruction = 8 rows; chunk XOR ((row >> 1) & 7)      (attention_bf16.hip K tile)
   unsigned w1off[4], w2off[4];
 #pragma unroll
@@ -114,28 +123,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
     const int r2 = inst * 8 + (lane >> 3);
     w2off[u] = (unsigned)(((size_t)r2 * p.F + (((lane & 7) ^ ((r2 >> 1) & 7)) * 8)) * 2);
   }
-  // Slice sequence of one hidden tile j: positions 0, 1, 2 = W1 k-slices, 3, 4, 5 = W2 n-thirds; the same for every row block.
-  // The kind of every slice is static at its issue and read sites (separate code paths: one buffer resource each).
-  auto issue = [&](auto Qc, int slot, int jj) {
-    constexpr int Q = decltype(Qc)::value;
+  // Slice stream in consumption order, the DMA running four slices ahead of the MFMAs.  Per row block: (PROJ) 18 slices of Wp,
+  // column pair cp x k-slice ks; then per hidden tile j positions 0, 1, 2 = W1 k-slices and 3, 4, 5 = W2 n-thirds.  The KIND of
+  // every slice is static at its issue site (0 Wp, 1 W1, 2 W2): one descriptor, a scalar offset, one of two lane-offset sets.
+  auto issue = [&](auto Kc, int slot, int a, int b) {
+    constexpr int K = decltype(Kc)::value;
     unsigned char* dst = smem + slot * SLICE + wave * 4096;
-    if constexpr (Q < 3) {
-      const unsigned soff = __builtin_amdgcn_readfirstlane((jj * HT * KD + Q * 128) * 2);
+    unsigned soff;
+    if constexpr (K == 0) soff = p.off_wp + (unsigned)((a * HT * KD + b * 128) * 2);
+    else if constexpr (K == 1) soff = p.off_w1 + (unsigned)((a * HT * KD + b * 128) * 2);
+    else soff = p.off_w2 + (unsigned)(((b * 128) * p.F + a * HT) * 2);
+    soff = __builtin_amdgcn_readfirstlane(soff);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, w1off[u], soff, 0, 0);
-    } else {
-      const unsigned soff = __builtin_amdgcn_readfirstlane((((Q - 3) * 128) * p.F + jj * HT) * 2);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, w2off[u], soff, 0, 0);
-    }
+    for (int u = 0; u < 4; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, K == 2 ? w2off[u] : w1off[u], soff, 0, 0);
   };
-  static_assert(NS == 5, "the issue schedule below is written for a ring of 5");
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+  // slice at position T (0..5) of hidden tile jj
+  auto issue_mlp = [&](auto Tc, int slot, int jj) {
+    constexpr int T = decltype(Tc)::value;
+    if constexpr (T < 3) issue(K1{}, slot, jj, T);
+    else issue(K2{}, slot, jj, T - 3);
+  };
+  static_assert(NS == 5, "the waits below are written for a ring of 5");
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-  // prologue: slices 0, 1, 2 in flight (every workgroup owns at least one row block = 6 NTL slices)
-  issue(I0{}, 0, 0); issue(I1{}, 1, 0); issue(I2{}, 2, 0);
+  // prologue: slices 0, 1, 2 in flight (every workgroup owns at least one row block)
+  if constexpr (PROJ) { issue(K0{}, 0, 0, 0); issue(K0{}, 1, 0, 1); issue(K0{}, 2, 0, 2); }
+  else { issue_mlp(I0{}, 0, 0); issue_mlp(I1{}, 1, 0); issue_mlp(I2{}, 2, 0); }
 
   // fragment addressing: fragment i of a slice at position Q (the i-th of its 16 MFMAs) in ring slot `slot`
   // (12 precomputed swizzled lane offsets: a read costs one v_add of the slot base)
@@ -157,19 +172,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   // "slice n = si + 1 is readable": it has landed for this wave when at most the two younger slices (4 DMAs each) are outstanding
   // -- loads complete in order among themselves, and whatever else is in flight (epilogue loads / stores, A rows) only adds to the
   // counter -- and for everybody after the barrier, which also says that every wave is done with slice si - 1: its slot takes
-  // slice si + 4 (position (Q + 4) % 6 of this tile or the next).  Runs in the MIDDLE of slice si, so that the tail of si can
+  // slice si + 4 (the next of the issue stream).  Runs in the MIDDLE of slice si, so that the tail of si can
   // already fetch the first fragments of si + 1.
-  auto open_next = [&](auto Qc, int j, int jn) {
-    constexpr int Q = decltype(Qc)::value;        // position of slice si
+  auto open_next = [&](auto issue_fn) {   // issue_fn(slot): the DMA of slice si + 4, whose kind the caller knows statically
     __builtin_amdgcn_sched_barrier(0);
     if (si + 1 < total) {
       if (si + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (si + 4 < total) {
-        const int islot = rslot == 0 ? NS - 1 : rslot - 1;
-        issue(std::integral_constant<int, (Q + 4) % 6>{}, islot, Q < 2 ? j : jn);
-      }
+      if (si + 4 < total) issue_fn(rslot == 0 ? NS - 1 : rslot - 1);   // into the slot of slice si - 1
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -187,7 +198,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   // open slice 0 and fetch its first four fragments; from here on wf[] always holds the fragments of the next four MFMAs
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  issue(I3{}, 3, 0);
+  if constexpr (PROJ) issue(K0{}, 3, 1, 0);
+  else issue_mlp(I3{}, 3, 0);
   bf16x8_t wf[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) wf[i] = frag(I0{}, 0, i);
@@ -201,6 +213,94 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     const int m0w = rb * BM + wave * 32;
     const long long c_p0 = now();
+    f32x16_t out[12];
+    auto residual_update = [&](const float* bias_tab, const float* ls_vec) {
+      // ---- residual update: x[rows of this wave][384] += (out + bias) (* ls), 128 columns at a time through the wave's LDS image ----
+      // (the staging area does not overlap the ring: the W stream of the next row block keeps flowing meanwhile).  The residual
+      // rows are fetched one 128-column chunk ahead: a wave alone on its SIMD has nothing else to hide a load behind.
+      u32x4_t xr0[16], xr1[16];
+      auto load_x = [&](int c, u32x4_t (&dst)[16]) {
+  #pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldx + 128 * c) * 4);
+          dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, cvoff, so, 0);
+        }
+      };
+      load_x(0, xr0);
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (c == 0) load_x(1, xr1);
+        if (c == 1) load_x(2, xr0);
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16_t& a = out[4 * c + tt];
+            const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+            *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
+          }
+        const f32x4_t b4 = *(const f32x4_t*)(bias_tab + 128 * c + (lane & 31) * 4);
+        f32x4_t l4 = {1.f, 1.f, 1.f, 1.f};
+        if (ls_vec) l4 = *(const f32x4_t*)(ls_vec + 128 * c + (lane & 31) * 4);
+  #pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldx + 128 * c) * 4);
+          const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
+          const u32x4_t r = (c & 1) ? xr1[it] : xr0[it];
+          u32x4_t o;
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[e]));
+          store_b128_guarded(o, rs_x, cvoff, so);  // rows >= M fall outside num_records: dropped
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if constexpr (PROJ) {
+      // ---- attention projection of this block first: x += (attn Wp^T + bp) (* ls1), the wave's 32 rows, all 384 columns ----
+      bf16x8_t af[KD / 16];
+      {
+        const bf16_t* ap = p.attn + (size_t)min(m0w + l31, p.M - 1) * p.lda_attn + hi * 8;
+#pragma unroll
+        for (int s = 0; s < KD / 16; ++s) af[s] = *(const bf16x8_t*)(ap + s * 16);
+      }
+#pragma unroll
+      for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+      // one slice of Wp: rows (output columns) 64 cp .. + 63, k 128 ks .. + 127: 16 MFMAs on out[2 cp], out[2 cp + 1]
+      auto pslice = [&](auto CPc, auto KSc) {
+        constexpr int cp = decltype(CPc)::value, ks = decltype(KSc)::value;
+        const int nslot = rslot == NS - 1 ? 0 : rslot + 1;
+        auto step = [&](int i) {
+          out[2 * cp + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 3], af[ks * 8 + (i >> 1)], out[2 * cp + (i & 1)], 0, 0, 0);
+          wf[i & 3] = i + 4 < 16 ? frag(I0{}, rslot, i + 4) : frag(I0{}, nslot, i + 4 - 16);   // (the next slice is W1-shaped too)
+        };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) step(i);
+        shape8();
+        open_next([&](int slot) {   // slice 3 cp + ks + 4 of this row block: still Wp, or one of the first four of hidden tile 0
+          constexpr int t = 3 * cp + ks + 4;
+          if constexpr (t < 18) issue(K0{}, slot, t / 3, t % 3);
+          else issue_mlp(std::integral_constant<int, t - 18>{}, slot, 0);
+        });
+#pragma unroll
+        for (int i = 8; i < 16; ++i) step(i);
+        shape8();
+        ++si;
+        rslot = nslot;
+      };
+      pslice(I0{}, I0{}); pslice(I0{}, I1{}); pslice(I0{}, I2{});
+      pslice(I1{}, I0{}); pslice(I1{}, I1{}); pslice(I1{}, I2{});
+      pslice(I2{}, I0{}); pslice(I2{}, I1{}); pslice(I2{}, I2{});
+      pslice(I3{}, I0{}); pslice(I3{}, I1{}); pslice(I3{}, I2{});
+      pslice(I4{}, I0{}); pslice(I4{}, I1{}); pslice(I4{}, I2{});
+      pslice(I5{}, I0{}); pslice(I5{}, I1{}); pslice(I5{}, I2{});
+      residual_update(bp_l, p.ls1);
+      // the LayerNorm below reads back the rows this wave has just written (its own stores, the CU's own L1: coherent once complete)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
     // ---- A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7); rows past M are clamped ----
     bf16x8_t xf[KD / 16];
     if constexpr (LNF) {
@@ -264,7 +364,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
     }
     if constexpr (TIMING) tm[0] += now() - c_p0;
-    f32x16_t out[12];
 #pragma unroll
     for (int t = 0; t < 12; ++t)
 #pragma unroll
@@ -298,7 +397,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) step(i);
         shape8();
-        open_next(Qc, j, jn);
+        open_next([&](int slot) {   // position Q + 4: of this tile, of the next tile, or (PROJ, last tile) a Wp slice of the next row block
+          if constexpr (Q < 2) issue_mlp(std::integral_constant<int, Q + 4>{}, slot, j);
+          else if (PROJ && j + 1 == NTL) issue(K0{}, slot, (Q - 2) / 3, (Q - 2) % 3);
+          else issue_mlp(std::integral_constant<int, Q - 2>{}, slot, jn);
+        });
 #pragma unroll
         for (int i = 8; i < 16; ++i) step(i);
         shape8();
@@ -331,48 +434,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       if constexpr (TIMING) { tm[1] += c1 - c0; tm[2] += c2 - c1; tm[3] += now() - c2; }
     }
     const long long c_e0 = now();
-
-    // ---- epilogue: x[rows of this wave][384] += out + b2, 128 columns at a time through the wave's LDS image ----
-    // (the staging area does not overlap the ring: the W stream of the next row block keeps flowing meanwhile).  The residual
-    // rows are fetched one 128-column chunk ahead: a wave alone on its SIMD has nothing else to hide a load behind.
-    u32x4_t xr0[16], xr1[16];
-    auto load_x = [&](int c, u32x4_t (&dst)[16]) {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldx + 128 * c) * 4);
-        dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, cvoff, so, 0);
-      }
-    };
-    load_x(0, xr0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (c == 0) load_x(1, xr1);
-      if (c == 1) load_x(2, xr0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x16_t& a = out[4 * c + tt];
-          const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-          *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
-        }
-      const f32x4_t b4 = *(const f32x4_t*)(b2_l + 128 * c + (lane & 31) * 4);
-      f32x4_t l4 = {1.f, 1.f, 1.f, 1.f};
-      if (p.ls) l4 = *(const f32x4_t*)(p.ls + 128 * c + (lane & 31) * 4);
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldx + 128 * c) * 4);
-        const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
-        const u32x4_t r = (c & 1) ? xr1[it] : xr0[it];
-        u32x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[e]));
-        store_b128_guarded(o, rs_x, cvoff, so);  // rows >= M fall outside num_records: dropped
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    residual_update(b2_l, p.ls);
     if constexpr (TIMING) tm[4] += now() - c_e0;
   }
   if constexpr (TIMING) {
@@ -402,33 +464,58 @@ int mlp_fused_num_cus() {
 // LayerNorm(ln_g, ln_b, ln_eps) to the rows of x itself (once per row block).  WVN_ERR_ARG otherwise.
 long long* g_mlp_fused_dbg = nullptr;   // wvn_debug_mlp_fused_timing (scripts/bench_mlp_fused.py)
 
-int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,
-                         const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
-                         hipStream_t st) {
-  const bool lnf = xn == nullptr;
+static int mlp_fused_launch_impl(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1,
+                                 const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, const bf16_t* attn,
+                                 int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1, hipStream_t st) {
+  const bool lnf = xn == nullptr, proj = attn != nullptr;
   if (!W1 || !W2p || !x || M <= 0 || F <= 0 || (F % HT) != 0 || (ldx % 4) != 0) return WVN_ERR_ARG;
   if (lnf ? (!ln_g || !ln_b) : ((lda % 8) != 0 || ((uintptr_t)xn & 15) != 0)) return WVN_ERR_ARG;
   if ((((uintptr_t)W1 | (uintptr_t)W2p | (uintptr_t)x) & 15) != 0) return WVN_ERR_ARG;
-  const int lds = B1_OFF + F * 4 + 2 * KD * 4;
+  if (proj && (!lnf || !Wp || (lda_attn % 8) != 0 || (((uintptr_t)attn | (uintptr_t)Wp) & 15) != 0)) return WVN_ERR_ARG;
+  const int lds = B1_OFF + F * 4 + 3 * KD * 4;
   if (lds > 160 * 1024) return WVN_ERR_ARG;
-  if ((size_t)M * ldx * 4 >= (1ull << 32) || (size_t)F * KD * 2 >= (1ull << 32)) return WVN_ERR_ARG;
+  if ((size_t)M * ldx * 4 >= (1ull << 32)) return WVN_ERR_ARG;
+  // one buffer descriptor over the weight matrices: they must lie within 4 GB of each other (the backbone packs them per layer)
+  const uintptr_t e1 = (uintptr_t)W1 + (size_t)F * KD * 2, e2 = (uintptr_t)W2p + (size_t)KD * F * 2, ep = proj ? (uintptr_t)Wp + (size_t)KD * KD * 2 : 0;
+  uintptr_t lo = std::min((uintptr_t)W1, (uintptr_t)W2p), hi = std::max(e1, e2);
+  if (proj) { lo = std::min(lo, (uintptr_t)Wp); hi = std::max(hi, ep); }
+  if (hi - lo >= (1ull << 32)) return WVN_ERR_ARG;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   MlpFusedParams p{};
   p.A = xn; p.lda = lda; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.W1 = W1; p.W2 = W2p; p.b1 = b1; p.b2 = b2; p.ls = ls;
   p.X = x; p.ldx = ldx; p.M = M; p.F = F;
+  p.attn = attn; p.lda_attn = lda_attn; p.bp = bp; p.ls1 = ls1;
+  p.wbase = (const bf16_t*)lo; p.off_w1 = (unsigned)((uintptr_t)W1 - lo); p.off_w2 = (unsigned)((uintptr_t)W2p - lo);
+  p.off_wp = proj ? (unsigned)((uintptr_t)Wp - lo) : 0u; p.wbytes = (unsigned)(hi - lo);
   const int nrb = ceil_div(M, BM), ncu = mlp_fused_num_cus();
   const dim3 grid(nrb < ncu ? nrb : ncu);
   p.dbg = g_mlp_fused_dbg;
-  if (lnf && g_mlp_fused_dbg) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
+  if (proj) hipLaunchKernelGGL((mlp_fused_kernel<true, false, true>), grid, dim3(256), lds, st, p);
+  else if (lnf && g_mlp_fused_dbg) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
   else if (lnf) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
+}
+
+int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,
+                         const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
+                         hipStream_t st) {
+  return mlp_fused_launch_impl(xn, lda, ln_g, ln_b, ln_eps, W1, b1, W2p, b2, ls, x, ldx, M, F, nullptr, 0, nullptr, nullptr, nullptr, st);
+}
+
+// The same with the attention output projection of the block in front: x += (attn Wp^T + bp) (* ls1); x += MLP(LayerNorm(x)).
+int wvn_proj_mlp_fused_launch(const bf16_t* attn, int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1, const float* ln_g,
+                              const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1, const bf16_t* W2p, const float* b2,
+                              const float* ls2, float* x, int ldx, int M, int F, hipStream_t st) {
+  if (!attn) return WVN_ERR_ARG;
+  return mlp_fused_launch_impl(nullptr, 0, ln_g, ln_b, ln_eps, W1, b1, W2p, b2, ls2, x, ldx, M, F, attn, lda_attn, Wp, bp, ls1, st);
 }

@@ -43,6 +43,10 @@ int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const flo
 // gemm_proj.hip: x[M,384] += (A[M,384] W[384,384]^T + bias) (* ls): W resident in LDS, one 32-row group per wave at a time
 int wvn_proj_resid_launch(const bf16_t* A, int lda, const bf16_t* W, const float* bias, const float* ls, float* x, int ldx, int M,
                           hipStream_t st);
+// mlp_fused.hip, with the attention output projection of the block in its prologue: x += (attn Wp^T + bp) (* ls1); x += MLP(LN(x))
+int wvn_proj_mlp_fused_launch(const bf16_t* attn, int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1, const float* ln_g,
+                              const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1, const bf16_t* W2p, const float* b2,
+                              const float* ls2, float* x, int ldx, int M, int F, hipStream_t st);
 // qkv_fused.hip: LayerNorm(x) -> q | k | v^T in the layouts of attention_bf16.hip (D = 384, heads = 6), one launch
 int wvn_qkv_fused_launch(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W, const float* bias,
                          bf16_t* q, bf16_t* k, bf16_t* vt, int heads, int npad, int ntok_s, float q_scale, int M, hipStream_t st);

@@ -50,7 +50,8 @@ class DinoInterface:
         max_chunk: int = 16,
         allow_synthetic: bool = False,
         fuse_mlp: Optional[bool] = None,
-        fuse_qkv: Optional[bool] = None,  # None: fused block MLP wherever it applies (bf16, dim 384); False: the un-fused pair
+        fuse_qkv: Optional[bool] = None,
+        fuse_proj: bool = True,  # None: fused block MLP wherever it applies (bf16, dim 384); False: the un-fused pair
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(backbone=backbone, backbone_type=backbone_type, input_size=input_size,
@@ -74,7 +75,7 @@ class DinoInterface:
         self._precision = precision
         self._device = torch.device(device)
         self._model = VitBackbone(sd, c.input_size, c.patch_size, heads, device=self._device, precision=precision,
-                                  max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv)
+                                  max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv, fuse_proj=fuse_proj)
 
     def change_device(self, device):
         """dino_interface.py:61-68: move the model to another device (another GPU: the HIP path has no CPU form)."""

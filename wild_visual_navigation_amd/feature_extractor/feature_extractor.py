@@ -41,7 +41,7 @@ class FeatureExtractor:
                 probe_weights=kwargs.get("probe_weights"), model_path=kwargs.get("model_path"),
                 max_chunk=kwargs.get("max_chunk", 16), flip_tta=kwargs.get("flip_tta", False),
                 cluster_resolution=kwargs.get("cluster_resolution", "patch"),
-                allow_synthetic=kwargs.get("allow_synthetic", False), fuse_mlp=kwargs.get("fuse_mlp"), fuse_qkv=kwargs.get("fuse_qkv"),
+                allow_synthetic=kwargs.get("allow_synthetic", False), fuse_mlp=kwargs.get("fuse_mlp"), fuse_qkv=kwargs.get("fuse_qkv"), fuse_proj=kwargs.get("fuse_proj", True),
             )
         elif "dino" in self._feature_type:
             self._feature_dim = 384  # the reference hard-codes 384 for any dino type (feature_extractor.py:56)
@@ -51,7 +51,7 @@ class FeatureExtractor:
                 backbone_type=kwargs.get("backbone_type", "vit_small"),
                 pretrained_weights=kwargs.get("pretrained_weights"), precision=precision,
                 max_chunk=kwargs.get("max_chunk", 16), allow_synthetic=kwargs.get("allow_synthetic", False),
-                fuse_mlp=kwargs.get("fuse_mlp"), fuse_qkv=kwargs.get("fuse_qkv"),
+                fuse_mlp=kwargs.get("fuse_mlp"), fuse_qkv=kwargs.get("fuse_qkv"), fuse_proj=kwargs.get("fuse_proj", True),
             )
             self._feature_dim = self._extractor.feature_dim
         elif self._feature_type == "none":

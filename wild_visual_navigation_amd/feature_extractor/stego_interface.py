@@ -110,6 +110,7 @@ class StegoInterface:
         allow_synthetic: bool = False,
         fuse_mlp: Optional[bool] = None,
         fuse_qkv: Optional[bool] = None,
+        fuse_proj: bool = True,
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(model_path=model_path, input_size=input_size, run_crf=run_crf,
@@ -145,7 +146,7 @@ class StegoInterface:
                               "(shapes and speed are real, the segmentation is meaningless); pass model_path=... or "
                               "allow_synthetic=True to silence", stacklevel=2)
         self._bb = VitBackbone(sd, self._cfg.input_size, patch_size, heads, device=self._device, precision=precision,
-                               max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv)
+                               max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv, fuse_proj=fuse_proj)
         self._precision = precision
         self._flip_tta = flip_tta
         self._cluster_resolution = cluster_resolution

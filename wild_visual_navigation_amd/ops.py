@@ -378,6 +378,18 @@ def qkv_fused(x: torch.Tensor, ln: Tuple[torch.Tensor, torch.Tensor, float], w: 
     return q, k, vt
 
 
+def proj_mlp_fused(attn: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tensor], ln: Tuple[torch.Tensor, torch.Tensor, float], w1: torch.Tensor,
+                   b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor], x: torch.Tensor,
+                   ls1: Optional[torch.Tensor] = None, ls2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x += (attn @ wp^T + bp) (* ls1); x += MLP(LayerNorm(x)) in ONE launch, in place (csrc/mlp_fused.hip with the projection in its
+    prologue).  ``wp``, ``w1``, ``w2p`` must be views of one allocation (within 4 GB of each other)."""
+    M, F = x.shape[0], w1.shape[0]
+    g, b, eps = ln
+    check(lib().wvn_proj_mlp_fused(ptr(attn), attn.stride(0), ptr(wp), ptr(bp), ptr(ls1), ptr(g), ptr(b), float(eps), ptr(w1), ptr(b1),
+                                   ptr(w2p), ptr(b2), ptr(ls2), ptr(x), x.stride(0), M, F, stream()), "wvn_proj_mlp_fused")
+    return x
+
+
 def mlp_fused(xn: Optional[torch.Tensor], w1: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor],
               x: torch.Tensor, ls: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
     """x [M,384] fp32 += gelu(xn [M,384] bf16 @ w1[F,384]^T + b1) @ w2^T + b2 in ONE launch, in place.  ``w2p`` is fc2.weight
