@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
     const int m0w = rb * BM + wave * 32;
     const long long c_p0 = now();
     f32x16_t out[12];
-    auto residual_update = [&](const float* bias_tab, const float* ls_vec) {
+    f32x4_t xq[KD / 8];   // the wave's rows in the fragment layout (lane = row l31, columns 16 k + 8 hi .. + 7), fp32: LayerNorm input
+    // keep_tag: also hand the updated rows over in xq (the LayerNorm that follows then needs no memory at all)
+    auto residual_update = [&](const float* bias_tab, const float* ls_vec, auto keep_tag) {
+      constexpr bool KEEP = decltype(keep_tag)::value;
       // ---- residual update: x[rows of this wave][384] += (out + bias) (* ls), 128 columns at a time through the wave's LDS image ----
       // (the staging area does not overlap the ring: the W stream of the next row block keeps flowing meanwhile).  The residual
       // rows are fetched one 128-column chunk ahead: a wave alone on its SIMD has nothing else to hide a load behind.
@@ -253,6 +256,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[e]));
           store_b128_guarded(o, rs_x, cvoff, so);  // rows >= M fall outside num_records: dropped
+          if constexpr (KEEP) {   // back into the image, in place (row layout): the new rows
+            f32x4_t of;
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) of[e] = __uint_as_float(o[e]);
+            *(f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4) = of;
+          }
+        }
+        if constexpr (KEEP) {     // ... and out again in the fragment layout: 8 k-steps of this 128-column chunk
+  #pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            xq[2 * (8 * c + kk)] = *(const f32x4_t*)(stg + l31 * STG_PITCH + 16 * kk + 8 * hi);
+            xq[2 * (8 * c + kk) + 1] = *(const f32x4_t*)(stg + l31 * STG_PITCH + 16 * kk + 8 * hi + 4);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -297,9 +313,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       pslice(I3{}, I0{}); pslice(I3{}, I1{}); pslice(I3{}, I2{});
       pslice(I4{}, I0{}); pslice(I4{}, I1{}); pslice(I4{}, I2{});
       pslice(I5{}, I0{}); pslice(I5{}, I1{}); pslice(I5{}, I2{});
-      residual_update(bp_l, p.ls1);
-      // the LayerNorm below reads back the rows this wave has just written (its own stores, the CU's own L1: coherent once complete)
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      residual_update(bp_l, p.ls1, std::true_type{});   // ... and the updated rows stay in registers for the LayerNorm below
     }
     // ---- A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7); rows past M are clamped ----
     bf16x8_t xf[KD / 16];
@@ -309,8 +323,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       // The rows come in coalesced (an instruction = 4 rows x 256 contiguous bytes = 8 whole lines; the fragment layout would
       // touch 32 lines for the same 1 KB, and the L1 takes lines, not bytes) and reach the fragment layout through the wave's LDS
       // image, 64 columns at a time.
-      f32x4_t xq[KD / 8];
-      {
+      if constexpr (!PROJ) {
         const int lr = lane >> 4, lc = (lane & 15) * 4;            // loader: row 4 i + lr, columns lc .. lc + 3 of the chunk
         f32x4_t buf[2][8];
         auto load_chunk = [&](int c, f32x4_t (&b)[8]) {
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       if constexpr (TIMING) { tm[1] += c1 - c0; tm[2] += c2 - c1; tm[3] += now() - c2; }
     }
     const long long c_e0 = now();
-    residual_update(b2_l, p.ls);
+    residual_update(b2_l, p.ls, std::false_type{});
     if constexpr (TIMING) tm[4] += now() - c_e0;
   }
   if constexpr (TIMING) {
