@@ -118,8 +118,7 @@ int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b,
                   void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream);
 /* Attention projection + block MLP in one launch: x += (attn [M,lda] bf16 * Wp[384,384]^T + bp) (* ls1), then the block MLP of
  * wvn_mlp_fused with the LayerNorm inside on the updated rows.  What wvn_vit_forward uses where WVN_VIT_MLP_FUSED applies: the
- * projection's separate pass over the residual stream disappears (the rows are re-read from the L2 they were just written to).
- * Wp, W1 and W2p must lie within 4 GB of each other (one buffer descriptor). */
+ * projection's separate pass over the residual stream disappears (the updated rows stay in registers for the LayerNorm). */
 int wvn_proj_mlp_fused(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
                        const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
                        const float* ls2, float* x, int ldx, int M, int F, void* stream);

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_mlp_fused.py -x -q 2>&1 | tail -3
-for o in "" "--no-fuse-proj" ""; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $o 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$o', d['value'], d['step_ms']['median'], {k:round(v['ms_total']/10,2) for k,v in d['kernel_ms'].items()})"; done
+for i in 1 2; do
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 > gpurun_out/suite_$i.log; grep -E "^FAILED|passed|failed" gpurun_out/suite_$i.log | cut -c1-300
+done
+timeout 300 python bench.py 2>&1 | tail -1 > gpurun_out/bench_r02o.json; cut -c1-160 gpurun_out/bench_r02o.json

@@ -95,7 +95,7 @@ def test_projection_in_the_prologue(dev, M, scaled):
     ls1 = (torch.rand(384, generator=g(14)) + 0.5).to(dev) if scaled else None
     ls2 = (torch.rand(384, generator=g(15)) + 0.5).to(dev) if scaled else None
     w2p = w2[:, ops.vt_token_order(Fh, device=dev)]
-    pack = torch.cat([wp.reshape(-1), w1.reshape(-1), w2p.reshape(-1)]).contiguous()   # one allocation: one buffer descriptor
+    pack = torch.cat([wp.reshape(-1), w1.reshape(-1), w2p.reshape(-1)]).contiguous()   # (as the backbone packs a layer)
     n0, n1 = wp.numel(), w1.numel()
     wp_v, w1_v, w2p_v = pack[:n0].view(384, 384), pack[n0:n0 + n1].view(Fh, 384), pack[n0 + n1:].view(384, Fh)
     # reference: the two kernels

@@ -179,8 +179,8 @@ class VitBackbone:
                 w2 = sd[p + "mlp.fc2.weight"]
                 L.fc2_w = mat(w2)
                 if self.fuse_mlp:
-                    # the fused kernel addresses proj.weight, fc1.weight and its own copy of fc2.weight (hidden index in the order the
-                    # fc1 accumulators hand it over, wvn_hip.h) through ONE buffer descriptor: one allocation per layer
+                    # proj.weight, fc1.weight and the fused kernel's own copy of fc2.weight (hidden index in the order the fc1
+                    # accumulators hand it over, wvn_hip.h), one allocation per layer
                     k = torch.arange(self.mlp_dim)
                     parts = [sd[p + "attn.proj.weight"], sd[p + "mlp.fc1.weight"], w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)]]
                     pack = torch.cat([t.detach().float().reshape(-1) for t in parts]).to(self.device).to(torch.bfloat16).contiguous()

@@ -292,7 +292,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
                                                (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b, L.ls2, w.x, d.D, M,
                                                d.F, st);
       if (rc == WVN_OK) continue;
-      if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: the three weight matrices are not within 4 GB of each other -- separate kernels)
+      if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
     { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
     if (!mlp_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }

@@ -71,7 +71,7 @@ struct MlpFusedParams {
   const bf16_t* attn; int lda_attn;   // attention output rows [M][384] bf16
   const float* bp;               // [384]
   const float* ls1;              // optional LayerScale of the attention branch
-  const bf16_t* wbase; unsigned off_wp, off_w1, off_w2, wbytes;   // one buffer descriptor over Wp [384][384] / W1 / W2 (byte offsets)
+  const bf16_t* Wp;              // [384][384]
   long long* dbg;   // TIMING: per wave {prologue (rows / LayerNorm), fc1 slices, GELU + pack, fc2 slices, epilogue, total} in shader cycles
 };
 
@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   if constexpr (PROJ)
     for (int i = tid; i < KD; i += 256) bp_l[i] = p.bp ? p.bp[i] : 0.f;
 
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wbase, 0, p.wbytes, 0x00020000);   // Wp | W1 | W2
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, (unsigned)((size_t)p.F * KD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, (unsigned)((size_t)KD * p.F * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc((void*)(PROJ ? p.Wp : p.W1), 0, (unsigned)(KD * KD * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((size_t)p.M * p.ldx * 4), 0x00020000);
   // ---- DMA lane offsets: 16 wave-instructions of 1 KB per slice, 4 per wave ------------------------------------------------
   // W1 / Wp slice [64 rows][128 k]: LDS rows of 256 B, instruction = 4 rows; chunk XOR (row & 15)    (gemm_a384.hip)
@@ -125,18 +127,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   }
   // Slice stream in consumption order, the DMA running four slices ahead of the MFMAs.  Per row block: (PROJ) 18 slices of Wp,
   // column pair cp x k-slice ks; then per hidden tile j positions 0, 1, 2 = W1 k-slices and 3, 4, 5 = W2 n-thirds.  The KIND of
-  // every slice is static at its issue site (0 Wp, 1 W1, 2 W2): one descriptor, a scalar offset, one of two lane-offset sets.
+  // every slice is static at its issue site (0 Wp, 1 W1, 2 W2): its own descriptor, a scalar offset, one of two lane-offset sets.
   auto issue = [&](auto Kc, int slot, int a, int b) {
     constexpr int K = decltype(Kc)::value;
     unsigned char* dst = smem + slot * SLICE + wave * 4096;
-    unsigned soff;
-    if constexpr (K == 0) soff = p.off_wp + (unsigned)((a * HT * KD + b * 128) * 2);
-    else if constexpr (K == 1) soff = p.off_w1 + (unsigned)((a * HT * KD + b * 128) * 2);
-    else soff = p.off_w2 + (unsigned)(((b * 128) * p.F + a * HT) * 2);
-    soff = __builtin_amdgcn_readfirstlane(soff);
+    const unsigned soff = __builtin_amdgcn_readfirstlane(K == 2 ? (unsigned)(((b * 128) * p.F + a * HT) * 2) : (unsigned)((a * HT * KD + b * 128) * 2));
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, K == 2 ? w2off[u] : w1off[u], soff, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      if constexpr (K == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wp, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, w1off[u], soff, 0, 0);
+      else if constexpr (K == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, w1off[u], soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, w2off[u], soff, 0, 0);
+    }
   };
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
   // slice at position T (0..5) of hidden tile jj
@@ -488,11 +489,7 @@ static int mlp_fused_launch_impl(const bf16_t* xn, int lda, const float* ln_g, c
   const int lds = B1_OFF + F * 4 + 3 * KD * 4;
   if (lds > 160 * 1024) return WVN_ERR_ARG;
   if ((size_t)M * ldx * 4 >= (1ull << 32)) return WVN_ERR_ARG;
-  // one buffer descriptor over the weight matrices: they must lie within 4 GB of each other (the backbone packs them per layer)
-  const uintptr_t e1 = (uintptr_t)W1 + (size_t)F * KD * 2, e2 = (uintptr_t)W2p + (size_t)KD * F * 2, ep = proj ? (uintptr_t)Wp + (size_t)KD * KD * 2 : 0;
-  uintptr_t lo = std::min((uintptr_t)W1, (uintptr_t)W2p), hi = std::max(e1, e2);
-  if (proj) { lo = std::min(lo, (uintptr_t)Wp); hi = std::max(hi, ep); }
-  if (hi - lo >= (1ull << 32)) return WVN_ERR_ARG;
+  if ((size_t)F * KD * 2 >= (1ull << 32)) return WVN_ERR_ARG;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -506,8 +503,7 @@ static int mlp_fused_launch_impl(const bf16_t* xn, int lda, const float* ln_g, c
   p.A = xn; p.lda = lda; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.W1 = W1; p.W2 = W2p; p.b1 = b1; p.b2 = b2; p.ls = ls;
   p.X = x; p.ldx = ldx; p.M = M; p.F = F;
   p.attn = attn; p.lda_attn = lda_attn; p.bp = bp; p.ls1 = ls1;
-  p.wbase = (const bf16_t*)lo; p.off_w1 = (unsigned)((uintptr_t)W1 - lo); p.off_w2 = (unsigned)((uintptr_t)W2p - lo);
-  p.off_wp = proj ? (unsigned)((uintptr_t)Wp - lo) : 0u; p.wbytes = (unsigned)(hi - lo);
+  p.Wp = Wp;
   const int nrb = ceil_div(M, BM), ncu = mlp_fused_num_cus();
   const dim3 grid(nrb < ncu ? nrb : ncu);
   p.dbg = g_mlp_fused_dbg;

@@ -382,7 +382,7 @@ def proj_mlp_fused(attn: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tens
                    b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor], x: torch.Tensor,
                    ls1: Optional[torch.Tensor] = None, ls2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x += (attn @ wp^T + bp) (* ls1); x += MLP(LayerNorm(x)) in ONE launch, in place (csrc/mlp_fused.hip with the projection in its
-    prologue).  ``wp``, ``w1``, ``w2p`` must be views of one allocation (within 4 GB of each other)."""
+    prologue)."""
     M, F = x.shape[0], w1.shape[0]
     g, b, eps = ln
     check(lib().wvn_proj_mlp_fused(ptr(attn), attn.stride(0), ptr(wp), ptr(bp), ptr(ls1), ptr(g), ptr(b), float(eps), ptr(w1), ptr(b1),
