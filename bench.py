@@ -440,6 +440,11 @@ def main():
             "config": {"workload": workload, "frames_per_gpu_per_step": B, "backbone_chunk": chunk, "input_pool": len(pool),
                        "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP statistics + gradients)",
                        "ranks_seen": ranks_seen,
+                       "block_kernels": ("separate LayerNorm / GEMM kernels" if args.precision != "bf16" or args.mode == "dinov2" else
+                                         "LayerNorm+QKV: %s; proj+LayerNorm+MLP: %s (kernel_ms: a fused kernel is booked under its first stage, "
+                                         "qkv_gemm / fc1_gemm)" % ("separate" if args.no_fuse_qkv else "one kernel",
+                                                                     "separate" if args.no_fuse_mlp else
+                                                                     ("MLP fused, projection separate" if args.no_fuse_proj else "one kernel"))),
                        "schedule": "one stream" if pipe is None else
                                    "two HIP streams: backbone of step i+1 overlaps clustering / pooling / MLP step of step i"},
             "step_ms": percentiles(step_ms),

@@ -1,5 +1,6 @@
+# scratch job file for /usr/local/graft/bin/gpurun -- 'bash scripts/_gpurun_job.sh' (rewritten per experiment); this is the
+# standard end-of-change verification: the GPU test suite, the smoke entry and one default bench line
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 > gpurun_out/suite_$i.log; grep -E "^FAILED|passed|failed" gpurun_out/suite_$i.log | cut -c1-300
-done
-timeout 300 python bench.py 2>&1 | tail -1 > gpurun_out/bench_r02o.json; cut -c1-160 gpurun_out/bench_r02o.json
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+timeout 300 python bench.py 2>&1 | tail -1 | cut -c1-300
