@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--chunk", type=int, default=64, help="frames pushed through the backbone per launch sequence")
     ap.add_argument("--segmentation", default="stego", choices=["stego", "grid"])
+    ap.add_argument("--stego-reading", default="patch", choices=["patch", "upstream"],
+                    help="the external STEGO package is absent (parity unpinned): 'patch' = single pass, k-means over the patch codes "
+                         "(default, stated in config.workload); 'upstream' = the other reading: code averaged with the mirrored "
+                         "frame's (flip TTA, two backbone passes) and k-means over the H x H up-sampled code pixels")
     ap.add_argument("--pool", type=int, default=4, help="distinct input batches cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attn-variant", type=int, default=None, help="A/B: 0 exact per-tile row max, 1 lazy (alarm on the row sums)")
@@ -133,7 +137,9 @@ def make_pipeline(args, dev):
         fe = FeatureExtractor(dev, segmentation_type=seg, feature_type=ftype, input_size=args.size,
                               backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
                               max_chunk=args.chunk, allow_synthetic=True, fuse_mlp=False if args.no_fuse_mlp else None,
-                              fuse_qkv=False if args.no_fuse_qkv else None, fuse_proj=not args.no_fuse_proj)
+                              fuse_qkv=False if args.no_fuse_qkv else None, fuse_proj=not args.no_fuse_proj,
+                              flip_tta=args.stego_reading == "upstream",
+                              cluster_resolution="pixel" if args.stego_reading == "upstream" else "patch")
     if args.attn_variant is not None:
         from wild_visual_navigation_amd import _lib
         _lib.lib().wvn_debug_attention_variant(args.attn_variant)
@@ -419,9 +425,13 @@ def main():
             workload = f"BASELINE configs[1]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU, feature extraction only"
         else:
             metric = "frames/sec (448x448 DINO-ViT-S/8 + seg + MLP train-step)"
-            segdesc = ("STEGO head + per-image cosine k-means (20 clusters, at patch resolution, single pass: no flip TTA)"
-                       if args.segmentation == "stego" else "grid segmentation (32-pixel cells)")
-            workload = (f"BASELINE configs[2]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU + {segdesc} + fused segment "
+            segdesc = ("grid segmentation (32-pixel cells)" if args.segmentation != "stego" else
+                       "STEGO head + per-image cosine k-means (20 clusters, at patch resolution, single pass: no flip TTA)"
+                       if args.stego_reading == "patch" else
+                       "STEGO head with flip TTA (two backbone passes per frame) + per-image cosine k-means over the 448x448 "
+                       "up-sampled code pixels (20 clusters)")
+            workload = (f"BASELINE configs[2]: DINO ViT-S/8 {args.size}x{args.size} batch={B}/GPU + {segdesc} + "
+                        f"{'fused' if args.stego_reading == 'patch' or args.segmentation != 'stego' else 'general (bilinear-weight)'} segment "
                         f"pooling + 1 traversability-MLP Adam step on {rows} rows/GPU")
         out = {
             "metric": metric,
