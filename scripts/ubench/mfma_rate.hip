@@ -36,10 +36,10 @@ __global__ __launch_bounds__(256 * WAVES_PER_SIMD, 1) void k(const bf16x8_t* in,
 
 // FILL: 1 = one s_nop after every MFMA, 2 = the fused-MLP pattern: every MFMA's A operand comes from a ds_read_b128 issued 4 MFMAs
 // earlier (ring of 4 fragments), 3 = same + 4 VALU ops per MFMA
-template <int NCHAIN, int FILL>
-__global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, long long* cyc, int iters) {
+template <int NCHAIN, int FILL, int W = 1>   // W = waves per SIMD (256 * W threads per workgroup, one workgroup per CU)
+__global__ __launch_bounds__(256 * W, 1) void kf(const bf16x8_t* in, float* out, long long* cyc, int iters) {
   __shared__ bf16x8_t lds[64 * 32];
-  for (int i = threadIdx.x; i < 64 * 32; i += 256) lds[i] = in[i];
+  for (int i = threadIdx.x; i < 64 * 32; i += 256 * W) lds[i] = in[i];
   bf16x8_t b = in[threadIdx.x & 63];
   f32x16_t acc[NCHAIN];
   float v[4] = {1.f, 2.f, 3.f, 4.f};
@@ -160,26 +160,27 @@ __global__ __launch_bounds__(256, 1) void kf(const bf16x8_t* in, float* out, lon
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += acc[c][r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 * W + threadIdx.x / 64] = t1 - t0;
 }
 
-template <int NCHAIN, int FILL>
+template <int NCHAIN, int FILL, int W = 1>
 void runf(int grid, const bf16x8_t* in, float* out, long long* cyc, const char* tag) {
   const int iters = 2000;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((kf<NCHAIN, FILL>), dim3(grid), dim3(256), 0, 0, in, out, cyc, iters);
+  hipLaunchKernelGGL((kf<NCHAIN, FILL, W>), dim3(grid), dim3(256 * W), 0, 0, in, out, cyc, iters);
   (void)hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((kf<NCHAIN, FILL>), dim3(grid), dim3(256), 0, 0, in, out, cyc, iters);
+  hipLaunchKernelGGL((kf<NCHAIN, FILL, W>), dim3(grid), dim3(256 * W), 0, 0, in, out, cyc, iters);
   (void)hipEventRecord(e1, 0);
   (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-  std::vector<long long> h(grid * 4);
+  std::vector<long long> h(grid * 4 * W);
   (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
   double mean = 0; for (auto v : h) mean += v; mean /= h.size();
   const double n = (double)iters * 32;
-  printf("%-36s grid %4d: %.1f ticks/MFMA/wave, wall %.3f ms -> %.2f ns/MFMA/wave, %.0f TFLOP/s\n", tag, grid, mean / n, ms, ms * 1e6 / n,
-         n * grid * 4 * 32768.0 / (ms * 1e-3) / 1e12);
+  // W waves share a SIMD: ticks per MFMA per SIMD = ticks per MFMA per wave / W
+  printf("%-36s grid %4d W %d: %.1f ticks/MFMA/SIMD, wall %.3f ms -> %.2f ns/MFMA/SIMD, %.0f TFLOP/s\n", tag, grid, W, mean / n / W, ms,
+         ms * 1e6 / n / W, n * grid * 4 * W * 32768.0 / (ms * 1e-3) / 1e12);
 }
 
 template <int NCHAIN, int W>
@@ -203,7 +204,7 @@ void run(int grid, const bf16x8_t* in, float* out, long long* cyc, const char* t
 
 int main() {
   bf16x8_t* in; float* out; long long* cyc;
-  (void)hipMalloc(&in, 64 * 64 * sizeof(bf16x8_t)); (void)hipMalloc(&out, 1024 * 512 * 4); (void)hipMalloc(&cyc, 1024 * 8 * 8);
+  (void)hipMalloc(&in, 64 * 64 * sizeof(bf16x8_t)); (void)hipMalloc(&out, 1024 * 1024 * 4); (void)hipMalloc(&cyc, 1024 * 16 * 8);
   std::vector<unsigned short> h(64 * 64 * 8);
   for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 2654435761u) >> 20 & 0x3ff);  // random-ish bf16 near 1
   hipMemcpy(in, h.data(), h.size() * 2, hipMemcpyHostToDevice);
@@ -230,6 +231,15 @@ int main() {
     runf<4, 13>(grid, in, out, cyc, "2 exp + cvt_pk + 1 v_add_f32");
     runf<4, 8>(grid, in, out, cyc, "1 exp + 1 poly exp2, cvt, dot2c");
     runf<4, 9>(grid, in, out, cyc, "1.5 exp + 0.5 poly exp2, cvt, dot2c");
+    // the same mixes with two (three) waves per SIMD: does a second wave's MFMA fill the first one's VALU / transcendental time?
+    runf<4, 2, 2>(grid, in, out, cyc, "4 chains + ds_read ring");
+    runf<4, 6, 2>(grid, in, out, cyc, "4 chains + ds_read + 2 exp2");
+    runf<4, 5, 2>(grid, in, out, cyc, "4 chains + ds_read + attn mix (5)");
+    runf<4, 7, 2>(grid, in, out, cyc, "lazy attn mix: 2 exp, cvt, dot2c");
+    runf<4, 12, 2>(grid, in, out, cyc, "2 exp + cvt_pk + 2 v_add_f32");
+    runf<4, 4, 2>(grid, in, out, cyc, "4 chains + ds_read + 4 exp2");
+    runf<2, 7, 3>(grid, in, out, cyc, "lazy attn mix, 2 chains");
+    runf<2, 7, 4>(grid, in, out, cyc, "lazy attn mix, 2 chains");
     run<1, 1>(grid, in, out, cyc, "1 chain, 1 wave/SIMD");
     run<2, 1>(grid, in, out, cyc, "2 chains, 1 wave/SIMD");
     run<4, 1>(grid, in, out, cyc, "4 chains, 1 wave/SIMD");
