@@ -14,6 +14,7 @@
    device copy ordered by an event, no file, no host sync."""
 import os
 import tempfile
+import threading
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -143,31 +144,38 @@ class DeviceWeightsHandoff:
         self.version = 0
         self._seen = 0
         self._ready: Optional[torch.cuda.Event] = None
+        self._read_done = [None, None]     # per slot: event after the consumer's last copy out of it
+        self._lock = threading.Lock()      # version / events change together (publisher and consumer may be different threads)
 
     def publish(self, model, confidence_generator) -> int:
-        back = (self.version + 1) & 1
-        n = self.slots.shape[1] - 3
-        with torch.no_grad():
-            self.slots[back, :n].copy_(model.flat_params())
-            self.slots[back, n:n + 1].copy_(confidence_generator.mean.reshape(-1))
-            self.slots[back, n + 1:n + 2].copy_(confidence_generator.var.reshape(-1))
-            self.slots[back, n + 2:n + 3].copy_(confidence_generator.std.reshape(-1))
-        ev = torch.cuda.Event()
-        ev.record()
-        self._ready = ev
-        self.version += 1
-        return self.version
+        with self._lock:   # held while the copies are ENQUEUED (microseconds): slot choice, events and version move together
+            back = (self.version + 1) & 1
+            if self._read_done[back] is not None:   # a consumer copy out of this slot may still be in flight on another stream
+                torch.cuda.current_stream().wait_event(self._read_done[back])
+            n = self.slots.shape[1] - 3
+            with torch.no_grad():
+                self.slots[back, :n].copy_(model.flat_params())
+                self.slots[back, n:n + 1].copy_(confidence_generator.mean.reshape(-1))
+                self.slots[back, n + 1:n + 2].copy_(confidence_generator.var.reshape(-1))
+                self.slots[back, n + 2:n + 3].copy_(confidence_generator.std.reshape(-1))
+            self._ready = torch.cuda.Event()
+            self._ready.record()
+            self.version += 1
+            return self.version
 
     def consume(self, model, confidence_generator) -> bool:
-        if self.version == self._seen or self._ready is None:
-            return False
-        torch.cuda.current_stream().wait_event(self._ready)
-        front = self.version & 1
-        n = self.slots.shape[1] - 3
-        with torch.no_grad():
-            model.flat_params().copy_(self.slots[front, :n])
-            confidence_generator.mean.copy_(self.slots[front, n:n + 1])
-            confidence_generator.var.copy_(self.slots[front, n + 1:n + 2].reshape(1, 1))
-            confidence_generator.std.copy_(self.slots[front, n + 2:n + 3])
-        self._seen = self.version
-        return True
+        with self._lock:
+            if self.version == self._seen or self._ready is None:
+                return False
+            torch.cuda.current_stream().wait_event(self._ready)
+            front = self.version & 1
+            n = self.slots.shape[1] - 3
+            with torch.no_grad():
+                model.flat_params().copy_(self.slots[front, :n])
+                confidence_generator.mean.copy_(self.slots[front, n:n + 1])
+                confidence_generator.var.copy_(self.slots[front, n + 1:n + 2].reshape(1, 1))
+                confidence_generator.std.copy_(self.slots[front, n + 2:n + 3])
+            self._read_done[front] = torch.cuda.Event()
+            self._read_done[front].record()
+            self._seen = self.version
+            return True

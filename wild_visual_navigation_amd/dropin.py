@@ -33,6 +33,19 @@ UTILS_HOT = ("Data", "Batch", "ConfidenceGenerator", "TraversabilityLoss", "Anom
              "make_dense_plane", "make_polygon_from_points")
 
 
+def _alias_submodules(pkg_mod, alias: str) -> None:
+    """Register every sub-module of ``pkg_mod`` under the reference's dotted name too (``wild_visual_navigation.
+    traversability_estimator.nodes`` -> the module object of ``wild_visual_navigation_amd.traversability_estimator.nodes``).
+    Without this, ``from wild_visual_navigation.traversability_estimator.nodes import TwistNode`` (supervision_generator.py:8)
+    would find nodes.py through the package's search path and execute it a SECOND time under the alias name -- different class
+    objects, and its relative imports would resolve against the wrong parent."""
+    import pkgutil
+
+    for info in pkgutil.walk_packages(pkg_mod.__path__, prefix=pkg_mod.__name__ + "."):
+        sub = importlib.import_module(info.name)
+        sys.modules[alias + info.name[len(pkg_mod.__name__):]] = sub
+
+
 def install(force_synthetic: bool = False) -> str:
     """Returns "overlay" (reference present, hot-path modules replaced) or "synthetic" (stand-alone alias package)."""
     import wild_visual_navigation_amd as amd
@@ -59,14 +72,17 @@ def install(force_synthetic: bool = False) -> str:
         for name, m in mods.items():
             sys.modules[f"wild_visual_navigation.{name}"] = m
             setattr(pkg, name, m)
+            _alias_submodules(m, f"wild_visual_navigation.{name}")
         sys.modules["wild_visual_navigation.utils"] = amd_utils
         pkg.utils = amd_utils
+        _alias_submodules(amd_utils, "wild_visual_navigation.utils")
         return "synthetic"
     for name, m in mods.items():
         if name == "cfg":
             continue   # the reference's own config tree (OmegaConf dataclasses) works as is: the estimator reads it by key
         sys.modules[f"wild_visual_navigation.{name}"] = m
         setattr(ref, name, m)
+        _alias_submodules(m, f"wild_visual_navigation.{name}")
     ref_utils = importlib.import_module("wild_visual_navigation.utils")
     for n in UTILS_HOT:
         setattr(ref_utils, n, getattr(amd_utils, n))

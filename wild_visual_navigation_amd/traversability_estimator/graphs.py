@@ -212,3 +212,55 @@ class DistanceWindowGraph(BaseGraph):
 
 
 MissionGraph = BaseGraph  # round-1 name of the mission-node store
+
+
+def _chain(graph, n: int):
+    """n BaseNodes, one per second, 0.1 m apart along x, added in order."""
+    import torch
+
+    from .nodes import BaseNode
+
+    nodes = []
+    for i in range(n):
+        T = torch.eye(4)
+        T[0, 3] = i / 10.0
+        nodes.append(BaseNode(timestamp=i, pose_base_in_world=T))
+        graph.add_node(nodes[-1])
+    return nodes
+
+
+def run_base_graph():
+    """The reference's graph self-check (graphs.py:318-369, called by its tests/test_traversability_estimator.py): ten chained
+    states; node list, counts, radius query, time-span queries (open / closed), removal, mutability of the stored nodes."""
+    graph = BaseGraph()
+    nodes = _chain(graph, 10)
+    assert nodes == graph.get_nodes()
+    assert graph.get_num_nodes() == 10 and graph.get_num_edges() == 9
+    query = graph.get_node_with_timestamp(5.0)
+    for n in graph.get_nodes_within_radius_range(query, min_radius=0, max_radius=0.2):
+        assert float(query.distance_to(n)) <= 0.2 + 1e-6
+    assert len(graph.get_nodes_within_timespan(0.0, 3.0, open_interval=True)) == 2
+    closed = graph.get_nodes_within_timespan(0.0, 3.0, open_interval=False)
+    assert len(closed) == 4
+    graph.remove_nodes(closed)
+    assert graph.get_num_nodes() == 6
+    for n in graph.get_nodes():
+        before = n.timestamp
+        n.timestamp = 2
+        assert before != n.timestamp
+
+
+def run_temporal_window_graph():
+    """graphs.py:372-392: fifty states into a 25-second window; the oldest STORED state is never older than the window.  (The
+    reference's version asserts this on ``get_first_node()``, which it sets on the first insertion only and never moves -- that
+    function is not called by the reference's tests and fails as written; the stored-node form is what the class guarantees.)"""
+    import torch
+
+    from .nodes import BaseNode
+
+    graph = TemporalWindowGraph(edge_distance=0.0, time_window=25)
+    for i in range(50):
+        T = torch.eye(4)
+        T[0, 3] = i / 10.0
+        graph.add_node(BaseNode(timestamp=i, pose_base_in_world=T))
+        assert graph.get_nodes()[0].timestamp >= i - 25

@@ -240,3 +240,42 @@ class SupervisionNode(BaseNode):
 
     def is_valid(self):
         return isinstance(self._supervision_state, torch.Tensor)
+
+
+class TwistNode(BaseNode):
+    """nodes.py:620-664: a pose with the desired and the measured twist (used by the reference's supervision generator, which
+    keeps importing it from this module when only the hot-path packages are overlaid -- dropin.py)."""
+
+    _name = "twist_node"
+
+    def __init__(self, timestamp: float = 0.0, pose_base_in_world: torch.Tensor = torch.eye(4),
+                 desired_twist: torch.Tensor = torch.zeros(6), current_twist: torch.Tensor = torch.zeros(6)):
+        assert isinstance(pose_base_in_world, torch.Tensor) and isinstance(desired_twist, torch.Tensor) \
+            and isinstance(current_twist, torch.Tensor)
+        super().__init__(timestamp=timestamp, pose_base_in_world=pose_base_in_world)
+        self._desired_twist = desired_twist
+        self._current_twist = current_twist
+
+    def change_device(self, device):
+        super().change_device(device)
+        self._desired_twist = self._desired_twist.to(device)
+        self._current_twist = self._current_twist.to(device)
+
+    desired_twist = property(lambda s: s._desired_twist, lambda s, v: setattr(s, "_desired_twist", v))
+    current_twist = property(lambda s: s._current_twist, lambda s, v: setattr(s, "_current_twist", v))
+
+
+def _translated(x: float) -> torch.Tensor:
+    T = torch.eye(4)
+    T[0, 3] = x
+    return T
+
+
+def run_base_state():
+    """The reference's self-check of the node algebra (nodes.py:667-686, called by its tests/test_traversability_estimator.py):
+    two states one metre and one second apart."""
+    a, b = BaseNode(1, pose_base_in_world=_translated(1.0)), BaseNode(2, pose_base_in_world=_translated(2.0))
+    assert abs(float(b.distance_to(a)) - 1.0) < 1e-6
+    assert a != b
+    assert b.timestamp - a.timestamp == 1.0
+    assert BaseNode.from_node(a) == a

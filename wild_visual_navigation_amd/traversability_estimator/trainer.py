@@ -38,8 +38,11 @@ class MlpTrainer:
         if self._state_dev != dev:
             n = self.model.flat_params().numel()
             self.grads = torch.zeros(n + 2, dtype=torch.float32, device=dev)
-            self.m = torch.zeros(n, dtype=torch.float32, device=dev)
-            self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+            if self._state_dev is not None:   # change_device in the middle of a mission: the Adam moments move with the model
+                self.m, self.v = self.m.to(dev), self.v.to(dev)
+            else:
+                self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+                self.v = torch.zeros(n, dtype=torch.float32, device=dev)
             self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
             self.losses = torch.zeros(5, dtype=torch.float32, device=dev)
             self._state_dev = dev
