@@ -81,7 +81,10 @@ def unpack_image_features(packet, device) -> Tuple[torch.Tensor, torch.Tensor]:
     if not isinstance(packet, ImageFeaturesPacket):
         packet = ImageFeaturesPacket(np.frombuffer(bytes(packet), dtype=np.uint8) if not isinstance(packet, np.ndarray) else packet)
     dev = torch.device(device)
-    buf = torch.from_numpy(np.ascontiguousarray(packet.buffer)).to(dev, non_blocking=True)
+    host = np.ascontiguousarray(packet.buffer)
+    if not host.flags.writeable:     # bytes handed over by a transport: torch wants a writable array to wrap
+        host = host.copy()
+    buf = torch.from_numpy(host).to(dev, non_blocking=True)
     feat = torch.empty(packet.S, packet.D, dtype=torch.float32, device=dev)
     seg = torch.empty(packet.H, packet.W, dtype=torch.int64, device=dev)
     _lib.check(_lib.lib().wvn_wire_unpack(buf.data_ptr(), seg.data_ptr(), 0, feat.data_ptr(), packet.H, packet.W, packet.S,
