@@ -30,6 +30,10 @@ extern "C" {
                            per-token scales of the activations (computed by the LayerNorm / row-quantise kernels), per-output-channel \
                            scales of the weights, fp32 accumulate; attention, patch embedding, LayerNorm and the residual stream as   \
                            in WVN_PREC_BF16 */
+#define WVN_PREC_F16 4  /* the WVN_PREC_BF16 path with fp16 operands: the same kernels compiled for v_mfma_f32_32x32x16_f16 /      \
+                           v_cvt_pk_f16_f32 / v_dot2c_f32_f16 (same matrix rate and instruction counts), 11 significand bits        \
+                           instead of 8 -- 8x less operand rounding; accumulation, residual stream, LayerNorm and softmax            \
+                           statistics are fp32 in both.  Range: csrc/operand.h.  Weights: fp16 bits in the bf16 layouts */
 
 int wvn_version(void);
 
@@ -90,7 +94,7 @@ size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch);
 
 /* img [B,3,S,S] fp32 in [0,1] (already resized/cropped, dino_interface.py:54-57) ->
  *   tokens_f32  [B, G*G, D]  final-LayerNorm'ed patch tokens (class token dropped), may be NULL
- *   tokens_lowp [B*G*G rows, ld_lowp] same values in the model precision (bf16/f32), may be NULL (must be NULL for
+ *   tokens_lowp [B*G*G rows, ld_lowp] same values in the model precision (bf16 / fp16 / f32), may be NULL (must be NULL for
  *               WVN_PREC_X3: split the fp32 tokens with wvn_split_planes where planes are needed)
  * The workspace needs no initialisation (padding rows are reset by every call). */
 int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
@@ -98,9 +102,24 @@ int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* 
 
 /* Same, for raw 8-bit frames: img [B,3,S,S] uint8 (4-byte aligned).  x/255 is fused into the patch gather, bit-identical
  * to wvn_vit_forward on img.float()/255 (what quick_start.py:160-161 and ros_converter.py:113-126 hand the reference),
- * with a quarter of the upload/HBM bytes.  bf16 models with patch 8 only (WVN_ERR_ARG otherwise). */
+ * with a quarter of the upload/HBM bytes.  bf16 / fp16 / fp8 models with patch 8 only (WVN_ERR_ARG otherwise; the general
+ * form is wvn_vit_forward_frames). */
 int wvn_vit_forward_u8(const wvn_vit_model* m, const unsigned char* img, int batch, float* tokens_f32, void* tokens_lowp,
                        int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Frame ingest fused into the patch gather: frames [B,3,src_h,src_w] (fp32 in [0,1], or raw uint8 when
+ * frames_u8) straight from the camera; network pixel (y, x) of frame b is frame pixel (rows[y], cols[x]).  rows / cols: device
+ * int32 [S] -- the composition of T.Resize(input_size, NEAREST) and T.CenterCrop(input_size) (dino_interface.py:52-59,
+ * stego_interface.py:51-58) or of ImageProjector.resize_image (image_projector.py:56-59, 199-200) as index tables, built once
+ * per camera geometry by the host layer (feature_extractor/transforms.py).  Bit-identical to wvn_vit_forward on the resized /
+ * cropped image; the resized image never exists.  Every precision and patch size. */
+int wvn_vit_forward_frames(const wvn_vit_model* m, const void* frames, int frames_u8, int src_h, int src_w, const int* rows,
+                           const int* cols, int batch, float* tokens_f32, void* tokens_lowp, int ld_lowp, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* The same gather as an image op (ImageProjector.resize_image, image_projector.py:199-200, whose result the callers also
+ * display): out [planes, out_h, out_w] = in [planes, src_h, src_w][.., rows[y], cols[x]]; elem_bytes 1 (uint8) or 4 (fp32, int32). */
+int wvn_resize_nearest_crop(const void* in, void* out, long long planes, int src_h, int src_w, const int* rows, const int* cols,
+                            int out_h, int out_w, int elem_bytes, void* stream);
 
 /* Per-kernel-category HIP-event timing of wvn_vit_forward (bench.py roofline leg).  Categories:
  * 0 patchify 1 patch_gemm 2 layernorm 3 qkv_gemm 4 attention 5 proj_gemm 6 fc1_gemm 7 fc2_gemm */
@@ -133,6 +152,19 @@ int wvn_mlp_fused(const void* xn, int lda, const float* ln_g, const float* ln_b,
  * 4 f32 out += (residual), 5 same as 4.  A/W bf16, K % 64 == 0. */
 int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
                   int K, int epi, void* stream);
+/* fp16-operand twins of the five entries above and of wvn_attention_bf16 below (WVN_PREC_F16: same layouts with fp16 bits, same
+ * epilogue codes -- "bf16 out" reads "fp16 out") */
+int wvn_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int epi,
+                 void* stream);
+int wvn_qkv_fused_f16(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
+                      void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream);
+int wvn_proj_mlp_fused_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
+                           const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
+                           const float* ls2, float* x, int ldx, int M, int F, void* stream);
+int wvn_mlp_fused_f16(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
+                      const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream);
+int wvn_attention_f16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad, float scale,
+                      void* stream);
 /* The same GEMM in exact mode (WVN_PREC_X3): A and W as hi / lo bf16 planes (same leading dimensions), three MFMAs per
  * product.  epi 0-2 write C as hi / lo planes (C, C_lo, bf16 [M, ldc] each; gelu = exact erf form), epi 3-5 write fp32 C
  * (C_lo ignored). */
@@ -174,6 +206,8 @@ int wvn_attention_f32(const float* q, const float* k, const float* v, float* out
 int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream);
 int wvn_patchify_u8(const unsigned char* img, void* patches_bf16, int B, int S, int P, void* stream); /* P == 8 */
 int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
+/* strided rows: dst[r][c] = (bf16 | fp16 when to_f16) src[r][c], fp32 src with leading dimension lds, 16-bit dst with ldd */
+int wvn_cast_rows(const float* src, int lds, void* dst, int ldd, int rows, int cols, int to_f16, void* stream);
 
 /* F.interpolate(features, (H,H), mode="bilinear", align_corners=True) of dino_interface.py:87-90 /
  * stego_interface.py:107: tokens [B,G*G,D] -> dense [B,D,H,H] fp32. */
@@ -230,7 +264,8 @@ int wvn_label_pool_batched(const wvn_label_pool_node* nodes_dev, int n, int C, i
  * updated IN PLACE (inside the projected polygon: fmin(old, value); elsewhere untouched = fmin(old, NaN)), projected [npts][2]
  * (optional out; NaN for points behind the camera).  points: [npts][3] world coordinates shared by all nodes, or
  * [n][npts][3] when points_batched.  value = colour * traversability, read from value_dev[0] if non-NULL (no host sync when
- * the traversability lives on the GPU).  npts <= 256.  Arithmetic order: csrc/supervision.hip header.
+ * the traversability lives on the GPU).  npts: any count whose vertex arrays fit the 64 KB of LDS beside the 2*H row limits (H = 448: 7700; the
+ * untraversable plane of SupervisionNode.make_footprint_with_node has 1000).  Scan lines touched by a NaN edge stay unfilled (torch min / max).  Arithmetic order: csrc/supervision.hip header.
  * ------------------------------------------------------------------------------------------- */
 typedef struct wvn_render_node {
   const float* K;
@@ -269,7 +304,22 @@ int wvn_argmax_rows(const float* x, int ld, int rows, int cols, int* out, void* 
 /* deterministic cosine k-means per image on xn [B,P,C]; labels [B,P] int32; nseg [B] distinct ids;
  * relabel != 0 compacts ids to 0..K'-1 ascending (feature_extractor.py:245-246). C in {16,64,90}.
  * scratch: wvn_kmeans_scratch_bytes(B,P,C,K) bytes (centroids + per-chunk partial sums). */
+/* Summation order of the centroid update (both forms): chunks of 64 consecutive points, members of a cluster in ascending point
+ * order; chunk partials in ascending order inside groups of 8 chunks; group partials in ascending order; every chain starts from
+ * +0.  Normalisation: x * (1 / max(||x||, 1e-12)) with one correctly rounded reciprocal per row. */
 size_t wvn_kmeans_scratch_bytes(int B, int P, int C, int K);
+/* The same k-means over the H x H code PIXELS of every frame (stego_interface.py:94-109 read as "postprocess clusters the
+ * up-sampled code"): code [B, G*G, C] fp32 patch codes (NOT normalised); the points are the rows of
+ * normalise(F.interpolate(code, (H,H), bilinear, align_corners=True)), re-created on the fly in every pass from the L2-resident
+ * patch codes -- the [B, H*H, C] array (4.6 GB per 64 frames at 448^2) never exists.  labels [B, H*H] int32.  Bit-identical to
+ * wvn_upsample_bilinear + wvn_normalize_rows + wvn_kmeans_cosine on the materialised rows.  C in {16, 90}. */
+size_t wvn_kmeans_pixels_scratch_bytes(int B, int G, int H, int C, int K);
+int wvn_kmeans_cosine_pixels(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K, int iters,
+                             int relabel, void* stream);
+/* out = 0.5 * (a + flip_x(mirrored)) on [B, G, G, C] fp32 patch maps: the code of a frame averaged with the flipped-back code of
+ * its mirror image (the second pass of the upstream Stego.get_code; the mirror pass itself is wvn_vit_forward_frames with a
+ * reversed column table).  out may alias a. */
+int wvn_flip_average(const float* a, const float* mirrored, float* out, int B, int G, int C, void* stream);
 int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, void* scratch, int B, int P, int C, int K, int iters,
                       int relabel, void* stream);
 

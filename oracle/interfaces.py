@@ -71,6 +71,7 @@ def dino_inference(sd, img: torch.Tensor, input_size: int, patch: int, heads: in
 STEGO_CODE_DIM = 90
 KMEANS_ITERS = 10
 KMEANS_CHUNK = 64
+KMEANS_SUPER = 8   # chunk partials are folded in groups of 8 consecutive chunks
 
 
 def make_stego_head_state_dict(D: int = 384, C: int = STEGO_CODE_DIM, seed: int = 0) -> Dict[str, torch.Tensor]:
@@ -107,10 +108,13 @@ def _seq_dot_f32(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 
 def _normalize_rows_f32(x: np.ndarray) -> np.ndarray:
+    """x * (1 / max(||x||, 1e-12)): one correctly rounded reciprocal per row, one fp32 multiply per element (the HIP kernels'
+    form -- the pixel-resolution k-means re-creates its rows in every pass, and 90 multiplies are cheaper than 90 divisions)."""
     n2 = _seq_dot_f32(x, x)
     n = np.sqrt(n2).astype(np.float32)
     n = np.maximum(n, np.float32(1e-12))
-    return (x / n[..., None]).astype(np.float32)
+    rinv = (np.float32(1.0) / n).astype(np.float32)
+    return (x * rinv[..., None]).astype(np.float32)
 
 
 def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) -> np.ndarray:
@@ -119,6 +123,7 @@ def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) ->
     code: [P, C] fp32.  Returns int32 labels [P] in 0..K-1 (not yet compacted).
       x_p   = code_p / max(||code_p||, 1e-12)
       c_k^0 = x at index floor((2k+1) P / (2K))
+      (normalisation everywhere: x * (1 / max(||x||, 1e-12)), _normalize_rows_f32)
       repeat ``iters`` times: label_p = argmax_k <x_p, c_k> (lowest k wins ties);
                               c_k = normalise(sum of its x_p in ascending p); empty cluster keeps c_k.
       final labels = one more assignment against the last centroids.
@@ -137,13 +142,17 @@ def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) ->
     for _ in range(iters):
         lab = assign(cent)
         # centroid sums in the kernel's fixed order: chunks of KMEANS_CHUNK consecutive points, members of a
-        # cluster added in ascending point order inside a chunk (from 0), chunk partials added in ascending
-        # chunk order (from 0) -- one fp32 rounding per addition
+        # cluster added in ascending point order inside a chunk (from 0); chunk partials added in ascending
+        # chunk order inside groups of KMEANS_SUPER consecutive chunks (from 0); group partials added in
+        # ascending group order (from 0) -- one fp32 rounding per addition
         sums = np.zeros((K, C), dtype=np.float32)
-        for p0 in range(0, P, KMEANS_CHUNK):
-            part = np.zeros((K, C), dtype=np.float32)
-            np.add.at(part, lab[p0:p0 + KMEANS_CHUNK], x[p0:p0 + KMEANS_CHUNK])  # unbuffered: ascending order
-            sums = (sums + part).astype(np.float32)
+        for g0 in range(0, P, KMEANS_CHUNK * KMEANS_SUPER):
+            grp = np.zeros((K, C), dtype=np.float32)
+            for p0 in range(g0, min(P, g0 + KMEANS_CHUNK * KMEANS_SUPER), KMEANS_CHUNK):
+                part = np.zeros((K, C), dtype=np.float32)
+                np.add.at(part, lab[p0:p0 + KMEANS_CHUNK], x[p0:p0 + KMEANS_CHUNK])  # unbuffered: ascending order
+                grp = (grp + part).astype(np.float32)
+            sums = (sums + grp).astype(np.float32)
         cnt = np.bincount(lab, minlength=K)
         new = _normalize_rows_f32(sums)
         cent = np.where((cnt > 0)[:, None], new, cent).astype(np.float32)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwvn_hip.so")
 
 WVN_MAX_DEPTH = 32
-PREC_F32, PREC_BF16, PREC_X3, PREC_FP8 = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_X3, PREC_FP8, PREC_F16 = 0, 1, 2, 3, 4
 VIT_MLP_FUSED = 1
 VIT_QKV_FUSED = 2
 VIT_FUSE_ANY_SIZE = 4
@@ -58,6 +58,8 @@ _SIGNATURES = {
     "wvn_vit_workspace_bytes": ([_p, _i], _sz),
     "wvn_vit_forward": ([_p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
     "wvn_vit_forward_u8": ([_p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
+    "wvn_vit_forward_frames": ([_p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
+    "wvn_resize_nearest_crop": ([_p, _p, _ll, _i, _i, _p, _p, _i, _i, _i, _p], _i),
     "wvn_prof_enable": ([_i], _i),
     "wvn_prof_collect": ([_p, _p], _i),
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
@@ -67,6 +69,11 @@ _SIGNATURES = {
     "wvn_qkv_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),
     "wvn_proj_mlp_fused": ([_p, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_mlp_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "wvn_gemm_f16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_qkv_fused_f16": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),
+    "wvn_proj_mlp_fused_f16": ([_p, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "wvn_mlp_fused_f16": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "wvn_attention_f16": ([_p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "wvn_gemm_x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_quantize_rows_fp8": ([_p, _i, _i, _p, _i, _p, _i, _i, _p], _i),
     "wvn_gemm_fp8": ([_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
@@ -99,6 +106,10 @@ _SIGNATURES = {
     "wvn_normalize_rows": ([_p, _i, _p, _i, _i, _p], _i),
     "wvn_argmax_rows": ([_p, _i, _i, _i, _p, _p], _i),
     "wvn_kmeans_scratch_bytes": ([_i, _i, _i, _i], _sz),
+    "wvn_kmeans_pixels_scratch_bytes": ([_i, _i, _i, _i, _i], _sz),
+    "wvn_kmeans_cosine_pixels": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_flip_average": ([_p, _p, _p, _i, _i, _i, _p], _i),
+    "wvn_cast_rows": ([_p, _i, _p, _i, _i, _i, _i, _p], _i),
     "wvn_kmeans_cosine": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "wvn_mlp_param_count": ([_p], _sz),
     "wvn_mlp_workspace_bytes": ([_p, _i], _sz),

@@ -85,7 +85,8 @@ def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
 
 
 class VitBackbone:
-    """Device-resident DINO / DINOv2 ViT.  ``precision``: "bf16" (MFMA fast path), "exact" (hi + lo split bf16 operands, three
+    """Device-resident DINO / DINOv2 ViT.  ``precision``: "bf16" (MFMA fast path), "fp16" (the same kernels with fp16 operands:
+    same speed, 8x less operand rounding -- csrc/operand.h), "exact" (hi + lo split bf16 operands, three
     MFMAs per product: fp32-class results on the matrix pipe, the <= 1e-3 parity mode) or "fp32" (the same gate on fp32 FMA
     kernels; slow, kept as the independent cross-check of "exact") or "fp8" (BASELINE configs[4]: the four linears of every block on
     e4m3 MFMA at twice the bf16 rate, per-token / per-channel scales; everything else as "bf16")."""
@@ -97,7 +98,9 @@ class VitBackbone:
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
         self.lib = _lib.lib()
-        self.precision = {"bf16": _lib.PREC_BF16, "fp32": _lib.PREC_F32, "exact": _lib.PREC_X3, "fp8": _lib.PREC_FP8}[precision]
+        self.precision = {"bf16": _lib.PREC_BF16, "fp16": _lib.PREC_F16, "fp32": _lib.PREC_F32, "exact": _lib.PREC_X3,
+                          "fp8": _lib.PREC_FP8}[precision]
+        self._lowp16 = {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_FP8: torch.bfloat16, _lib.PREC_F16: torch.float16}.get(self.precision)
         self.precision_name = precision
         self.img_size, self.patch, self.heads = img_size, patch, heads
         self.grid = img_size // patch
@@ -106,14 +109,15 @@ class VitBackbone:
         self.mlp_dim = state_dict["blocks.0.mlp.fc1.weight"].shape[0]
         self.max_chunk = max_chunk
         # block MLP as one kernel with the hidden activation kept on chip (csrc/mlp_fused.hip): bf16, D = 384
-        can_fuse = self.precision == _lib.PREC_BF16 and self.dim == 384 and self.mlp_dim % 64 == 0 and self.mlp_dim <= 2176
+        lowp16 = self.precision in (_lib.PREC_BF16, _lib.PREC_F16)
+        can_fuse = lowp16 and self.dim == 384 and self.mlp_dim % 64 == 0 and self.mlp_dim <= 2176
         if fuse_mlp and not can_fuse:
-            raise _lib.WvnError("fuse_mlp needs precision 'bf16', dim 384 and mlp_dim % 64 == 0")
+            raise _lib.WvnError("fuse_mlp needs precision 'bf16' or 'fp16', dim 384 and mlp_dim % 64 == 0")
         self.fuse_mlp = can_fuse if fuse_mlp is None else bool(fuse_mlp)
         # LayerNorm 1 + QKV projection as one kernel (csrc/qkv_fused.hip): bf16, D = 384 with 6 heads
-        can_fuse_qkv = self.precision == _lib.PREC_BF16 and self.dim == 384 and heads == 6
+        can_fuse_qkv = lowp16 and self.dim == 384 and heads == 6
         if fuse_qkv and not can_fuse_qkv:
-            raise _lib.WvnError("fuse_qkv needs precision 'bf16', dim 384 and 6 heads")
+            raise _lib.WvnError("fuse_qkv needs precision 'bf16' or 'fp16', dim 384 and 6 heads")
         self.fuse_qkv = can_fuse_qkv if fuse_qkv is None else bool(fuse_qkv)
         self._fuse_args = (fuse_mlp, fuse_qkv, fuse_proj)
         self._sd = state_dict  # kept (host / original tensors) so that .to(device) can re-home the model
@@ -124,8 +128,8 @@ class VitBackbone:
             if pad_cols:
                 t = F.pad(t, (0, pad_cols))
             t = t.to(self.device)
-            if self.precision in (_lib.PREC_BF16, _lib.PREC_FP8):
-                t = t.to(torch.bfloat16).contiguous()
+            if self._lowp16 is not None:
+                t = t.to(self._lowp16).contiguous()
             elif self.precision == _lib.PREC_X3:  # two stacked bf16 planes: hi = bf16(w), lo = bf16(w - hi)
                 t = split_planes(t)
             else:
@@ -183,7 +187,7 @@ class VitBackbone:
                     # accumulators hand it over, wvn_hip.h), one allocation per layer
                     k = torch.arange(self.mlp_dim)
                     parts = [sd[p + "attn.proj.weight"], sd[p + "mlp.fc1.weight"], w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)]]
-                    pack = torch.cat([t.detach().float().reshape(-1) for t in parts]).to(self.device).to(torch.bfloat16).contiguous()
+                    pack = torch.cat([t.detach().float().reshape(-1) for t in parts]).to(self.device).to(self._lowp16).contiguous()
                     self._keep.append(pack)
                     n0, n1 = parts[0].numel(), parts[1].numel()
                     L.proj_w, L.fc1_w, L.fc2_w_fused = pack.data_ptr(), pack.data_ptr() + 2 * n0, pack.data_ptr() + 2 * (n0 + n1)
@@ -218,44 +222,62 @@ class VitBackbone:
     @property
     def lowp_dtype(self):
         """dtype of ``lowp_out`` rows (None: the exact mode hands out fp32 tokens only)."""
-        return {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_FP8: torch.bfloat16, _lib.PREC_F32: torch.float32}.get(self.precision)
+        return {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_FP8: torch.bfloat16, _lib.PREC_F16: torch.float16,
+                _lib.PREC_F32: torch.float32}.get(self.precision)
 
     def forward_tokens(self, img: torch.Tensor, out: Optional[torch.Tensor] = None,
-                       lowp_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """img [B,3,S,S] fp32 in [0,1] (or raw uint8 frames: x/255 is then fused into the patch gather of the
-        bf16 path, bit-identical to passing ``img.float() / 255``) -> final-LN patch tokens [B, G*G, D] fp32 (fresh tensor unless
-        ``out`` is given).  ``lowp_out`` (optional, [B*G*G, ld] in the model precision) receives the same
-        values for a following MFMA GEMM (STEGO head).  Frames are pushed through in chunks of
-        ``max_chunk`` so a chunk's activations stay resident in the 256 MB Infinity Cache."""
+                       lowp_out: Optional[torch.Tensor] = None, flip: bool = False) -> torch.Tensor:
+        """img [B,3,H,W]: fp32 in [0,1] or raw uint8 frames (x/255 is then fused into the patch gather, bit-identical to passing
+        ``img.float() / 255``), at the network size or at ANY camera size -- the NEAREST resize + centre crop of
+        dino_interface.py:52-59 is then fused into the same gather through index tables (``transforms.ingest_tables``;
+        ``wvn_vit_forward_frames``).  ``flip``: run on the horizontally mirrored network input (STEGO's second pass; reversed
+        column table, no copy).  -> final-LN patch tokens [B, G*G, D] fp32 (fresh tensor unless ``out`` is given).
+        ``lowp_out`` (optional, [B*G*G, ld] in the model precision) receives the same values for a following MFMA GEMM
+        (STEGO head).  Frames are pushed through in chunks of ``max_chunk`` so a chunk's activations stay resident in the
+        256 MB Infinity Cache."""
         _lib.require_cuda(img, "img")
-        B, Cc, S, S2 = img.shape
-        if Cc != 3 or S != self.img_size or S2 != self.img_size:
-            raise _lib.WvnError(f"expected [B,3,{self.img_size},{self.img_size}], got {tuple(img.shape)}")
+        B, Cc, Hs, Ws = img.shape
+        if Cc != 3:
+            raise _lib.WvnError(f"expected [B,3,H,W], got {tuple(img.shape)}")
         if lowp_out is not None and self.precision == _lib.PREC_X3:
             raise _lib.WvnError("precision 'exact' returns fp32 tokens only (split them with ops.split_planes)")
-        u8 = img.dtype == torch.uint8 and self.precision in (_lib.PREC_BF16, _lib.PREC_FP8) and self.patch == 8
-        if u8:
-            img = img.contiguous()
-        elif img.dtype == torch.uint8:
-            img = img.contiguous().float() / 255
-        else:
-            img = img.contiguous().float()
-        fwd, fwd_name = (self.lib.wvn_vit_forward_u8, "wvn_vit_forward_u8") if u8 else (self.lib.wvn_vit_forward, "wvn_vit_forward")
+        if img.dtype != torch.uint8:
+            img = img.float()
+        img = img.contiguous()
+        u8 = img.dtype == torch.uint8
+        direct = Hs == self.img_size and Ws == self.img_size and not flip
+        tab = None
+        if not direct:
+            from .feature_extractor.transforms import ingest_tables
+            tab = ingest_tables(Hs, Ws, self.img_size, self.device, flip=flip)
+        if direct and u8 and not (self._lowp16 is not None and self.patch == 8):
+            img = img.float() / 255   # wvn_vit_forward_u8 covers the 16-bit-operand precisions at patch 8; others take fp32 here
+            u8 = False
         P = self.grid * self.grid
         if out is None:
             out = torch.empty(B, P, self.dim, dtype=torch.float32, device=self.device)
         chunk = min(self.max_chunk, B)
         ws = self._workspace(chunk)
         st = _lib.stream()
-        esz = 2 if self.precision in (_lib.PREC_BF16, _lib.PREC_FP8) else 4
+        esz = 2 if self._lowp16 is not None else 4
+        frame_bytes = 3 * Hs * Ws * img.element_size()
         for b0 in range(0, B, chunk):
             nb = min(chunk, B - b0)
             lp, ld = 0, 0
             if lowp_out is not None:
                 ld = lowp_out.stride(0)
                 lp = lowp_out.data_ptr() + b0 * P * ld * esz
-            rc = fwd(C.byref(self.model), img[b0:].data_ptr(), nb, out[b0:].data_ptr(), lp, ld, ws.data_ptr(), ws.numel(), st)
-            _lib.check(rc, fwd_name)
+            src = img.data_ptr() + b0 * frame_bytes
+            if tab is not None:
+                rc = self.lib.wvn_vit_forward_frames(C.byref(self.model), src, int(u8), Hs, Ws, tab.rows.data_ptr(), tab.cols.data_ptr(),
+                                                     nb, out[b0:].data_ptr(), lp, ld, ws.data_ptr(), ws.numel(), st)
+                _lib.check(rc, "wvn_vit_forward_frames")
+            elif u8:
+                _lib.check(self.lib.wvn_vit_forward_u8(C.byref(self.model), src, nb, out[b0:].data_ptr(), lp, ld, ws.data_ptr(), ws.numel(), st),
+                           "wvn_vit_forward_u8")
+            else:
+                _lib.check(self.lib.wvn_vit_forward(C.byref(self.model), src, nb, out[b0:].data_ptr(), lp, ld, ws.data_ptr(), ws.numel(), st),
+                           "wvn_vit_forward")
         return out
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:

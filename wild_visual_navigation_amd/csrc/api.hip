@@ -42,6 +42,20 @@ struct Span {
   }
 };
 
+// the launchers of the 16-bit-operand speed path, per operand format (operand.h)
+struct OperandKernels {
+  int fmt;  // 1 bf16, 2 fp16 (the y_fmt / out_mode codes of the elementwise launchers: patchify out_mode = fmt == 2 ? 3 : 1)
+  decltype(&wvn_gemm_bf16_launch) gemm;
+  decltype(&wvn_qkv_fused_launch) qkv_fused;
+  decltype(&wvn_attention_bf16_launch) attention;
+  decltype(&wvn_proj_mlp_fused_launch) proj_mlp_fused;
+  decltype(&wvn_mlp_fused_launch) mlp_fused;
+};
+const OperandKernels OPK_BF16 = {1, wvn_gemm_bf16_launch, wvn_qkv_fused_launch, wvn_attention_bf16_launch, wvn_proj_mlp_fused_launch,
+                                 wvn_mlp_fused_launch};
+const OperandKernels OPK_F16 = {2, wvn_gemm_bf16_launch_f16, wvn_qkv_fused_launch_f16, wvn_attention_bf16_launch_f16,
+                                wvn_proj_mlp_fused_launch_f16, wvn_mlp_fused_launch_f16};
+
 struct VitDims {
   int B, S, P, G, D, H, F, KP, KPs, ntok, ntok_s, npad, npatch;
   bool fp8;
@@ -58,7 +72,7 @@ VitDims vit_dims(const wvn_vit_model* m, int batch) {
   d.fp8 = m->precision == WVN_PREC_FP8;
   d.ntok_s = (d.ntok + 15) / 16 * 16;  // rows per frame: 8-token (16 B) chunks and the 16-token V^T permutation groups never straddle frames
   d.npad = (d.ntok + 127) / 128 * 128;
-  d.esz = (m->precision == WVN_PREC_BF16 || m->precision == WVN_PREC_FP8) ? 2 : 4;  // exact mode (X3): two bf16 planes = 4 bytes per element
+  d.esz = (m->precision == WVN_PREC_BF16 || m->precision == WVN_PREC_FP8 || m->precision == WVN_PREC_F16) ? 2 : 4;  // exact mode (X3): two bf16 planes = 4 bytes per element
   d.M = (long long)batch * d.ntok_s; d.Mp = (long long)batch * d.npatch;
   return d;
 }
@@ -112,28 +126,42 @@ size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch) {
   return vit_carve(d, nullptr).total;
 }
 
-static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, int batch, float* tokens_f32,
+static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, const WvnIngest* ing, int batch, float* tokens_f32,
                             void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
 
 int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
                     int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
-  return vit_forward_impl(m, img, 0, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
+  return vit_forward_impl(m, img, 0, nullptr, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
 }
 
 int wvn_vit_forward_u8(const wvn_vit_model* m, const unsigned char* img, int batch, float* tokens_f32, void* tokens_lowp,
                        int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
-  if (m && ((m->precision != WVN_PREC_BF16 && m->precision != WVN_PREC_FP8) || m->patch != 8)) return WVN_ERR_ARG;
-  return vit_forward_impl(m, img, 1, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
+  if (m && ((m->precision != WVN_PREC_BF16 && m->precision != WVN_PREC_FP8 && m->precision != WVN_PREC_F16) || m->patch != 8)) return WVN_ERR_ARG;
+  return vit_forward_impl(m, img, 1, nullptr, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
+}
+
+int wvn_vit_forward_frames(const wvn_vit_model* m, const void* frames, int frames_u8, int src_h, int src_w, const int* rows,
+                           const int* cols, int batch, float* tokens_f32, void* tokens_lowp, int ld_lowp, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (!rows || !cols || src_h <= 0 || src_w <= 0) return WVN_ERR_ARG;
+  const WvnIngest ing{rows, cols, src_h, src_w};
+  return vit_forward_impl(m, frames, frames_u8 != 0, &ing, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
+}
+
+int wvn_resize_nearest_crop(const void* in, void* out, long long planes, int src_h, int src_w, const int* rows, const int* cols,
+                            int out_h, int out_w, int elem_bytes, void* stream) {
+  const WvnIngest ing{rows, cols, src_h, src_w};
+  return wvn_gather_image_launch(in, out, planes, out_h, out_w, elem_bytes, &ing, (hipStream_t)stream);
 }
 
 }  // extern "C"
 
-static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, int batch, float* tokens_f32,
+static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, const WvnIngest* ing, int batch, float* tokens_f32,
                             void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
   if (!m || !img || !workspace || batch <= 0) return WVN_ERR_ARG;
   if (m->dim != m->heads * 64 || m->depth <= 0 || m->depth > WVN_MAX_DEPTH || m->img_size % m->patch) return WVN_ERR_ARG;
   if (m->dim % 128 || m->mlp_dim % 128) return WVN_ERR_ARG;
-  if (m->precision < WVN_PREC_F32 || m->precision > WVN_PREC_FP8) return WVN_ERR_ARG;
+  if (m->precision < WVN_PREC_F32 || m->precision > WVN_PREC_F16) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const VitDims d = vit_dims(m, batch);
   const VitWs w = vit_carve(d, workspace);
@@ -141,15 +169,19 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   const bool fp8 = m->precision == WVN_PREC_FP8;
   if (fp8 && ((d.D % 128) || (d.F % 128))) return WVN_ERR_ARG;
   // fp8: everything that is not one of the four block linears runs exactly as in the bf16 mode
-  const bool bf = m->precision == WVN_PREC_BF16 || fp8, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
+  // "bf": the 16-bit-operand speed path, in either operand format (opk)
+  const bool f16 = m->precision == WVN_PREC_F16;
+  const OperandKernels& opk = f16 ? OPK_F16 : OPK_BF16;
+  const bool bf = m->precision == WVN_PREC_BF16 || fp8 || f16, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
+  const bool lowp16 = m->precision == WVN_PREC_BF16 || f16;   // the precisions the single-kernel block stages exist for
   // The single-kernel block stages are persistent one-workgroup-per-CU kernels (128 / 256 rows per workgroup): measured against the
   // separate kernels (scripts/small_batch_latency.py, 448^2 and 224^2 frames) they win from about half a chip of row blocks on and
   // lose below -- a single live frame is 25 / 13 row blocks on 256 CUs, 2.5 ms against 1.7.
   const bool mlp_ok = (m->flags & WVN_VIT_MLP_FUSED) != 0, qkv_ok = (m->flags & WVN_VIT_QKV_FUSED) != 0;
-  if (qkv_ok && (m->precision != WVN_PREC_BF16 || d.D != 384 || d.H != 6 || (d.ntok_s % 16) != 0)) return WVN_ERR_ARG;
+  if (qkv_ok && (!lowp16 || d.D != 384 || d.H != 6 || (d.ntok_s % 16) != 0)) return WVN_ERR_ARG;
   const bool any_size = (m->flags & WVN_VIT_FUSE_ANY_SIZE) != 0, proj_in_mlp = (m->flags & WVN_VIT_NO_PROJ_IN_MLP) == 0;
   const bool mlp_fused = mlp_ok && (any_size || d.M >= 128 * 128), qkv_fused = qkv_ok && (any_size || d.M >= 144 * 256);
-  if (mlp_ok && (m->precision != WVN_PREC_BF16 || d.D != 384 || (d.F % 64) != 0)) return WVN_ERR_ARG;
+  if (mlp_ok && (!lowp16 || d.D != 384 || (d.F % 64) != 0)) return WVN_ERR_ARG;
   if (x3 && tokens_lowp) return WVN_ERR_ARG;  // exact mode hands out fp32 tokens only (callers split with wvn_split_planes)
   const float scale = 1.0f / sqrtf(64.f);
   const int M = (int)d.M, Mp = (int)d.Mp;
@@ -186,13 +218,13 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       p.A_lo = lo(A, a_plane); p.W_lo = lo(W, (size_t)N * K); p.C_lo = C ? lo(C, c_plane) : nullptr;
       return wvn_gemm_x3_launch(p, epi, st);
     }
-    return wvn_gemm_bf16_launch(p, epi, st);
+    return opk.gemm(p, epi, st);
   };
 
   {
     Span s(0, st);
-    RET_IF(wvn_patchify_launch(img, img_u8, w.patches, x3 ? lo(w.patches, pl_pat) : nullptr, f32 ? 0 : (x3 ? 2 : 1), d.KPs, d.B,
-                               d.S, d.P, st));
+    RET_IF(wvn_patchify_launch(img, img_u8, w.patches, x3 ? lo(w.patches, pl_pat) : nullptr, f32 ? 0 : (x3 ? 2 : (f16 ? 3 : 1)), d.KPs, d.B,
+                               d.S, d.P, st, ing));
     if (d.KPs != d.KP) {  // zero the K padding of the patch rows (weights are zero there too, but NaN * 0 must not happen)
       RET_IF(wvn_pad_zero_launch(w.patches, (long long)Mp * (x3 ? 2 : 1), (long long)d.KPs * 2, (long long)d.KP * 2,
                                  (long long)(d.KPs - d.KP) * 2, st));
@@ -264,10 +296,10 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     }
     if (qkv_fused) {  // LayerNorm 1 + QKV projection: one launch, no xn round trip
       Span s(3, st);
-      RET_IF(wvn_qkv_fused_launch(w.x, d.D, L.ln1_g, L.ln1_b, 1e-6f, (const bf16_t*)L.qkv_w, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
+      RET_IF(opk.qkv_fused(w.x, d.D, L.ln1_g, L.ln1_b, 1e-6f, (const bf16_t*)L.qkv_w, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
                                   (bf16_t*)w.v, d.H, d.npad, d.ntok_s, scale * 1.44269504088896340736f, M, st));
     } else {
-    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, f32 ? 0 : opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     {
       Span s(3, st);
       GemmBf16Params e{};
@@ -281,25 +313,25 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     }
     {
       Span s(4, st);
-      if (bf) RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st));
+      if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st));
       else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
     if (mlp_fused && proj_in_mlp) {  // attention projection + LayerNorm 2 + fc1 + GELU + fc2 + both residual updates: one launch
       Span s(6, st);
       if (!L.fc2_w_fused) return WVN_ERR_ARG;
-      const int rc = wvn_proj_mlp_fused_launch((const bf16_t*)w.xn, d.D, (const bf16_t*)L.proj_w, L.proj_b, L.ls1, L.ln2_g, L.ln2_b, 1e-6f,
+      const int rc = opk.proj_mlp_fused((const bf16_t*)w.xn, d.D, (const bf16_t*)L.proj_w, L.proj_b, L.ls1, L.ln2_g, L.ln2_b, 1e-6f,
                                                (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b, L.ls2, w.x, d.D, M,
                                                d.F, st);
       if (rc == WVN_OK) continue;
       if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
     { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
-    if (!mlp_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, !f32, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    if (!mlp_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, f32 ? 0 : opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     if (mlp_fused) {  // LayerNorm 2 + fc1 + GELU + fc2 + residual: one launch, no xn / hid round trip
       Span s(6, st);
       if (!L.fc2_w_fused) return WVN_ERR_ARG;
-      RET_IF(wvn_mlp_fused_launch(nullptr, 0, L.ln2_g, L.ln2_b, 1e-6f, (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b,
+      RET_IF(opk.mlp_fused(nullptr, 0, L.ln2_g, L.ln2_b, 1e-6f, (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b,
                                   L.ls2, w.x, d.D, M, d.F, st));
       continue;
     }
@@ -308,7 +340,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   }
   {
     Span s(2, st);
-    RET_IF(wvn_layernorm_launch(w.x, m->norm_g, m->norm_b, tokens_lowp, bf, ld_lowp, tokens_f32, d.D, Mp, d.D, 1e-6f, 1, d.ntok, d.ntok_s, st));
+    RET_IF(wvn_layernorm_launch(w.x, m->norm_g, m->norm_b, tokens_lowp, bf ? opk.fmt : 0, ld_lowp, tokens_f32, d.D, Mp, d.D, 1e-6f, 1, d.ntok, d.ntok_s, st));
   }
   return WVN_OK;
 }
@@ -325,6 +357,36 @@ int wvn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* b
   p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   return wvn_gemm_bf16_launch(p, epi, (hipStream_t)stream);
+}
+
+int wvn_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                 int K, int epi, void* stream) {
+  if (epi < 0 || epi > EPI_ACCUM_F32 || !C) return WVN_ERR_ARG;
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  return wvn_gemm_bf16_launch_f16(p, epi, (hipStream_t)stream);
+}
+int wvn_qkv_fused_f16(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
+                      void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream) {
+  return wvn_qkv_fused_launch_f16(x, ldx, ln_g, ln_b, ln_eps, (const bf16_t*)W, bias, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, heads, npad,
+                                  ntok_s, q_scale, M, (hipStream_t)stream);
+}
+int wvn_proj_mlp_fused_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
+                           const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
+                           const float* ls2, float* x, int ldx, int M, int F, void* stream) {
+  return wvn_proj_mlp_fused_launch_f16((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, ls1, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1,
+                                       (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream);
+}
+int wvn_mlp_fused_f16(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
+                      const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream) {
+  return wvn_mlp_fused_launch_f16((const bf16_t*)xn, lda, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1, (const bf16_t*)W2p, b2, ls, x,
+                                  ldx, M, F, (hipStream_t)stream);
+}
+int wvn_attention_f16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad, float scale,
+                      void* stream) {
+  return wvn_attention_bf16_launch_f16((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, B, heads, ntok, ntok,
+                                       npad, scale, (hipStream_t)stream);
 }
 
 int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
@@ -378,11 +440,9 @@ int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const
 }
 
 int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
-extern long long* g_mlp_fused_dbg;
 int wvn_debug_mlp_fused_timing(long long* dbg) { g_mlp_fused_dbg = dbg; return WVN_OK; }
-extern long long* g_qkv_fused_dbg;
 int wvn_debug_qkv_fused_timing(long long* dbg) { g_qkv_fused_dbg = dbg; return WVN_OK; }
-int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); return WVN_OK; }
+int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); wvn_attention_bf16_set_variant_f16(v); return WVN_OK; }
 
 int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                               int N, int K, int epi, long long* dbg, void* stream) {
@@ -413,7 +473,7 @@ int wvn_gemm_f32(const float* A, int lda, int transA, const float* B, int ldb, i
 int wvn_layernorm(const float* x, const float* gamma, const float* beta, void* y, int y_is_bf16, int rows, int D,
                   float eps, void* stream) {
   if (!y) return WVN_ERR_ARG;
-  return wvn_layernorm_launch(x, gamma, beta, y, y_is_bf16, D, nullptr, 0, rows, D, eps, 0, 0, 0, (hipStream_t)stream);
+  return wvn_layernorm_launch(x, gamma, beta, y, y_is_bf16 ? 1 : 0, D, nullptr, 0, rows, D, eps, 0, 0, 0, (hipStream_t)stream);
 }
 
 int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad,
@@ -435,6 +495,10 @@ int wvn_patchify_u8(const unsigned char* img, void* patches_bf16, int B, int S, 
 int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
   if (!src || !dst || n <= 0 || n > 0x7fffffffll) return WVN_ERR_ARG;
   return wvn_cast_f32_bf16_launch(src, (int)n, (bf16_t*)dst, (int)n, 1, (int)n, (hipStream_t)stream);
+}
+int wvn_cast_rows(const float* src, int lds, void* dst, int ldd, int rows, int cols, int to_f16, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < cols) return WVN_ERR_ARG;
+  return wvn_cast_f32_bf16_launch(src, lds, (bf16_t*)dst, ldd, rows, cols, (hipStream_t)stream, to_f16 != 0);
 }
 int wvn_upsample_bilinear(const float* tokens, float* dense, int B, int G, int D, int H, void* stream) {
   return wvn_upsample_bilinear_launch(tokens, dense, B, G, D, H, (hipStream_t)stream);
@@ -503,6 +567,16 @@ int wvn_argmax_rows(const float* x, int ld, int rows, int cols, int* out, void* 
 }
 size_t wvn_kmeans_scratch_bytes(int B, int P, int C, int K) {
   return (B > 0 && P > 0 && C > 0 && K > 0) ? wvn_kmeans_scratch_floats(B, P, C, K) * sizeof(float) : 0;
+}
+size_t wvn_kmeans_pixels_scratch_bytes(int B, int G, int H, int C, int K) {
+  return (B > 0 && G > 0 && H > 0 && C > 0 && K > 0) ? wvn_kmeans_pixels_scratch_floats(B, G, H, C, K) * sizeof(float) : 0;
+}
+int wvn_kmeans_cosine_pixels(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K, int iters,
+                             int relabel, void* stream) {
+  return wvn_kmeans_pixels_launch(code, labels, nseg, (float*)scratch, B, G, H, C, K, iters, relabel, (hipStream_t)stream);
+}
+int wvn_flip_average(const float* a, const float* mirrored, float* out, int B, int G, int C, void* stream) {
+  return wvn_flip_average_launch(a, mirrored, out, B, G, C, (hipStream_t)stream);
 }
 int wvn_kmeans_cosine(const float* xn, int* labels, int* nseg, void* scratch, int B, int P, int C, int K, int iters,
                       int relabel, void* stream) {

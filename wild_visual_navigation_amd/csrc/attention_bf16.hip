@@ -45,7 +45,7 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "operand.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -56,7 +56,6 @@ constexpr int DH = 64;             // head dim
 constexpr int TILE_BYTES = KVB * DH * 2;  // 8 KB (K tile; V^T tile is the same size)
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
 
 // The softmax is bounded by per-wave VALU issue, so instruction count matters: the row max uses 3-input max.
 // This file is compiled with -fno-honor-nans so that fmaxf on MFMA results needs no canonicalising v_max (scores
@@ -69,10 +68,10 @@ __device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a,
 // only when the max moves): the accumulators come out as exp2 arguments and the 16 v_pk_fma per tile disappear.
 // SUM: how the row sums are formed.  0: v_dot2c_f32_bf16 on the packed P (16 per tile); 1: plain adds on the fp32 P.
 template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false, int SUM = 0, bool LAZY = false>
-__global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* __restrict__ q,
-                                                                  const bf16_t* __restrict__ k,
-                                                                  const bf16_t* __restrict__ vt,
-                                                                  bf16_t* __restrict__ out, int heads, int nbh,
+__global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* __restrict__ q,
+                                                                  const op16_t* __restrict__ k,
+                                                                  const op16_t* __restrict__ vt,
+                                                                  op16_t* __restrict__ out, int heads, int nbh,
                                                                   int nqb, int ntok, int ntok_s, int npad,
                                                                   float c_exp, long long* dbg) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE_BYTES];  // [stage][K | Vt][64][128 B]
@@ -120,10 +119,10 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     if (t < nt) issue(t);
 
   // ---- Q^T fragments (B operand): query l31, d = 16 s + 8 hi .. + 7 ------------------------------------------
-  const bf16_t* qg = q + ((size_t)bh * npad + q0 + l31) * DH + hi * 8;
-  bf16x8_t qf[4];
+  const op16_t* qg = q + ((size_t)bh * npad + q0 + l31) * DH + hi * 8;
+  opx8_t qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8_t*)(qg + s * 16);
+  for (int s = 0; s < 4; ++s) qf[s] = *(const opx8_t*)(qg + s * 16);
   // Make the Q fragments "used" here: otherwise hipcc places their vmcnt wait at the first use INSIDE the
   // tile loop, where it would also drain the K/V DMA queue on every trip.
 #pragma unroll
@@ -175,9 +174,9 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8_t kf = *(const bf16x8_t*)(lds + fa[s] + t * 4096);
-        if (s == 0) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], PRE ? cneg : (f32x16_t)(0.f), 0, 0, 0);
-        else st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
+        const opx8_t kf = *(const opx8_t*)(lds + fa[s] + t * 4096);
+        if (s == 0) st[t] = wvn_mfma_32x32x16(kf, qf[s], PRE ? cneg : (f32x16_t)(0.f), 0, 0, 0);
+        else st[t] = wvn_mfma_32x32x16(kf, qf[s], st[t], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -269,15 +268,14 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int t = ks >> 1, h8 = (ks & 1) * 8;
-      union { u32x4_t u; bf16x8_t v; } pf;
+      union { u32x4_t u; opx8_t v; } pf;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const uint32_t pk = pack_bf16x2(st[t][h8 + 2 * e], st[t][h8 + 2 * e + 1]);
+        const uint32_t pk = pack_op2(st[t][h8 + 2 * e], st[t][h8 + 2 * e + 1]);
         pf.u[e] = pk;  // (bit_cast of the scalar, not of the vector element: clang reads element 0 for the latter)
-        const bf16x2v_t pp = __builtin_bit_cast(bf16x2v_t, pk), one2 = __builtin_bit_cast(bf16x2v_t, 0x3f803f80u);
-        if constexpr (SUM == 0) {  // row sum of the bf16-rounded P (exactly what the PV MFMA multiplies)
-          if (e & 1) l_run1 = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, l_run1, false);
-          else l_run = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, l_run, false);
+        if constexpr (SUM == 0) {  // row sum of the rounded P (exactly what the PV MFMA multiplies)
+          if (e & 1) l_run1 = dot2_ones_op(pk, l_run1);
+          else l_run = dot2_ones_op(pk, l_run);
         } else {  // plain adds on the fp32 P.  NOT inline asm: its operands are v_exp results, and hipcc pads the
                   // transcendental-result hazard only for instructions it emits itself (an asm v_add read stale values)
           l_run += st[t][h8 + 2 * e];
@@ -286,8 +284,8 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
       }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8_t vf = *(const bf16x8_t*)(lds + fa[ks] + TILE_BYTES + dt * 4096);
-        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, ot[dt], 0, 0, 0);
+        const opx8_t vf = *(const opx8_t*)(lds + fa[ks] + TILE_BYTES + dt * 4096);
+        ot[dt] = wvn_mfma_32x32x16(vf, pf.v, ot[dt], 0, 0, 0);
       }
     }
     if constexpr (PRE) __builtin_amdgcn_s_setprio(0);
@@ -321,8 +319,8 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bf16x8_t kf = *(const bf16x8_t*)(lds + fa[s] + t * 4096);
-          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? cneg : st[t], 0, 0, 0);
+          const opx8_t kf = *(const opx8_t*)(lds + fa[s] + t * 4096);
+          st[t] = wvn_mfma_32x32x16(kf, qf[s], s == 0 ? cneg : st[t], 0, 0, 0);
         }
       if (MAYBE_TAIL && kv0 + KVB > ntok) {
 #pragma unroll
@@ -343,11 +341,10 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
         const int t = ks >> 1, h8 = (ks & 1) * 8;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const uint32_t pk = pack_bf16x2(__builtin_amdgcn_exp2f(st[t][h8 + 2 * e]), __builtin_amdgcn_exp2f(st[t][h8 + 2 * e + 1]));
+          const uint32_t pk = pack_op2(__builtin_amdgcn_exp2f(st[t][h8 + 2 * e]), __builtin_amdgcn_exp2f(st[t][h8 + 2 * e + 1]));
           pfu[ks][e] = pk;
-          const bf16x2v_t pp = __builtin_bit_cast(bf16x2v_t, pk), one2 = __builtin_bit_cast(bf16x2v_t, 0x3f803f80u);
-          if (e & 1) s1 = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, s1, false);
-          else s0 = __builtin_amdgcn_fdot2_f32_bf16(pp, one2, s0, false);
+          if (e & 1) s1 = dot2_ones_op(pk, s1);
+          else s0 = dot2_ones_op(pk, s0);
         }
       }
     };
@@ -356,7 +353,9 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     if (t_issue >= 0) issue(t_issue);
     __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_sched_barrier(0);
-    constexpr float ALARM = 65536.f;
+    // fp16 operands: a probability must stay below 65504, so the alarm rings at 2^12 (a lane's partial sum of 16 values
+    // <= 2^12 each cannot reach fp16's infinity unnoticed: anything above 2^12 already fires)
+    constexpr float ALARM = WVN_OPERAND_F16 ? 4096.f : 65536.f;
     if (!fresh) expsum();
     if (fresh || __any(s0 + s1 > ALARM)) {
       if (!fresh) qk();   // the exponentials overwrote the scores
@@ -392,12 +391,12 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      union { u32x4_t u; bf16x8_t v; } pf;
+      union { u32x4_t u; opx8_t v; } pf;
       pf.u = pfu[ks];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8_t vf = *(const bf16x8_t*)(lds + fa[ks] + TILE_BYTES + dt * 4096);
-        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, ot[dt], 0, 0, 0);
+        const opx8_t vf = *(const opx8_t*)(lds + fa[ks] + TILE_BYTES + dt * 4096);
+        ot[dt] = wvn_mfma_32x32x16(vf, pf.v, ot[dt], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -440,14 +439,14 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const bf16_t* 
   const float inv = 1.0f / l_tot;
   const int qi = q0 + l31;
   if (qi < ntok) {
-    bf16_t* og = out + ((size_t)b * ntok_s + qi) * (heads * DH) + head * DH;
+    op16_t* og = out + ((size_t)b * ntok_s + qi) * (heads * DH) + head * DH;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2_t o;
-        o[0] = pack_bf16x2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
-        o[1] = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+        o[0] = pack_op2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
+        o[1] = pack_op2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
         *(u32x2_t*)(og + dt * 32 + 8 * g + 4 * hi) = o;
       }
   }
@@ -458,7 +457,7 @@ long long* g_attn_dbg = nullptr;  // set by wvn_debug_attention_timing (scripts/
 constexpr int ATTN_DEFAULT = 1;
 int g_attn_variant = ATTN_DEFAULT;   // 0: exact per-tile row max, 1: lazy (alarm on the row sums; what ships: -4 % attention time)
 
-void launch_pre(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
+void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out,
                 int heads, int nbh, int nqb, int ntok, int ntok_s, int npad) {
   // 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for 3 stages /
   // 3 workgroups and 13.2 for 4 stages / 2); row sums by v_dot2c_f32_bf16 on the packed P (plain fp32 adds, which hipcc packs
@@ -482,7 +481,7 @@ void launch_pre(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16
 }
 
 template <int NST, int OCC>
-void launch_v(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
+void launch_v(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out,
               int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, float c_exp) {
   if (g_attn_dbg) {
     hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb,
@@ -499,12 +498,12 @@ void launch_v(bool xcd, dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t
 
 }  // namespace
 
-void wvn_attention_bf16_set_debug(long long* dbg) { g_attn_dbg = dbg; }
-void wvn_attention_bf16_set_variant(int v) { g_attn_variant = v < 0 ? ATTN_DEFAULT : v; }  // < 0: back to the default
+void WVN_OPSYM(wvn_attention_bf16_set_debug)(long long* dbg) { g_attn_dbg = dbg; }
+void WVN_OPSYM(wvn_attention_bf16_set_variant)(int v) { g_attn_variant = v < 0 ? ATTN_DEFAULT : v; }  // < 0: back to the default
 
 // scale > 0: q holds the raw projections.  scale == 0: q is pre-multiplied by softmax_scale * log2(e) (EPI_QKV with
 // q_scale set), the kernel with the running max folded into the S^T MFMA chain runs.
-int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
+int WVN_OPSYM(wvn_attention_bf16_launch)(const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out, int B, int heads,
                               int ntok, int ntok_s, int npad, float scale, hipStream_t st) {
   if (!q || !k || !vt || !out || npad % QB != 0 || npad < ntok) return WVN_ERR_ARG;
   const int nqb = ceil_div(ntok, QB), nbh = B * heads;

@@ -22,7 +22,9 @@ SOURCES = [
     "attention_x3.hip", "attention_f32.hip",
     "segments.hip", "stego.hip", "mlp.hip", "pixel_mlp.hip", "supervision.hip", "slic.hip", "wire.hip",
 ]
-HEADERS = ["common.h", "wvn_internal.h", os.path.join("..", "..", "include", "wvn_hip.h")]
+# the kernels of the 16-bit-operand speed path are compiled twice (operand.h): bf16 operands, and fp16 operands (-> <name>_f16.o)
+DUAL_OPERAND = ["gemm_bf16.hip", "gemm_a384.hip", "gemm_n384.hip", "mlp_fused.hip", "qkv_fused.hip", "gemm_proj.hip", "attention_bf16.hip"]
+HEADERS = ["common.h", "operand.h", "wvn_internal.h", os.path.join("..", "..", "include", "wvn_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall",
          "-Wno-unused-function"]
 # bit-exact integer outputs need un-fused multiply/add in the k-means kernels (see stego.hip)
@@ -50,11 +52,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.normpath(os.path.join(HERE, h)) for h in HEADERS] + [os.path.abspath(__file__)]
     hipcc = _hipcc()
     jobs = []
-    for s in SOURCES:
+    units = [(s, s.replace(".hip", ".o"), []) for s in SOURCES] + \
+            [(s, s.replace(".hip", "_f16.o"), ["-DWVN_OPERAND_F16=1"]) for s in DUAL_OPERAND]
+    for s, o, defs in units:
         src = os.path.join(HERE, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(OBJ, o)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append((s, [hipcc] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj]))
+            jobs.append((o, [hipcc] + FLAGS + EXTRA.get(s, []) + defs + ["-c", src, "-o", obj]))
 
     def run(job):
         name, cmd = job
@@ -68,7 +72,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     print(f"[hipcc {name}]\n{log}", file=sys.stderr)
                 if rc != 0:
                     raise RuntimeError(f"hipcc failed on {name}:\n{log}")
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, o) for _, o, _ in units]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

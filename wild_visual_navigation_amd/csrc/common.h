@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #define WVN_OK 0
 #define WVN_ERR_ARG 1001      // bad shape / null pointer / unsupported configuration
 #define WVN_ERR_WORKSPACE 1002  // caller-provided workspace too small
@@ -43,7 +45,25 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, b);
 }
 
+// ---- fp16 operand format (WVN_PREC_F16: the speed path with 11 significand bits, operand.h) -----------------------------------
+typedef struct { uint16_t bits; } f16raw_t;  // raw fp16 bits in HBM, as a distinct type for the ElemIO dispatch below
+typedef __attribute__((ext_vector_type(2))) _Float16 wvn_f16x2_t;
+__host__ __device__ inline uint16_t f32_to_f16(float f) {
+  const _Float16 h = (_Float16)f;  // round-to-nearest-even, overflow -> inf
+  return __builtin_bit_cast(uint16_t, h);
+}
+__host__ __device__ inline float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ inline uint32_t pack_f16x2(float lo, float hi) {  // v_cvt_pk_f16_f32
+  const wvn_f32x2_t v = {lo, hi};
+  const wvn_f16x2_t b = __builtin_convertvector(v, wvn_f16x2_t);
+  return __builtin_bit_cast(uint32_t, b);
+}
+
 template <typename T> struct ElemIO;
+template <> struct ElemIO<f16raw_t> {
+  __device__ static inline float load(const f16raw_t* p) { return f16_to_f32(p->bits); }
+  __device__ static inline void store(f16raw_t* p, float v) { p->bits = f32_to_f16(v); }
+};
 template <> struct ElemIO<float> {
   __device__ static inline float load(const float* p) { return *p; }
   __device__ static inline void store(float* p, float v) { *p = v; }
@@ -70,6 +90,27 @@ __device__ inline double wave_sum_d(double v) {
   return v;
 }
 
+// ---- bilinear sampling with align_corners=True (dino_interface.py:87-90, stego_interface.py:107) in ONE fixed, explicitly
+// rounded operation order: the up-sampling kernel and the kernels that interpolate on the fly (pixel-resolution k-means)
+// must produce the same bits whatever contraction flags their translation unit is compiled with.
+// ATen: src = dst * (G-1)/(H-1) (fp32), i0 = (int)src, i1 = i0 + (i0 < G-1), w1 = src - i0, w0 = 1 - w1.
+struct LerpTap { int i0, i1; float w0, w1; };
+__host__ __device__ inline float lerp_scale(int G, int H) { return H > 1 ? (float)(G - 1) / (float)(H - 1) : 0.f; }
+__device__ inline LerpTap lerp_tap(int o, int G, float scale) {
+  const float s = __fmul_rn(scale, (float)o);
+  LerpTap t;
+  t.i0 = (int)s;
+  t.i1 = t.i0 + (t.i0 < G - 1 ? 1 : 0);
+  t.w1 = __fsub_rn(s, (float)t.i0);
+  t.w0 = __fsub_rn(1.f, t.w1);
+  return t;
+}
+__device__ inline float bilerp_fixed(float v00, float v01, float v10, float v11, float wx0, float wx1, float wy0, float wy1) {
+  const float t0 = __fmaf_rn(wx1, v01, __fmul_rn(wx0, v00));
+  const float t1 = __fmaf_rn(wx1, v11, __fmul_rn(wx0, v10));
+  return __fmaf_rn(wy1, t1, __fmul_rn(wy0, t0));
+}
+
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -89,6 +130,28 @@ __device__ inline int xcd_remap(int bid, int nblk) {
     hipError_t e__ = hipGetLastError();            \
     if (e__ != hipSuccess) return (int)e__;        \
   } while (0)
+
+// Opt kernels in to more than 64 KB of dynamic LDS.  The attribute is per DEVICE and one process may drive several GPUs
+// (DinoInterface.change_device, dino_interface.py:61-68), so `done` keeps one bit per device ordinal.  Setting the attribute
+// twice is harmless: two host threads racing here cost one redundant call, never a missing one.
+struct LdsOptIn {
+  std::atomic<unsigned long long> done{0};
+  template <typename... Fn>
+  int operator()(int bytes, Fn... fns) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    const void* list[] = {fns...};
+    for (const void* f : list) {
+      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e != hipSuccess) return (int)e;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+  }
+};
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

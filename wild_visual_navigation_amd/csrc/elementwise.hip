@@ -3,6 +3,8 @@
 //   cls rows  : token 0 of every frame = cls_token + pos[0]
 //   layernorm : one 64-lane wave per token row, two-pass statistics in registers, fp32 math
 //   upsample  : bilinear align_corners=True  token-major [B,G*G,D] -> NCHW [B,D,H,H]
+#include <type_traits>
+
 #include "common.h"
 #include "wvn_internal.h"
 
@@ -15,8 +17,18 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // ldp: row stride of the patch matrix in elements (>= 3*P*P; the pad columns, if any, are zeroed by the caller).
 // out_lo != nullptr (T = bf16_t only): exact mode, out receives the hi plane and out_lo the lo plane of the same value.
-template <typename T, int P>
-__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, T* __restrict__ out_lo, int ldp, int B, int S) {
+// Frame ingest: with gather tables (rows / cols != nullptr) the network input pixel (y, x) is pixel
+// (rows[y], cols[x]) of the [B,3,Hs,Ws] SOURCE frame -- T.Resize(NEAREST) + T.CenterCrop (dino_interface.py:52-59,
+// image_projector.py:56-59) never materialise; TIN = unsigned char: raw 8-bit pixels, x / 255 fused as well.
+struct Gather { const int* rows; const int* cols; int Hs, Ws; };
+template <typename TIN>
+__device__ inline float load_pixel(const TIN* p) {
+  if constexpr (sizeof(TIN) == 1) return (float)*p / 255.0f;  // == torch's x.float() / 255
+  else return *p;
+}
+template <typename T, int P, typename TIN = float>
+__global__ void patchify_kernel(const TIN* __restrict__ img, T* __restrict__ out, T* __restrict__ out_lo, int ldp, int B, int S,
+                                Gather gt = Gather{nullptr, nullptr, 0, 0}) {
   const int G = S / P;
   const long long total = (long long)B * G * G * 3 * P;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,14 +42,16 @@ __global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ o
   int b = (int)(r / 3);
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
-  const float* src = img + (((size_t)b * 3 + c) * S + (gy * P + py)) * S + gx * P;
+  const int Hs = gt.rows ? gt.Hs : S, Ws = gt.rows ? gt.Ws : S;
+  const TIN* src = img + (((size_t)b * 3 + c) * Hs + (gt.rows ? gt.rows[gy * P + py] : gy * P + py)) * Ws;
   const size_t doff = ((size_t)b * G * G + gy * G + gx) * ldp + c * P * P + py * P;
   T* dst = out + doff;
 #pragma unroll
   for (int px = 0; px < P; ++px) {
-    const float v = (src[px] - mean[c]) / stdv[c];
+    const int x = gx * P + px;
+    const float v = (load_pixel(src + (gt.cols ? gt.cols[x] : x)) - mean[c]) / stdv[c];
     ElemIO<T>::store(dst + px, v);
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
       if (out_lo) out_lo[doff + px] = f32_to_bf16(v - bf16_to_f32(f32_to_bf16(v)));
     }
   }
@@ -47,8 +61,9 @@ __global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ o
 // as float4 (fully coalesced, 43 KB), normalised, converted, and scattered into an LDS image that already has the output
 // order [gx][c][py][px]; the 21 KB image then leaves as contiguous 16-byte stores (the element-order kernel above writes
 // 16-byte fragments 384 B apart).
-template <typename TIN>  // float: pixels in [0,1]; unsigned char: raw 8-bit pixels, x / 255 is fused (frame ingest without the
+template <typename TIN, bool F16 = false>  // float: pixels in [0,1]; unsigned char: raw 8-bit pixels, x / 255 is fused (frame ingest without the
                          // 4x larger fp32 upload: quick_start.py:160-161 / ros_converter.py:113-126 do the division on the host side)
+                         // F16: fp16 instead of bf16 operands (WVN_PREC_F16)
 __global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const TIN* __restrict__ img, bf16_t* __restrict__ out, int S) {
   extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192]
   const int G = S / 8, gy = blockIdx.x, b = blockIdx.y;
@@ -67,12 +82,45 @@ __global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const TIN* __r
     }
     const int gx = x4 >> 1, px = (x4 & 1) * 4;
     const float m = mean[c], sd = stdv[c];
-    u32x2_t o = {pack_bf16x2((v[0] - m) / sd, (v[1] - m) / sd), pack_bf16x2((v[2] - m) / sd, (v[3] - m) / sd)};
+    auto pk = [](float a, float b2) { return F16 ? pack_f16x2(a, b2) : pack_bf16x2(a, b2); };
+    u32x2_t o = {pk((v[0] - m) / sd, (v[1] - m) / sd), pk((v[2] - m) / sd, (v[3] - m) / sd)};
     *(u32x2_t*)(prow + gx * 192 + c * 64 + py * 8 + px) = o;
   }
   __syncthreads();
   u32x4_t* dst = (u32x4_t*)(out + ((size_t)b * G * G + (size_t)gy * G) * 192);
   for (int i = threadIdx.x; i < G * 192 / 8; i += 256) dst[i] = ((const u32x4_t*)prow)[i];
+}
+
+// The same patch-row panel gathered from a larger source frame through the ingest tables (one element per thread and step:
+// a NEAREST down-sampling touches isolated pixels, there is nothing to vectorise on the read side).
+template <typename TIN, bool F16>
+__global__ __launch_bounds__(256) void patchify8_gather_rows_kernel(const TIN* __restrict__ img, bf16_t* __restrict__ out, int S,
+                                                                    Gather gt) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192]
+  const int G = S / 8, gy = blockIdx.x, b = blockIdx.y;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  for (int i = threadIdx.x; i < 3 * 8 * S; i += 256) {
+    const int c = i / (8 * S), r = i - c * 8 * S, py = r / S, x = r - py * S;
+    const float raw = load_pixel(img + (((size_t)b * 3 + c) * gt.Hs + gt.rows[gy * 8 + py]) * gt.Ws + gt.cols[x]);
+    const float v = (raw - mean[c]) / stdv[c];
+    prow[(x >> 3) * 192 + c * 64 + py * 8 + (x & 7)] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
+  }
+  __syncthreads();
+  u32x4_t* dst = (u32x4_t*)(out + ((size_t)b * G * G + (size_t)gy * G) * 192);
+  for (int i = threadIdx.x; i < G * 192 / 8; i += 256) dst[i] = ((const u32x4_t*)prow)[i];
+}
+
+// NEAREST resize + crop as an image (ImageProjector.resize_image, image_projector.py:199-200): out[b,c,y,x] = in[b,c,rows[y],cols[x]]
+template <typename T>
+__global__ void gather_image_kernel(const T* __restrict__ in, T* __restrict__ out, long long planes, int Ho, int Wo, Gather gt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= planes * Ho * Wo) return;
+  const int x = (int)(i % Wo);
+  const long long r = i / Wo;
+  const int y = (int)(r % Ho);
+  const long long pl = r / Ho;
+  out[i] = in[(pl * gt.Hs + gt.rows[y]) * gt.Ws + gt.cols[x]];
 }
 
 __global__ void cls_rows_kernel(const float* __restrict__ cls_pos, float* __restrict__ x, int B, int ntok, int D) {
@@ -123,7 +171,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     int c = lane + 64 * i;
     float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
     if (y) ElemIO<T>::store(y + (size_t)row * ldy + c, o);
-    if constexpr (sizeof(T) == 2) {  // exact mode: lo plane of the same value
+    if constexpr (std::is_same<T, bf16_t>::value) {  // exact mode: lo plane of the same value
       if (y_lo) y_lo[(size_t)row * ldy + c] = f32_to_bf16(o - bf16_to_f32(f32_to_bf16(o)));
     }
     if (y2) y2[(size_t)row * ldy2 + c] = o;
@@ -135,7 +183,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // store, a wave handles 4 rows per pass and LN_RPW rows in all (gamma / beta stay in registers).  Same two-pass fp32
 // statistics as the generic kernel.
 constexpr int LN_RPW = 16;
-template <bool PLANES>  // PLANES: exact mode, y_lo receives the lo plane (x - bf16(x)) of every output value
+template <bool PLANES, bool F16 = false>  // PLANES: exact mode, y_lo receives the lo plane (x - bf16(x)) of every output value; F16: fp16 output
 __global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                 bf16_t* __restrict__ y_lo, int ldy, int rows, float eps) {
@@ -184,7 +232,8 @@ __global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __r
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[2 * i + (e >> 2)][e & 3] - mean) * rstd * gm[2 * i + (e >> 2)][e & 3] + bt[2 * i + (e >> 2)][e & 3];
-        const u32x4_t u = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        auto pk = [](float a, float b2) { return F16 ? pack_f16x2(a, b2) : pack_bf16x2(a, b2); };
+        const u32x4_t u = {pk(o[0], o[1]), pk(o[2], o[3]), pk(o[4], o[5]), pk(o[6], o[7])};
         *(u32x4_t*)(y + (size_t)row * ldy + 128 * i + 8 * sub) = u;
         if constexpr (PLANES) {
           u32x4_t w;
@@ -198,12 +247,14 @@ __global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __r
   }
 }
 
+template <bool F16>
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd,
                                      int rows, int cols) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * cols) return;
   int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
-  dst[(size_t)r * ldd + c] = f32_to_bf16(src[(size_t)r * lds_ + c]);
+  const float v = src[(size_t)r * lds_ + c];
+  dst[(size_t)r * ldd + c] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
 }
 
 // fp32 [rows, cols] -> hi / lo bf16 planes (exact-mode operands of gemm_x3.hip)
@@ -230,11 +281,9 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
                                                        int G, int D, int H) {
   extern __shared__ float rows[];  // [2][G][UP_CH+1]
   const int y = blockIdx.x, cs = blockIdx.y * UP_CH, b = blockIdx.z;
-  const float scale = (H > 1) ? (float)(G - 1) / (float)(H - 1) : 0.f;
-  const float sy = scale * (float)y;
-  const int y0 = (int)sy;
-  const int y1 = y0 + (y0 < G - 1 ? 1 : 0);
-  const float wy1 = sy - (float)y0, wy0 = 1.f - wy1;
+  const float scale = lerp_scale(G, H);
+  const LerpTap ty = lerp_tap(y, G, scale);
+  const int y0 = ty.i0, y1 = ty.i1;
   const int tid = threadIdx.x;
   const int nload = 2 * G * UP_CH;
   for (int i = tid; i < nload; i += blockDim.x) {
@@ -249,13 +298,10 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   for (int i = tid; i < UP_CH * H; i += blockDim.x) {
     int xo = i % H, c = i / H;
     if (cs + c >= D) continue;
-    float sx = scale * (float)xo;
-    int x0 = (int)sx;
-    int x1 = x0 + (x0 < G - 1 ? 1 : 0);
-    float wx1 = sx - (float)x0, wx0 = 1.f - wx1;
-    float t0 = wx0 * rows[(0 * G + x0) * (UP_CH + 1) + c] + wx1 * rows[(0 * G + x1) * (UP_CH + 1) + c];
-    float t1 = wx0 * rows[(1 * G + x0) * (UP_CH + 1) + c] + wx1 * rows[(1 * G + x1) * (UP_CH + 1) + c];
-    out[(((size_t)b * D + cs + c) * H + y) * H + xo] = wy0 * t0 + wy1 * t1;
+    const LerpTap tx = lerp_tap(xo, G, scale);
+    out[(((size_t)b * D + cs + c) * H + y) * H + xo] =
+        bilerp_fixed(rows[(0 * G + tx.i0) * (UP_CH + 1) + c], rows[(0 * G + tx.i1) * (UP_CH + 1) + c],
+                     rows[(1 * G + tx.i0) * (UP_CH + 1) + c], rows[(1 * G + tx.i1) * (UP_CH + 1) + c], tx.w0, tx.w1, ty.w0, ty.w1);
   }
 }
 
@@ -275,42 +321,77 @@ __global__ void upsample_nearest_i32_kernel(const int* __restrict__ lab, int* __
 
 }  // namespace
 
-// out_mode: 0 fp32, 1 bf16, 2 hi/lo bf16 planes (exact mode; lo plane = patches_lo).  ldp: row stride of the patch
-// matrix in elements (0 = 3*P*P).  P in {8, 14, 16}.
-int wvn_patchify_launch(const void* img_v, int img_u8, void* patches, void* patches_lo, int out_mode, int ldp, int B, int S, int P,
+// out_mode: 0 fp32, 1 bf16, 2 hi/lo bf16 planes (exact mode; lo plane = patches_lo), 3 fp16.  ldp: row stride of the patch
+// matrix in elements (0 = 3*P*P).  P in {8, 14, 16}.  ing != nullptr: the frames are [B,3,src_h,src_w] and network pixel (y, x)
+// is frame pixel (rows[y], cols[x]) -- NEAREST resize + centre crop fused into the patch gather.
+template <typename TIN>
+static int patchify_any(const TIN* img, void* patches, void* patches_lo, int out_mode, int ldp, int B, int S, int P, const Gather& gt,
                         hipStream_t st) {
-  const float* img = (const float*)img_v;
-  const int KP = 3 * P * P;
-  if (ldp == 0) ldp = KP;
-  if (ldp < KP || (out_mode == 2 && !patches_lo)) return WVN_ERR_ARG;
-  if (img_u8) {  // 8-bit frames: bf16 / P = 8 row-panel kernel only
-    if (!img_v || !patches || out_mode != 1 || P != 8 || ldp != KP || (S % 8) != 0 || (((uintptr_t)img_v & 3) != 0) ||
-        (((uintptr_t)patches & 15) != 0) || (S / 8) * 192 * 2 > 64 * 1024)
-      return WVN_ERR_ARG;
-    hipLaunchKernelGGL(patchify8_bf16_rows_kernel<unsigned char>, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st,
-                       (const unsigned char*)img_v, (bf16_t*)patches, S);
-    WVN_LAUNCH_CHECK();
-    return WVN_OK;
-  }
-  if (!img || !patches || S % P != 0) return WVN_ERR_ARG;
-  const int G = S / P;
-  long long total = (long long)B * G * G * 3 * P;
+  const int G = S / P, KP = 3 * P * P;
+  const long long total = (long long)B * G * G * 3 * P;
   dim3 grid((unsigned)((total + 255) / 256));
   bf16_t* lo = out_mode == 2 ? (bf16_t*)patches_lo : nullptr;
-  if (P == 8) {
-    if (out_mode == 1 && ldp == KP && (S % 8) == 0 && (((uintptr_t)img | (uintptr_t)patches) & 15) == 0 && (S / 8) * 192 * 2 <= 64 * 1024)
-      hipLaunchKernelGGL(patchify8_bf16_rows_kernel<float>, dim3(S / 8, B), dim3(256), (S / 8) * 192 * 2, st, img, (bf16_t*)patches, S);
-    else if (out_mode) hipLaunchKernelGGL((patchify_kernel<bf16_t, 8>), grid, dim3(256), 0, st, img, (bf16_t*)patches, lo, ldp, B, S);
-    else hipLaunchKernelGGL((patchify_kernel<float, 8>), grid, dim3(256), 0, st, img, (float*)patches, (float*)nullptr, ldp, B, S);
-  } else if (P == 16) {
-    if (out_mode) hipLaunchKernelGGL((patchify_kernel<bf16_t, 16>), grid, dim3(256), 0, st, img, (bf16_t*)patches, lo, ldp, B, S);
-    else hipLaunchKernelGGL((patchify_kernel<float, 16>), grid, dim3(256), 0, st, img, (float*)patches, (float*)nullptr, ldp, B, S);
-  } else if (P == 14) {
-    if (out_mode) hipLaunchKernelGGL((patchify_kernel<bf16_t, 14>), grid, dim3(256), 0, st, img, (bf16_t*)patches, lo, ldp, B, S);
-    else hipLaunchKernelGGL((patchify_kernel<float, 14>), grid, dim3(256), 0, st, img, (float*)patches, (float*)nullptr, ldp, B, S);
-  } else {
-    return WVN_ERR_ARG;
+  const bool rows_ok = P == 8 && ldp == KP && (S % 8) == 0 && (((uintptr_t)patches) & 15) == 0 && (S / 8) * 192 * 2 <= 64 * 1024;
+  const size_t shm = (size_t)(S / 8) * 192 * 2;
+  if (rows_ok && (out_mode == 1 || out_mode == 3)) {
+    if (gt.rows) {
+      if (out_mode == 3) hipLaunchKernelGGL((patchify8_gather_rows_kernel<TIN, true>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S, gt);
+      else hipLaunchKernelGGL((patchify8_gather_rows_kernel<TIN, false>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S, gt);
+      return WVN_OK;
+    }
+    if ((((uintptr_t)img) & (sizeof(TIN) == 1 ? 3 : 15)) == 0) {
+      if (out_mode == 3) hipLaunchKernelGGL((patchify8_bf16_rows_kernel<TIN, true>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S);
+      else hipLaunchKernelGGL((patchify8_bf16_rows_kernel<TIN, false>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S);
+      return WVN_OK;
+    }
   }
+#define WVN_PATCHIFY_P(PP)                                                                                                              \
+  do {                                                                                                                                 \
+    if (out_mode == 3) hipLaunchKernelGGL((patchify_kernel<f16raw_t, PP, TIN>), grid, dim3(256), 0, st, img, (f16raw_t*)patches,        \
+                                          (f16raw_t*)nullptr, ldp, B, S, gt);                                                          \
+    else if (out_mode) hipLaunchKernelGGL((patchify_kernel<bf16_t, PP, TIN>), grid, dim3(256), 0, st, img, (bf16_t*)patches, lo, ldp,   \
+                                          B, S, gt);                                                                                   \
+    else hipLaunchKernelGGL((patchify_kernel<float, PP, TIN>), grid, dim3(256), 0, st, img, (float*)patches, (float*)nullptr, ldp, B,   \
+                            S, gt);                                                                                                    \
+  } while (0)
+  if (P == 8) WVN_PATCHIFY_P(8);
+  else if (P == 16) WVN_PATCHIFY_P(16);
+  else if (P == 14) WVN_PATCHIFY_P(14);
+  else return WVN_ERR_ARG;
+#undef WVN_PATCHIFY_P
+  return WVN_OK;
+}
+
+int wvn_patchify_launch(const void* img_v, int img_u8, void* patches, void* patches_lo, int out_mode, int ldp, int B, int S, int P,
+                        hipStream_t st, const WvnIngest* ing) {
+  const int KP = 3 * P * P;
+  if (ldp == 0) ldp = KP;
+  if (!img_v || !patches || B <= 0 || P <= 0 || S % P != 0 || out_mode < 0 || out_mode > 3 || ldp < KP ||
+      (out_mode == 2 && !patches_lo))
+    return WVN_ERR_ARG;
+  Gather gt{nullptr, nullptr, 0, 0};
+  if (ing) {
+    if (!ing->rows || !ing->cols || ing->src_h <= 0 || ing->src_w <= 0) return WVN_ERR_ARG;
+    gt = Gather{ing->rows, ing->cols, ing->src_h, ing->src_w};
+  }
+  const int rc = img_u8 ? patchify_any((const unsigned char*)img_v, patches, patches_lo, out_mode, ldp, B, S, P, gt, st)
+                        : patchify_any((const float*)img_v, patches, patches_lo, out_mode, ldp, B, S, P, gt, st);
+  if (rc != WVN_OK) return rc;
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+// out[planes, out_h, out_w] = in[planes, src_h, src_w] gathered through the ingest tables; elem_bytes 1 (uint8) or 4 (fp32 / int32)
+int wvn_gather_image_launch(const void* in, void* out, long long planes, int out_h, int out_w, int elem_bytes, const WvnIngest* ing,
+                            hipStream_t st) {
+  if (!in || !out || !ing || !ing->rows || !ing->cols || planes <= 0 || out_h <= 0 || out_w <= 0 || ing->src_h <= 0 || ing->src_w <= 0)
+    return WVN_ERR_ARG;
+  const Gather gt{ing->rows, ing->cols, ing->src_h, ing->src_w};
+  const long long n = planes * out_h * out_w;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (elem_bytes == 1) hipLaunchKernelGGL(gather_image_kernel<unsigned char>, grid, dim3(256), 0, st, (const unsigned char*)in, (unsigned char*)out, planes, out_h, out_w, gt);
+  else if (elem_bytes == 4) hipLaunchKernelGGL(gather_image_kernel<unsigned int>, grid, dim3(256), 0, st, (const unsigned int*)in, (unsigned int*)out, planes, out_h, out_w, gt);
+  else return WVN_ERR_ARG;
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -358,30 +439,32 @@ static int ln_dispatch(const float* x, const float* g, const float* b, T* y, int
   return WVN_OK;
 }
 
-// y_lo != nullptr (with y_bf16): exact mode, y / y_lo receive the hi / lo planes
-int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
+// y_fmt: 0 fp32, 1 bf16, 2 fp16 output rows.  y_lo != nullptr (with y_fmt == 1): exact mode, y / y_lo receive the hi / lo planes
+int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_fmt, int ldy,
                          float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
                          int ntok_s, hipStream_t st, void* y_lo) {
-  if (!x || !gamma || !beta || (D % 64) != 0 || rows_out <= 0 || (y_lo && (!y_bf16 || !y))) return WVN_ERR_ARG;
-  if (y_bf16 && y && !y2 && !drop_cls && D == 384 && (ldy % 8) == 0 &&
+  if (!x || !gamma || !beta || (D % 64) != 0 || rows_out <= 0 || y_fmt < 0 || y_fmt > 2 || (y_lo && (y_fmt != 1 || !y))) return WVN_ERR_ARG;
+  if (y_fmt && y && !y2 && !drop_cls && D == 384 && (ldy % 8) == 0 &&
       ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)y_lo) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0) {
+    const dim3 grid(ceil_div(rows_out, 4 * LN_RPW));
     if (y_lo)
-      hipLaunchKernelGGL(layernorm384_bf16_kernel<true>, dim3(ceil_div(rows_out, 4 * LN_RPW)), dim3(256), 0, st, x, gamma, beta,
-                         (bf16_t*)y, (bf16_t*)y_lo, ldy, rows_out, eps);
+      hipLaunchKernelGGL((layernorm384_bf16_kernel<true>), grid, dim3(256), 0, st, x, gamma, beta, (bf16_t*)y, (bf16_t*)y_lo, ldy, rows_out, eps);
+    else if (y_fmt == 2)
+      hipLaunchKernelGGL((layernorm384_bf16_kernel<false, true>), grid, dim3(256), 0, st, x, gamma, beta, (bf16_t*)y, (bf16_t*)nullptr, ldy, rows_out, eps);
     else
-      hipLaunchKernelGGL(layernorm384_bf16_kernel<false>, dim3(ceil_div(rows_out, 4 * LN_RPW)), dim3(256), 0, st, x, gamma, beta,
-                         (bf16_t*)y, (bf16_t*)nullptr, ldy, rows_out, eps);
+      hipLaunchKernelGGL((layernorm384_bf16_kernel<false>), grid, dim3(256), 0, st, x, gamma, beta, (bf16_t*)y, (bf16_t*)nullptr, ldy, rows_out, eps);
     WVN_LAUNCH_CHECK();
     return WVN_OK;
   }
-  if (y_bf16) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, (bf16_t*)y_lo, st);
+  if (y_fmt == 2) return ln_dispatch<f16raw_t>(x, gamma, beta, (f16raw_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, (f16raw_t*)nullptr, st);
+  if (y_fmt == 1) return ln_dispatch<bf16_t>(x, gamma, beta, (bf16_t*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, (bf16_t*)y_lo, st);
   return ln_dispatch<float>(x, gamma, beta, (float*)y, ldy, y2, ldy2, rows_out, D, eps, drop_cls, ntok, ntok_s, (float*)nullptr, st);
 }
 
-int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st) {
+int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st, int f16) {
   long long n = (long long)rows * cols;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds_, dst, ldd,
-                     rows, cols);
+  if (f16) hipLaunchKernelGGL(cast_f32_bf16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
+  else hipLaunchKernelGGL(cast_f32_bf16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

@@ -28,7 +28,7 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "common.h"
+#include "operand.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -48,14 +48,14 @@ constexpr int BM = 256;
 enum { A_BF16 = 0, A_GELU = 1, A_RELU = 2, A_RESID = 3, A_QK = 4, A_V = 5 };  // QKV runs as two launches: q|k (TR tiles) and v (V^T tiles)
 
 struct A384Params {
-  const bf16_t* A; int lda;
-  const bf16_t* W;     // [N][384]
+  const op16_t* A; int lda;
+  const op16_t* W;     // [N][384]
   const float* bias;   // [N] or nullptr
   void* C; int ldc;    // bf16 or fp32 (A_RESID: in/out)
   int M, N;
-  bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad; int ntok_s;
+  op16_t* q; op16_t* k; op16_t* vt; int heads; int npad; int ntok_s;
   float q_scale;       // A_QK: multiplier of the q column tiles (1 = none)
-  bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;  // one buffer descriptor for q / k / v^T (byte offsets from qkv_base)
+  op16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;  // one buffer descriptor for q / k / v^T (byte offsets from qkv_base)
   long long* dbg;  // TIMING builds: per wave {wait+barrier, mfma, epilogue, total} shader cycles
 };
 
@@ -141,11 +141,11 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
 
   // ---- bias -> LDS, A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7) --------
   for (int i = tid; i < p.N; i += 512) ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
-  bf16x8_t xf[KD / 16];
+  opx8_t xf[KD / 16];
   auto load_a = [&]() {
-    const bf16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
+    const op16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
 #pragma unroll
-    for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
+    for (int s = 0; s < KD / 16; ++s) xf[s] = *(const opx8_t*)(ap + s * 16);
   };
 
   f32x16_t acc[2], prev[2];
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
     int xc = xorc;
     asm volatile("" : "+v"(xc));  // keep the 8 swizzled offsets from being hoisted out of the loop (8 live VGPRs otherwise)
     auto rd = [&](int s, int t) {
-      return *(const bf16x8_t*)(base + t * 8192 + (((2 * s + hi) ^ xc) << 4));
+      return *(const opx8_t*)(base + t * 8192 + (((2 * s + hi) ^ xc) << 4));
     };
     constexpr int LA = 2;  // k-steps of fragments in flight
-    bf16x8_t wf[2 * LA];
+    opx8_t wf[2 * LA];
 #pragma unroll
     for (int i = 0; i < 2 * LA; ++i) wf[i] = rd(i >> 1, i & 1);
 #pragma unroll
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
       for (int t = 0; t < 2; ++t) {
         const int slot = (s % LA) * 2 + t;
         if constexpr (TR)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[slot], xf[ks * 8 + s], acc[t], 0, 0, 0);
+          acc[t] = wvn_mfma_32x32x16(wf[slot], xf[ks * 8 + s], acc[t], 0, 0, 0);
         else
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks * 8 + s], wf[slot], acc[t], 0, 0, 0);
+          acc[t] = wvn_mfma_32x32x16(xf[ks * 8 + s], wf[slot], acc[t], 0, 0, 0);
         if (s + LA < 8) wf[slot] = rd(s + LA, t);
       }
     }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
             f32x4_t o = {a[0], a[1], b[0], b[1]};
             *(f32x4_t*)(stg + l31 * 272 + c * 4) = o;
           } else {
-            u32x2_t o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1])};
+            u32x2_t o = {pack_op2(a[0], a[1]), pack_op2(b[0], b[1])};
             *(u32x2_t*)(stg + l31 * 144 + c * 2) = o;
           }
         }
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
           // tokens 8g + 4hi + e of the wave's 32; V^T is stored with bits 2 and 3 of the token index swapped
           // inside every aligned group of 16 (attention_bf16.hip): position 16 (g >> 1) + 8 hi + 4 (g & 1) + e
           const int mloc = 16 * (g >> 1) + 8 * hi + 4 * (g & 1);
-          u32x2_t o = {pack_bf16x2(prev[t][4 * g + 0], prev[t][4 * g + 1]),
-                       pack_bf16x2(prev[t][4 * g + 2], prev[t][4 * g + 3])};
+          u32x2_t o = {pack_op2(prev[t][4 * g + 0], prev[t][4 * g + 1]),
+                       pack_op2(prev[t][4 * g + 2], prev[t][4 * g + 3])};
           *(u32x2_t*)(stg + (32 * t + l31) * 80 + mloc * 2) = o;
         }
       }
@@ -431,13 +431,8 @@ int a384_num_cus() {
 
 template <int EPI, bool TIMING>
 int launch_k(const A384Params& p, int lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_a384_kernel<EPI, TIMING>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, A384_LDS_MAX);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(A384_LDS_MAX, (const void*)gemm_a384_kernel<EPI, TIMING>)) return rc;
   // one persistent workgroup per CU (144 KB of LDS each), never more workgroups than (row block, column tile) units
   const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
   const int grid = (int)(units < a384_num_cus() ? units : a384_num_cus());
@@ -457,7 +452,7 @@ int launch(const A384Params& p, hipStream_t st) {
 
 // Eligibility: K == 384, N % 64 == 0, 16-byte aligned operands; returns WVN_ERR_ARG otherwise so the
 // caller can use the generic tiled kernel.  epi uses the GemmEpilogue codes of wvn_internal.h.
-int wvn_gemm_a384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
+int WVN_OPSYM(wvn_gemm_a384_launch)(const GemmBf16Params& g, int epi, hipStream_t st) {
   if (g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.A || !g.W || (g.lda % 8) != 0) return WVN_ERR_ARG;
   if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return WVN_ERR_ARG;
   A384Params p{};
@@ -480,7 +475,7 @@ int wvn_gemm_a384_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
       const uintptr_t hi = std::max({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
       const size_t one = (size_t)(g.M / (g.ntok_s > 0 ? g.ntok_s : 1)) * g.heads * g.npad * 64 * 2;
       if (hi - lo + one >= (1ull << 31)) return WVN_ERR_ARG;  // one 32-bit-offset buffer descriptor must span q, k and v^T
-      p.qkv_base = (bf16_t*)lo; p.q_off = (unsigned)((uintptr_t)g.q - lo); p.k_off = (unsigned)((uintptr_t)g.k - lo);
+      p.qkv_base = (op16_t*)lo; p.q_off = (unsigned)((uintptr_t)g.q - lo); p.k_off = (unsigned)((uintptr_t)g.k - lo);
       p.v_off = (unsigned)((uintptr_t)g.vt - lo); p.qkv_bytes = (unsigned)(hi - lo + one);
       if (g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 16) || (g.M % 16) || (g.npad % 16)) return WVN_ERR_ARG;
       const int D = g.heads * 64;

@@ -21,7 +21,7 @@
 //
 // Fragment maps (v_mfma_f32_32x32x16_bf16): A: lane l holds row l&31, k-slots (l>>5)*8+j;
 // B: lane l holds col l&31, same k-slots; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
-#include "common.h"
+#include "operand.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -62,7 +62,7 @@ constexpr bool out_is_bf16() {
 // TR = false: accumulators hold C   (lane = col n, regs = rows m)  -> LDS image [n][m]   (V^T tiles)
 template <int EPI, bool TR, int PD, int NK>
 __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsigned char* smem) {
-  bf16_t* lds = (bf16_t*)smem;
+  op16_t* lds = (op16_t*)smem;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -81,8 +81,8 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
   // waits only for the tile it is about to move to LDS while PD-1 younger tiles stay in flight.
   u32x4_t ra[PD][4], rb[PD][4];
   const int srow = tid >> 3, skc = tid & 7;
-  const bf16_t* pa[4];
-  const bf16_t* pb[4];
+  const op16_t* pa[4];
+  const op16_t* pb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     pa[i] = p.A + (size_t)min(m0 + srow + 32 * i, p.M - 1) * p.lda + skc * 8;
@@ -96,8 +96,8 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
     }
   };
   auto store_regs = [&](int stage, const u32x4_t (&a)[4], const u32x4_t (&b)[4]) {
-    bf16_t* As = lds + stage * STAGE_ELEMS;
-    bf16_t* Bs = As + BM * LDS_STRIDE;
+    op16_t* As = lds + stage * STAGE_ELEMS;
+    op16_t* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int row = srow + 32 * i;
@@ -115,25 +115,25 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int stage) {
-    const bf16_t* As = lds + stage * STAGE_ELEMS;
-    const bf16_t* Bs = As + BM * LDS_STRIDE;
-    const bf16_t* a_base = As + (wm * 64 + l31) * LDS_STRIDE + hi * 8;
-    const bf16_t* b_base = Bs + (wn * 64 + l31) * LDS_STRIDE + hi * 8;
+    const op16_t* As = lds + stage * STAGE_ELEMS;
+    const op16_t* Bs = As + BM * LDS_STRIDE;
+    const op16_t* a_base = As + (wm * 64 + l31) * LDS_STRIDE + hi * 8;
+    const op16_t* b_base = Bs + (wn * 64 + l31) * LDS_STRIDE + hi * 8;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8_t af[2], bfr[2];
+      opx8_t af[2], bfr[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8_t*)(a_base + i * 32 * LDS_STRIDE + s * 16);
+      for (int i = 0; i < 2; ++i) af[i] = *(const opx8_t*)(a_base + i * 32 * LDS_STRIDE + s * 16);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8_t*)(b_base + j * 32 * LDS_STRIDE + s * 16);
+      for (int j = 0; j < 2; ++j) bfr[j] = *(const opx8_t*)(b_base + j * 32 * LDS_STRIDE + s * 16);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (TR)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = wvn_mfma_32x32x16(bfr[j], af[i], acc[i][j], 0, 0, 0);
           else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = wvn_mfma_32x32x16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
   };
@@ -202,8 +202,8 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
           }
         }
         if constexpr (OB) {
-          u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *(u32x2_t*)((bf16_t*)smem + lane_dim * CT_BF16_STRIDE + c) = o;
+          u32x2_t o = {pack_op2(v[0], v[1]), pack_op2(v[2], v[3])};
+          *(u32x2_t*)((op16_t*)smem + lane_dim * CT_BF16_STRIDE + c) = o;
         } else {
           f32x4_t o = {v[0], v[1], v[2], v[3]};
           *(f32x4_t*)((float*)smem + lane_dim * CT_F32_STRIDE + c) = o;
@@ -218,7 +218,7 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
     const int which = n0 / D;  // tile-uniform (D % 128 == 0)
     const int cbase = n0 - which * D;
     if constexpr (TR) {  // q / k : image [m][n]; dst[(b*h + head)*npad + t][d]
-      bf16_t* dst = which == 0 ? p.q : p.k;
+      op16_t* dst = which == 0 ? p.q : p.k;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int ch = tid + 256 * it, row = ch >> 4, c8 = (ch & 15) * 8;
@@ -226,7 +226,7 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
         if (m >= p.M) continue;
         const int b = m / p.ntok_s, t = m - b * p.ntok_s;
         const int cc = cbase + c8, head = cc >> 6, d = cc & 63;
-        const u32x4_t val = *(const u32x4_t*)((const bf16_t*)smem + row * CT_BF16_STRIDE + c8);
+        const u32x4_t val = *(const u32x4_t*)((const op16_t*)smem + row * CT_BF16_STRIDE + c8);
         *(u32x4_t*)(dst + (((size_t)b * p.heads + head) * p.npad + t) * 64 + d) = val;
       }
     } else {  // v : image [n = (head, d)][m]; vt[(b*h + head)*64 + d][t], 8 tokens per store
@@ -237,19 +237,19 @@ __device__ inline void gemm_tile(const GemmBf16Params& p, int tm, int tn, unsign
         if (m >= p.M) continue;  // M % 16 == 0 (ntok_s % 16 == 0): a chunk (and its permutation group of 16) is entirely in or out
         const int b = m / p.ntok_s, t = m - b * p.ntok_s;
         const int cc = cbase + row, head = cc >> 6, d = cc & 63;
-        const u32x4_t val = *(const u32x4_t*)((const bf16_t*)smem + row * CT_BF16_STRIDE + c8);
+        const u32x4_t val = *(const u32x4_t*)((const op16_t*)smem + row * CT_BF16_STRIDE + c8);
         *(u32x4_t*)(p.vt + (((size_t)b * p.heads + head) * 64 + d) * p.npad + t) = val;
       }
     }
   } else if constexpr (OB) {
-    bf16_t* C = (bf16_t*)p.C;
+    op16_t* C = (op16_t*)p.C;
     const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)C & 15) == 0);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int ch = tid + 256 * it, row = ch >> 4, c8 = (ch & 15) * 8;
       const int m = m0 + row, n = n0 + c8;
       if (m >= p.M || n >= p.N) continue;
-      const bf16_t* src = (const bf16_t*)smem + row * CT_BF16_STRIDE + c8;
+      const op16_t* src = (const op16_t*)smem + row * CT_BF16_STRIDE + c8;
       if (vec_ok && n + 8 <= p.N) {
         *(u32x4_t*)(C + (size_t)m * p.ldc + n) = *(const u32x4_t*)src;
       } else {
@@ -305,13 +305,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
 
 template <int EPI, int PD, int NK>
 int launch_v(const GemmBf16Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, PD, NK>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(GEMM_LDS_BYTES, (const void*)gemm_bf16_kernel<EPI, PD, NK>)) return rc;
   int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, PD, NK>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
@@ -344,22 +339,22 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
 
 }  // namespace
 
-int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
+int WVN_OPSYM(wvn_gemm_bf16_launch)(const GemmBf16Params& p, int epi, hipStream_t st) {
   if (!p.A || !p.W || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 8) != 0 || (p.ldw % 8) != 0)
     return WVN_ERR_ARG;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return WVN_ERR_ARG;
   // attention projection + residual at sizes that fill the chip: W resident in LDS, built for HBM throughput (gemm_proj.hip)
   if (epi == EPI_RESID_F32 && p.N == 384 && p.K == 384 && p.ldw == 384 && p.M >= 32768 && !p.dbg) {
-    const int rc = wvn_proj_resid_launch(p.A, p.lda, p.W, p.bias, p.ls, (float*)p.C, p.ldc, p.M, st);
+    const int rc = WVN_OPSYM(wvn_proj_resid_launch)(p.A, p.lda, p.W, p.bias, p.ls, (float*)p.C, p.ldc, p.M, st);
     if (rc != WVN_ERR_ARG) return rc;
   }
   if (p.K == 384 && !p.ls) {  // A-stationary kernel for the K = 384 linears
-    const int rc = wvn_gemm_a384_launch(p, epi, st);
+    const int rc = WVN_OPSYM(wvn_gemm_a384_launch)(p, epi, st);
     if (rc != WVN_ERR_ARG) return rc;
   }
   if (p.N == 384 && p.K > 384 && !p.ls) {  // row-panel kernel for the fc2 residual update
     int done = 0;
-    const int rc = wvn_gemm_n384_launch(p, epi, st, &done);
+    const int rc = WVN_OPSYM(wvn_gemm_n384_launch)(p, epi, st, &done);
     if (rc != WVN_ERR_ARG) {
       if (rc != WVN_OK || done >= p.M) return rc;
       GemmBf16Params rest = p;  // the rows of a thin last round go through the tiled kernel below

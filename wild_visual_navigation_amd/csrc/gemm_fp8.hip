@@ -294,12 +294,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmFp8Params p) {
 
 template <int EPI>
 int launch_epi(const GemmFp8Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(GEMM_LDS_BYTES, (const void*)gemm_fp8_kernel<EPI>)) return rc;
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   hipLaunchKernelGGL((gemm_fp8_kernel<EPI>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();

@@ -15,7 +15,7 @@
 // MFMA: v_mfma_f32_32x32x16_bf16, orientation mfma(Wfrag, Afrag): lane = output row, registers = 4 consecutive columns.
 #include <type_traits>
 
-#include "common.h"
+#include "operand.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -35,8 +35,8 @@ constexpr int BIAS_OFF = 8 * STG_BYTES;                    // 135,168 (> RING_BY
 constexpr int LDS_BYTES = BIAS_OFF + NN * 4;
 
 struct N384Params {
-  const bf16_t* A; int lda;
-  const bf16_t* W; int ldw;   // [384][K]
+  const op16_t* A; int lda;
+  const op16_t* W; int ldw;   // [384][K]
   const float* bias;
   float* C; int ldc;          // fp32, updated in place
   int M, K;
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(512, 2) void gemm_n384_kernel(N384Params p) {
       asm volatile("" : "+v"(xc));
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8_t af = *(const bf16x8_t*)(st + rda + (((2 * s + hi) ^ xc) << 4));
-        auto rd = [&](int t) { return *(const bf16x8_t*)(st + rdw + t * 2048 + (((2 * s + hi) ^ xc) << 4)); };
-        bf16x8_t wf[4];
+        const opx8_t af = *(const opx8_t*)(st + rda + (((2 * s + hi) ^ xc) << 4));
+        auto rd = [&](int t) { return *(const opx8_t*)(st + rdw + t * 2048 + (((2 * s + hi) ^ xc) << 4)); };
+        opx8_t wf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) wf[t] = rd(t);
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t & 3], af, acc[t], 0, 0, 0);
+          acc[t] = wvn_mfma_32x32x16(wf[t & 3], af, acc[t], 0, 0, 0);
           if (t + 4 < NTILE) wf[t & 3] = rd(t + 4);
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
@@ -180,7 +180,7 @@ int n384_num_cus() {
 // WVN_ERR_ARG otherwise (the caller then uses the generic tiled kernel).  *rows_done = number of leading rows handled
 // here (a multiple of 256 unless it is M); the caller finishes rows [*rows_done, M).
 // force != 0 (tests): take every row block here, whatever their number
-int wvn_gemm_n384_launch(const GemmBf16Params& g, int epi, hipStream_t st, int* rows_done, int force) {
+int WVN_OPSYM(wvn_gemm_n384_launch)(const GemmBf16Params& g, int epi, hipStream_t st, int* rows_done, int force) {
   if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
   if (g.N != NN || g.K <= 0 || (g.K % BKS) != 0 || g.M <= 0 || !g.A || !g.W || !g.C) return WVN_ERR_ARG;
   if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 4)) return WVN_ERR_ARG;
@@ -201,12 +201,8 @@ int wvn_gemm_n384_launch(const GemmBf16Params& g, int epi, hipStream_t st, int* 
   if (rows_done) *rows_done = m_here;
   N384Params p{};
   p.A = g.A; p.lda = g.lda; p.W = g.W; p.ldw = g.ldw; p.bias = g.bias; p.C = (float*)g.C; p.ldc = g.ldc; p.M = m_here; p.K = g.K;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_n384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(LDS_BYTES, (const void*)gemm_n384_kernel)) return rc;
   const int nrb = ceil_div(m_here, BM);
   const int grid = nrb < ncu ? nrb : ncu;
   hipLaunchKernelGGL(gemm_n384_kernel, dim3(grid), dim3(512), LDS_BYTES, st, p);

@@ -13,7 +13,7 @@
 //     behind the matrix work and behind the other seven waves);
 //   * the two workgroups that own the two column halves of the same rows run on the same XCD at the same time (blockIdx b and
 //     b + 8), so the second read of the attention rows is an L2 hit, not HBM traffic.
-#include "common.h"
+#include "operand.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -25,8 +25,8 @@ constexpr int W_BYTES = NH * WROW;      // 147,456
 constexpr int TAB_OFF = W_BYTES;        // bias [192], LayerScale [192] (fp32)
 
 struct ProjParams {
-  const bf16_t* A; int lda;
-  const bf16_t* W;          // [384][384]
+  const op16_t* A; int lda;
+  const op16_t* W;          // [384][384]
   const float* bias;        // [384] or nullptr
   const float* ls;          // [384] or nullptr
   float* X; int ldx;
@@ -75,20 +75,20 @@ __global__ __launch_bounds__(512, 1) void proj_resid_kernel(ProjParams p) {
   // W fragment of column tile T (32 columns), k-step s: row n = 32 T + l31, chunk 2 s + hi
   const unsigned wrow = l31 * WROW;
   const int wx = l31 & 15;
-  auto wfrag = [&](int T, int s) -> bf16x8_t {
+  auto wfrag = [&](int T, int s) -> opx8_t {
     const int c = 2 * s + hi;
-    return *(const bf16x8_t*)(smem + T * 32 * WROW + wrow + ((((c & ~15) | ((c ^ wx) & 15))) << 4));
+    return *(const opx8_t*)(smem + T * 32 * WROW + wrow + ((((c & ~15) | ((c ^ wx) & 15))) << 4));
   };
   const int ngroups = (p.M + 31) / 32;
   for (int rg = pair * 8 + wave; rg < ngroups; rg += npairs * 8) {
     const int m0 = rg * 32;
     const int m = min(m0 + l31, p.M - 1);                      // rows past M: clamped reads, dropped stores
     // rows -> MFMA operand fragments (row l31, k = 16 s + 8 hi .. + 7)
-    bf16x8_t af[KD / 16];
+    opx8_t af[KD / 16];
     {
-      const bf16_t* ap = p.A + (size_t)m * p.lda + hi * 8;
+      const op16_t* ap = p.A + (size_t)m * p.lda + hi * 8;
 #pragma unroll
-      for (int s = 0; s < KD / 16; ++s) af[s] = *(const bf16x8_t*)(ap + s * 16);
+      for (int s = 0; s < KD / 16; ++s) af[s] = *(const opx8_t*)(ap + s * 16);
     }
     // Residual addressing in the STRAIGHT accumulator layout (A operand = rows, B operand = W): lane = column n_base + 32 T + l31,
     // register 4 g + e = row m0 + 8 g + 4 hi + e.  One dword per lane, but an instruction covers two whole 128-byte lines (32
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512, 1) void proj_resid_kernel(ProjParams p) {
       for (int s = 0; s < KD / 16; ++s)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], wfrag(3 * pass + t, s), acc[t], 0, 0, 0);
+          acc[t] = wvn_mfma_32x32x16(af[s], wfrag(3 * pass + t, s), acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
@@ -148,7 +148,7 @@ int proj_num_cus() {
 
 // Eligibility: N == K == 384, 16-byte aligned operands, 32-bit byte offsets, a CU count that is a multiple of 16 (the pairing of
 // the two column halves on one XCD).  WVN_ERR_ARG otherwise.
-int wvn_proj_resid_launch(const bf16_t* A, int lda, const bf16_t* W, const float* bias, const float* ls, float* x, int ldx, int M,
+int WVN_OPSYM(wvn_proj_resid_launch)(const op16_t* A, int lda, const op16_t* W, const float* bias, const float* ls, float* x, int ldx, int M,
                           hipStream_t st) {
   if (!A || !W || !x || M <= 0 || (lda % 8) != 0 || (ldx % 4) != 0) return WVN_ERR_ARG;
   if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)x) & 15) != 0) return WVN_ERR_ARG;
@@ -156,12 +156,8 @@ int wvn_proj_resid_launch(const bf16_t* A, int lda, const bf16_t* W, const float
   const int ncu = proj_num_cus();
   if (ncu % 16) return WVN_ERR_ARG;
   const int lds = TAB_OFF + 2 * NH * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)proj_resid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(160 * 1024, (const void*)proj_resid_kernel)) return rc;
   ProjParams p{};
   p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.ls = ls; p.X = x; p.ldx = ldx; p.M = M;
   hipLaunchKernelGGL(proj_resid_kernel, dim3(ncu), dim3(512), lds, st, p);

@@ -300,12 +300,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmBf16Params p) {
 
 template <int EPI>
 int launch(const GemmBf16Params& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(X3_LDS_BYTES, (const void*)gemm_x3_kernel<EPI>)) return rc;
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   hipLaunchKernelGGL((gemm_x3_kernel<EPI>), dim3(tiles), dim3(256), X3_LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();

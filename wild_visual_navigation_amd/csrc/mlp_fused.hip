@@ -21,7 +21,7 @@
 //
 // GELU: the 0.25-bf16-ulp polynomial form of gemm_a384.hip (same code, same bits as the un-fused fc1 epilogue).
 #include <type_traits>
-#include "common.h"
+#include "operand.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -57,21 +57,21 @@ __device__ inline f32x2_t gelu_fast2(f32x2_t x) {
 }
 
 struct MlpFusedParams {
-  const bf16_t* A; int lda;      // xn [M][384] bf16 (LNF = false)
+  const op16_t* A; int lda;      // xn [M][384] bf16 (LNF = false)
   const float *ln_g, *ln_b;      // LayerNorm affine (LNF = true: the kernel normalises X's rows itself)
   float ln_eps;
-  const bf16_t* W1;              // [F][384]
-  const bf16_t* W2;              // [384][F], hidden index permuted (bits 2 <-> 3 inside groups of 16)
+  const op16_t* W1;              // [F][384]
+  const op16_t* W2;              // [384][F], hidden index permuted (bits 2 <-> 3 inside groups of 16)
   const float* b1;               // [F]
   const float* b2;               // [384]
   const float* ls;               // optional LayerScale [384] (nullptr = none)
   float* X; int ldx;             // residual stream [M][384] fp32, updated in place
   int M, F;
   // PROJ: the attention output projection of the same block runs in this kernel's prologue: x += (attn Wp^T + bp) (* ls1) first
-  const bf16_t* attn; int lda_attn;   // attention output rows [M][384] bf16
+  const op16_t* attn; int lda_attn;   // attention output rows [M][384] bf16
   const float* bp;               // [384]
   const float* ls1;              // optional LayerScale of the attention branch
-  const bf16_t* Wp;              // [384][384]
+  const op16_t* Wp;              // [384][384]
   long long* dbg;   // TIMING: per wave {prologue (rows / LayerNorm), fc1 slices, GELU + pack, fc2 slices, epilogue, total} in shader cycles
 };
 
@@ -160,10 +160,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   for (int s = 0; s < 8; ++s) off1[s] = l31 * 256 + (((2 * s + hi) ^ (l31 & 15)) << 4);          // W1 slice: row l31, k-step s
 #pragma unroll
   for (int sg = 0; sg < 4; ++sg) off2[sg] = l31 * 128 + (((2 * sg + hi) ^ ((l31 >> 1) & 7)) << 4);  // W2 slice: row l31, k-step sg
-  auto frag = [&](auto Qc, int slot, int i) -> bf16x8_t {
+  auto frag = [&](auto Qc, int slot, int i) -> opx8_t {
     constexpr int Q = decltype(Qc)::value;
-    if constexpr (Q < 3) return *(const bf16x8_t*)(smem + slot * SLICE + off1[i >> 1] + (i & 1) * 8192);   // sub-tile t = i & 1
-    else return *(const bf16x8_t*)(smem + slot * SLICE + off2[i >> 2] + (i & 3) * 4096);                    // column tile T = i & 3
+    if constexpr (Q < 3) return *(const opx8_t*)(smem + slot * SLICE + off1[i >> 1] + (i & 1) * 8192);   // sub-tile t = i & 1
+    else return *(const opx8_t*)(smem + slot * SLICE + off2[i >> 2] + (i & 3) * 4096);                    // column tile T = i & 3
   };
   const unsigned cvoff = (unsigned)(((lane >> 5) * p.ldx + (lane & 31) * 4) * 4);
   float* stg = (float*)(smem + STG_OFF + wave * STG_BYTES);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   __builtin_amdgcn_s_barrier();
   if constexpr (PROJ) issue(K0{}, 3, 1, 0);
   else issue_mlp(I3{}, 3, 0);
-  bf16x8_t wf[4];
+  opx8_t wf[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) wf[i] = frag(I0{}, 0, i);
 
@@ -276,11 +276,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
     };
     if constexpr (PROJ) {
       // ---- attention projection of this block first: x += (attn Wp^T + bp) (* ls1), the wave's 32 rows, all 384 columns ----
-      bf16x8_t af[KD / 16];
+      opx8_t af[KD / 16];
       {
-        const bf16_t* ap = p.attn + (size_t)min(m0w + l31, p.M - 1) * p.lda_attn + hi * 8;
+        const op16_t* ap = p.attn + (size_t)min(m0w + l31, p.M - 1) * p.lda_attn + hi * 8;
 #pragma unroll
-        for (int s = 0; s < KD / 16; ++s) af[s] = *(const bf16x8_t*)(ap + s * 16);
+        for (int s = 0; s < KD / 16; ++s) af[s] = *(const opx8_t*)(ap + s * 16);
       }
 #pragma unroll
       for (int t = 0; t < 12; ++t)
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
         constexpr int cp = decltype(CPc)::value, ks = decltype(KSc)::value;
         const int nslot = rslot == NS - 1 ? 0 : rslot + 1;
         auto step = [&](int i) {
-          out[2 * cp + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 3], af[ks * 8 + (i >> 1)], out[2 * cp + (i & 1)], 0, 0, 0);
+          out[2 * cp + (i & 1)] = wvn_mfma_32x32x16(wf[i & 3], af[ks * 8 + (i >> 1)], out[2 * cp + (i & 1)], 0, 0, 0);
           wf[i & 3] = i + 4 < 16 ? frag(I0{}, rslot, i + 4) : frag(I0{}, nslot, i + 4 - 16);   // (the next slice is W1-shaped too)
         };
 #pragma unroll
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       residual_update(bp_l, p.ls1, std::true_type{});   // ... and the updated rows stay in registers for the LayerNorm below
     }
     // ---- A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7); rows past M are clamped ----
-    bf16x8_t xf[KD / 16];
+    opx8_t xf[KD / 16];
     if constexpr (LNF) {
       // LayerNorm of the wave's 32 residual rows, once per row block: a lane holds half a row (the k-slots it feeds the MFMAs),
       // its partner lane ^ 32 the other half
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       const float rstd = 1.0f / sqrtf(q / 384.f + p.ln_eps);
 #pragma unroll
       for (int s = 0; s < KD / 16; ++s) {
-        union { u32x4_t u; bf16x8_t v; } o;
+        union { u32x4_t u; opx8_t v; } o;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const f32x4_t g4 = *(const f32x4_t*)(lng_l + 16 * s + 8 * hi + 4 * h2);
@@ -367,15 +367,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
           float y[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = (xq[2 * s + h2][e] - mean) * rstd * g4[e] + b4[e];
-          o.u[2 * h2] = pack_bf16x2(y[0], y[1]);
-          o.u[2 * h2 + 1] = pack_bf16x2(y[2], y[3]);
+          o.u[2 * h2] = pack_op2(y[0], y[1]);
+          o.u[2 * h2 + 1] = pack_op2(y[2], y[3]);
         }
         xf[s] = o.v;
       }
     } else {
-      const bf16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
+      const op16_t* ap = p.A + (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
 #pragma unroll
-      for (int s = 0; s < KD / 16; ++s) xf[s] = *(const bf16x8_t*)(ap + s * 16);
+      for (int s = 0; s < KD / 16; ++s) xf[s] = *(const opx8_t*)(ap + s * 16);
     }
     if constexpr (TIMING) tm[0] += now() - c_p0;
 #pragma unroll
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) hacc[t][4 * g + e] = b4[e];
         }
-      bf16x8_t hf[4];
+      opx8_t hf[4];
       // one slice = 16 MFMAs; MFMA i takes wf[i & 3], which is then refilled with fragment i + 4 -- of this slice, or (i >= 12) of
       // the next one, opened half-way through
       auto slice = [&](auto Qc) {
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
         constexpr int QN = (Q + 1) % 6;
         const int nslot = rslot == NS - 1 ? 0 : rslot + 1;
         auto step = [&](int i) {
-          if constexpr (Q < 3) hacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 3], xf[Q * 8 + (i >> 1)], hacc[i & 1], 0, 0, 0);
-          else out[4 * (Q - 3) + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 3], hf[i >> 2], out[4 * (Q - 3) + (i & 3)], 0, 0, 0);
+          if constexpr (Q < 3) hacc[i & 1] = wvn_mfma_32x32x16(wf[i & 3], xf[Q * 8 + (i >> 1)], hacc[i & 1], 0, 0, 0);
+          else out[4 * (Q - 3) + (i & 3)] = wvn_mfma_32x32x16(wf[i & 3], hf[i >> 2], out[4 * (Q - 3) + (i & 3)], 0, 0, 0);
           if (i + 4 < 16) wf[i & 3] = frag(Qc, rslot, i + 4);
           else wf[i & 3] = frag(std::integral_constant<int, QN>{}, nslot, i + 4 - 16);
         };
@@ -430,14 +430,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
-          union { u32x4_t u; bf16x8_t v; } o;
+          union { u32x4_t u; opx8_t v; } o;
 #pragma unroll
           for (int q = 0; q < 2; ++q) {   // g = 2 gp + q: slots j = 4 q + e
             const int g = 2 * gp + q;
             const f32x2_t a = gelu_fast2(f32x2_t{hacc[t][4 * g + 0], hacc[t][4 * g + 1]});
             const f32x2_t b = gelu_fast2(f32x2_t{hacc[t][4 * g + 2], hacc[t][4 * g + 3]});
-            o.u[2 * q] = pack_bf16x2(a[0], a[1]);
-            o.u[2 * q + 1] = pack_bf16x2(b[0], b[1]);
+            o.u[2 * q] = pack_op2(a[0], a[1]);
+            o.u[2 * q + 1] = pack_op2(b[0], b[1]);
           }
           hf[2 * t + gp] = o.v;
         }
@@ -476,11 +476,11 @@ int mlp_fused_num_cus() {
 // Eligibility: D == 384, F % 64 == 0 (F * 4 + 154,112 bytes of LDS), 16-byte aligned operands, 32-bit byte offsets.
 // W2 must be stored with the hidden index permuted (wvn_hip.h: WVN_VIT_MLP_FUSED).  xn == nullptr: the kernel applies
 // LayerNorm(ln_g, ln_b, ln_eps) to the rows of x itself (once per row block).  WVN_ERR_ARG otherwise.
-long long* g_mlp_fused_dbg = nullptr;   // wvn_debug_mlp_fused_timing (scripts/bench_mlp_fused.py)
+long long* WVN_OPSYM(g_mlp_fused_dbg) = nullptr;   // wvn_debug_mlp_fused_timing (scripts/bench_mlp_fused.py)
 
-static int mlp_fused_launch_impl(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1,
-                                 const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, const bf16_t* attn,
-                                 int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1, hipStream_t st) {
+static int mlp_fused_launch_impl(const op16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const op16_t* W1, const float* b1,
+                                 const op16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, const op16_t* attn,
+                                 int lda_attn, const op16_t* Wp, const float* bp, const float* ls1, hipStream_t st) {
   const bool lnf = xn == nullptr, proj = attn != nullptr;
   if (!W1 || !W2p || !x || M <= 0 || F <= 0 || (F % HT) != 0 || (ldx % 4) != 0) return WVN_ERR_ARG;
   if (lnf ? (!ln_g || !ln_b) : ((lda % 8) != 0 || ((uintptr_t)xn & 15) != 0)) return WVN_ERR_ARG;
@@ -490,15 +490,8 @@ static int mlp_fused_launch_impl(const bf16_t* xn, int lda, const float* ln_g, c
   if (lds > 160 * 1024) return WVN_ERR_ARG;
   if ((size_t)M * ldx * 4 >= (1ull << 32)) return WVN_ERR_ARG;
   if ((size_t)F * KD * 2 >= (1ull << 32)) return WVN_ERR_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_fused_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(160 * 1024, (const void*)mlp_fused_kernel<false>, (const void*)mlp_fused_kernel<true>, (const void*)mlp_fused_kernel<true, true>, (const void*)mlp_fused_kernel<true, false, true>)) return rc;
   MlpFusedParams p{};
   p.A = xn; p.lda = lda; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.W1 = W1; p.W2 = W2p; p.b1 = b1; p.b2 = b2; p.ls = ls;
   p.X = x; p.ldx = ldx; p.M = M; p.F = F;
@@ -506,7 +499,7 @@ static int mlp_fused_launch_impl(const bf16_t* xn, int lda, const float* ln_g, c
   p.Wp = Wp;
   const int nrb = ceil_div(M, BM), ncu = mlp_fused_num_cus();
   const dim3 grid(nrb < ncu ? nrb : ncu);
-  p.dbg = g_mlp_fused_dbg;
+  p.dbg = WVN_OPSYM(g_mlp_fused_dbg);
   if (proj) hipLaunchKernelGGL((mlp_fused_kernel<true, false, true>), grid, dim3(256), lds, st, p);
   else if (lnf && g_mlp_fused_dbg) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
   else if (lnf) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(256), lds, st, p);
@@ -515,15 +508,15 @@ static int mlp_fused_launch_impl(const bf16_t* xn, int lda, const float* ln_g, c
   return WVN_OK;
 }
 
-int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,
-                         const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
+int WVN_OPSYM(wvn_mlp_fused_launch)(const op16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const op16_t* W1,
+                         const float* b1, const op16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
                          hipStream_t st) {
   return mlp_fused_launch_impl(xn, lda, ln_g, ln_b, ln_eps, W1, b1, W2p, b2, ls, x, ldx, M, F, nullptr, 0, nullptr, nullptr, nullptr, st);
 }
 
 // The same with the attention output projection of the block in front: x += (attn Wp^T + bp) (* ls1); x += MLP(LayerNorm(x)).
-int wvn_proj_mlp_fused_launch(const bf16_t* attn, int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1, const float* ln_g,
-                              const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1, const bf16_t* W2p, const float* b2,
+int WVN_OPSYM(wvn_proj_mlp_fused_launch)(const op16_t* attn, int lda_attn, const op16_t* Wp, const float* bp, const float* ls1, const float* ln_g,
+                              const float* ln_b, float ln_eps, const op16_t* W1, const float* b1, const op16_t* W2p, const float* b2,
                               const float* ls2, float* x, int ldx, int M, int F, hipStream_t st) {
   if (!attn) return WVN_ERR_ARG;
   return mlp_fused_launch_impl(nullptr, 0, ln_g, ln_b, ln_eps, W1, b1, W2p, b2, ls2, x, ldx, M, F, attn, lda_attn, Wp, bp, ls1, st);

@@ -544,12 +544,8 @@ int pix_infer(const void* packed, void* zx, int ldzx, int B, int G, int out_h, i
   p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
   p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor; p.conf_dev = conf_state;
   auto kern = pixel_mlp_kernel<1, D>;  // bilinear weights split hi + lo (16 mantissa bits)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(K::LDS_BYTES, (const void*)kern)) return rc;
   const int ntiles = B * p.nty * p.ntx;
   const int cap = 2 * pix_num_cus();
   hipLaunchKernelGGL(kern, dim3(ntiles < cap ? ntiles : cap), dim3(512), K::LDS_BYTES, st, p);
@@ -595,12 +591,8 @@ int pix_infer_exact(const float* params, const void* packed, const float* tokens
   p.B = B; p.G = G; p.Ho = out_h; p.Wo = out_w;
   p.nty = ceil_div(out_h, TILE); p.ntx = ceil_div(out_w, TILE);
   p.sy = sy; p.sx = sx; p.mean = mean; p.std = std; p.std_factor = std_factor; p.conf_dev = conf_state;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pixel_mlp_x3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, K::XLDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(K::XLDS_BYTES, (const void*)pixel_mlp_x3_kernel<D>)) return rc;
   const int ntiles = B * p.nty * p.ntx;
   const int cap = pix_num_cus();
   hipLaunchKernelGGL(pixel_mlp_x3_kernel<D>, dim3(ntiles < cap ? ntiles : cap), dim3(512), K::XLDS_BYTES, st, p);

@@ -20,7 +20,7 @@
 // column tiles over all workgroups (each re-normalises its rows: cheap next to idling 236 CUs for a whole round).
 #include <type_traits>
 
-#include "common.h"
+#include "operand.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -42,9 +42,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 struct QkvFusedParams {
   const float* X; int ldx;       // residual stream [M][384] fp32
   const float *ln_g, *ln_b; float ln_eps;
-  const bf16_t* W;               // [3 * heads * 64][384]
+  const op16_t* W;               // [3 * heads * 64][384]
   const float* bias;             // [3 * heads * 64]
-  bf16_t* base; unsigned q_off, k_off, v_off, bytes;   // one buffer descriptor over q / k / v^T
+  op16_t* base; unsigned q_off, k_off, v_off, bytes;   // one buffer descriptor over q / k / v^T
   int heads, npad, ntok_s;
   float q_scale;
   int M;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
   unsigned off[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) off[s] = l31 * 256 + (((2 * s + hi) ^ (l31 & 15)) << 4);
-  auto frag = [&](int slot, int i) -> bf16x8_t { return *(const bf16x8_t*)(smem + slot * SLICE + off[i >> 1] + (i & 1) * 8192); };
+  auto frag = [&](int slot, int i) -> opx8_t { return *(const opx8_t*)(smem + slot * SLICE + off[i >> 1] + (i & 1) * 8192); };
   unsigned char* stg = smem + STG_OFF + wave * STG_BYTES;
 
   int si = 0, rslot = 0;   // slice being multiplied (workgroup-local index) and its ring slot
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
   if (total < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (issued < total) issue_next();
-  bf16x8_t wf[4];
+  opx8_t wf[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) wf[i] = frag(0, i);
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
     const int m0w = seg_rb(s) * BM + wave * RW;
     const long long c_ln0 = now();
     // ---- LayerNorm of the wave's 64 rows -> MFMA operand fragments xf[row sub-tile][k-step] (row l31, k = 16 s + 8 hi .. + 7) ----
-    bf16x8_t xf[2][KD / 16];
+    opx8_t xf[2][KD / 16];
     int dep = 0;   // serialises the two 32-row passes (384 fp32 values in flight at once would not fit the register file)
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
       const float rstd = 1.0f / sqrtf(q / 384.f + p.ln_eps);
 #pragma unroll
       for (int k = 0; k < KD / 16; ++k) {
-        union { u32x4_t u; bf16x8_t v; } o;
+        union { u32x4_t u; opx8_t v; } o;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const f32x4_t g4 = *(const f32x4_t*)(lng_l + 16 * k + 8 * hi + 4 * h2);
@@ -229,18 +229,18 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
           float y[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = (xq[2 * k + h2][e] - mean) * rstd * g4[e] + b4[e];
-          o.u[2 * h2] = pack_bf16x2(y[0], y[1]);
-          o.u[2 * h2 + 1] = pack_bf16x2(y[2], y[3]);
+          o.u[2 * h2] = pack_op2(y[0], y[1]);
+          o.u[2 * h2 + 1] = pack_op2(y[2], y[3]);
         }
         // park the fragment in accumulation registers right away (MFMA operands may live there): left to itself the register
         // allocator keeps it next to the 192 fp32 row values in the architectural half of the file and spills both
-        union { u32x4_t u; bf16x8_t v; } a;
+        union { u32x4_t u; opx8_t v; } a;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { uint32_t t; asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(t) : "v"(o.u[e])); a.u[e] = t; }
         xf[rs][k] = a.v;
       }
       {
-        union { bf16x8_t v; u32x4_t u; } last;
+        union { opx8_t v; u32x4_t u; } last;
         last.v = xf[rs][KD / 16 - 1];
         asm volatile("" : "+v"(dep) : "a"(last.u[3]));
       }
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
         auto step = [&](int i) {
 #pragma unroll
           for (int rs = 0; rs < 2; ++rs) {
-            if constexpr (TR) acc[rs][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 3], xf[rs][ks * 8 + (i >> 1)], acc[rs][i & 1], 0, 0, 0);
-            else acc[rs][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[rs][ks * 8 + (i >> 1)], wf[i & 3], acc[rs][i & 1], 0, 0, 0);
+            if constexpr (TR) acc[rs][i & 1] = wvn_mfma_32x32x16(wf[i & 3], xf[rs][ks * 8 + (i >> 1)], acc[rs][i & 1], 0, 0, 0);
+            else acc[rs][i & 1] = wvn_mfma_32x32x16(xf[rs][ks * 8 + (i >> 1)], wf[i & 3], acc[rs][i & 1], 0, 0, 0);
           }
           wf[i & 3] = i + 4 < 16 ? frag(rslot, i + 4) : frag(nslot, i + 4 - 16);
         };
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
             for (int g = 0; g < 4; ++g) {
               const f32x2_t a = f32x2_t{acc[rs][t][4 * g + 0], acc[rs][t][4 * g + 1]} * f32x2_t{qs, qs};
               const f32x2_t b = f32x2_t{acc[rs][t][4 * g + 2], acc[rs][t][4 * g + 3]} * f32x2_t{qs, qs};
-              const u32x2_t o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1])};
+              const u32x2_t o = {pack_op2(a[0], a[1]), pack_op2(b[0], b[1])};
               *(u32x2_t*)(stg + (rs * 32 + l31) * STG_ROW + (32 * t + 8 * g + 4 * hi) * 2) = o;
             }
         const int D = p.heads * 64;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
             for (int g = 0; g < 4; ++g) {
               // tokens 32 rs + 8 g + 4 hi + e of the wave's 64 -> stored position 32 rs + 16 (g >> 1) + 8 hi + 4 (g & 1) + e
               const int mloc = 32 * rs + 16 * (g >> 1) + 8 * hi + 4 * (g & 1);
-              const u32x2_t o = {pack_bf16x2(acc[rs][t][4 * g + 0], acc[rs][t][4 * g + 1]), pack_bf16x2(acc[rs][t][4 * g + 2], acc[rs][t][4 * g + 3])};
+              const u32x2_t o = {pack_op2(acc[rs][t][4 * g + 0], acc[rs][t][4 * g + 1]), pack_op2(acc[rs][t][4 * g + 2], acc[rs][t][4 * g + 3])};
               *(u32x2_t*)(stg + (32 * t + l31) * STG_ROW + mloc * 2) = o;
             }
         const int head = (n0 - 2 * p.heads * 64) >> 6;
@@ -379,10 +379,10 @@ int qkv_fused_num_cus() {
 }  // namespace
 
 // Eligibility: D == 384 (heads == 6), ntok_s % 16 == 0, M % 16 == 0, npad % 16 == 0, q / k / v^T within 2 GB of each other.
-long long* g_qkv_fused_dbg = nullptr;   // wvn_debug_qkv_fused_timing (scripts/bench_qkv_fused.py)
+long long* WVN_OPSYM(g_qkv_fused_dbg) = nullptr;   // wvn_debug_qkv_fused_timing (scripts/bench_qkv_fused.py)
 
-int wvn_qkv_fused_launch(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W, const float* bias,
-                         bf16_t* q, bf16_t* k, bf16_t* vt, int heads, int npad, int ntok_s, float q_scale, int M, hipStream_t st) {
+int WVN_OPSYM(wvn_qkv_fused_launch)(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const op16_t* W, const float* bias,
+                         op16_t* q, op16_t* k, op16_t* vt, int heads, int npad, int ntok_s, float q_scale, int M, hipStream_t st) {
   if (!x || !ln_g || !ln_b || !W || !q || !k || !vt || M <= 0 || heads * 64 != KD || (ldx % 4) != 0) return WVN_ERR_ARG;
   if ((ntok_s % 16) || (M % 16) || (npad % 16)) return WVN_ERR_ARG;
   if ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) != 0) return WVN_ERR_ARG;
@@ -390,20 +390,15 @@ int wvn_qkv_fused_launch(const float* x, int ldx, const float* ln_g, const float
   const size_t frames = (size_t)ceil_div(M, ntok_s), one = frames * heads * npad * 64 * 2;
   if (hi - lo + one >= (1ull << 31)) return WVN_ERR_ARG;
   const int N = 3 * heads * 64, lds = TAB_OFF + (N + 2 * KD) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)qkv_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)qkv_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static LdsOptIn lds_opt_in;   // per device (common.h)
+  if (const int rc = lds_opt_in(160 * 1024, (const void*)qkv_fused_kernel<false>, (const void*)qkv_fused_kernel<true>)) return rc;
   QkvFusedParams p{};
   p.X = x; p.ldx = ldx; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.W = W; p.bias = bias;
-  p.base = (bf16_t*)lo; p.q_off = (unsigned)((uintptr_t)q - lo); p.k_off = (unsigned)((uintptr_t)k - lo); p.v_off = (unsigned)((uintptr_t)vt - lo);
+  p.base = (op16_t*)lo; p.q_off = (unsigned)((uintptr_t)q - lo); p.k_off = (unsigned)((uintptr_t)k - lo); p.v_off = (unsigned)((uintptr_t)vt - lo);
   p.bytes = (unsigned)(hi - lo + one);
   p.heads = heads; p.npad = npad; p.ntok_s = ntok_s; p.q_scale = q_scale != 0.f ? q_scale : 1.f; p.M = M;
   const int nrb = ceil_div(M, BM), ncu = qkv_fused_num_cus();
-  p.dbg = g_qkv_fused_dbg;
+  p.dbg = WVN_OPSYM(g_qkv_fused_dbg);
   if (g_qkv_fused_dbg) hipLaunchKernelGGL(qkv_fused_kernel<true>, dim3(nrb < ncu ? nrb : ncu), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(qkv_fused_kernel<false>, dim3(nrb < ncu ? nrb : ncu), dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();

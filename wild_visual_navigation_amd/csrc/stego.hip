@@ -8,7 +8,10 @@
 //   * dot products / norms : strictly sequential over the channel index
 //   * centroid sums        : points are cut into chunks of KM_CHUNK (64) consecutive indices; inside a
 //                            chunk the members of a cluster are added in ascending point order starting
-//                            from 0, and the chunk partials are then added in ascending chunk order
+//                            from 0; the chunk partials are added in ascending chunk order inside groups
+//                            of KM_SUPER (8) consecutive chunks, and the group partials in ascending group
+//                            order (the three-level order lets the pixel-resolution form keep a group's
+//                            running sums on chip; at every level an addition chain starts from +0)
 //   * argmax               : first maximum (lowest cluster id wins ties)
 // oracle/interfaces.py::kmeans_cosine_labels mirrors this operation for operation.
 //
@@ -24,6 +27,7 @@ namespace {
 
 constexpr int KM_MAXK = 64;
 constexpr int KM_CHUNK = 64;
+constexpr int KM_SUPER = 8;   // chunk partials are folded in groups of 8 consecutive chunks (512 points)
 
 // Rows of [rows][C] (C <= 128) are staged through LDS so that global traffic is coalesced (a row is 360 B at
 // C = 90; one thread walking its own row touches 64 cache lines per load instruction) while each thread still
@@ -52,7 +56,8 @@ __device__ inline bool rows_contiguous(const float* src, int ld, int row0, int C
   return ld == C && ((C * ROWS_PER_BLOCK) & 3) == 0 && (((uintptr_t)(src + (size_t)row0 * C)) & 15) == 0;
 }
 
-// xn[p][:] = code[p][:] / max(||code[p]||, 1e-12)
+// xn[p][:] = code[p][:] * (1 / max(||code[p]||, 1e-12)): ONE correctly rounded reciprocal per row, then a multiply per element
+// (the pixel-resolution k-means below re-creates every row on the fly in every pass: 90 multiplies instead of 90 divisions)
 __global__ __launch_bounds__(ROWS_PER_BLOCK) void normalize_rows_kernel(const float* __restrict__ code, int ldc,
                                                                         float* __restrict__ xn, int rows, int C) {
   extern __shared__ __attribute__((aligned(16))) float tile[];  // [128][pitch]
@@ -65,8 +70,8 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void normalize_rows_kernel(const fl
     float* r = tile + threadIdx.x * pitch;
     float n2 = 0.f;
     for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(r[d], r[d]));
-    const float n = fmaxf(__fsqrt_rn(n2), 1e-12f);
-    for (int d = 0; d < C; ++d) r[d] = __fdiv_rn(r[d], n);
+    const float rinv = __fdiv_rn(1.f, fmaxf(__fsqrt_rn(n2), 1e-12f));
+    for (int d = 0; d < C; ++d) r[d] = __fmul_rn(r[d], rinv);
   }
   __syncthreads();
   const int nrow = min(ROWS_PER_BLOCK, rows - row0);
@@ -147,15 +152,19 @@ __global__ void km_partial_kernel(const float* __restrict__ xn, const int* __res
 // independent, only the adds are chained), thread 0 forms the squared norm over d in index order -- the same arithmetic,
 // in the same order, as a single workgroup per frame would do, on K times as many CUs.
 __global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict__ part, const int* __restrict__ pcnt,
-                                                        float* __restrict__ cent, int C, int K, int nchunk) {
+                                                        float* __restrict__ cent, int C, int K, int nchunk, int group) {
   __shared__ float sums[128];
   __shared__ float nrm_s;
   __shared__ int cnt_s;
   const int k = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   if (d < C) {
     float s = 0.f;
-#pragma unroll 7
-    for (int c = 0; c < nchunk; ++c) s = __fadd_rn(s, part[(((size_t)b * nchunk + c) * K + k) * C + d]);
+    for (int c0 = 0; c0 < nchunk; c0 += group) {   // group = KM_SUPER for chunk partials, 1 when `part` holds group partials
+      float gsum = 0.f;
+      const int c1 = min(nchunk, c0 + group);
+      for (int c = c0; c < c1; ++c) gsum = __fadd_rn(gsum, part[(((size_t)b * nchunk + c) * K + k) * C + d]);
+      s = __fadd_rn(s, gsum);
+    }
     sums[d] = s;
   }
   if (d == 127) {
@@ -167,10 +176,10 @@ __global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict_
   if (d == 0) {
     float n2 = 0.f;
     for (int i = 0; i < C; ++i) n2 = __fadd_rn(n2, __fmul_rn(sums[i], sums[i]));
-    nrm_s = fmaxf(__fsqrt_rn(n2), 1e-12f);
+    nrm_s = __fdiv_rn(1.f, fmaxf(__fsqrt_rn(n2), 1e-12f));
   }
   __syncthreads();
-  if (d < C && cnt_s > 0) cent[((size_t)b * K + k) * C + d] = __fdiv_rn(sums[d], nrm_s);
+  if (d < C && cnt_s > 0) cent[((size_t)b * K + k) * C + d] = __fmul_rn(sums[d], nrm_s);
 }
 
 // compaction of the used ids to 0..K'-1 in ascending order (feature_extractor.py:245-246) + distinct count
@@ -212,12 +221,256 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
     hipLaunchKernelGGL(km_partial_kernel, dim3(nchunk, B), dim3(threads_c), shm_kc + K * sizeof(int), st, xn, labels,
                        part, pcnt, P, C, K, nchunk);
     WVN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, part, pcnt, cent, C, K, nchunk);
+    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, part, pcnt, cent, C, K, nchunk, KM_SUPER);
     WVN_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(km_relabel_kernel, dim3(B), dim3(1024), 0, st, labels, nseg, P, K, relabel);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pixel-resolution clustering (the reading of the absent STEGO package in which postprocess() clusters the CODE PIXELS,
+// stego_interface.py:94-109): the points are the H x H bilinearly up-sampled (align_corners=True), normalised code rows.
+// That array is 4.6 GB per 64 frames at 448^2 and the k-means passes over it 21 times; here it never exists: every pass
+// re-creates its rows from the G x G patch codes (1.1 MB per frame, L2-resident) with the same explicitly rounded
+// interpolation the up-sampling kernel uses (common.h: lerp_tap / bilerp_fixed), multiplied by the row's reciprocal norm
+// (computed once per pixel, 4 B).  Same algorithm, same summation orders, same bits as run_kmeans on the materialised rows.
+//   rinv    : lane = pixel; the block's two source code rows in LDS
+//   assign  : lane = pixel, x[C] in registers, centroids through the scalar cache (uniform addresses), four independent
+//             dot-product chains in flight
+//   partial : one 128-lane workgroup per group of KM_SUPER chunks, lane = channel.  Per pixel everything but the four code
+//             values is wave-uniform (tap tables, label, reciprocal norm: scalar loads); a cluster's running sum of the
+//             current chunk stays in a register while consecutive pixels carry the same label (the usual case) and is parked
+//             in LDS when the label changes -- the addition order is exactly the sequential one.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PixTabs { const int* i0; const int* i1; const float* w0; const float* w1; };   // [H] each
+
+__global__ void km_pix_tables_kernel(int* __restrict__ i0, int* __restrict__ i1, float* __restrict__ w0, float* __restrict__ w1,
+                                     int G, int H) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= H) return;
+  const LerpTap t = lerp_tap(o, G, lerp_scale(G, H));
+  i0[o] = t.i0; i1[o] = t.i1; w0[o] = t.w0; w1[o] = t.w1;
+}
+
+// stage code rows y0 / y1 of frame b ([G][C] each) into LDS: rows[0][G*C], rows[1][G*C]
+__device__ inline void pix_stage_rows(const float* __restrict__ code, int b, int G, int C, int y0, int y1, float* rows) {
+  const int n = G * C;   // contiguous in memory
+  const float* r0 = code + ((size_t)b * G * G + (size_t)y0 * G) * C;
+  const float* r1 = code + ((size_t)b * G * G + (size_t)y1 * G) * C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { rows[i] = r0[i]; rows[n + i] = r1[i]; }
+}
+
+template <int C>
+__device__ inline void pix_row(const float* rows, int G, const LerpTap& tx, const LerpTap& ty, float* v) {
+  const float* a0 = rows + tx.i0 * C;
+  const float* a1 = rows + tx.i1 * C;
+  const float* b0 = rows + G * C + tx.i0 * C;
+  const float* b1 = rows + G * C + tx.i1 * C;
+#pragma unroll
+  for (int d = 0; d < C; ++d) v[d] = bilerp_fixed(a0[d], a1[d], b0[d], b1[d], tx.w0, tx.w1, ty.w0, ty.w1);
+}
+
+// rinv[b][y*H + x] = 1 / max(||v||, 1e-12), v = the interpolated code row of pixel (y, x)
+template <int C>
+__global__ __launch_bounds__(256) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H) {
+  extern __shared__ float rows[];  // [2][G][C]
+  const int y = blockIdx.x, b = blockIdx.y;
+  const float scale = lerp_scale(G, H);
+  const LerpTap ty = lerp_tap(y, G, scale);
+  pix_stage_rows(code, b, G, C, ty.i0, ty.i1, rows);
+  __syncthreads();
+  for (int x = threadIdx.x; x < H; x += blockDim.x) {
+    const LerpTap tx = lerp_tap(x, G, scale);
+    float v[C];
+    pix_row<C>(rows, G, tx, ty, v);
+    float n2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(v[d], v[d]));
+    rinv[(size_t)b * H * H + (size_t)y * H + x] = __fdiv_rn(1.f, fmaxf(__fsqrt_rn(n2), 1e-12f));
+  }
+}
+
+// cent[b][k][:] = x at pixel floor((2k+1) P / 2K), P = H*H
+__global__ void km_pix_init_kernel(const float* __restrict__ code, const float* __restrict__ rinv, float* __restrict__ cent, int G,
+                                   int H, int C, int K) {
+  const int b = blockIdx.x;
+  const long long P = (long long)H * H;
+  const float scale = lerp_scale(G, H);
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+    const int k = i / C, d = i - k * C;
+    const long long p0 = ((long long)(2 * k + 1) * P) / (2 * K);
+    const int y = (int)(p0 / H), x = (int)(p0 - (long long)y * H);
+    const LerpTap ty = lerp_tap(y, G, scale), tx = lerp_tap(x, G, scale);
+    const float* cb = code + (size_t)b * G * G * C;
+    const float v = bilerp_fixed(cb[((size_t)ty.i0 * G + tx.i0) * C + d], cb[((size_t)ty.i0 * G + tx.i1) * C + d],
+                                 cb[((size_t)ty.i1 * G + tx.i0) * C + d], cb[((size_t)ty.i1 * G + tx.i1) * C + d], tx.w0, tx.w1,
+                                 ty.w0, ty.w1);
+    cent[(size_t)b * K * C + i] = __fmul_rn(v, rinv[(size_t)b * P + p0]);
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+                                                            const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
+                                                            int K) {
+  extern __shared__ float rows[];  // [2][G][C]
+  const int y = blockIdx.x, b = blockIdx.y;
+  const float scale = lerp_scale(G, H);
+  const LerpTap ty = lerp_tap(y, G, scale);
+  pix_stage_rows(code, b, G, C, ty.i0, ty.i1, rows);
+  __syncthreads();
+  const float* __restrict__ cb = cent + (size_t)b * K * C;   // uniform addresses: served by the scalar cache
+  for (int x = threadIdx.x; x < H; x += blockDim.x) {
+    const LerpTap tx = lerp_tap(x, G, scale);
+    const size_t p = (size_t)b * H * H + (size_t)y * H + x;
+    float v[C];
+    pix_row<C>(rows, G, tx, ty, v);
+    const float ri = rinv[p];
+#pragma unroll
+    for (int d = 0; d < C; ++d) v[d] = __fmul_rn(v[d], ri);
+    int best = 0;
+    float bv = -INFINITY;
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {   // four independent chains; each dot product still strictly in index order
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float* c0 = cb + (size_t)k * C;
+#pragma unroll
+      for (int d = 0; d < C; ++d) {
+        a0 = __fadd_rn(a0, __fmul_rn(v[d], c0[d]));
+        a1 = __fadd_rn(a1, __fmul_rn(v[d], c0[C + d]));
+        a2 = __fadd_rn(a2, __fmul_rn(v[d], c0[2 * C + d]));
+        a3 = __fadd_rn(a3, __fmul_rn(v[d], c0[3 * C + d]));
+      }
+      if (a0 > bv) { bv = a0; best = k; }
+      if (a1 > bv) { bv = a1; best = k + 1; }
+      if (a2 > bv) { bv = a2; best = k + 2; }
+      if (a3 > bv) { bv = a3; best = k + 3; }
+    }
+    for (; k < K; ++k) {
+      float a0 = 0.f;
+      const float* c0 = cb + (size_t)k * C;
+#pragma unroll
+      for (int d = 0; d < C; ++d) a0 = __fadd_rn(a0, __fmul_rn(v[d], c0[d]));
+      if (a0 > bv) { bv = a0; best = k; }
+    }
+    labels[p] = best;
+  }
+}
+
+// part[b][group][k][d] = the group's partial (chunk partials added in ascending chunk order), pcnt[b][group][k] = member count
+__global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+                                                             const int* __restrict__ labels, PixTabs tb, float* __restrict__ part,
+                                                             int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup) {
+  extern __shared__ float lds[];   // tab[K][C] (current chunk), grp[K][C] (group so far), cnt[K]
+  float* tab = lds;
+  float* grp = lds + K * C;
+  int* cn = (int*)(grp + K * C);
+  const int g = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const long long P = (long long)H * H;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) { tab[i] = 0.f; grp[i] = 0.f; }
+  for (int i = threadIdx.x; i < K; i += blockDim.x) cn[i] = 0;
+  __syncthreads();
+  const float* __restrict__ cb = code + (size_t)b * G * G * C;
+  const int* __restrict__ lab = labels + (size_t)b * P;
+  const float* __restrict__ rv = rinv + (size_t)b * P;
+  const long long g0 = (long long)g * KM_SUPER * KM_CHUNK;
+  const bool act = d < C;
+  for (int c = 0; c < KM_SUPER; ++c) {
+    const long long p0 = g0 + (long long)c * KM_CHUNK;
+    if (p0 >= P) break;                                  // (uniform)
+    const int p1 = (int)min(P, p0 + KM_CHUNK);
+    int y = (int)(p0 / H), x = (int)(p0 - (long long)y * H);
+    int kcur = -1;
+    float acc = 0.f;
+    for (int p = (int)p0; p < p1; ++p) {
+      const int k = __builtin_amdgcn_readfirstlane(lab[p]);   // uniform: scalar compare / branch below
+      if (k != kcur) {                                    // park the running sum of the previous label, fetch this label's
+        if (act && kcur >= 0) tab[kcur * C + d] = acc;
+        if (act) acc = tab[k * C + d];
+        kcur = k;
+      }
+      if (act) {
+        const int y0 = tb.i0[y], y1 = tb.i1[y], x0 = tb.i0[x], x1 = tb.i1[x];
+        const float v = bilerp_fixed(cb[((size_t)y0 * G + x0) * C + d], cb[((size_t)y0 * G + x1) * C + d],
+                                     cb[((size_t)y1 * G + x0) * C + d], cb[((size_t)y1 * G + x1) * C + d], tb.w0[x], tb.w1[x],
+                                     tb.w0[y], tb.w1[y]);
+        acc = __fadd_rn(acc, __fmul_rn(v, rv[p]));
+      }
+      if (d == 0) cn[k] += 1;
+      if (++x == H) { x = 0; ++y; }
+    }
+    if (act && kcur >= 0) tab[kcur * C + d] = acc;
+    // fold the chunk into the group partial (ascending chunk order) and clear the chunk table: lane d owns column d
+    if (act)
+      for (int k = 0; k < K; ++k) {
+        grp[k * C + d] = __fadd_rn(grp[k * C + d], tab[k * C + d]);
+        tab[k * C + d] = 0.f;
+      }
+  }
+  __syncthreads();
+  float* dst = part + ((size_t)b * ngroup + g) * K * C;
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) dst[i] = grp[i];
+  for (int i = threadIdx.x; i < K; i += blockDim.x) pcnt[((size_t)b * ngroup + g) * K + i] = cn[i];
+}
+
+struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; int* i0; int* i1; float* w0; float* w1; size_t floats; };
+PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
+  const size_t P = (size_t)H * H, ngroup = (P + (size_t)KM_SUPER * KM_CHUNK - 1) / ((size_t)KM_SUPER * KM_CHUNK);
+  PixScratch s;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return base ? base + o : (float*)nullptr; };
+  s.cent = take((size_t)B * K * C);
+  s.part = take((size_t)B * ngroup * K * C);
+  s.pcnt = (int*)take((size_t)B * ngroup * K);
+  s.rinv = take((size_t)B * P);
+  s.i0 = (int*)take(H); s.i1 = (int*)take(H); s.w0 = take(H); s.w1 = take(H);
+  s.floats = off;
+  return s;
+}
+
+template <int C>
+int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int K, int iters, int relabel,
+                      hipStream_t st) {
+  const size_t P = (size_t)H * H;
+  const int ngroup = (int)((P + (size_t)KM_SUPER * KM_CHUNK - 1) / ((size_t)KM_SUPER * KM_CHUNK));
+  const PixScratch s = pix_carve(scratch, B, G, H, C, K);
+  const size_t shm_rows = (size_t)2 * G * C * sizeof(float);
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C>)) return rc;
+  hipLaunchKernelGGL(km_pix_tables_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, st, s.i0, s.i1, s.w0, s.w1, G, H);
+  hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(H, B), dim3(256), shm_rows, st, code, s.rinv, G, H);
+  hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K);
+  WVN_LAUNCH_CHECK();
+  const PixTabs tb{s.i0, s.i1, s.w0, s.w1};
+  for (int it = 0; it <= iters; ++it) {
+    hipLaunchKernelGGL((km_pix_assign_kernel<C>), dim3(H, B), dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
+    WVN_LAUNCH_CHECK();
+    if (it == iters) break;
+    hipLaunchKernelGGL(km_pix_partial_kernel, dim3(ngroup, B), dim3(128), (size_t)(2 * K * C + K) * sizeof(float), st, code, s.rinv,
+                       labels, tb, s.part, s.pcnt, G, H, C, K, ngroup);
+    WVN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1);
+    WVN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(km_relabel_kernel, dim3(B), dim3(1024), 0, st, labels, nseg, (int)P, K, relabel);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+// out[b][gy][gx][:] = 0.5 * (a[b][gy][gx][:] + m[b][gy][G-1-gx][:]): the code averaged with the flipped-back code of the mirrored
+// frame (the flip pass of the upstream get_code)
+__global__ void flip_average_kernel(const float* __restrict__ a, const float* __restrict__ m, float* __restrict__ out, long long n,
+                                    int G, int C) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long long r = i / C;
+  const int gx = (int)(r % G);
+  const long long row = r / G;
+  out[i] = __fmul_rn(__fadd_rn(a[i], m[(row * G + (G - 1 - gx)) * C + c]), 0.5f);
 }
 
 // out[r] = argmax_c x[r][c], lowest index wins ties (torch.argmax semantics on finite rows): the label maps of the STEGO
@@ -266,4 +519,23 @@ int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, float* scratch, i
   if (C == 64) return run_kmeans<64>(xn, labels, nseg, scratch, B, P, K, iters, relabel, st);
   if (C == 16) return run_kmeans<16>(xn, labels, nseg, scratch, B, P, K, iters, relabel, st);
   return WVN_ERR_ARG;
+}
+
+size_t wvn_kmeans_pixels_scratch_floats(int B, int G, int H, int C, int K) { return pix_carve(nullptr, B, G, H, C, K).floats; }
+
+int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K, int iters,
+                             int relabel, hipStream_t st) {
+  if (!code || !labels || !nseg || !scratch || K <= 0 || K > KM_MAXK || G <= 0 || H <= 0 || B <= 0) return WVN_ERR_ARG;
+  if ((size_t)2 * G * C * sizeof(float) > 96 * 1024 || (size_t)(2 * K * C + K) * sizeof(float) > 60 * 1024) return WVN_ERR_ARG;
+  if (C == 90) return run_kmeans_pixels<90>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st);
+  if (C == 16) return run_kmeans_pixels<16>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st);
+  return WVN_ERR_ARG;
+}
+
+int wvn_flip_average_launch(const float* a, const float* mirrored, float* out, int B, int G, int C, hipStream_t st) {
+  if (!a || !mirrored || !out || B <= 0 || G <= 0 || C <= 0) return WVN_ERR_ARG;
+  const long long n = (long long)B * G * G * C;
+  hipLaunchKernelGGL(flip_average_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, mirrored, out, n, G, C);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
 }

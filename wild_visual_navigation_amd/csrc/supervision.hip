@@ -24,7 +24,9 @@
 
 namespace {
 
-constexpr int MAX_PTS = 256;
+// vertex arrays live in dynamic LDS: the footprint of a traversable node has <= 40 points, the "untraversable plane" of
+// SupervisionNode.make_footprint_with_node (nodes.py:575-580: make_dense_plane, a 10 x 10 x 10 grid) has 1000
+constexpr size_t MAX_LDS_BYTES = 64 * 1024;
 
 struct RenderNode {
   const float* K;      // [4][4] scaled camera matrix of this node
@@ -37,11 +39,12 @@ __global__ __launch_bounds__(256) void project_render_fmin_kernel(const RenderNo
                                                                   const float* __restrict__ pts, int pts_batched, int N,
                                                                   int C, int H, int W, const float* __restrict__ value_dev,
                                                                   float value_host) {
-  __shared__ float px[MAX_PTS + 1], py[MAX_PTS + 1];
   __shared__ int closed_n;
-  extern __shared__ float rows[];  // [H] x_left, [H] x_right
+  extern __shared__ float rows[];  // [H] x_left, [H] x_right, [N + 1] px, [N + 1] py
   float* xl = rows;
   float* xr = rows + H;
+  float* px = rows + 2 * H;
+  float* py = px + (N + 1);
   const RenderNode nd = nodes[blockIdx.x];
   const float* P = pts + (pts_batched ? (size_t)blockIdx.x * N * 3 : 0);
   const float value = value_dev ? value_dev[0] : value_host;
@@ -81,16 +84,21 @@ __global__ __launch_bounds__(256) void project_render_fmin_kernel(const RenderNo
   for (int y = tid; y < H; y += blockDim.x) {
     const float fy = (float)y;
     float l = (float)W, r = -1.f;
+    bool poisoned = false;
     for (int e = 0; e < ne; ++e) {
       const float x0 = px[e], y0 = py[e], x1 = px[e + 1], y1 = py[e + 1];
       const bool act = (y0 <= fy && fy <= y1) || (y0 >= fy && fy >= y1);
       if (!act) continue;
       float dx = (x1 - x0) / ((y1 - y0) + 1e-12f);
-      dx = fminf(fmaxf(dx, -(float)W), (float)W);
+      if (dx == dx) dx = fminf(fmaxf(dx, -(float)W), (float)W);   // torch.clamp keeps a NaN (inf - inf over an infinite vertex)
       const float xs = (fy - y0) * dx + x0;
-      l = fminf(l, xs);   // (xs is finite here: both endpoints passed a comparison)
+      // torch's min / max over the edges propagate a NaN (an infinite vertex passes the comparisons above; inf * 0 and
+      // inf - inf are NaN): such a scan line is left unfilled
+      poisoned |= xs != xs;
+      l = fminf(l, xs);
       r = fmaxf(r, xs);
     }
+    if (poisoned) l = r = __builtin_nanf("");
     xl[y] = l; xr[y] = r;
   }
   __syncthreads();
@@ -115,9 +123,10 @@ __global__ __launch_bounds__(256) void project_render_fmin_kernel(const RenderNo
 
 int wvn_project_render_fmin_launch(const void* nodes, int n, const float* points, int points_batched, int npts, int C, int H,
                                    int W, const float* value_dev, float value, hipStream_t st) {
-  if (!nodes || !points || n <= 0 || npts < 2 || npts > MAX_PTS || C <= 0 || H <= 0 || W <= 0 || (size_t)H * 8 > 60 * 1024)
-    return WVN_ERR_ARG;
-  hipLaunchKernelGGL(project_render_fmin_kernel, dim3(n), dim3(256), (size_t)H * 2 * sizeof(float), st,
+  if (!nodes || !points || n <= 0 || npts < 2 || C <= 0 || H <= 0 || W <= 0) return WVN_ERR_ARG;
+  const size_t lds = ((size_t)H * 2 + ((size_t)npts + 1) * 2) * sizeof(float);
+  if (lds > MAX_LDS_BYTES) return WVN_ERR_ARG;   // H = 448: up to 7700 footprint points
+  hipLaunchKernelGGL(project_render_fmin_kernel, dim3(n), dim3(256), lds, st,
                      (const RenderNode*)nodes, points, points_batched, npts, C, H, W, value_dev, value);
   WVN_LAUNCH_CHECK();
   return WVN_OK;

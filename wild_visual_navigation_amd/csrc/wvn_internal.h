@@ -32,26 +32,42 @@ struct GemmBf16Params {
   const bf16_t* A_lo; const bf16_t* W_lo; void* C_lo; bf16_t* q_lo; bf16_t* k_lo; bf16_t* vt_lo;
   long long* dbg;  // optional: per-wave phase timings of the A-stationary kernel (scripts/ab_kernels.py --timing)
 };
-int wvn_gemm_bf16_launch(const GemmBf16Params& p, int epi, hipStream_t st);
-// A-stationary kernel for K == 384 (gemm_a384.hip); WVN_ERR_ARG when the shape is not eligible
-int wvn_gemm_a384_launch(const GemmBf16Params& p, int epi, hipStream_t st);
-// mlp_fused.hip: x += gelu(xn W1^T + b1) W2p^T + b2 with the hidden activation kept in registers (D = 384 only);
-// xn == nullptr: xn = LayerNorm(x; ln_g, ln_b, ln_eps) computed in the kernel, once per row block
-int wvn_mlp_fused_launch(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,
-                         const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F,
-                         hipStream_t st);
-// gemm_proj.hip: x[M,384] += (A[M,384] W[384,384]^T + bias) (* ls): W resident in LDS, one 32-row group per wave at a time
-int wvn_proj_resid_launch(const bf16_t* A, int lda, const bf16_t* W, const float* bias, const float* ls, float* x, int ldx, int M,
-                          hipStream_t st);
-// mlp_fused.hip, with the attention output projection of the block in its prologue: x += (attn Wp^T + bp) (* ls1); x += MLP(LN(x))
-int wvn_proj_mlp_fused_launch(const bf16_t* attn, int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1, const float* ln_g,
-                              const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1, const bf16_t* W2p, const float* b2,
-                              const float* ls2, float* x, int ldx, int M, int F, hipStream_t st);
-// qkv_fused.hip: LayerNorm(x) -> q | k | v^T in the layouts of attention_bf16.hip (D = 384, heads = 6), one launch
-int wvn_qkv_fused_launch(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W, const float* bias,
-                         bf16_t* q, bf16_t* k, bf16_t* vt, int heads, int npad, int ntok_s, float q_scale, int M, hipStream_t st);
-// row-panel kernel for N == 384 residual updates with long K (gemm_n384.hip); WVN_ERR_ARG when not eligible
-int wvn_gemm_n384_launch(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done, int force = 0);
+// The launchers of the 16-bit-operand speed path exist twice, once per operand format (operand.h): the plain names take bf16
+// operands, the *_f16 names fp16 operands (same kernels, compiled with -DWVN_OPERAND_F16=1).  "bf16_t" in these signatures
+// is the raw 16-bit storage type of either format.
+#define WVN_DECLARE_OPERAND_LAUNCHERS(SFX)                                                                                          \
+  int wvn_gemm_bf16_launch##SFX(const GemmBf16Params& p, int epi, hipStream_t st);                                                  \
+  /* A-stationary kernel for K == 384 (gemm_a384.hip); WVN_ERR_ARG when the shape is not eligible */                                \
+  int wvn_gemm_a384_launch##SFX(const GemmBf16Params& p, int epi, hipStream_t st);                                                  \
+  /* mlp_fused.hip: x += gelu(xn W1^T + b1) W2p^T + b2 with the hidden activation kept in registers (D = 384 only);                 \
+     xn == nullptr: xn = LayerNorm(x; ln_g, ln_b, ln_eps) computed in the kernel, once per row block */                             \
+  int wvn_mlp_fused_launch##SFX(const bf16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1,    \
+                                const float* b1, const bf16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M,     \
+                                int F, hipStream_t st);                                                                             \
+  /* gemm_proj.hip: x[M,384] += (A[M,384] W[384,384]^T + bias) (* ls): W resident in LDS, one 32-row group per wave at a time */    \
+  int wvn_proj_resid_launch##SFX(const bf16_t* A, int lda, const bf16_t* W, const float* bias, const float* ls, float* x, int ldx,  \
+                                 int M, hipStream_t st);                                                                            \
+  /* mlp_fused.hip, with the attention output projection of the block in its prologue:                                              \
+     x += (attn Wp^T + bp) (* ls1); x += MLP(LN(x)) */                                                                              \
+  int wvn_proj_mlp_fused_launch##SFX(const bf16_t* attn, int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1,         \
+                                     const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1,         \
+                                     const bf16_t* W2p, const float* b2, const float* ls2, float* x, int ldx, int M, int F,         \
+                                     hipStream_t st);                                                                               \
+  /* qkv_fused.hip: LayerNorm(x) -> q | k | v^T in the layouts of attention_bf16.hip (D = 384, heads = 6), one launch */            \
+  int wvn_qkv_fused_launch##SFX(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W,       \
+                                const float* bias, bf16_t* q, bf16_t* k, bf16_t* vt, int heads, int npad, int ntok_s,               \
+                                float q_scale, int M, hipStream_t st);                                                              \
+  /* row-panel kernel for N == 384 residual updates with long K (gemm_n384.hip); WVN_ERR_ARG when not eligible */                   \
+  int wvn_gemm_n384_launch##SFX(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done, int force = 0);                   \
+  /* attention_bf16.hip */                                                                                                          \
+  int wvn_attention_bf16_launch##SFX(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads, int ntok,   \
+                                     int ntok_s, int npad, float scale, hipStream_t st);                                            \
+  void wvn_attention_bf16_set_debug##SFX(long long* dbg); /* per-wave phase timings (TIMING build), nullptr = off */                \
+  void wvn_attention_bf16_set_variant##SFX(int v);                                                                                  \
+  extern long long* g_mlp_fused_dbg##SFX;                                                                                           \
+  extern long long* g_qkv_fused_dbg##SFX;
+WVN_DECLARE_OPERAND_LAUNCHERS()
+WVN_DECLARE_OPERAND_LAUNCHERS(_f16)
 // exact mode: hi/lo bf16 planes, three MFMAs per product (gemm_x3.hip); same epilogue codes, plane-typed outputs for the
 // "bf16" ones
 int wvn_gemm_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
@@ -104,27 +120,29 @@ struct GemmF32Params {
 int wvn_gemm_f32_launch(const GemmF32Params& p, int epi, hipStream_t st);
 
 // ---- elementwise / normalisation (elementwise.hip) --------------------------------------------
-// img: fp32 in [0,1], or raw uint8 pixels when img_u8 != 0 (bf16 output, P == 8 only).  out_mode: 0 fp32, 1 bf16, 2 hi / lo
-// bf16 planes (patches_lo); ldp: row stride in elements (0 = 3*P*P; pad columns are NOT written)
+// Frame ingest: NEAREST resize + centre crop as two index tables over the source frame.  Network pixel (y, x) is
+// frame pixel (rows[y], cols[x]) of a [.., src_h, src_w] frame; rows / cols: device int32 [S].
+struct WvnIngest { const int* rows; const int* cols; int src_h, src_w; };
+// img: fp32 in [0,1], or raw uint8 pixels when img_u8 != 0.  out_mode: 0 fp32, 1 bf16, 2 hi / lo bf16 planes (patches_lo), 3 fp16;
+// ldp: row stride in elements (0 = 3*P*P; pad columns are NOT written); ing: optional gather tables (the frames are then
+// [B,3,src_h,src_w])
 int wvn_patchify_launch(const void* img, int img_u8, void* patches, void* patches_lo, int out_mode, int ldp, int B, int S, int P,
-                        hipStream_t st);
+                        hipStream_t st, const WvnIngest* ing = nullptr);
+int wvn_gather_image_launch(const void* in, void* out, long long planes, int out_h, int out_w, int elem_bytes, const WvnIngest* ing,
+                            hipStream_t st);
 int wvn_split_planes_launch(const float* src, int lds_, bf16_t* hi, bf16_t* lo, int ldd, int rows, int cols, hipStream_t st);
 int wvn_cls_rows_launch(const float* cls_pos, float* x, int B, int ntok_s, int D, hipStream_t st);
 // zero bytes [col0, col0 + ncol) of each of nrows rows (all multiples of 4)
 int wvn_pad_zero_launch(void* base, long long nrows, long long row_stride_bytes, long long col0_bytes,
                         long long ncol_bytes, hipStream_t st);
-// LayerNorm over rows of x[rows, D] (fp32) -> y (bf16 or f32, leading dim ldy); optional second fp32 output.
+// LayerNorm over rows of x[rows, D] (fp32) -> y (y_fmt: 0 fp32, 1 bf16, 2 fp16; leading dim ldy); optional second fp32 output.
 // row_map: 0 = identity; 1 = drop the class token (input row b*ntok+1+p -> output row b*(ntok-1)+p)
-int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, int ldy,
+int wvn_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int y_fmt, int ldy,
                          float* y2, int ldy2, int rows_out, int D, float eps, int drop_cls, int ntok,
                          int ntok_s, hipStream_t st, void* y_lo = nullptr);  // y_lo: exact mode, lo plane of the bf16 output
-int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st);
+int wvn_cast_f32_bf16_launch(const float* src, int lds_, bf16_t* dst, int ldd, int rows, int cols, hipStream_t st, int f16 = 0);
 
 // ---- attention (attention_bf16.hip / attention_f32.hip) ---------------------------------------
-int wvn_attention_bf16_launch(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads,
-                              int ntok, int ntok_s, int npad, float scale, hipStream_t st);
-void wvn_attention_bf16_set_debug(long long* dbg);
-void wvn_attention_bf16_set_variant(int v);  // per-wave phase timings (TIMING build), nullptr = off
 int wvn_attention_f32_launch(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok,
                              int ntok_s, int npad, float scale, hipStream_t st);
 // exact mode on the matrix pipe (attention_x3.hip): hi / lo planes of q, k [B,h,npad,64], v^T [B,h,64,npad] (token-permuted),
@@ -151,6 +169,10 @@ int wvn_adjacency_launch(const int* seg, long long* edges, int* count, unsigned 
 int wvn_normalize_rows_launch(const float* code, int ldc, float* xn, int rows, int C, hipStream_t st);
 int wvn_argmax_rows_launch(const float* x, int ld, int rows, int cols, int* out, hipStream_t st);
 size_t wvn_kmeans_scratch_floats(int B, int P, int C, int K);
+size_t wvn_kmeans_pixels_scratch_floats(int B, int G, int H, int C, int K);
+int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K, int iters,
+                             int relabel, hipStream_t st);
+int wvn_flip_average_launch(const float* a, const float* mirrored, float* out, int B, int G, int C, hipStream_t st);
 int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, float* scratch, int B, int P, int C, int K, int iters,
                       int relabel, hipStream_t st);
 int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int ldx, const unsigned char* valid,

@@ -46,7 +46,7 @@ class DinoInterface:
         dropout_p: float = 0,
         pretrained_weights=None,  # path to a DINO checkpoint, or a state dict; None -> seeded synthetic
         cfg=None,
-        precision: str = "bf16",  # extension: "bf16" (MFMA) | "exact" (<= 1e-3 parity mode on MFMA) | "fp32" (same gate, FMA)
+        precision: str = "bf16",  # extension: "bf16" | "fp16" (MFMA speed path, 8 / 11 significand bits) | "exact" (<= 1e-3 parity mode on MFMA) | "fp32" (same gate, FMA)
         max_chunk: int = 16,
         allow_synthetic: bool = False,
         fuse_mlp: Optional[bool] = None,
@@ -86,8 +86,8 @@ class DinoInterface:
     @torch.no_grad()
     def inference_tokens(self, img: torch.Tensor) -> torch.Tensor:
         """[B,3,H,W] in [0,1] -> patch tokens [B,G*G,D] fp32 (the un-upsampled feature map, NHWC)."""
-        img = img.to(self._device)
-        return self._model.forward_tokens(resize_nearest_center_crop(img, self._cfg.input_size))
+        # T.Resize(NEAREST) + T.CenterCrop + T.Normalize of dino_interface.py:52-59 all happen inside the patch gather
+        return self._model.forward_tokens(img.to(self._device))
 
     @torch.no_grad()
     def inference(self, img: torch.Tensor) -> torch.Tensor:

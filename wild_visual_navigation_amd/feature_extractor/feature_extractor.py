@@ -189,7 +189,8 @@ class FeatureExtractor:
         B, H = img.shape[0], img.shape[2]
         G = self._grid()
         stego = self._feature_type == "stego"
-        exact = (self._extractor._precision != "bf16") if stego else (self._extractor._model.lowp_dtype != torch.bfloat16)
+        prec = self._extractor._precision
+        exact = prec in ("exact", "fp32")
         if exact:   # fp32 extractor: hi + lo split MFMA operands in the fused kernel
             tokens = self.backbone_stage(img)
             return model.forward_per_pixel_exact(tokens.reshape(B * G * G, -1), B, G, (H, H), mean, std, f, want_loss=want_loss,
@@ -200,9 +201,10 @@ class FeatureExtractor:
             zx[:, model.X_COL: model.X_COL + code.shape[1]] = code
         else:
             zx = torch.empty(B * G * G, model.ZX_COLS, dtype=torch.bfloat16, device=self._device)
-            from .transforms import resize_nearest_center_crop
-            self._extractor._model.forward_tokens(resize_nearest_center_crop(img, self._extractor.input_size),
-                                                  lowp_out=zx[:, model.X_COL:])
+            if prec == "fp16":   # the per-pixel kernel takes bf16 features: hand it the fp32 tokens rounded once
+                ops.cast_rows_bf16(self._extractor._model.forward_tokens(img).reshape(B * G * G, -1), zx[:, model.X_COL:])
+            else:
+                self._extractor._model.forward_tokens(img, lowp_out=zx[:, model.X_COL:])
         return model.forward_per_pixel(zx, B, G, (H, H), mean, std, f, want_loss=want_loss, conf_state=conf_state)
 
     def _grid(self) -> int:

@@ -24,7 +24,6 @@ import torch
 from .. import _lib, ops
 from ..backbone import ARCH, VitBackbone, split_planes
 from .dino_interface import _Cfg, _load_state_dict
-from .transforms import resize_nearest_center_crop
 
 STEGO_CODE_DIM = 90
 KMEANS_ITERS = 10
@@ -160,10 +159,10 @@ class StegoInterface:
         self._b_code = (head["cluster1.0.bias"] + head["cluster2.2.bias"]).float().to(dev).contiguous()
         self._b_lin = head["cluster1.0.bias"].float().to(dev).contiguous()
         self._b_nl = head["cluster2.2.bias"].float().to(dev).contiguous()
-        if precision in ("bf16", "fp8"):   # the (tiny) head stays on the bf16 kernels in the fp8 mode
-            self._w_hid = head["cluster2.0.weight"].to(dev, torch.bfloat16).contiguous()
-            self._w_code = torch.cat([head["cluster1.0.weight"], head["cluster2.2.weight"]], dim=1).to(
-                dev, torch.bfloat16).contiguous()  # [C, 2D] acting on [tok | hid]
+        if precision in ("bf16", "fp8", "fp16"):   # the (tiny) head stays on the bf16 kernels in the fp8 mode
+            lp = self._bb.lowp_dtype
+            self._w_hid = head["cluster2.0.weight"].to(dev, lp).contiguous()
+            self._w_code = torch.cat([head["cluster1.0.weight"], head["cluster2.2.weight"]], dim=1).to(dev, lp).contiguous()  # [C, 2D] acting on [tok | hid]
         elif precision == "exact":  # hi / lo planes for the x3 MFMA GEMMs
             self._w_hid = split_planes(head["cluster2.0.weight"].float().to(dev))
             self._w_lin = split_planes(head["cluster1.0.weight"].float().to(dev))
@@ -205,21 +204,21 @@ class StegoInterface:
         self._device = device
 
     # ---- code (STEGO head) at patch resolution --------------------------------------------------------
-    def _code_once(self, img: torch.Tensor) -> torch.Tensor:
+    def _code_once(self, img: torch.Tensor, flip: bool = False) -> torch.Tensor:
         B = img.shape[0]
         P, D = self._bb.grid ** 2, self._D
-        if self._precision in ("bf16", "fp8"):
-            cat = torch.empty(B * P, 2 * D, dtype=torch.bfloat16, device=self._device)  # [tok | hid]
-            self._bb.forward_tokens(img, lowp_out=cat)
+        if self._precision in ("bf16", "fp8", "fp16"):
+            cat = torch.empty(B * P, 2 * D, dtype=self._bb.lowp_dtype, device=self._device)  # [tok | hid]
+            self._bb.forward_tokens(img, lowp_out=cat, flip=flip)
             ops.gemm_bf16(cat[:, :D], self._w_hid, self._b_hid, _lib.EPI_RELU_BF16, out=cat[:, D:])
             code = ops.gemm_bf16(cat, self._w_code, self._b_code, _lib.EPI_F32)
         elif self._precision == "exact":
-            tok = ops.split_planes(self._bb.forward_tokens(img).reshape(B * P, D))
+            tok = ops.split_planes(self._bb.forward_tokens(img, flip=flip).reshape(B * P, D))
             hid = ops.gemm_x3(tok, self._w_hid, self._b_hid, _lib.EPI_RELU_BF16)
             code = ops.gemm_x3(tok, self._w_lin, self._b_lin, _lib.EPI_F32)
             ops.gemm_x3(hid, self._w_nl, self._b_nl, _lib.EPI_RESID_F32, out=code)
         else:
-            tok = self._bb.forward_tokens(img).reshape(B * P, D)
+            tok = self._bb.forward_tokens(img, flip=flip).reshape(B * P, D)
             hid = ops.gemm_f32(tok, self._w_hid, self._b_hid, _lib.F32_RELU)
             code = ops.gemm_f32(tok, self._w_lin, self._b_lin, _lib.F32_NONE)
             ops.gemm_f32(hid, self._w_nl, self._b_nl, _lib.F32_RESID, out=code)
@@ -228,12 +227,11 @@ class StegoInterface:
     @torch.no_grad()
     def code_tokens(self, img: torch.Tensor) -> torch.Tensor:
         """[B,3,H,W] in [0,1] -> STEGO code [B, G*G, 90] fp32 (patch resolution)."""
-        img = resize_nearest_center_crop(img.to(self._device), self._cfg.input_size)
+        # T.Resize(NEAREST) + T.CenterCrop + T.Normalize (stego_interface.py:51-58, 87) happen inside the backbone's patch gather
+        img = img.to(self._device)
         code = self._code_once(img)
-        if self._flip_tta:  # code averaged with the flipped-back code of the mirrored frame
-            G = self._bb.grid
-            c2 = self._code_once(img.flip(-1)).reshape(-1, G, G, self._C).flip(2).reshape(code.shape)
-            code = (code + c2) * 0.5
+        if self._flip_tta:  # code averaged with the flipped-back code of the mirrored frame (the mirror is a reversed column table)
+            code = ops.flip_average(code, self._code_once(img, flip=True), self._bb.grid)
         return code
 
     @torch.no_grad()
@@ -251,12 +249,11 @@ class StegoInterface:
         self._H = H
         self._labels_patch = None
         if self._cluster_resolution == "pixel":      # cluster the H x H up-sampled code pixels
-            dense = self.features                                          # [B, C, H, H]
-            pix = dense.permute(0, 2, 3, 1).reshape(B, H * H, self._C)
-            if self._cfg.run_clustering:
-                labels, self._n_segments = ops.kmeans_cosine(pix, self._cfg.n_image_clusters, KMEANS_ITERS, relabel=True)
+            if self._cfg.run_clustering:   # rows interpolated on the fly from the patch codes: the dense code is never built
+                labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, H, self._cfg.n_image_clusters, KMEANS_ITERS, relabel=True)
             else:
-                labels = self._probe_labels(pix.reshape(B * H * H, self._C), self._clusters, None, cosine=True)
+                pix = self.features.permute(0, 2, 3, 1).reshape(B * H * H, self._C)   # [B, C, H, H] -> pixel rows
+                labels = self._probe_labels(pix, self._clusters, None, cosine=True)
                 self._n_segments = None
             self._cluster_pred = labels.reshape(1, B, H, H)
         else:

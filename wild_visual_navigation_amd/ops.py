@@ -268,6 +268,44 @@ def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = T
     return labels, nseg
 
 
+def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int = 10, relabel: bool = True):
+    """code [B, G*G, C] fp32 patch codes -> (labels [B, H*H] int32, n_segments [B] int32): the k-means of ``kmeans_cosine`` over
+    the H x H bilinearly up-sampled, normalised code pixels, interpolated on the fly (the [B, H*H, C] array is never built)."""
+    require_cuda(code, "code")
+    B, P, Cc = code.shape
+    if P != G * G:
+        raise _lib.WvnError(f"kmeans_cosine_pixels: {P} code rows for a {G} x {G} grid")
+    code = code.contiguous()
+    dev = code.device
+    labels = torch.empty(B, H * H, dtype=torch.int32, device=dev)
+    nseg = torch.empty(B, dtype=torch.int32, device=dev)
+    scratch = torch.empty(lib().wvn_kmeans_pixels_scratch_bytes(B, G, H, Cc, K), dtype=torch.uint8, device=dev)
+    check(lib().wvn_kmeans_cosine_pixels(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters, int(relabel),
+                                         stream()), "wvn_kmeans_cosine_pixels")
+    return labels, nseg
+
+
+def flip_average(code: torch.Tensor, mirrored: torch.Tensor, G: int) -> torch.Tensor:
+    """0.5 * (code + flip_x(mirrored)) on [B, G*G, C] fp32 patch maps (in place on ``code``)."""
+    require_cuda(code, "code")
+    B, P, Cc = code.shape
+    if not (code.is_contiguous() and mirrored.is_contiguous()) or mirrored.shape != code.shape or P != G * G:
+        raise _lib.WvnError("flip_average: contiguous [B, G*G, C] fp32 pairs expected")
+    check(lib().wvn_flip_average(ptr(code), ptr(mirrored), ptr(code), B, G, Cc, stream()), "wvn_flip_average")
+    return code
+
+
+def cast_rows_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[r, :cols] = src[r, :] rounded to dst's 16-bit format (bf16 / fp16); fp32 rows with any row stride."""
+    require_cuda(src, "src")
+    R, Cc = src.shape
+    if src.stride(1) != 1 or dst.stride(1) != 1 or dst.shape[0] != R or dst.shape[1] < Cc or dst.dtype not in (torch.bfloat16, torch.float16):
+        raise _lib.WvnError("cast_rows_bf16: fp32 [R, C] rows -> 16-bit [R, >= C] rows expected")
+    check(lib().wvn_cast_rows(ptr(src), src.stride(0), ptr(dst), dst.stride(0), R, Cc, int(dst.dtype == torch.float16), stream()),
+          "wvn_cast_rows")
+    return dst
+
+
 def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     """x [R, C] fp32 -> int32 [R] index of the row maximum (lowest index wins ties)."""
     require_cuda(x, "x")
@@ -290,14 +328,34 @@ def normalize_rows(x: torch.Tensor) -> torch.Tensor:
 
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epi: int,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """epilogue(a[M,K] @ w[N,K]^T + bias); a, w bf16 (row strides allowed)."""
+    """epilogue(a[M,K] @ w[N,K]^T + bias); a, w bf16 or fp16 (both the same; row strides allowed).  The operand format picks
+    the library entry: wvn_gemm_bf16 / wvn_gemm_f16 (the same tile kernel compiled per format, csrc/operand.h)."""
     M, K = a.shape
     N = w.shape[0]
+    if a.dtype != w.dtype or a.dtype not in (torch.bfloat16, torch.float16):
+        raise _lib.WvnError(f"gemm_bf16: operands must both be bfloat16 or both float16, got {a.dtype} / {w.dtype}")
     if out is None:
-        dt = torch.bfloat16 if epi in (_lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_RELU_BF16) else torch.float32
+        dt = a.dtype if epi in (_lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_RELU_BF16) else torch.float32
         out = torch.empty(M, N, dtype=dt, device=a.device)
-    check(lib().wvn_gemm_bf16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K,
-                              epi, stream()), "wvn_gemm_bf16")
+    fn, name = (lib().wvn_gemm_f16, "wvn_gemm_f16") if a.dtype == torch.float16 else (lib().wvn_gemm_bf16, "wvn_gemm_bf16")
+    check(fn(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), M, N, K, epi, stream()), name)
+    return out
+
+
+gemm_lowp = gemm_bf16
+
+
+def resize_nearest_crop(img: torch.Tensor, tables) -> torch.Tensor:
+    """out[..., y, x] = img[..., tables.rows[y], tables.cols[x]] (uint8 / fp32 / int32 images [..., H, W]): T.Resize(NEAREST) +
+    T.CenterCrop of ImageProjector.resize_image (image_projector.py:199-200) as one gather (``transforms.ingest_tables``)."""
+    require_cuda(img, "img")
+    if img.shape[-2] != tables.src_h or img.shape[-1] != tables.src_w or img.element_size() not in (1, 4):
+        raise _lib.WvnError(f"resize_nearest_crop: image {tuple(img.shape)} {img.dtype} does not match the tables ({tables.src_h} x {tables.src_w})")
+    img = img.contiguous()
+    planes = img.numel() // (tables.src_h * tables.src_w)
+    out = torch.empty(*img.shape[:-2], tables.out_h, tables.out_w, dtype=img.dtype, device=img.device)
+    check(lib().wvn_resize_nearest_crop(ptr(img), ptr(out), planes, tables.src_h, tables.src_w, ptr(tables.rows), ptr(tables.cols),
+                                        tables.out_h, tables.out_w, img.element_size(), stream()), "wvn_resize_nearest_crop")
     return out
 
 
