@@ -15,13 +15,20 @@ the 64-frame batch over the ranks):
   --mode backbone (configs[1]): --batch 32 frames through the ViT only (feature extraction).
   --mode dinov2   (configs[4]): DINOv2 ViT-B/14 at 518x518 (1370 tokens, LayerScale) + STEGO head, --batch 16 frames per GPU
                   (128 over 8 GPUs); meant for --precision fp8 (block linears on e4m3 MFMA), also runs in bf16 / exact.
-  --precision bf16 : bf16 MFMA operands, fp32 accumulate / residual / statistics (the speed path)
+  --precision fp16 : fp16 MFMA operands (11 significand bits), fp32 accumulate / residual / statistics: the speed path (default)
+  --precision bf16 : the same kernels with bf16 operands (8 significand bits; same speed, 8x the operand rounding)
   --precision exact: hi + lo split bf16 operands, three MFMAs per product -- fp32-class results on the matrix pipe, the
                      north_star "<= 1e-3" parity mode, timed on the same workload
 Inputs (a pool of distinct batches) are resident in HBM before the timed region; weights are seeded synthetic (no network).
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = fused attention, HIP-event timed on the launch stream inside
 the timed region), `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N = 1 only) and `parity`
 (the GPU path against that oracle on the same frames: what BASELINE.md 4.5 asks to be reported with every speed number).
+The default run (N = 1, --mode full) times two more legs of the SAME workload after the headline leg, each >= 20 steps, and
+reports them inside the same line:
+  `parity_mode`    : --precision exact (the path that meets the north_star's <= 1e-3 clause), with its own roofline and parity
+  `stego_upstream` : the other reading of the absent STEGO package (flip TTA = two backbone passes per frame, k-means over the
+                     448 x 448 up-sampled code pixels, general pooling) in the headline precision
+(--no-extra-legs skips them; A/B runs and N > 1 runs never run them).
 """
 import argparse
 import json
@@ -44,8 +51,8 @@ def attention_traffic_per_launch(frames_per_launch, precision):
     of a launch, so the profiled figure is rescaled to this run's launch size.  None when no profile is committed."""
     try:
         t = json.load(open(TRAFFIC_FILE))
-        if precision != "bf16":
-            t = t[precision]   # sub-entry of the exact-mode kernel; the top level is the bf16 kernel
+        if precision not in ("bf16", "fp16", "fp8"):   # fp16: the same kernel and byte counts as bf16 (16-bit operands)
+            t = t[precision]   # sub-entry of the exact-mode kernel; the top level is the 16-bit-operand kernel
         return (t["fetch_bytes_corrected"] + t["write_bytes"]) * frames_per_launch / t["frames_per_launch"]
     except Exception:
         return None
@@ -82,8 +89,13 @@ def parse():
     ap.add_argument("--no-fuse-mlp", action="store_true", help="A/B: run the block MLP as the un-fused fc1 / fc2 kernel pair")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (about 15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--precision", default=None, choices=["bf16", "exact", "fp32", "fp8"],
-                    help="default: bf16 (fp8 for --mode dinov2)")
+    ap.add_argument("--precision", default=None, choices=["fp16", "bf16", "exact", "fp32", "fp8"],
+                    help="default: fp16 (fp8 for --mode dinov2)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline leg only (no parity_mode / stego_upstream legs)")
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each extra leg (after 5 warm-up steps)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (default nccl = RCCL; gloo: the multi-process path on a box with one GPU, "
+                         "all ranks on cuda:0 -- tests/test_gpu_distributed.py)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run every step on one stream (default: the backbone of step i+1 runs on a second HIP stream while "
                          "clustering / pooling / the MLP step of step i -- small kernels that do not fill the GPU -- finish)")
@@ -91,7 +103,7 @@ def parse():
     if args.batch is None:
         args.batch = {"full": 64, "backbone": 32, "dinov2": 16}[args.mode]
     if args.precision is None:
-        args.precision = "fp8" if args.mode == "dinov2" else "bf16"
+        args.precision = "fp8" if args.mode == "dinov2" else "fp16"
     if args.mode == "dinov2":
         args.size, args.chunk = 518, min(args.chunk, args.batch)
     if args.precision == "fp8" and args.mode == "full":
@@ -106,7 +118,7 @@ def maybe_spawn(args):
     import torch
 
     n = torch.cuda.device_count()
-    if n < args.gpus:
+    if n < args.gpus and args.backend != "gloo":
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but this node exposes {n} GPU(s); refusing to print a line "
                          "for a configuration that did not run")
     port = 29500 + (os.getpid() % 2000)
@@ -116,7 +128,9 @@ def maybe_spawn(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def make_pipeline(args, dev):
+def make_pipeline(args, dev, precision=None, stego_reading=None):
+    precision = precision or args.precision
+    stego_reading = stego_reading or args.stego_reading
     from wild_visual_navigation_amd.feature_extractor import FeatureExtractor
     from wild_visual_navigation_amd.model import SimpleMLP
     from wild_visual_navigation_amd.traversability_estimator import MlpTrainer
@@ -128,18 +142,18 @@ def make_pipeline(args, dev):
         from wild_visual_navigation_amd.feature_extractor.stego_interface import synthetic_stego_head
 
         fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=518, n_image_clusters=20,
-                              precision=args.precision, max_chunk=args.chunk, backbone_type="vit_base", patch_size=14,
+                              precision=precision, max_chunk=args.chunk, backbone_type="vit_base", patch_size=14,
                               pretrained_weights=synthetic_vit_state_dict("vit_base", 14, pretrain_grid=37, seed=0, dinov2=True),
                               head_weights=synthetic_stego_head(768), allow_synthetic=True)
     else:
         ftype = "stego" if (args.segmentation == "stego" and args.mode == "full") else "dino"
         seg = args.segmentation if args.mode == "full" else "grid"
         fe = FeatureExtractor(dev, segmentation_type=seg, feature_type=ftype, input_size=args.size,
-                              backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=args.precision,
+                              backbone_type="vit_small", patch_size=8, n_image_clusters=20, precision=precision,
                               max_chunk=args.chunk, allow_synthetic=True, fuse_mlp=False if args.no_fuse_mlp else None,
                               fuse_qkv=False if args.no_fuse_qkv else None, fuse_proj=not args.no_fuse_proj,
-                              flip_tta=args.stego_reading == "upstream",
-                              cluster_resolution="pixel" if args.stego_reading == "upstream" else "patch")
+                              flip_tta=stego_reading == "upstream",
+                              cluster_resolution="pixel" if stego_reading == "upstream" else "patch")
     if args.attn_variant is not None:
         from wild_visual_navigation_amd import _lib
         _lib.lib().wvn_debug_attention_variant(args.attn_variant)
@@ -152,18 +166,19 @@ def hot_path_step(fe, trainer, img, labels_u, args, backbone_out=None):
     """One pass: frames -> features/segments -> pooled rows -> one MLP optimisation step."""
     import torch
 
+    from wild_visual_navigation_amd import ops
+
     feat, seg, nseg = fe.extract_batch(img, backbone_out=backbone_out)
     B, S, D = feat.shape
-    if args.segmentation == "stego":
-        keep = (torch.arange(S, device=feat.device)[None] < nseg[:, None]).reshape(-1)  # ids that exist per image
-        x = feat.reshape(B * S, D)[keep]
-        u = labels_u.reshape(B * S, 2)[keep]
+    rows_dev = None
+    if args.segmentation == "stego":   # ids a frame's k-means did not produce are dropped -- on the device: the rows that exist
+        x, u, rows_dev = ops.compact_segment_rows(feat, nseg, labels_u)   # move to the front, the count never visits the host
     else:
         x = feat.reshape(B * S, D)
         u = labels_u.reshape(B * S, 2)
     y_valid = u[:, 0] < 0.16  # 16 % labelled segments, like assets/graph/graph.pt (16 / 100)
     y = y_valid.float() * (0.5 + 0.5 * u[:, 1])
-    return trainer.train_step(x, y, y_valid), x.shape[0]
+    return trainer.train_step(x, y, y_valid, rows_dev=rows_dev), (rows_dev if rows_dev is not None else x.shape[0])
 
 
 class TwoStreamPipeline:
@@ -195,8 +210,7 @@ class TwoStreamPipeline:
 
     def step(self, img, labels_u, next_img=None):
         """Runs one step on ``img``; ``next_img`` (the following step's frames, None for the last step) gets its backbone
-        stage enqueued FIRST, so that the host-side synchronisation inside this step's tail (boolean-mask row selection)
-        does not keep the GPU from starting it."""
+        stage enqueued FIRST (the tail itself no longer synchronises with the host: rows are compacted on the device)."""
         torch = self.torch
         tok, ready = self.pending if self.pending is not None else self._enqueue_backbone(img)
         self.pending = self._enqueue_backbone(next_img) if next_img is not None else None
@@ -214,12 +228,10 @@ class TwoStreamPipeline:
         cur.wait_stream(self.b)
 
 
-def cpu_baseline_and_parity(args, fe, dev):
+def cpu_oracle_sample(args, fe):
     """CPU oracle (a PORT: PyTorch/numpy restatement of the reference algorithm, oracle/) on a bounded sample of the same
     workload -- `cpu_frames` frames through backbone + STEGO head + k-means + pooling, then one MLP step on their rows --
-    timed on this box's host cores; then the SAME frames through the GPU path with the SAME weights, compared stage by stage
-    (the parity figures BASELINE.md 4.5 wants beside every speed number)."""
-    import numpy as np
+    timed on this box's host cores.  Returns (cpu_baseline dict, the oracle's intermediate results for the parity legs)."""
     import torch
 
     from oracle import interfaces as OI, mlp as OM, segments as OS, vit as OV
@@ -270,40 +282,80 @@ def cpu_baseline_and_parity(args, fe, dev):
             "backbone": "ViT-S/8 12 blocks fp32", "dinov2": "DINOv2 ViT-B/14 12 blocks fp32 + STEGO head"}[args.mode]
     base = {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} frames {args.size}x{args.size} through the CPU oracle ({what}), {dt:.1f} s wall"}
+    return base, {"img": img, "toks": toks, "codes": codes, "segs": segs, "sd": sd, "head": head, "G": G, "P": P, "heads": heads}
 
-    # ---- parity of the GPU path on the same frames, same weights ----
+
+def gpu_parity(args, fe, dev, orc, precision):
+    """The GPU path in `precision` on the oracle's frames, with the SAME weights, compared stage by stage (the parity figures
+    BASELINE.md 4.5 wants beside every speed number).  For k-means segment maps two figures: `seg_equal_frames` (end to end:
+    the GPU's map against the oracle's map from the oracle's own code -- a 1e-4 difference in the code moves borderline
+    points) and `seg_equal_given_gpu_code` (the integer stage alone: the oracle's k-means run on the GPU's code)."""
+    import torch
+
+    from oracle import interfaces as OI, segments as OS
+
+    n, G = args.cpu_frames, orc["G"]
+    stego = fe.feature_type == "stego"
+    bb = fe._extractor._bb if stego else fe._extractor._model
     with torch.no_grad():
-        gi = img.to(dev)
+        gi = orc["img"].to(dev)
         gtok = bb.forward_tokens(gi).cpu()
-        otok = torch.cat(toks)
-        par = {"mode": args.precision, "frames": n, "against": "oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned)",
+        otok = torch.cat(orc["toks"])
+        par = {"mode": precision, "frames": n, "against": "oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned)",
                "max_abs_tokens": float((gtok - otok).abs().max()), "rel_l2_tokens": float((gtok - otok).norm() / otok.norm())}
         if args.mode == "dinov2":
             gcode = fe.backbone_stage(gi).cpu()
-            ocode = torch.cat(codes)
+            ocode = torch.cat(orc["codes"])
             par["max_abs_code"] = float((gcode - ocode).abs().max())
             par["rel_l2_code"] = float((gcode - ocode).norm() / ocode.norm())
         if args.mode == "full":
             feat, seg, nseg = fe.extract_batch(gi)
             seg = seg.cpu().long()
-            oseg = torch.stack(segs)
+            oseg = torch.stack(orc["segs"])
             same = [bool(torch.equal(seg[b], oseg[b])) for b in range(n)]
             par["seg_equal_frames"] = f"{sum(same)}/{n}"
             par["seg_pixel_agreement"] = float((seg == oseg).float().mean())
             if stego:
                 gcode = fe._extractor.feature_tokens.cpu()
-                par["max_abs_code"] = float((gcode - torch.cat(codes)).abs().max())
+                par["max_abs_code"] = float((gcode - torch.cat(orc["codes"])).abs().max())
+                given = 0
+                for b in range(n):   # the integer stage on identical input: bit-exact by construction (tests pin it too)
+                    lab = OI.relabel_ascending(OI.kmeans_cosine_labels(gcode[b].numpy(), 20))
+                    want = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), args.size)[0, 0].long()
+                    given += int(torch.equal(seg[b], want))
+                par["seg_equal_given_gpu_code"] = f"{given}/{n}"
             # pooled features: the oracle's dense features pooled over the GPU's own segment map (so that the figure measures
             # the features, not a label permutation, when the maps differ)
             worst = 0.0
             for b in range(n):
-                fmap = (codes[b] if stego else toks[b]).reshape(1, G, G, -1).permute(0, 3, 1, 2)
+                fmap = (orc["codes"][b] if stego else orc["toks"][b]).reshape(1, G, G, -1).permute(0, 3, 1, 2)
                 want = OS.sparsify_features(OI.upsample_bilinear_ac(fmap, args.size), seg[b])
                 got = feat[b, : want.shape[0]].cpu()
                 ok = ~torch.isnan(want).any(1)
                 worst = max(worst, float((got[ok] - want[ok]).abs().max()))
             par["max_abs_pooled"] = worst
-    return base, par
+    return par
+
+
+def upstream_parity(args, fe, dev, orc):
+    """The upstream-reading leg against the oracle on ONE frame (its numpy k-means over 200 704 code pixels takes ~25 s):
+    flip-averaged code vs the oracle's, and the pixel-resolution segment map bit for bit given the GPU's own code."""
+    import numpy as np
+    import torch
+
+    from oracle import interfaces as OI, vit as OV
+
+    G, P, heads = orc["G"], orc["P"], orc["heads"]
+    img = orc["img"][:1]
+    with torch.no_grad():
+        feat, seg, nseg = fe.extract_batch(img.to(dev))
+        gcode = fe._extractor.feature_tokens.cpu()
+        tok_m = OV.vit_tokens(orc["sd"], OI.normalize(img).flip(-1), P, heads)[:, 1:]
+        ocode = OI.stego_code_flip_average(orc["head"], orc["toks"][0], tok_m, G)
+        want = OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(gcode[0].numpy(), G, args.size, 20))
+    got = seg[0].cpu().numpy().reshape(-1)
+    return {"frames": 1, "max_abs_code": float((gcode - ocode).abs().max()),
+            "seg_equal_given_gpu_code": f"{int(np.array_equal(got, want))}/1", "seg_pixel_agreement_given_gpu_code": float((got == want).mean())}
 
 
 def percentiles(xs):
@@ -314,40 +366,22 @@ def percentiles(xs):
     return {"median": round(statistics.median(xs), 3), "p10": round(pick(0.1), 3), "p90": round(pick(0.9), 3)}
 
 
-def main():
-    args = parse()
-    maybe_spawn(args)
+KERNEL_NAME = {"fp16": "attention_bf16_kernel (fp16-operand build)", "bf16": "attention_bf16_kernel", "exact": "attention_x3_kernel",
+               "fp32": "attention_f32_kernel", "fp8": "attention_bf16_kernel"}
+DTYPE = {"fp16": "f16", "bf16": "bf16", "exact": "bf16x3 (hi+lo split operands, fp32-class)", "fp32": "f32",
+         "fp8": "fp8-e4m3 linears (per-token / per-channel scales), bf16 attention, fp32 residual"}
+
+
+def timed_leg(args, dev, world, rank, steps, warmup, precision, stego_reading, pool, labels, B):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize pairs.  Returns the leg's figures (the
+    headline leg's go to the top level of the JSON line, the extra legs' into their own objects)."""
     import torch
 
     from wild_visual_navigation_amd import distributed as D, ops
 
-    rank, world, local = D.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    dev = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(dev)
-    ranks_seen = world
-    if world > 1:   # prove the process group spans `world` ranks over RCCL before timing anything
-        t = torch.ones(1, device=dev)
-        torch.distributed.all_reduce(t)
-        ranks_seen = int(t.item())
-        assert ranks_seen == world, f"RCCL all-reduce saw {ranks_seen} ranks, expected {world}"
-    fe, model, trainer = make_pipeline(args, dev)
-    if args.scaling == "strong":
-        b0, b1 = D.shard_range(args.batch, rank, world)
-        B = b1 - b0
-        if B <= 0:
-            raise SystemExit("--scaling strong: more ranks than frames")
-    else:
-        B = args.batch
-    gen = torch.Generator().manual_seed(1000 + rank)
-    pool = [torch.rand(B, 3, args.size, args.size, generator=gen).to(dev) for _ in range(max(1, args.pool))]  # resident in HBM
-    n_lab = 20 if args.segmentation == "stego" else (args.size // 32) ** 2
-    labels = [torch.rand(B, n_lab, 2, generator=gen).to(dev) for _ in range(len(pool))]
+    fe, model, trainer = make_pipeline(args, dev, precision, stego_reading)
     backbone_only = args.mode in ("backbone", "dinov2")
     bb = (fe._extractor._bb if fe.feature_type == "stego" else fe._extractor._model) if backbone_only else None
-
     pipe = None if (args.no_overlap or backbone_only) else TwoStreamPipeline(fe, trainer, args, dev)
     marks = []
 
@@ -366,8 +400,8 @@ def main():
         marks.append(e)
         return out
 
-    for i in range(args.warmup):
-        run_step(i, i == args.warmup - 1)      # the pipeline is empty again when the timed region starts
+    for i in range(warmup):
+        run_step(i, i == warmup - 1)      # the pipeline is empty again when the timed region starts
     if pipe is not None:
         pipe.drain()
         pipe.marks.clear()
@@ -380,9 +414,9 @@ def main():
     start = torch.cuda.Event(enable_timing=True)
     start.record()
     t0 = time.perf_counter()
-    rows = 0
-    for i in range(args.steps):
-        losses, rows = run_step(i, i == args.steps - 1)   # exactly `steps` backbone stages and `steps` tails in the timed region
+    rows, losses = 0, None
+    for i in range(steps):
+        losses, rows = run_step(i, i == steps - 1)   # exactly `steps` backbone stages and `steps` tails in the timed region
     if pipe is not None:
         pipe.drain()
     torch.cuda.synchronize()
@@ -399,23 +433,82 @@ def main():
     comm_ms = None
     if trainer.comm_events:
         per = [a.elapsed_time(b) for a, b in trainer.comm_events]
-        comm_ms = {"per_step_total": round(sum(per) / args.steps, 4), "stats_allreduce": percentiles(per[0::2]),
+        comm_ms = {"per_step_total": round(sum(per) / steps, 4), "stats_allreduce": percentiles(per[0::2]),
                    "grad_allreduce": percentiles(per[1::2])}
         comm_ms["per_step_total"] = D.max_over_ranks(comm_ms["per_step_total"], dev)
+    if torch.is_tensor(rows):
+        rows = int(rows.item())       # (after the timed region: the count lived on the device)
     loss_val = float(losses[0].item()) if not backbone_only else None
 
+    total_frames = (args.batch if args.scaling == "strong" else world * B) * steps
+    total_flops, attn_flops_block = (vit_flops_per_frame(518, 14, 768) if args.mode == "dinov2" else vit_flops_per_frame(args.size))
+    passes = 2 if (stego_reading == "upstream" and args.mode == "full" and args.segmentation == "stego") else 1   # flip TTA
+    att_ms, att_n = prof["attention"]
+    frames_per_launch = (B * steps * 12 * passes) / max(att_n, 1)  # 12 attention launches per frame-chunk and pass
+    att_avg_ms = att_ms / max(att_n, 1)
+    att_tflops = attn_flops_block * frames_per_launch / (att_avg_ms * 1e-3) / 1e12 if att_n else 0.0
+    roof = {"bound": "mfma", "kernel": KERNEL_NAME[precision], "achieved": round(att_tflops, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(att_tflops / PEAK_BF16_TFLOPS, 4),
+            "traffic": attention_traffic_per_launch(frames_per_launch, precision), "avg_launch_ms": round(att_avg_ms, 4),
+            "algorithmic_flops_per_launch": attn_flops_block * frames_per_launch}
+    if precision == "exact":  # three MFMAs per algorithmic product: what the matrix pipe actually issues
+        roof["mfma_issued"] = round(3 * att_tflops, 1)
+        roof["frac_issued"] = round(3 * att_tflops / PEAK_BF16_TFLOPS, 4)
+    return {"fe": fe, "pipe": pipe, "rows": rows, "dt": dt, "value": round(total_frames / dt, 2),
+            "ms_per_step": round(dt / steps * 1e3, 3), "step_ms": percentiles(step_ms),
+            "backbone_tflops": round(total_flops * passes * total_frames / dt / 1e12 / world, 1), "final_loss": loss_val,
+            "roofline": roof, "kernel_ms": {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
+            "allreduce_ms": comm_ms, "steps": steps, "warmup": warmup}
+
+
+def main():
+    args = parse()
+    maybe_spawn(args)
+    import torch
+
+    from wild_visual_navigation_amd import distributed as D
+
+    rank, world, local = D.init_from_env(args.backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if args.backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)   # more ranks than GPUs (one-GPU box): ranks share devices
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    ranks_seen = world
+    if world > 1:   # prove the process group spans `world` ranks (over RCCL unless --backend gloo) before timing anything
+        t = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(t)
+        ranks_seen = int(t.item())
+        assert ranks_seen == world, f"all-reduce saw {ranks_seen} ranks, expected {world}"
+    if args.scaling == "strong":
+        b0, b1 = D.shard_range(args.batch, rank, world)
+        B = b1 - b0
+        if B <= 0:
+            raise SystemExit("--scaling strong: more ranks than frames")
+    else:
+        B = args.batch
+    gen = torch.Generator().manual_seed(1000 + rank)
+    pool = [torch.rand(B, 3, args.size, args.size, generator=gen).to(dev) for _ in range(max(1, args.pool))]  # resident in HBM
+    n_lab = 20 if args.segmentation == "stego" else (args.size // 32) ** 2
+    labels = [torch.rand(B, n_lab, 2, generator=gen).to(dev) for _ in range(len(pool))]
+    backbone_only = args.mode in ("backbone", "dinov2")
+
+    head = timed_leg(args, dev, world, rank, args.steps, args.warmup, args.precision, args.stego_reading, pool, labels, B)
+    # the two extra legs: the plain default run only (N = 1, configs[2], no A/B switch), the workload unchanged
+    plain = (world == 1 and args.mode == "full" and args.segmentation == "stego" and args.stego_reading == "patch"
+             and not args.no_extra_legs and args.attn_variant is None
+             and not (args.no_fuse_proj or args.no_fuse_qkv or args.no_fuse_mlp or args.no_overlap))
+    legs = {}
+    if plain and args.precision != "exact":
+        legs["parity_mode"] = timed_leg(args, dev, world, rank, max(20, args.extra_steps), 5, "exact", "patch", pool, labels, B)
+    if plain:
+        legs["stego_upstream"] = timed_leg(args, dev, world, rank, max(20, args.extra_steps), 5, args.precision, "upstream", pool, labels, B)
+
     if rank == 0:
-        total_frames = (args.batch if args.scaling == "strong" else world * B) * args.steps
-        total_flops, attn_flops_block = (vit_flops_per_frame(518, 14, 768) if args.mode == "dinov2" else vit_flops_per_frame(args.size))
-        att_ms, att_n = prof["attention"]
-        chunk = min(args.chunk, B)
-        frames_per_launch = (B * args.steps * 12) / max(att_n, 1)  # 12 attention launches per frame-chunk
-        att_avg_ms = att_ms / max(att_n, 1)
-        att_tflops = attn_flops_block * frames_per_launch / (att_avg_ms * 1e-3) / 1e12 if att_n else 0.0
-        kern = {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in prof.items()}
-        x3 = args.precision == "exact"
-        kernel_name = {"bf16": "attention_bf16_kernel", "exact": "attention_x3_kernel", "fp32": "attention_f32_kernel",
-                       "fp8": "attention_bf16_kernel"}[args.precision]
+        rows, chunk = head["rows"], min(args.chunk, B)
+        lowp16 = args.precision in ("bf16", "fp16")
         if args.mode == "dinov2":
             metric = "frames/sec (518x518 DINOv2 ViT-B/14 + STEGO head)"
             workload = (f"BASELINE configs[4]: DINOv2 ViT-B/14 518x518 batch={B}/GPU (1370 tokens, LayerScale) + STEGO head -> 90-d "
@@ -435,45 +528,56 @@ def main():
                         f"pooling + 1 traversability-MLP Adam step on {rows} rows/GPU")
         out = {
             "metric": metric,
-            "value": round(total_frames / dt, 2),
+            "value": head["value"],
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "exact": "bf16x3 (hi+lo split operands, fp32-class)", "fp32": "f32",
-                      "fp8": "fp8-e4m3 linears (per-token / per-channel scales), bf16 attention, fp32 residual"}[args.precision],
+            "dtype": DTYPE[args.precision],
             "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu_per_step": B, "backbone_chunk": chunk, "input_pool": len(pool),
-                       "parallelism": f"dp{world} (frame sharding, RCCL all-reduce of MLP statistics + gradients)",
+                       "parallelism": f"dp{world} (frame sharding, {'gloo' if args.backend == 'gloo' else 'RCCL'} all-reduce of MLP statistics + gradients)",
                        "ranks_seen": ranks_seen,
-                       "block_kernels": ("separate LayerNorm / GEMM kernels" if args.precision != "bf16" or args.mode == "dinov2" else
+                       "block_kernels": ("separate LayerNorm / GEMM kernels" if not lowp16 or args.mode == "dinov2" else
                                          "LayerNorm+QKV: %s; proj+LayerNorm+MLP: %s (kernel_ms: a fused kernel is booked under its first stage, "
                                          "qkv_gemm / fc1_gemm)" % ("separate" if args.no_fuse_qkv else "one kernel",
                                                                      "separate" if args.no_fuse_mlp else
                                                                      ("MLP fused, projection separate" if args.no_fuse_proj else "one kernel"))),
-                       "schedule": "one stream" if pipe is None else
+                       "schedule": "one stream" if head["pipe"] is None else
                                    "two HIP streams: backbone of step i+1 overlaps clustering / pooling / MLP step of step i"},
-            "step_ms": percentiles(step_ms),
-            "backbone_tflops": round(total_flops * total_frames / dt / 1e12 / world, 1),
-            "final_loss": loss_val,
-            "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": round(att_tflops, 1),
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(att_tflops / PEAK_BF16_TFLOPS, 4),
-                         "traffic": attention_traffic_per_launch(frames_per_launch, args.precision),
-                         "avg_launch_ms": round(att_avg_ms, 4),
-                         "algorithmic_flops_per_launch": attn_flops_block * frames_per_launch},
-            "kernel_ms": kern,
+            "step_ms": head["step_ms"],
+            "backbone_tflops": head["backbone_tflops"],
+            "final_loss": head["final_loss"],
+            "roofline": head["roofline"],
+            "kernel_ms": head["kernel_ms"],
         }
-        if x3:  # three MFMAs per algorithmic product: what the matrix pipe actually issues
-            out["roofline"]["mfma_issued"] = round(3 * att_tflops, 1)
-            out["roofline"]["frac_issued"] = round(3 * att_tflops / PEAK_BF16_TFLOPS, 4)
-        if comm_ms is not None:
-            out["allreduce_ms"] = comm_ms
+        if head["allreduce_ms"] is not None:
+            out["allreduce_ms"] = head["allreduce_ms"]
+        orc = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(args, fe, dev)
+            out["cpu_baseline"], orc = cpu_oracle_sample(args, head["fe"])
+            out["parity"] = gpu_parity(args, head["fe"], dev, orc, args.precision)
+        for name, leg in legs.items():
+            o = {"value": leg["value"], "unit": "frames/s", "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
+                 "warmup": leg["warmup"], "step_ms": leg["step_ms"], "backbone_tflops": leg["backbone_tflops"],
+                 "roofline": leg["roofline"], "kernel_ms": leg["kernel_ms"]}
+            if name == "parity_mode":
+                o["dtype"] = DTYPE["exact"]
+                o["workload"] = "the headline workload with --precision exact (hi + lo split operands on the matrix pipe): the <= 1e-3 parity path"
+                if orc is not None:
+                    o["parity"] = gpu_parity(args, leg["fe"], dev, orc, "exact")
+            else:
+                o["dtype"] = DTYPE[args.precision]
+                o["workload"] = ("the other reading of the absent STEGO package: code averaged with the mirrored frame's (flip TTA: two "
+                                 "backbone passes per frame), per-image cosine k-means over the 448x448 up-sampled code pixels (rows "
+                                 f"interpolated on the fly), general segment pooling, 1 MLP Adam step on {leg['rows']} rows")
+                if orc is not None and args.segmentation == "stego":
+                    o["parity"] = upstream_parity(args, leg["fe"], dev, orc)
+            out[name] = o
         print(json.dumps(out))
     D.barrier()
 

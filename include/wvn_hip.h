@@ -175,6 +175,10 @@ int wvn_gemm_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, c
  * epi 0 (bf16 out), 1 (gelu -> bf16), 3 (fp32 out), 4 (fp32 +=).  K % 128 == 0, lda / ldw % 16 == 0. */
 int wvn_quantize_rows_fp8(const void* src, int src_is_bf16, int lds, void* q, int ldq, float* scale, int rows, int cols,
                           void* stream);
+/* LayerNorm (fp32 rows of x [rows, D], D % 64 == 0, biased variance, eps inside the sqrt) fused with the row quantiser: q [rows, ldq]
+ * e4m3 + scale [rows] of the NORMALISED rows -- what every fp8 block runs in front of its QKV / fc1 GEMM */
+int wvn_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* q, int ldq, float* scale, int rows, int D,
+                      float eps, void* stream);
 int wvn_gemm_fp8(const void* A_q, int lda, const void* W_q, int ldw, const float* sa, const float* sw, const float* bias,
                  void* C, int ldc, int M, int N, int K, int epi, void* stream);
 /* fp32 [rows, lds] -> hi = bf16(x), lo = bf16(x - hi), both [rows, ldd] */
@@ -262,7 +266,7 @@ int wvn_label_pool_batched(const wvn_label_pool_node* nodes_dev, int n, int C, i
  * kornia draw_convex_polygon) fused with the torch.fmin merge of traversability_estimator.py:281-286, for n mission nodes in
  * one launch.  Per node: K [4][4] (the projector's scaled camera matrix), pose [4][4] = pose_cam_in_world, mask [C][H][W]
  * updated IN PLACE (inside the projected polygon: fmin(old, value); elsewhere untouched = fmin(old, NaN)), projected [npts][2]
- * (optional out; NaN for points behind the camera).  points: [npts][3] world coordinates shared by all nodes, or
+ * + depth [npts] (optional outs; the polygon itself is drawn with the behind-the-camera vertices set to NaN, :180).  points: [npts][3] world coordinates shared by all nodes, or
  * [n][npts][3] when points_batched.  value = colour * traversability, read from value_dev[0] if non-NULL (no host sync when
  * the traversability lives on the GPU).  npts: any count whose vertex arrays fit the 64 KB of LDS beside the 2*H row limits (H = 448: 7700; the
  * untraversable plane of SupervisionNode.make_footprint_with_node has 1000).  Scan lines touched by a NaN edge stay unfilled (torch min / max).  Arithmetic order: csrc/supervision.hip header.
@@ -271,7 +275,9 @@ typedef struct wvn_render_node {
   const float* K;
   const float* pose;
   float* mask;
-  float* projected;
+  float* projected; /* [npts][2] out, optional: the RAW pinhole coordinates of every point (finite also behind the camera, as
+                       ImageProjector.project returns them, image_projector.py:126-150) */
+  float* depth;     /* [npts] out, optional: camera-frame z of every point (valid_z = depth >= 0, check_validity :112-124) */
 } wvn_render_node;
 int wvn_project_render_fmin(const wvn_render_node* nodes_dev, int n, const float* points, int points_batched, int npts, int C,
                             int H, int W, const float* value_dev, float value, void* stream);
@@ -358,6 +364,21 @@ int wvn_mlp_train_phase_b(const wvn_mlp_desc* d, const float* params, const floa
 int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* grads, float* adam_m, float* adam_v,
                           int step, float lr, const double* stats, float w_trav, float w_reco, float* losses,
                           void* stream);
+/* The step on a COMPACTED batch whose row count lives in device memory (no host synchronisation between segmentation and
+ * training): R rows are passed, the first *rows_dev of them are real; the others contribute nothing to statistics, losses or
+ * gradients (rows_dev == NULL: all R rows, = the entry points above).  wvn_compact_segment_rows builds such a batch from the
+ * pooled features of a frame batch: feat [B][S][D] (+ optional per-row side data [B][S][Dside], e.g. labels), nseg [B] = number
+ * of segments that exist per frame -> x_out [B*S][D] / side_out [B*S][Dside] holding the rows (b, s < nseg[b]) front to back in
+ * (b, s) order, zeros behind them, and *rows_dev = sum(nseg).  Replaces feat[keep] (traversability_estimator.py:432-446 builds
+ * the batch from nodes that all exist; a batched extractor has to drop the ids a frame did not produce). */
+int wvn_compact_segment_rows(const float* feat, int D, const float* side, int Dside, const int* nseg, int B, int S, float* x_out,
+                             float* side_out, int* rows_dev, void* stream);
+int wvn_mlp_train_phase_a_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const unsigned char* y_valid,
+                               int R, const int* rows_dev, double* stats, void* workspace, size_t workspace_bytes, void* stream);
+int wvn_mlp_train_phase_b_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
+                               const unsigned char* y_valid, int R, const int* rows_dev, const double* stats, float std_factor,
+                               float w_trav, float w_reco, float* grads, float* confidence_out, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* quick_start.py:194-210 / loss.py:162-164: trav[r] = out[r][0], conf[r] = confidence(mse(out[r][1:], x[r])) */
 int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,
                        float* trav, float* conf, int R, int D, void* stream);

@@ -159,6 +159,65 @@ def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) ->
     return assign(cent)
 
 
+def _fma32(a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """Correctly rounded fp32 fused multiply-add of fp32 arrays.  The product of two fp32 values is exact in fp64; the fp64 sum
+    with c can carry a rounding error, which matters only when the fp64 sum lands exactly on an fp32 rounding midpoint -- the
+    error term of the addition (TwoSum) then decides the direction."""
+    a64, b64, c64 = a.astype(np.float64), b.astype(np.float64), np.broadcast_to(c, np.broadcast_shapes(a.shape, b.shape, np.shape(c))).astype(np.float64)
+    p = a64 * b64
+    s = p + c64
+    bb = s - p
+    err = (p - (s - bb)) + (c64 - bb)
+    r = s.astype(np.float32)
+    r64 = r.astype(np.float64)
+    other = np.where(s > r64, np.nextafter(r, np.float32(np.inf)), np.nextafter(r, np.float32(-np.inf))).astype(np.float32)
+    tie = (s != r64) & (np.abs(s - r64) == np.abs(other.astype(np.float64) - s))
+    # on a tie numpy rounded to even; the true value s + err lies on err's side of the midpoint
+    want_other = tie & (((err > 0) & (other.astype(np.float64) > r64)) | ((err < 0) & (other.astype(np.float64) < r64)))
+    return np.where(want_other, other, r).astype(np.float32)
+
+
+def upsample_bilinear_fixed(code: np.ndarray, H: int) -> np.ndarray:
+    """[G, G, C] fp32 patch map -> [H, H, C] fp32: F.interpolate(.., (H, H), mode="bilinear", align_corners=True) in the ONE
+    fixed operation order of the HIP kernels (csrc/common.h lerp_tap / bilerp_fixed: ATen's coordinates, then
+    t0 = fma(wx1, v01, wx0 * v00), t1 = fma(wx1, v11, wx0 * v10), out = fma(wy1, t1, wy0 * t0)), bit for bit -- ATen's own CPU
+    kernel rounds in another order, so integer results derived from the up-sampled code are pinned through this form."""
+    code = np.ascontiguousarray(code, dtype=np.float32)
+    G = code.shape[0]
+    f32 = np.float32
+    scale = (f32(G - 1) / f32(H - 1)) if H > 1 else f32(0)
+    o = np.arange(H, dtype=np.float32)
+    sc = (scale * o).astype(np.float32)
+    i0 = sc.astype(np.int32)
+    i1 = i0 + (i0 < G - 1)
+    w1 = (sc - i0.astype(np.float32)).astype(np.float32)
+    w0 = (f32(1) - w1).astype(np.float32)
+    wx0, wx1 = w0[None, :, None], w1[None, :, None]
+    out = np.empty((H, H, code.shape[2]), dtype=np.float32)
+    for y in range(H):   # row by row: the whole [H, H, C] set of temporaries would be several GB at 448^2 x 90
+        r0, r1 = code[i0[y]][None], code[i1[y]][None]                   # [1, G, C]
+        t0 = _fma32(wx1, r0[:, i1], (wx0 * r0[:, i0]).astype(np.float32))
+        t1 = _fma32(wx1, r1[:, i1], (wx0 * r1[:, i0]).astype(np.float32))
+        out[y] = _fma32(np.full_like(t1, w1[y]), t1, (w0[y] * t0).astype(np.float32))[0]
+    return out
+
+
+def stego_code_flip_average(head: Dict[str, torch.Tensor], tok: torch.Tensor, tok_mirror: torch.Tensor, G: int) -> torch.Tensor:
+    """The flip pass of the upstream Stego.get_code as this build reads it: the code of the frame averaged with the
+    flipped-back code of its mirror image.  tok / tok_mirror: patch tokens [B, G*G, D] of the frame and of img.flip(-1)."""
+    code = stego_code_tokens(head, tok)
+    B, P, C = code.shape
+    c2 = stego_code_tokens(head, tok_mirror).reshape(B, G, G, C).flip(2).reshape(B, P, C)
+    return (code + c2) * 0.5
+
+
+def kmeans_cosine_labels_pixels(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = KMEANS_ITERS) -> np.ndarray:
+    """cluster_resolution="pixel": the k-means above over the H x H up-sampled (fixed-order bilinear, align_corners=True) code
+    pixels of one frame.  code_tokens [G*G, C] -> int32 labels [H*H] (not compacted)."""
+    dense = upsample_bilinear_fixed(code_tokens.reshape(G, G, -1), H)
+    return kmeans_cosine_labels(dense.reshape(H * H, -1), K, iters)
+
+
 def relabel_ascending(seg: np.ndarray) -> np.ndarray:
     """feature_extractor.py:245-246: replace the sorted unique ids by 0..K'-1."""
     uniq = np.unique(seg)

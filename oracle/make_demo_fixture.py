@@ -1,4 +1,4 @@
-"""Build tests/golden/demo_frames_224.pt from the reference's own demo images.
+"""Build tests/golden/demo_frames_224.pt (and demo_frames_raw.pt: the undecimated frames) from the reference's own demo images.
 
 Run in the build container only (needs /root/reference):   python -m oracle.make_demo_fixture
 
@@ -21,9 +21,10 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def main():
-    names, frames = [], []
+    names, frames, raw = [], [], []
     for p in sorted(glob.glob(os.path.join(REF, "*.png"))):
         img = torch.from_numpy(np.array(Image.open(p).convert("RGB"))).permute(2, 0, 1)[None].float()
+        raw.append(img[0].to(torch.uint8))
         img = OI.resize_nearest_center_crop(img, 224)  # NEAREST: values stay integers in [0,255]
         assert img.shape == (1, 3, 224, 224) and torch.equal(img, img.round())
         frames.append(img[0].to(torch.uint8))
@@ -31,6 +32,12 @@ def main():
     torch.save({"names": names, "frames_u8": torch.stack(frames),
                 "source": "leggedrobotics/wild_visual_navigation assets/demo_data, quick_start.py:156-174 preprocessing"}, OUT)
     print("wrote", OUT, names, torch.stack(frames).shape)
+    # the same frames UNRESIZED (224 x 299, what the camera / PNG decoder hands over): inputs of the fused-ingest parity tests
+    # (NEAREST resize + centre crop inside the patch gather, tests/test_gpu_ingest.py)
+    out_raw = os.path.join(os.path.dirname(OUT), "demo_frames_raw.pt")
+    torch.save({"names": names, "frames_u8": torch.stack(raw),
+                "source": "leggedrobotics/wild_visual_navigation assets/demo_data, decoded as quick_start.py:156-161 (no resize)"}, out_raw)
+    print("wrote", out_raw, torch.stack(raw).shape)
     # the one real 448 x 448 frame the reference ships (assets/graph/img.png, the visualiser demo's input): BASELINE's full size
     p448 = "/root/reference/assets/graph/img.png"
     img = torch.from_numpy(np.array(Image.open(p448).convert("RGB"))).permute(2, 0, 1).contiguous()

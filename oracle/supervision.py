@@ -14,8 +14,9 @@ import numpy as np
 f32 = np.float32
 
 
-def project_points(K: np.ndarray, pose_cam_in_world: np.ndarray, pts: np.ndarray) -> np.ndarray:
-    """K [4,4], pose [4,4], pts [N,3] -> [N,2] pixel coordinates (NaN behind the camera)."""
+def project_points_raw(K: np.ndarray, pose_cam_in_world: np.ndarray, pts: np.ndarray):
+    """ImageProjector.project (image_projector.py:126-150): K [4,4], pose [4,4], pts [N,3] -> (raw pixel coordinates [N,2],
+    finite also behind the camera; camera-frame depth z [N]; valid_z = z >= 0)."""
     K, T, P = K.astype(f32), pose_cam_in_world.astype(f32), pts.astype(f32)
     X, Y, Z = P[:, 0], P[:, 1], P[:, 2]
     pc = []
@@ -29,10 +30,15 @@ def project_points(K: np.ndarray, pose_cam_in_world: np.ndarray, pts: np.ndarray
     with np.errstate(divide="ignore", invalid="ignore"):
         s = np.where(np.abs(zp) > f32(1e-8), f32(1.0) / (zp + f32(1e-8)), f32(1.0)).astype(f32)
     u, v = (xp * s).astype(f32), (yp * s).astype(f32)
-    behind = ~(pc[2] >= 0)
-    u[behind] = np.nan
-    v[behind] = np.nan
-    return np.stack([u, v], axis=1)
+    return np.stack([u, v], axis=1), pc[2].astype(f32)
+
+
+def project_points(K: np.ndarray, pose_cam_in_world: np.ndarray, pts: np.ndarray) -> np.ndarray:
+    """The polygon vertices as project_and_render draws them: behind the camera -> NaN (image_projector.py:180)."""
+    uv, z = project_points_raw(K, pose_cam_in_world, pts)
+    uv = uv.copy()
+    uv[~(z >= 0)] = np.nan
+    return uv
 
 
 def convex_edges(poly: np.ndarray, H: int, W: int):
@@ -46,9 +52,10 @@ def convex_edges(poly: np.ndarray, H: int, W: int):
     ys = np.arange(H, dtype=f32)[:, None]
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         dx = ((x1 - x0) / ((y1 - y0) + f32(1e-12))).astype(f32)
-        dx = np.minimum(np.maximum(dx, f32(-W)), f32(W))     # fminf / fmaxf: a NaN operand yields the other one
+        dx = np.minimum(np.maximum(dx, f32(-W)), f32(W))     # torch.clamp / np.minimum keep a NaN (inf - inf over an infinite vertex)
         xs = (((ys - y0[None]) * dx[None]).astype(f32) + x0[None]).astype(f32)
     act = ((y0[None] <= ys) & (ys <= y1[None])) | ((y0[None] >= ys) & (ys >= y1[None]))
+    # torch's min / max over the edge axis propagate a NaN (np.min / np.max do too): such a scan line is never filled
     left = np.where(act, xs, f32(W)).min(axis=1).astype(f32) if xs.shape[1] else np.full(H, f32(W))
     right = np.where(act, xs, f32(-1)).max(axis=1).astype(f32) if xs.shape[1] else np.full(H, f32(-1))
     return left, right

@@ -45,8 +45,10 @@ def test_vit_bf16_mode(dev, S, depth, B):
     bb = VitBackbone(sd, S, 8, 6, device=dev, precision="bf16", max_chunk=2)
     got = bb.forward_tokens(img.to(dev)).cpu()
     # bf16 operands (2^-9 relative rounding per GEMM input) through `depth` residual blocks; outputs are
-    # LayerNorm'ed (O(1) magnitudes).  Measured error is reported by bench.py / DESIGN.md.
-    assert rel_l2(got, want) < 2.5e-2 and (got - want).abs().max().item() < 0.25
+    # LayerNorm'ed (O(1) magnitudes).  Gates at about twice the measured error (printed; 12 blocks at 448^2: max 3.0e-2,
+    # rel-L2 5.0e-3 -- bench.py `parity`): a 2x accuracy regression fails.
+    print(f"bf16 tokens S={S} depth={depth}: max|err| {(got - want).abs().max().item():.3e} rel-L2 {rel_l2(got, want):.3e}")
+    assert rel_l2(got, want) < 1.0e-2 and (got - want).abs().max().item() < 0.06
     cos = torch.nn.functional.cosine_similarity(got.reshape(-1, 384), want.reshape(-1, 384), dim=1)
     assert cos.min().item() > 0.995
 

@@ -141,3 +141,29 @@ def test_estimator_train_skips_collectively(dev):
     stepped1 = [v is not None and v != -1 for v in l1]
     assert stepped0 == stepped1
     assert [a for a, ok in zip(l0, stepped0) if ok] == [a for a, ok in zip(l1, stepped1) if ok]
+
+
+def test_bench_two_ranks_through_its_own_launcher(tmp_path):
+    """The driver's 8-GPU tier is the first time bench.py meets torch.distributed.run: run that exact path here with two ranks
+    (bench.py re-executes itself under torch.distributed.run; --backend gloo lets both ranks share the box's one GPU).  Checks
+    the launcher, the rendezvous, ranks_seen, the per-step all-reduce timings, and that n_gpus / value follow the rank count."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--backend", "gloo", "--batch", "8", "--chunk", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                          # rank 0 alone prints, exactly one line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["config"]["frames_per_gpu_per_step"] == 8
+    assert abs(out["value"] - 2 * 8 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 0.02      # whole-job frames / max-over-ranks time
+    ar = out["allreduce_ms"]
+    assert ar["per_step_total"] > 0 and ar["stats_allreduce"]["median"] > 0 and ar["grad_allreduce"]["median"] > 0
+    assert "parity_mode" not in out and "stego_upstream" not in out     # the extra legs are an N = 1 matter
+    assert out["roofline"]["achieved"] > 0 and out["final_loss"] == out["final_loss"]

@@ -1,0 +1,93 @@
+"""Frame ingest fused into the patch gather: T.Resize(input_size, NEAREST) + T.CenterCrop(input_size)
+(dino_interface.py:52-59, stego_interface.py:51-58, image_projector.py:56-59, 199-200) never build an image -- the backbone's
+patch gather reads the camera frame through two index tables (wvn_vit_forward_frames).  Bit-identical to running the library on
+the host-side resized / cropped image, on the reference's four 224 x 299 demo frames and on a 1080 x 1440 frame."""
+import pytest
+import torch
+
+from oracle import interfaces as OI, vit as OV
+from wild_visual_navigation_amd import ops
+from wild_visual_navigation_amd.backbone import VitBackbone
+from wild_visual_navigation_amd.feature_extractor import DinoInterface, StegoInterface
+from wild_visual_navigation_amd.feature_extractor.transforms import ingest_tables, resize_nearest_center_crop
+from wild_visual_navigation_amd.image_projector import ImageProjector
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_tables_are_the_image_op(golden):
+    """The tables are DERIVED from the image op (two index images through resize_nearest_center_crop), so gathering through them
+    is that op on any image: checked here on the demo frames against the oracle's dino_transform geometry (CPU)."""
+    raw = golden("demo_frames_raw.pt")["frames_u8"]                                   # [4,3,224,299]
+    for size in (224, 448, 160):
+        t = ingest_tables(raw.shape[2], raw.shape[3], size, "cpu")
+        want = OI.resize_nearest_center_crop(raw.float(), size)
+        got = raw.float()[:, :, t.rows.long()][:, :, :, t.cols.long()]
+        assert torch.equal(got, want)
+    assert torch.equal(OI.resize_nearest_center_crop(raw.float(), 224).to(torch.uint8), golden("demo_frames_224.pt")["frames_u8"])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "exact", "fp32"])
+def test_demo_frames_ingest_is_bit_identical(dev, golden, prec):
+    raw = golden("demo_frames_raw.pt")["frames_u8"].to(dev)                           # the reference's frames, undecimated
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=3, depth=2)
+    bb = VitBackbone(sd, 224, 8, 6, device=dev, precision=prec, max_chunk=4)
+    pre = resize_nearest_center_crop(raw, 224).contiguous()                            # host-side image op (torch indexing)
+    want = bb.forward_tokens(pre.float() / 255)
+    assert torch.equal(bb.forward_tokens(raw), want)                                   # uint8 camera frames
+    assert torch.equal(bb.forward_tokens(raw.float() / 255), want)                     # fp32 frames in [0, 1]
+    # up-sizing ingest (224 x 299 -> 448 network input): rows / columns repeat
+    bb448 = VitBackbone(sd, 448, 8, 6, device=dev, precision=prec, max_chunk=2)
+    assert torch.equal(bb448.forward_tokens(raw[:2]), bb448.forward_tokens(resize_nearest_center_crop(raw[:2], 448).contiguous().float() / 255))
+    if prec == "exact":   # and against the CPU oracle's own transform + backbone at the north_star tolerance
+        ref = OV.vit_tokens(sd, OI.dino_transform(raw[:2].cpu().float() / 255, 224), 8, 6)[:, 1:]
+        assert (bb.forward_tokens(raw[:2]).cpu() - ref).abs().max().item() < 1e-3
+
+
+def test_camera_sized_frame_1080x1440_and_flip(dev):
+    frame = torch.randint(0, 256, (2, 3, 1080, 1440), generator=g(5), dtype=torch.uint8).to(dev)
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=4, depth=1)
+    for prec, P, heads, S, arch in (("bf16", 8, 6, 448, "vit_small"), ("fp16", 8, 6, 448, "vit_small"), ("bf16", 14, 6, 518, "vit_small")):
+        w = sd if P == 8 else OV.make_dinov2_state_dict(arch, 14, pretrain_grid=37, seed=3, depth=1)
+        bb = VitBackbone(w, S, P, heads, device=dev, precision=prec, max_chunk=2)
+        pre = resize_nearest_center_crop(frame, S).contiguous()
+        want = bb.forward_tokens(pre.float() / 255)
+        assert torch.equal(bb.forward_tokens(frame), want), (prec, P)
+        # the mirror pass of the STEGO flip reading: a reversed column table == running on the flipped crop
+        assert torch.equal(bb.forward_tokens(frame, flip=True), bb.forward_tokens(pre.flip(-1).contiguous().float() / 255)), (prec, P)
+
+
+def test_interfaces_take_camera_frames(dev, golden):
+    raw = golden("demo_frames_raw.pt")["frames_u8"][:1]
+    img = (raw.float() / 255).to(dev)
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=3, depth=2)
+    di = DinoInterface(dev, input_size=224, pretrained_weights=sd, precision="exact")
+    want = OI.dino_inference(sd, img.cpu(), 224, 8, 6)                                 # [1, 384, 224, 224]: H used for both dims
+    assert (di.inference(img).cpu() - want).abs().max().item() < 1e-3
+    head = OI.make_stego_head_state_dict(384, 90, seed=4)
+    si = StegoInterface(dev, input_size=224, n_image_clusters=6, run_crf=False, run_clustering=True, backbone_weights=sd, head_weights=head,
+                        precision="exact", flip_tta=True)
+    x = OI.dino_transform(img.cpu(), 224)
+    tok, tok_m = OV.vit_tokens(sd, x, 8, 6)[:, 1:], OV.vit_tokens(sd, x.flip(-1), 8, 6)[:, 1:]
+    assert (si.code_tokens(img).cpu() - OI.stego_code_flip_average(head, tok, tok_m, 28)).abs().max().item() < 1e-3
+
+
+def test_image_projector_resize_image(dev, golden):
+    """ImageProjector.resize_image (image_projector.py:199-200) as one HIP gather: square crop and explicit [new_h, new_w]."""
+    raw = golden("demo_frames_raw.pt")["frames_u8"]
+    K = torch.eye(4)[None]
+    ip = ImageProjector(K.to(dev), torch.tensor(224), torch.tensor(299), new_h=160)
+    for img in (raw[0].to(dev), (raw[:2].float() / 255).to(dev)):
+        got = ip.resize_image(img)
+        want = resize_nearest_center_crop(img.cpu() if img.dim() == 4 else img.cpu()[None], 160)
+        assert torch.equal(got.cpu(), want if img.dim() == 4 else want[0])
+    ip2 = ImageProjector(K.to(dev), torch.tensor(224), torch.tensor(299), new_h=112, new_w=150)
+    got = ip2.resize_image((raw[:1].float() / 255).to(dev))
+    assert torch.equal(got.cpu(), torch.nn.functional.interpolate(raw[:1].float() / 255, size=(112, 150), mode="nearest"))
+    seg = torch.arange(224 * 299, dtype=torch.int32).reshape(1, 224, 299).to(dev)
+    t = ingest_tables(224, 299, 160, dev)
+    assert torch.equal(ops.resize_nearest_crop(seg, t).cpu(), resize_nearest_center_crop(seg.cpu().float()[None], 160)[0].to(torch.int32))

@@ -59,12 +59,13 @@ def test_project_render_fmin_matches_oracle_bit_for_bit(dev):
             m[:, :, : W // 2] = torch.rand(3, H, W // 2, generator=g)
         masks0.append(m)
     masks = [m.clone().to(dev) for m in masks0]
-    proj = ops.project_render_fmin([k.to(dev) for k in Ks], [p.to(dev) for p in poses], masks, pts.to(dev), 0.65,
-                                   want_projected=True).cpu().numpy()
+    proj, depth = ops.project_render_fmin([k.to(dev) for k in Ks], [p.to(dev) for p in poses], masks, pts.to(dev), 0.65,
+                                          want_projected=True)
+    proj, depth = proj.cpu().numpy(), depth.cpu().numpy()
     changed = 0
     for i in range(n):
-        want_p = OSV.project_points(Ks[i].numpy(), poses[i].numpy(), pts.numpy())
-        assert np.array_equal(proj[i], want_p, equal_nan=True), f"projected points of node {i}"
+        want_p, want_z = OSV.project_points_raw(Ks[i].numpy(), poses[i].numpy(), pts.numpy())   # raw: finite behind the camera too
+        assert np.array_equal(proj[i], want_p) and np.array_equal(depth[i], want_z), f"projected points of node {i}"
         want = OSV.render_fmin(masks0[i].numpy(), Ks[i].numpy(), poses[i].numpy(), pts.numpy(), 0.65)
         got = masks[i].cpu().numpy()
         assert np.array_equal(got, want, equal_nan=True), f"mask of node {i}"
@@ -93,6 +94,56 @@ def test_image_projector_project_and_render(dev):
     assert float(overlay[0, 0][torch.from_numpy(inside).to(dev)].min()) == 1.0 and float(overlay[0, 0][~torch.from_numpy(inside).to(dev)].max()) == 0.0
     p2, v2, vz = ip.project(pose, quad)
     assert torch.equal(torch.nan_to_num(p2), torch.nan_to_num(proj)) and vz.all()
+    # a point behind the camera: project() returns its (finite) pinhole coordinates with valid_z False, as the reference's
+    # ImageProjector.project does (image_projector.py:126-150); project_and_render NaNs it (:180)
+    behind = torch.tensor([[[1.0, 0.3, 0.0], [-3.0, 0.2, 0.0], [2.0, -0.3, 0.0], [2.0, 0.3, 0.0]]], device=dev)
+    p3, v3, vz3 = ip.project(pose, behind)
+    raw, z = OSV.project_points_raw(ip.camera.intrinsics[0].cpu().numpy(), pose[0].cpu().numpy(), behind[0].cpu().numpy())
+    assert np.array_equal(p3[0].cpu().numpy(), raw) and torch.isfinite(p3).all()
+    assert vz3[0].tolist() == [True, False, True, True] and not bool(v3[0, 1])
+    _, _, p4, _ = ip.project_and_render(pose, behind, torch.tensor([1.0, 0.5, 0.25]))
+    assert torch.isnan(p4[0, 1]).all() and torch.equal(p4[0, [0, 2, 3]], p3[0, [0, 2, 3]])
+
+
+def test_untraversable_plane_and_infinite_vertices(dev):
+    """a supervision node with is_untraversable=True hands add_supervision_node the 10 x 10 x 10 dense plane of
+    make_dense_plane (1000 points; the kernel's vertex arrays are dynamic LDS now), and vertices at infinity (z' ~ 0) must
+    poison their scan lines the way torch's min / max / clamp propagate NaN -- both bit for bit against the oracle."""
+    from wild_visual_navigation_amd.traversability_estimator import SupervisionNode
+
+    H, W = 120, 160
+
+    def sup(t, x, untrav):
+        return SupervisionNode(timestamp=t, pose_base_in_world=_pose(x, 0, 0), pose_footprint_in_base=_pose(0, 0, 0, 0.0), width=0.7,
+                               length=1.0, height=0.4, supervision=torch.ones(1), traversability=torch.tensor([0.2]),
+                               traversability_var=torch.tensor([0.1]), is_untraversable=untrav)
+
+    fp = sup(1.0, 2.4, True).make_footprint_with_node(sup(0.0, 1.6, False))
+    assert fp.shape == (1000, 3)
+    Ks = [_K(115.0, 80.0, 60.0), _K(130.0, 82.0, 58.0)]
+    poses = [_cam_looking_forward_down(0.0, 0.0, 0.0), _cam_looking_forward_down(0.4, 0.2, -0.2)]
+    masks0 = [torch.full((3, H, W), float("nan")) for _ in range(2)]
+    masks = [m.clone().to(dev) for m in masks0]
+    ops.project_render_fmin([k.to(dev) for k in Ks], [p.to(dev) for p in poses], masks, fp.to(dev), 0.2)
+    touched = 0
+    for i in range(2):
+        want = OSV.render_fmin(masks0[i].numpy(), Ks[i].numpy(), poses[i].numpy(), fp.numpy(), 0.2)
+        assert np.array_equal(masks[i].cpu().numpy(), want, equal_nan=True), i
+        touched += int((~np.isnan(want[0])).sum())
+    assert touched > 500
+    # a vertex that projects to v = +inf (camera frame == world frame; y = 1e38 overflows the projection): the edge that STARTS at
+    # it evaluates to (y - inf) * 0 + x0 = NaN on every row it is active on -- torch's min / max over the edges propagate that
+    # NaN and those scan lines stay unfilled; fminf / fmaxf would have dropped the NaN and filled them from the other edges
+    K1 = _K(100.0, 80.0, 60.0)
+    pts = torch.tensor([[-0.3, -0.2, 1.0], [0.3, -0.2, 1.0], [0.1, 1e38, 1.0], [-0.3, 0.25, 1.0]])
+    uv = OSV.project_points(K1.numpy(), torch.eye(4).numpy(), pts.numpy())
+    assert np.isinf(uv[2, 1]) and np.isfinite(uv[[0, 1, 3]]).all()
+    m0 = torch.full((1, H, W), float("nan"))
+    m = [m0.clone().to(dev)]
+    ops.project_render_fmin([K1.to(dev)], [torch.eye(4).to(dev)], m, pts.to(dev), 0.5)
+    want = OSV.render_fmin(m0.numpy(), K1.numpy(), torch.eye(4).numpy(), pts.numpy(), 0.5)
+    assert np.array_equal(m[0].cpu().numpy(), want, equal_nan=True)
+    assert (~np.isnan(want[0, 40:85])).any() and np.isnan(want[0, 85:]).all()     # rows 40..84 filled, the poisoned rows below are not
 
 
 def test_label_pool_batched_equals_single_and_golden(dev, golden):
@@ -202,3 +253,23 @@ def test_add_supervision_node_end_to_end(dev):
         assert np.array_equal(n.supervision_mask.cpu().numpy(), w2, equal_nan=True)
     res = te.train()
     assert res["loss_total"] != -1 and te.step == 1
+    # a mission node in range that has no features / segments (its mask is merged, nothing is pooled, no exception),
+    # and a segment map whose ids run past the feature rows (signal length = seg.max() + 1 as in the reference, nodes.py:413)
+    bare = MissionNode(timestamp=20.0, pose_base_in_world=_pose(1.4, 0, 0), pose_cam_in_world=_cam_looking_forward_down(1.4, 0, 0).to(dev),
+                       image_projector=ImageProjector(K.to(dev), torch.tensor(H), torch.tensor(W)), use_for_training=False)
+    assert te.add_mission_node(bare) is False and bare.supervision_mask is None     # in the graph, but not prepared for training (:182-196)
+    wide = MissionNode(timestamp=21.0, pose_base_in_world=_pose(1.8, 0, 0), pose_cam_in_world=_cam_looking_forward_down(1.8, 0, 0).to(dev),
+                       image_projector=ImageProjector(K.to(dev), torch.tensor(H), torch.tensor(W)))
+    wide.features = torch.randn(S, 90, generator=g).to(dev)
+    wide.feature_segments = (seg + 3).to(dev)                       # ids 3 .. 18 against 16 feature rows
+    assert te.add_mission_node(wide) is True and wide.num_segments() == S + 3
+    newest2 = MissionNode(timestamp=22.0, pose_base_in_world=_pose(2.2, 0, 0), pose_cam_in_world=_cam_looking_forward_down(2.2, 0, 0).to(dev),
+                          image_projector=ImageProjector(K.to(dev), torch.tensor(H), torch.tensor(W)))
+    newest2.features = torch.randn(S, 90, generator=g).to(dev)
+    newest2.feature_segments = seg.to(dev)
+    assert te.add_mission_node(newest2) is True
+    assert te.add_supervision_node(sup(13.0, 4.2, 0.7)) is True
+    assert bare.supervision_signal is None and bare.supervision_mask is not None     # zeros substituted (:262-264), merged, nothing pooled
+    assert wide.supervision_signal.shape == (S + 3,)
+    sig, val = OS.update_supervision_signal(wide.supervision_mask.cpu(), seg + 3)
+    assert torch.allclose(wide.supervision_signal.cpu(), sig, atol=1e-6) and torch.equal(wide.supervision_signal_valid.cpu(), val)

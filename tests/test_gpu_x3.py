@@ -179,13 +179,13 @@ def test_bf16_shipped_instantiations_at_448(dev):
     auto = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=B).forward_tokens(img.to(dev)).cpu()
     rel = ((auto - want).norm() / want.norm()).item()
     print(f"bf16 448^2 B=16 (XCD attention, fused block stages): rel-L2 = {rel:.3e}, max|err| = {(auto - want).abs().max().item():.3e}")
-    assert rel < 1e-2 and (auto - want).abs().max().item() < 0.15
+    assert rel < 6e-3 and (auto - want).abs().max().item() < 0.06      # about twice the measured error (printed above)
     # (b) the separate kernels at the same size: A-stationary QKV / fc1, row-panel fc2 with its hand-over
     bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=B, fuse_mlp=False, fuse_qkv=False)
     got = bb.forward_tokens(img.to(dev)).cpu()
     rel = ((got - want).norm() / want.norm()).item()
     print(f"bf16 448^2 B=16 (XCD attention, row-panel fc2): rel-L2 = {rel:.3e}, max|err| = {(got - want).abs().max().item():.3e}")
-    assert rel < 1e-2 and (got - want).abs().max().item() < 0.15
+    assert rel < 6e-3 and (got - want).abs().max().item() < 0.06
     # the same frames one at a time take the non-XCD attention instantiation and the tiled fc2 kernel: same bits as (b)
     one = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16", max_chunk=1)
     for b in (0, 7, 15):

@@ -1,0 +1,66 @@
+"""CPU checks of the oracle pieces added with the pixel-resolution STEGO reading: the exact fp32 FMA emulation, the fixed-order
+bilinear up-sampling (against ATen's), the three-level centroid summation order, and the supervision oracle's NaN semantics."""
+import fractions
+
+import numpy as np
+import torch
+
+from oracle import interfaces as OI, supervision as OSV
+
+
+def _fma_exact(a, b, c):
+    v = fractions.Fraction(float(a)) * fractions.Fraction(float(b)) + fractions.Fraction(float(c))
+    x = np.float32(float(v))
+    cands = [x, np.nextafter(x, np.float32(np.inf)), np.nextafter(x, np.float32(-np.inf))]
+    return np.float32(min(cands, key=lambda t: (abs(fractions.Fraction(float(t)) - v), int(np.float32(t).view(np.uint32)) & 1)))
+
+
+def test_fma32_is_correctly_rounded():
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal(1500).astype(np.float32), rng.standard_normal(1500).astype(np.float32)
+    c = (rng.standard_normal(1500) * rng.choice([1e-6, 1.0, 1e3], 1500)).astype(np.float32)
+    got = OI._fma32(a, b, c)
+    assert all(_fma_exact(a[i], b[i], c[i]) == got[i] for i in range(1500))
+    # products that land exactly on rounding midpoints (1 + 2^-12)^2 = 1 + 2^-11 + 2^-24, shifted by multiples of 2^-25
+    a2 = np.full(8, 1 + 2.0 ** -12, np.float32)
+    c2 = np.array([0, 2.0 ** -24, -2.0 ** -24, 3 * 2.0 ** -24, 2.0 ** -23, 2.0 ** -25, -2.0 ** -25, 5 * 2.0 ** -25], np.float32)
+    g2 = OI._fma32(a2, a2, c2)
+    assert all(_fma_exact(a2[i], a2[i], c2[i]) == g2[i] for i in range(8))
+
+
+def test_fixed_order_upsampling_is_atens_up_to_rounding():
+    code = torch.randn(9, 9, 12, generator=torch.Generator().manual_seed(0)) * 3
+    got = torch.from_numpy(OI.upsample_bilinear_fixed(code.numpy(), 70))                                  # [70, 70, 12]
+    aten = torch.nn.functional.interpolate(code.permute(2, 0, 1)[None], (70, 70), mode="bilinear", align_corners=True)[0].permute(1, 2, 0)
+    assert (got - aten).abs().max().item() < 2e-6
+    assert torch.equal(got[0, 0], code[0, 0]) and torch.equal(got[-1, -1], code[-1, -1])                   # corners are exact
+
+
+def test_kmeans_group_fold_degenerates_for_short_inputs():
+    """Up to KMEANS_SUPER chunks (512 points) the three-level order IS the flat chunk order (0 + x = x exactly)."""
+    code = np.random.default_rng(1).standard_normal((500, 16)).astype(np.float32)
+    lab = OI.kmeans_cosine_labels(code, 4, iters=3)
+    keep = OI.KMEANS_SUPER
+    try:
+        OI.KMEANS_SUPER = 10 ** 6          # one group = the flat order
+        assert np.array_equal(OI.kmeans_cosine_labels(code, 4, iters=3), lab)
+    finally:
+        OI.KMEANS_SUPER = keep
+    lab_pix = OI.kmeans_cosine_labels_pixels(code[:49], 7, 20, 3, iters=2)
+    assert lab_pix.shape == (400,) and lab_pix.min() >= 0 and lab_pix.max() < 3
+
+
+def test_supervision_oracle_nan_scan_lines_and_raw_projection():
+    H, W = 40, 50
+    poly = np.array([[10.0, 5.0], [30.0, 5.0], [20.0, np.inf], [10.0, 30.0]], dtype=np.float32)           # one vertex at y = inf
+    left, right = OSV.convex_edges(poly, H, W)
+    # the edge (20, inf) -> (10, 30) is active on every row >= 30 and evaluates to (y - inf) * 0 + 20 = NaN there
+    assert np.isnan(left[30:]).all() and np.isnan(right[30:]).all()
+    assert not OSV.fill_mask(poly, H, W)[30:].any()                             # torch's min / max propagate the NaN: never filled
+    assert OSV.fill_mask(poly, H, W)[6:29].any() and np.isfinite(left[6:29]).all()
+    K, T = np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32)
+    K[0, 0] = K[1, 1] = 100.0
+    pts = np.array([[0.1, 0.2, 2.0], [0.1, 0.2, -2.0]], dtype=np.float32)
+    uv, z = OSV.project_points_raw(K, T, pts)
+    assert np.isfinite(uv).all() and z.tolist() == [2.0, -2.0]                  # ImageProjector.project: finite behind the camera too
+    assert np.isnan(OSV.project_points(K, T, pts)[1]).all() and np.isfinite(OSV.project_points(K, T, pts)[0]).all()

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "wvn_attention_f16": ([_p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "wvn_gemm_x3": ([_p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_quantize_rows_fp8": ([_p, _i, _i, _p, _i, _p, _i, _i, _p], _i),
+    "wvn_layernorm_fp8": ([_p, _p, _p, _p, _i, _p, _i, _i, _f, _p], _i),
     "wvn_gemm_fp8": ([_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_split_planes": ([_p, _i, _p, _p, _i, _i, _i, _p], _i),
     "wvn_attention_x3": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
@@ -116,6 +117,9 @@ _SIGNATURES = {
     "wvn_mlp_forward": ([_p, _p, _p, _i, _i, _p, _p, _p, _p, _sz, _p], _i),
     "wvn_mlp_train_phase_a": ([_p, _p, _p, _i, _p, _i, _p, _p, _sz, _p], _i),
     "wvn_mlp_train_phase_b": ([_p, _p, _p, _i, _p, _p, _i, _p, _f, _f, _f, _p, _p, _p, _sz, _p], _i),
+    "wvn_compact_segment_rows": ([_p, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p], _i),
+    "wvn_mlp_train_phase_a_rows": ([_p, _p, _p, _i, _p, _i, _p, _p, _p, _sz, _p], _i),
+    "wvn_mlp_train_phase_b_rows": ([_p, _p, _p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _p, _p, _p, _sz, _p], _i),
     "wvn_mlp_train_phase_c": ([_p, _p, _p, _p, _p, _i, _f, _p, _f, _f, _p, _p], _i),
     "wvn_mlp_confidence": ([_p, _i, _p, _i, _f, _f, _f, _p, _p, _i, _i, _p], _i),
     "wvn_pixel_mlp_pack_bytes": ([_p], _sz),

@@ -294,11 +294,15 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       }
       continue;
     }
+    bool qkv_done = false;
     if (qkv_fused) {  // LayerNorm 1 + QKV projection: one launch, no xn round trip
       Span s(3, st);
-      RET_IF(opk.qkv_fused(w.x, d.D, L.ln1_g, L.ln1_b, 1e-6f, (const bf16_t*)L.qkv_w, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
-                                  (bf16_t*)w.v, d.H, d.npad, d.ntok_s, scale * 1.44269504088896340736f, M, st));
-    } else {
+      const int rc = opk.qkv_fused(w.x, d.D, L.ln1_g, L.ln1_b, 1e-6f, (const bf16_t*)L.qkv_w, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
+                                   (bf16_t*)w.v, d.H, d.npad, d.ntok_s, scale * 1.44269504088896340736f, M, st);
+      if (rc != WVN_OK && rc != WVN_ERR_ARG) return rc;   // WVN_ERR_ARG: not eligible (e.g. q / k / v beyond the 2 GB a buffer
+      qkv_done = rc == WVN_OK;                            // descriptor spans) -- the separate kernels below, as proj_mlp does
+    }
+    if (!qkv_done) {
     { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, f32 ? 0 : opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     {
       Span s(3, st);
@@ -419,6 +423,10 @@ int wvn_gemm_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, c
 int wvn_quantize_rows_fp8(const void* src, int src_is_bf16, int lds, void* q, int ldq, float* scale, int rows, int cols,
                           void* stream) {
   return wvn_quantize_rows_fp8_launch(src, src_is_bf16, lds, (unsigned char*)q, ldq, scale, rows, cols, (hipStream_t)stream);
+}
+int wvn_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* q, int ldq, float* scale, int rows, int D,
+                      float eps, void* stream) {
+  return wvn_layernorm_fp8_launch(x, gamma, beta, (unsigned char*)q, ldq, scale, rows, D, eps, (hipStream_t)stream);
 }
 int wvn_gemm_fp8(const void* A_q, int lda, const void* W_q, int ldw, const float* sa, const float* sw, const float* bias,
                  void* C, int ldc, int M, int N, int K, int epi, void* stream) {
@@ -657,21 +665,39 @@ int wvn_mlp_forward(const wvn_mlp_desc* d, const float* params, const float* x, 
   return mlp_fwd(d, params, x, ldx, R, out, h1, h2, (hipStream_t)stream);
 }
 
-int wvn_mlp_train_phase_a(const wvn_mlp_desc* d, const float* params, const float* x, int ldx,
-                          const unsigned char* y_valid, int R, double* stats, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+int wvn_compact_segment_rows(const float* feat, int D, const float* side, int Dside, const int* nseg, int B, int S, float* x_out,
+                             float* side_out, int* rows_dev, void* stream) {
+  return wvn_compact_segment_rows_launch(feat, D, side, Dside, nseg, B, S, x_out, side_out, rows_dev, (hipStream_t)stream);
+}
+
+int wvn_mlp_train_phase_a_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx,
+                               const unsigned char* y_valid, int R, const int* rows_dev, double* stats, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (!d || !params || !x || !y_valid || !stats || !workspace || R <= 0) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   MlpWs w = mlp_carve(d, R, workspace);
   if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
   RET_IF(mlp_fwd(d, params, x, ldx, R, w.out, w.h1, w.h2, st));
-  return wvn_mlp_rowloss_stats_launch(w.out, 1 + d->D, x, ldx, y_valid, w.lr, stats, R, d->D, st);
+  return wvn_mlp_rowloss_stats_launch(w.out, 1 + d->D, x, ldx, y_valid, w.lr, stats, R, d->D, st, rows_dev);
+}
+int wvn_mlp_train_phase_a(const wvn_mlp_desc* d, const float* params, const float* x, int ldx,
+                          const unsigned char* y_valid, int R, double* stats, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  return wvn_mlp_train_phase_a_rows(d, params, x, ldx, y_valid, R, nullptr, stats, workspace, workspace_bytes, stream);
 }
 
 int wvn_mlp_train_phase_b(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
                           const unsigned char* y_valid, int R, const double* stats, float std_factor, float w_trav,
                           float w_reco, float* grads, float* confidence_out, void* workspace, size_t workspace_bytes,
                           void* stream) {
+  return wvn_mlp_train_phase_b_rows(d, params, x, ldx, y, y_valid, R, nullptr, stats, std_factor, w_trav, w_reco, grads,
+                                    confidence_out, workspace, workspace_bytes, stream);
+}
+
+int wvn_mlp_train_phase_b_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
+                               const unsigned char* y_valid, int R, const int* rows_dev, const double* stats, float std_factor,
+                               float w_trav, float w_reco, float* grads, float* confidence_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (!d || !params || !x || !y || !y_valid || !stats || !grads || !workspace || R <= 0) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   MlpWs w = mlp_carve(d, R, workspace);
@@ -679,7 +705,7 @@ int wvn_mlp_train_phase_b(const wvn_mlp_desc* d, const float* params, const floa
   const MlpOff o = mlp_off(d);
   const int O = o.O;
   RET_IF(wvn_mlp_gradout_launch(w.out, O, x, ldx, y, y_valid, w.lr, stats, std_factor, w_trav, w_reco, w.g_out, O,
-                                w.trav_w, w.trav_raw, confidence_out, grads + o.total, R, d->D, st));
+                                w.trav_w, w.trav_raw, confidence_out, grads + o.total, R, d->D, st, rows_dev));
   // layer 3
   RET_IF(mlp_wgrad(w.g_out, O, w.h2, d->H2, O, d->H2, R, w.part, grads + o.W3, st));
   RET_IF(wvn_colsum_launch(w.g_out, O, R, O, grads + o.b3, st));

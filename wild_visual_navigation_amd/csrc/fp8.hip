@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const TIN* __restric
     float qq = 0.f;
 #pragma unroll
     for (int g = 0; g < VPT4; ++g)
+      if (256 * g + 4 * lane < cols) {   // lanes past the row hold zeros: they must not add mean^2 each (D = 384: 128 of them)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = v[g][e] - mean; qq += d * d; }
+        for (int e = 0; e < 4; ++e) { const float d = v[g][e] - mean; qq += d * d; }
+      }
     const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)cols + eps);
 #pragma unroll
     for (int g = 0; g < VPT4; ++g) {

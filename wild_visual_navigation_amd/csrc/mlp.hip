@@ -13,10 +13,15 @@ namespace {
 // loss_reco[r] = mean_d (out[r][1+d] - x[r][d])^2        one wave per row
 __global__ __launch_bounds__(256) void mlp_rowloss_kernel(const float* __restrict__ out, int ldo,
                                                           const float* __restrict__ x, int ldx,
-                                                          float* __restrict__ lr, int R, int D) {
+                                                          float* __restrict__ lr, int R, int D,
+                                                          const int* __restrict__ rows_dev) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= R) return;
+  if (rows_dev && row >= *rows_dev) {   // a row past the device-side row count (compacted batch): contributes nothing
+    if (lane == 0) lr[row] = 0.f;
+    return;
+  }
   float s = 0.f;
   for (int d = lane; d < D; d += 64) {
     float e = out[(size_t)row * ldo + 1 + d] - x[(size_t)row * ldx + d];
@@ -29,8 +34,9 @@ __global__ __launch_bounds__(256) void mlp_rowloss_kernel(const float* __restric
 // stats = { n_valid, sum(lr[valid]), sum(lr[valid]^2), R }  in fp64, single workgroup, fixed order
 __global__ __launch_bounds__(1024) void mlp_stats_kernel(const float* __restrict__ lr,
                                                          const unsigned char* __restrict__ valid, int R,
-                                                         double* __restrict__ stats) {
+                                                         double* __restrict__ stats, const int* __restrict__ rows_dev) {
   __shared__ double sh[3][16];
+  if (rows_dev) R = min(R, *rows_dev);
   double n = 0, s1 = 0, s2 = 0;
   for (int r = threadIdx.x; r < R; r += 1024)
     if (valid[r]) { double v = lr[r]; n += 1.0; s1 += v; s2 += v * v; }
@@ -75,10 +81,16 @@ __global__ __launch_bounds__(256) void mlp_gradout_kernel(const float* __restric
                                                           const double* __restrict__ stats, float std_factor,
                                                           float w_trav, float w_reco, float* __restrict__ g, int ldg,
                                                           float* __restrict__ trav_w, float* __restrict__ trav_raw,
-                                                          float* __restrict__ conf_out, int R, int D) {
+                                                          float* __restrict__ conf_out, int R, int D,
+                                                          const int* __restrict__ rows_dev) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= R) return;
+  if (rows_dev && row >= *rows_dev) {   // absent row: zero gradient seed, zero loss terms (the GEMMs still walk it)
+    if (lane == 0) { trav_raw[row] = 0.f; trav_w[row] = 0.f; if (conf_out) conf_out[row] = 0.f; }
+    for (int d = lane; d < D + 1; d += 64) g[(size_t)row * ldg + d] = 0.f;
+    return;
+  }
   const ConfStats cs = conf_stats(stats);
   const float Rtot = (float)stats[3], nv = (float)stats[0];
   const bool v = valid[row] != 0;
@@ -192,13 +204,48 @@ __global__ __launch_bounds__(256) void mlp_confidence_kernel(const float* __rest
   }
 }
 
+// Rows of the segments that exist -- segment s of frame b exists iff s < nseg[b] -- packed front to back in (b, s) order, the
+// row count left in device memory.  Replaces the boolean-mask selection feat[keep] (a partition + a host synchronisation to
+// learn the count) in front of the training step: the step then runs on B*S rows of which the first *count are real.
+// Rows past the count are zeroed (finite inputs for the GEMMs that still walk them).  One workgroup per frame.
+__global__ __launch_bounds__(256) void compact_segment_rows_kernel(const float* __restrict__ feat, int D, const float* __restrict__ side,
+                                                                   int Ds, const int* __restrict__ nseg, int B, int S,
+                                                                   float* __restrict__ x, float* __restrict__ side_out,
+                                                                   int* __restrict__ count) {
+  const int b = blockIdx.x;
+  int off = 0, total = 0;
+  for (int i = 0; i < B; ++i) {   // (uniform, B <= a few hundred)
+    const int n = min(max(nseg[i], 0), S);
+    if (i < b) off += n;
+    total += n;
+  }
+  const int n = min(max(nseg[b], 0), S);
+  for (int i = threadIdx.x; i < n * D; i += blockDim.x) x[(size_t)off * D + i] = feat[(size_t)b * S * D + i];
+  if (side)
+    for (int i = threadIdx.x; i < n * Ds; i += blockDim.x) side_out[(size_t)off * Ds + i] = side[(size_t)b * S * Ds + i];
+  // the tail [total, B*S): frame b clears its share
+  const int tail = B * S - total, t0 = (int)((long long)tail * b / B), t1 = (int)((long long)tail * (b + 1) / B);
+  for (int i = threadIdx.x; i < (t1 - t0) * D; i += blockDim.x) x[(size_t)(total + t0) * D + i] = 0.f;
+  if (side)
+    for (int i = threadIdx.x; i < (t1 - t0) * Ds; i += blockDim.x) side_out[(size_t)(total + t0) * Ds + i] = 0.f;
+  if (b == 0 && threadIdx.x == 0) *count = total;
+}
+
 }  // namespace
 
-int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int ldx, const unsigned char* valid,
-                                 float* lr, double* stats, int R, int D, hipStream_t st) {
-  hipLaunchKernelGGL(mlp_rowloss_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, out, ldo, x, ldx, lr, R, D);
+int wvn_compact_segment_rows_launch(const float* feat, int D, const float* side, int Ds, const int* nseg, int B, int S, float* x,
+                                    float* side_out, int* count, hipStream_t st) {
+  if (!feat || !nseg || !x || !count || B <= 0 || S <= 0 || D <= 0 || (side && (!side_out || Ds <= 0))) return WVN_ERR_ARG;
+  hipLaunchKernelGGL(compact_segment_rows_kernel, dim3(B), dim3(256), 0, st, feat, D, side, Ds, nseg, B, S, x, side_out, count);
   WVN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mlp_stats_kernel, dim3(1), dim3(1024), 0, st, lr, valid, R, stats);
+  return WVN_OK;
+}
+
+int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int ldx, const unsigned char* valid,
+                                 float* lr, double* stats, int R, int D, hipStream_t st, const int* rows_dev) {
+  hipLaunchKernelGGL(mlp_rowloss_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, out, ldo, x, ldx, lr, R, D, rows_dev);
+  WVN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mlp_stats_kernel, dim3(1), dim3(1024), 0, st, lr, valid, R, stats, rows_dev);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -206,9 +253,9 @@ int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int 
 int wvn_mlp_gradout_launch(const float* out, int ldo, const float* x, int ldx, const float* y,
                            const unsigned char* valid, const float* lr, const double* stats, float std_factor,
                            float w_trav, float w_reco, float* g, int ldg, float* trav_w, float* trav_raw,
-                           float* conf_out, float* extra, int R, int D, hipStream_t st) {
+                           float* conf_out, float* extra, int R, int D, hipStream_t st, const int* rows_dev) {
   hipLaunchKernelGGL(mlp_gradout_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, out, ldo, x, ldx, y, valid, lr, stats,
-                     std_factor, w_trav, w_reco, g, ldg, trav_w, trav_raw, conf_out, R, D);
+                     std_factor, w_trav, w_reco, g, ldg, trav_w, trav_raw, conf_out, R, D, rows_dev);
   WVN_LAUNCH_CHECK();
   hipLaunchKernelGGL(mlp_losssum_kernel, dim3(1), dim3(1024), 0, st, trav_w, trav_raw, R, extra);
   WVN_LAUNCH_CHECK();

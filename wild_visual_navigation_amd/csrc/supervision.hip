@@ -32,7 +32,8 @@ struct RenderNode {
   const float* K;      // [4][4] scaled camera matrix of this node
   const float* pose;   // [4][4] pose_cam_in_world
   float* mask;         // [C][H][W] supervision mask, updated in place
-  float* projected;    // [N][2] out (may be null)
+  float* projected;    // [N][2] out (may be null): raw coordinates, finite also behind the camera
+  float* depth;        // [N] out (may be null): camera-frame z
 };
 
 __global__ __launch_bounds__(256) void project_render_fmin_kernel(const RenderNode* __restrict__ nodes,
@@ -67,9 +68,10 @@ __global__ __launch_bounds__(256) void project_render_fmin_kernel(const RenderNo
     const float zp = ((K[8] * pc[0] + K[9] * pc[1]) + K[10] * pc[2]) + K[11];
     const float s = fabsf(zp) > 1e-8f ? 1.0f / (zp + 1e-8f) : 1.0f;
     float u = xp * s, v = yp * s;
+    if (nd.projected) { nd.projected[2 * i] = u; nd.projected[2 * i + 1] = v; }
+    if (nd.depth) nd.depth[i] = pc[2];
     if (!(pc[2] >= 0.f)) { u = __builtin_nanf(""); v = __builtin_nanf(""); }
     px[i] = u; py[i] = v;
-    if (nd.projected) { nd.projected[2 * i] = u; nd.projected[2 * i + 1] = v; }
   }
   __syncthreads();
   if (tid == 0) {

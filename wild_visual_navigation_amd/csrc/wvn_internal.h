@@ -176,11 +176,13 @@ int wvn_flip_average_launch(const float* a, const float* mirrored, float* out, i
 int wvn_kmeans_launch(const float* xn, int* labels, int* nseg, float* scratch, int B, int P, int C, int K, int iters,
                       int relabel, hipStream_t st);
 int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int ldx, const unsigned char* valid,
-                                 float* lr, double* stats, int R, int D, hipStream_t st);
+                                 float* lr, double* stats, int R, int D, hipStream_t st, const int* rows_dev = nullptr);
+int wvn_compact_segment_rows_launch(const float* feat, int D, const float* side, int Ds, const int* nseg, int B, int S, float* x,
+                                    float* side_out, int* count, hipStream_t st);
 int wvn_mlp_gradout_launch(const float* out, int ldo, const float* x, int ldx, const float* y,
                            const unsigned char* valid, const float* lr, const double* stats, float std_factor,
                            float w_trav, float w_reco, float* g, int ldg, float* trav_w, float* trav_raw,
-                           float* conf_out, float* extra, int R, int D, hipStream_t st);
+                           float* conf_out, float* extra, int R, int D, hipStream_t st, const int* rows_dev = nullptr);
 int wvn_colsum_launch(const float* A, int lda, int R, int N, float* outv, hipStream_t st);
 int wvn_adam_launch(float* p, const float* g, float* m, float* v, int n, int step, float lr, float b1, float b2,
                     float eps, hipStream_t st);

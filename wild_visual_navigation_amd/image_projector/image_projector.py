@@ -5,7 +5,7 @@ csrc/supervision.hip; ``TraversabilityEstimator.add_supervision_node`` calls the
 import torch
 
 from .. import ops
-from ..feature_extractor.transforms import resize_nearest_center_crop
+from ..feature_extractor.transforms import ingest_tables, resize_nearest_center_crop
 
 
 class PinholeCamera:
@@ -75,13 +75,13 @@ class ImageProjector:
         return ops.project_render_fmin(Ks, poses, masks, points, value, want_projected=True)
 
     def project(self, pose_camera_in_world: torch.Tensor, points_W: torch.Tensor):
-        """image_projector.py:126-150 -> (projected [B,N,2], valid [B,N], valid_z [B,N]); points behind the camera come back
-        as NaN (the reference NaNs them right after, :180)."""
+        """image_projector.py:126-150 -> (projected [B,N,2] raw pinhole coordinates -- finite also for points behind the
+        camera, as in the reference --, valid [B,N], valid_z [B,N] = camera-frame z >= 0)."""
         B = self.camera.batch_size
         H, W = int(self.camera.height.item()), int(self.camera.width.item())
         scratch = [torch.full((1, H, W), float("nan"), device=points_W.device) for _ in range(B)]
-        proj = self._render(pose_camera_in_world, points_W, scratch, 1.0)
-        valid_z = ~torch.isnan(proj[..., 0])
+        proj, depth = self._render(pose_camera_in_world, points_W, scratch, 1.0)
+        valid_z = depth >= 0
         valid = (valid_z & (proj[..., 0] >= 0) & (proj[..., 0] <= self.camera.width) & (proj[..., 1] >= 0)
                  & (proj[..., 1] <= self.camera.height))
         return proj, valid, valid_z
@@ -97,7 +97,8 @@ class ImageProjector:
         if colors.dim() == 1:
             colors = colors[None].expand(B, 3)
         cover = [torch.full((1, H, W), float("nan"), dtype=torch.float32, device=dev) for _ in range(B)]
-        proj = self._render(pose_camera_in_world, points, cover, 1.0)          # ONE launch: inside = 1, outside stays NaN
+        proj, depth = self._render(pose_camera_in_world, points, cover, 1.0)   # ONE launch: inside = 1, outside stays NaN
+        proj = torch.where((depth >= 0)[..., None], proj, torch.full((), float("nan"), device=dev))   # :180
         inside = ~torch.isnan(torch.stack(cover))                                # [B,1,H,W]
         self.masks = torch.where(inside, colors[:, :, None, None].expand(B, 3, H, W), torch.zeros((), device=dev))
         self.masks[self.masks == 0.0] = float("nan")
@@ -105,7 +106,7 @@ class ImageProjector:
         if image is not None:
             img = image if image.dim() == 4 else image[None]
             overlay = torch.where(inside, colors[:, :, None, None].expand_as(img), img)
-        valid_z = ~torch.isnan(proj[..., 0])
+        valid_z = depth >= 0
         valid = (valid_z & (proj[..., 0] >= 0) & (proj[..., 0] <= self.camera.width) & (proj[..., 1] >= 0)
                  & (proj[..., 1] <= self.camera.height))
         return self.masks, overlay, proj, valid
@@ -113,8 +114,12 @@ class ImageProjector:
     def resize_image(self, image: torch.Tensor):
         """image_projector.py:199-200 (T.Resize(NEAREST) + T.CenterCrop, or a plain NEAREST resize to [new_h, new_w])."""
         nh, nw = self._crop
+        H, W = image.shape[-2:]
+        if image.is_cuda and image.element_size() in (1, 4):   # one HIP gather through the geometry's index tables
+            return ops.resize_nearest_crop(image, ingest_tables(H, W, nh, image.device, out_w=nw))
+        x = image if image.dim() == 4 else image[None]   # host tensors / other dtypes: the torch restatement (plumbing)
         if nw is None:
-            return resize_nearest_center_crop(image if image.dim() == 4 else image[None], nh)[0 if image.dim() == 3 else slice(None)]
-        x = image if image.dim() == 4 else image[None]
-        out = torch.nn.functional.interpolate(x.float(), size=(nh, nw), mode="nearest").to(image.dtype)
+            out = resize_nearest_center_crop(x, nh)
+        else:
+            out = torch.nn.functional.interpolate(x.float(), size=(nh, nw), mode="nearest").to(image.dtype)
         return out if image.dim() == 4 else out[0]

@@ -163,7 +163,7 @@ def project_render_fmin(Ks, poses, masks, points: torch.Tensor, value, want_proj
     """ImageProjector.project_and_render + torch.fmin merge for n nodes in one launch (csrc/supervision.hip).
     Ks / poses: lists of [4,4] fp32 CUDA tensors (scaled camera matrix, pose_cam_in_world); masks: list of contiguous
     [C,H,W] fp32 CUDA tensors, UPDATED IN PLACE; points [N,3] (shared) or [n,N,3]; value: float or 1-element CUDA tensor
-    (colour * traversability).  Returns the projected points [n,N,2] if asked."""
+    (colour * traversability).  ``want_projected``: returns (projected [n,N,2] raw pinhole coordinates, depth [n,N] camera-frame z)."""
     n = len(masks)
     dev = masks[0].device
     Cc, H, W = masks[0].shape
@@ -171,6 +171,7 @@ def project_render_fmin(Ks, poses, masks, points: torch.Tensor, value, want_proj
     batched = points.dim() == 3
     N = points.shape[-2]
     proj = torch.empty(n, N, 2, dtype=torch.float32, device=dev) if want_projected else None
+    depth = torch.empty(n, N, dtype=torch.float32, device=dev) if want_projected else None
     keep = []
     rows = []
     for i in range(n):
@@ -180,14 +181,14 @@ def project_render_fmin(Ks, poses, masks, points: torch.Tensor, value, want_proj
         m = masks[i]
         if m.dtype != torch.float32 or not m.is_contiguous() or tuple(m.shape) != (Cc, H, W):
             raise _lib.WvnError("project_render_fmin: masks must be contiguous fp32 [C,H,W] of one shape")
-        rows.append([ptr(K), ptr(T), ptr(m), ptr(proj[i]) if proj is not None else 0])
+        rows.append([ptr(K), ptr(T), ptr(m), ptr(proj[i]) if proj is not None else 0, ptr(depth[i]) if depth is not None else 0])
     table = _record_table(rows, dev)
     vdev = value if isinstance(value, torch.Tensor) else None
     if vdev is not None:
         vdev = vdev.to(dev, torch.float32).reshape(-1).contiguous()
     check(lib().wvn_project_render_fmin(ptr(table), n, ptr(points), int(batched), N, Cc, H, W, ptr(vdev),
                                         0.0 if vdev is not None else float(value), stream()), "wvn_project_render_fmin")
-    return proj
+    return (proj, depth) if want_projected else None
 
 
 _SLIC_TABLES = {}
@@ -306,6 +307,26 @@ def cast_rows_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def compact_segment_rows(feat: torch.Tensor, nseg: torch.Tensor, side: Optional[torch.Tensor] = None):
+    """feat [B,S,D] fp32 (rows of ids a frame did not produce are NaN), nseg [B] int32 (ids that exist per frame), side
+    [B,S,Ds] fp32 (optional per-row data) -> (x [B*S, D], side_out [B*S, Ds] | None, rows_dev int32 [1]): the existing rows
+    front to back, zeros behind, the count on the device -- no host synchronisation (``MlpTrainer.train_step(rows_dev=...)``)."""
+    require_cuda(feat, "feat")
+    B, S, D = feat.shape
+    feat = feat.contiguous()
+    nseg = nseg.to(torch.int32).contiguous()
+    x = torch.empty(B * S, D, dtype=torch.float32, device=feat.device)
+    so, Ds = None, 0
+    if side is not None:
+        side = side.float().contiguous()
+        Ds = side.shape[-1]
+        so = torch.empty(B * S, Ds, dtype=torch.float32, device=feat.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=feat.device)
+    check(lib().wvn_compact_segment_rows(ptr(feat), D, ptr(side), Ds, ptr(nseg), B, S, ptr(x), ptr(so), ptr(cnt), stream()),
+          "wvn_compact_segment_rows")
+    return x, so, cnt
+
+
 def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     """x [R, C] fp32 -> int32 [R] index of the row maximum (lowest index wins ties)."""
     require_cuda(x, "x")
@@ -380,6 +401,18 @@ def quantize_rows_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     sc = torch.empty(R, dtype=torch.float32, device=x.device)
     check(lib().wvn_quantize_rows_fp8(ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), ptr(q), Cc, ptr(sc), R, Cc, stream()),
           "wvn_quantize_rows_fp8")
+    return q, sc
+
+
+def layernorm_fp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6) -> Tuple[torch.Tensor, torch.Tensor]:
+    """LayerNorm(x [R, D] fp32 contiguous) quantised per row -> (q [R, D] float8_e4m3fn, scale [R]): LN(x) ~ q * scale."""
+    require_cuda(x, "x")
+    R, D = x.shape
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise _lib.WvnError("layernorm_fp8: contiguous fp32 rows expected")
+    q = torch.empty(R, D, dtype=torch.float8_e4m3fn, device=x.device)
+    sc = torch.empty(R, dtype=torch.float32, device=x.device)
+    check(lib().wvn_layernorm_fp8(ptr(x), ptr(gamma), ptr(beta), ptr(q), D, ptr(sc), R, D, eps, stream()), "wvn_layernorm_fp8")
     return q, sc
 
 

@@ -87,6 +87,7 @@ class MissionNode(BaseNode):
         self._supervision_signal_valid = None
         self._confidence = None
         self._seg_i32 = None   # int32 copy of feature_segments for the kernels (the reference keeps int64)
+        self._num_segments = None
 
     def clear_debug_data(self):
         """nodes.py:152-162: drop what training does not need."""
@@ -128,6 +129,7 @@ class MissionNode(BaseNode):
     def feature_segments(self, v):
         self._feature_segments = v
         self._seg_i32 = None
+        self._num_segments = None
 
     def segments_i32(self) -> torch.Tensor:
         if self._seg_i32 is None:
@@ -135,7 +137,12 @@ class MissionNode(BaseNode):
         return self._seg_i32
 
     def num_segments(self) -> int:
-        return int(self._features.shape[0])  # == feature_segments.max() + 1 for compacted ids (nodes.py:413)
+        """Length of the supervision signal: ``feature_segments.max() + 1`` as in the reference (nodes.py:413); one host sync
+        per node (cached: the map of a node does not change), never the feature-row count -- a map whose ids exceed the
+        feature rows would otherwise lose those pixels silently."""
+        if self._num_segments is None:
+            self._num_segments = int(self._feature_segments.max().item()) + 1
+        return self._num_segments
 
     def update_supervision_signal(self):
         """nodes.py:400-440: nanmean over the mask channels, then per-segment mean of the labelled pixels; 0 where a

@@ -92,9 +92,11 @@ class MlpTrainer:
 
     @torch.no_grad()
     def train_step(self, x: torch.Tensor, y: torch.Tensor, y_valid: torch.Tensor,
-                   want_confidence: bool = False) -> torch.Tensor:
+                   want_confidence: bool = False, rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [R,D] fp32, y [R] fp32, y_valid [R] bool (this rank's rows).  Returns the device tensor
-        losses[5] = {total, loss_trav, loss_reco, conf_mean, conf_std} (no host sync here)."""
+        losses[5] = {total, loss_trav, loss_reco, conf_mean, conf_std} (no host sync here).
+        ``rows_dev`` (int32 [1] on the device): only the first rows_dev[0] of the R rows are real (a batch compacted by
+        ``ops.compact_segment_rows``: its row count never visits the host); the rest contribute nothing."""
         _lib.require_cuda(x, "x")
         lib = _lib.lib()
         dev = x.device
@@ -113,17 +115,18 @@ class MlpTrainer:
 
         # A rank whose shard is empty this step (ragged frame sharding) still takes part in both collectives, contributing
         # zeros: every rank makes the same sequence of RCCL calls whatever its row count.
+        rd = _lib.ptr(rows_dev)
         if R > 0:
-            _lib.check(lib.wvn_mlp_train_phase_a(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), yv.data_ptr(), R,
-                                                 self.stats.data_ptr(), ws.data_ptr(), ws.numel(), st), "phase_a")
+            _lib.check(lib.wvn_mlp_train_phase_a_rows(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), yv.data_ptr(), R, rd,
+                                                      self.stats.data_ptr(), ws.data_ptr(), ws.numel(), st), "phase_a")
         else:
             self.stats.zero_()
         self._timed_allreduce(self.stats)
         if R > 0:
-            _lib.check(lib.wvn_mlp_train_phase_b(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), y.data_ptr(),
-                                                 yv.data_ptr(), R, self.stats.data_ptr(), self.std_factor, self.w_trav,
-                                                 self.w_reco, self.grads.data_ptr(), _lib.ptr(conf), ws.data_ptr(),
-                                                 ws.numel(), st), "phase_b")
+            _lib.check(lib.wvn_mlp_train_phase_b_rows(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), y.data_ptr(),
+                                                      yv.data_ptr(), R, rd, self.stats.data_ptr(), self.std_factor, self.w_trav,
+                                                      self.w_reco, self.grads.data_ptr(), _lib.ptr(conf), ws.data_ptr(),
+                                                      ws.numel(), st), "phase_b")
         else:
             self.grads.zero_()
         self._timed_allreduce(self.grads)

@@ -163,10 +163,15 @@ class TraversabilityEstimator:
         trav = pnode.traversability
         value = trav.to(self._device).float().reshape(-1)[:1] if isinstance(trav, torch.Tensor) else float(trav)
         ops.project_render_fmin(Ks, poses, masks, footprint.to(self._device), value)    # colour = 1 (:258)
-        pooled = ops.label_pool_batched(masks, [m.segments_i32() for m in mission_nodes],
-                                        [m.num_segments() for m in mission_nodes])
-        for m, (sig, val) in zip(mission_nodes, pooled):
+        # re-pool the labels (:287-289).  A node without features / segments (e.g. added with use_for_training=False before its
+        # features arrived) had its mask merged above but has nothing to pool: update_supervision_signal returns early for
+        # it in the reference too (nodes.py:401-402)
+        poolable = [m for m in mission_nodes if m.features is not None and m.feature_segments is not None]
+        pooled = ops.label_pool_batched([m.supervision_mask for m in poolable], [m.segments_i32() for m in poolable],
+                                        [m.num_segments() for m in poolable]) if poolable else []
+        for m, (sig, val) in zip(poolable, pooled):
             m._supervision_signal, m._supervision_signal_valid = sig, val
+        for m in mission_nodes:
             if str(self._mode).endswith("EXTRACT_LABELS") and self._extraction_store_folder is not None:
                 p = os.path.join(self._extraction_store_folder, "supervision_mask", str(m.timestamp).replace(".", "_") + ".pt")
                 os.makedirs(os.path.dirname(p), exist_ok=True)
