@@ -208,7 +208,7 @@ int wvn_attention_bf16(const void* q, const void* k, const void* vt, void* out, 
 int wvn_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int ntok, int npad,
                       float scale, void* stream);
 int wvn_patchify(const float* img, void* patches, int out_is_bf16, int B, int S, int P, void* stream);
-int wvn_patchify_u8(const unsigned char* img, void* patches_bf16, int B, int S, int P, void* stream); /* P == 8 */
+int wvn_patchify_u8(const unsigned char* img, void* patches_bf16, int B, int S, int P, void* stream); /* P in {8, 14, 16} */
 int wvn_cast_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
 /* strided rows: dst[r][c] = (bf16 | fp16 when to_f16) src[r][c], fp32 src with leading dimension lds, 16-bit dst with ldd */
 int wvn_cast_rows(const float* src, int lds, void* dst, int ldd, int rows, int cols, int to_f16, void* stream);
@@ -309,7 +309,8 @@ int wvn_normalize_rows(const float* code, int ldc, float* xn, int rows, int C, v
 int wvn_argmax_rows(const float* x, int ld, int rows, int cols, int* out, void* stream);
 /* deterministic cosine k-means per image on xn [B,P,C]; labels [B,P] int32; nseg [B] distinct ids;
  * relabel != 0 compacts ids to 0..K'-1 ascending (feature_extractor.py:245-246). C in {16,64,90}.
- * scratch: wvn_kmeans_scratch_bytes(B,P,C,K) bytes (centroids + per-chunk partial sums). */
+ * scratch: wvn_kmeans_scratch_bytes(B,P,C,K) bytes (centroids + per-chunk partial sums); on return its first B*K*C floats hold the
+ * final centroids [B][K][C] (both forms). */
 /* Summation order of the centroid update (both forms): chunks of 64 consecutive points, members of a cluster in ascending point
  * order; chunk partials in ascending order inside groups of 8 chunks; group partials in ascending order; every chain starts from
  * +0.  Normalisation: x * (1 / max(||x||, 1e-12)) with one correctly rounded reciprocal per row. */

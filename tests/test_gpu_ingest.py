@@ -33,18 +33,21 @@ def test_tables_are_the_image_op(golden):
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "exact", "fp32"])
 def test_demo_frames_ingest_is_bit_identical(dev, golden, prec):
-    raw = golden("demo_frames_raw.pt")["frames_u8"].to(dev)                           # the reference's frames, undecimated
+    raw_cpu = golden("demo_frames_raw.pt")["frames_u8"]                                # the reference's frames, undecimated
+    raw = raw_cpu.to(dev)
     sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=3, depth=2)
     bb = VitBackbone(sd, 224, 8, 6, device=dev, precision=prec, max_chunk=4)
-    pre = resize_nearest_center_crop(raw, 224).contiguous()                            # host-side image op (torch indexing)
-    want = bb.forward_tokens(pre.float() / 255)
+    # x / 255 on the HOST: the kernel divides (the CPU path's arithmetic, which the oracle follows); torch's GPU kernel for
+    # a scalar divisor multiplies by fl(1 / 255) instead -- one ulp apart on some pixels, visible in the fp32-class modes
+    f01 = raw_cpu.float() / 255
+    want = bb.forward_tokens(resize_nearest_center_crop(f01, 224).contiguous().to(dev))      # host-side image op (torch indexing)
     assert torch.equal(bb.forward_tokens(raw), want)                                   # uint8 camera frames
-    assert torch.equal(bb.forward_tokens(raw.float() / 255), want)                     # fp32 frames in [0, 1]
+    assert torch.equal(bb.forward_tokens(f01.to(dev)), want)                           # fp32 frames in [0, 1]
     # up-sizing ingest (224 x 299 -> 448 network input): rows / columns repeat
     bb448 = VitBackbone(sd, 448, 8, 6, device=dev, precision=prec, max_chunk=2)
-    assert torch.equal(bb448.forward_tokens(raw[:2]), bb448.forward_tokens(resize_nearest_center_crop(raw[:2], 448).contiguous().float() / 255))
+    assert torch.equal(bb448.forward_tokens(raw[:2]), bb448.forward_tokens(resize_nearest_center_crop(f01[:2], 448).contiguous().to(dev)))
     if prec == "exact":   # and against the CPU oracle's own transform + backbone at the north_star tolerance
-        ref = OV.vit_tokens(sd, OI.dino_transform(raw[:2].cpu().float() / 255, 224), 8, 6)[:, 1:]
+        ref = OV.vit_tokens(sd, OI.dino_transform(f01[:2], 224), 8, 6)[:, 1:]
         assert (bb.forward_tokens(raw[:2]).cpu() - ref).abs().max().item() < 1e-3
 
 
@@ -54,11 +57,11 @@ def test_camera_sized_frame_1080x1440_and_flip(dev):
     for prec, P, heads, S, arch in (("bf16", 8, 6, 448, "vit_small"), ("fp16", 8, 6, 448, "vit_small"), ("bf16", 14, 6, 518, "vit_small")):
         w = sd if P == 8 else OV.make_dinov2_state_dict(arch, 14, pretrain_grid=37, seed=3, depth=1)
         bb = VitBackbone(w, S, P, heads, device=dev, precision=prec, max_chunk=2)
-        pre = resize_nearest_center_crop(frame, S).contiguous()
-        want = bb.forward_tokens(pre.float() / 255)
+        pre = resize_nearest_center_crop(frame.cpu().float() / 255, S).contiguous()
+        want = bb.forward_tokens(pre.to(dev))
         assert torch.equal(bb.forward_tokens(frame), want), (prec, P)
         # the mirror pass of the STEGO flip reading: a reversed column table == running on the flipped crop
-        assert torch.equal(bb.forward_tokens(frame, flip=True), bb.forward_tokens(pre.flip(-1).contiguous().float() / 255)), (prec, P)
+        assert torch.equal(bb.forward_tokens(frame, flip=True), bb.forward_tokens(pre.flip(-1).contiguous().to(dev))), (prec, P)
 
 
 def test_interfaces_take_camera_frames(dev, golden):

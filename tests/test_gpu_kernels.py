@@ -207,7 +207,14 @@ def test_patchify_u8_equals_float_path(dev, S):
     check(lib().wvn_patchify(ptr(fd), ptr(a), 1, 3, S, 8, stream()))
     check(lib().wvn_patchify_u8(ptr(u8d), ptr(b), 3, S, 8, stream()))
     assert torch.equal(a, b)
-    assert lib().wvn_patchify_u8(ptr(u8d), ptr(b), 3, S, 16, stream()) == 1001   # P = 8 only
+    # other patch sizes go through the element-order kernel (the row-panel fast path is P = 8 only): same bits as well
+    G16 = S // 16
+    a16 = torch.empty(3 * G16 * G16, 768, dtype=torch.bfloat16, device=dev)
+    b16 = torch.empty_like(a16)
+    check(lib().wvn_patchify(ptr((u8.float() / 255).to(dev)), ptr(a16), 1, 3, S, 16, stream()))
+    check(lib().wvn_patchify_u8(ptr(u8d), ptr(b16), 3, S, 16, stream()))
+    assert torch.equal(a16, b16)
+    assert lib().wvn_patchify_u8(ptr(u8d), ptr(b), 3, S, 7, stream()) == 1001    # patch sizes 8, 14, 16
 
 
 @pytest.mark.parametrize("G,H,D", [(8, 64, 40), (28, 224, 90), (56, 448, 384), (14, 100, 33)])

@@ -33,12 +33,13 @@ def test_upsample_kernel_matches_fixed_order_oracle(dev):
 def test_pixel_kmeans_bit_exact(dev, G, H, C, K, B):
     """(7, 50) and (5, 33): chunks straddle image rows, the last group is ragged; (28, 224): the live node's default size."""
     code = torch.randn(B, G * G, C, generator=g(G * H)) * (1.0 + torch.rand(B, G * G, 1, generator=g(1)))
-    lab, nseg = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=False)
+    lab, nseg, cent = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=False, return_centroids=True)
     lab2, nseg2 = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=True)
-    # the materialised route on the GPU: up-sample, normalise, cluster the H*H rows -- must give the same bits
+    # the materialised route on the GPU: up-sample, normalise, cluster the H*H rows -- must give the same bits, labels AND
+    # centroids (labels alone are robust to last-place differences of the sums: a 1-ulp square root went unnoticed that way)
     dense = ops.upsample_bilinear(code.to(dev), G, H).permute(0, 2, 3, 1).reshape(B, H * H, C).contiguous()
-    lab_m, _ = ops.kmeans_cosine(dense, K, iters=10, relabel=False)
-    assert torch.equal(lab, lab_m)
+    lab_m, _, cent_m = ops.kmeans_cosine(dense, K, iters=10, relabel=False, return_centroids=True)
+    assert torch.equal(lab, lab_m) and torch.equal(cent, cent_m)
     for b in range(B):
         want = OI.kmeans_cosine_labels_pixels(code[b].numpy(), G, H, K, iters=10)
         assert np.array_equal(lab[b].cpu().numpy(), want), f"frame {b}"

@@ -116,7 +116,8 @@ def test_untraversable_plane_and_infinite_vertices(dev):
     def sup(t, x, untrav):
         return SupervisionNode(timestamp=t, pose_base_in_world=_pose(x, 0, 0), pose_footprint_in_base=_pose(0, 0, 0, 0.0), width=0.7,
                                length=1.0, height=0.4, supervision=torch.ones(1), traversability=torch.tensor([0.2]),
-                               traversability_var=torch.tensor([0.1]), is_untraversable=untrav)
+                               traversability_var=torch.tensor([0.1]), is_untraversable=untrav,
+                               twist_in_base=torch.tensor([0.8, 0.1, 0.0]))
 
     fp = sup(1.0, 2.4, True).make_footprint_with_node(sup(0.0, 1.6, False))
     assert fp.shape == (1000, 3)

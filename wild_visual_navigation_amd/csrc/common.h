@@ -97,7 +97,10 @@ __device__ inline double wave_sum_d(double v) {
 struct LerpTap { int i0, i1; float w0, w1; };
 __host__ __device__ inline float lerp_scale(int G, int H) { return H > 1 ? (float)(G - 1) / (float)(H - 1) : 0.f; }
 __device__ inline LerpTap lerp_tap(int o, int G, float scale) {
-  const float s = __fmul_rn(scale, (float)o);
+  // __fmul_rn / __fsub_rn are plain operators to the compiler, and under HIP's default -ffp-contract=fast the backend fuses
+  // s - i0 into fma(scale, o, -i0) whatever pragma the source carries: the product is made opaque before it is used again
+  float s = __fmul_rn(scale, (float)o);
+  asm volatile("" : "+v"(s));
   LerpTap t;
   t.i0 = (int)s;
   t.i1 = t.i0 + (t.i0 < G - 1 ? 1 : 0);

@@ -3,8 +3,8 @@
 //
 // Integer outputs (segment-index maps) must be bit-exact against the oracle given the same fp32
 // code, so every floating-point reduction here has a FIXED, documented order and uses the
-// correctly-rounded non-fused intrinsics (__fmul_rn/__fadd_rn/__fsqrt_rn/__fdiv_rn; this file is
-// compiled with -ffp-contract=off):
+// non-fused multiply / add (__fmul_rn / __fadd_rn are plain operators: this file is compiled with
+// -ffp-contract=off) and square roots / reciprocals formed in fp64 (rinv_norm below):
 //   * dot products / norms : strictly sequential over the channel index
 //   * centroid sums        : points are cut into chunks of KM_CHUNK (64) consecutive indices; inside a
 //                            chunk the members of a cluster are added in ascending point order starting
@@ -24,6 +24,15 @@
 #include "wvn_internal.h"
 
 namespace {
+
+// 1 / max(sqrt(n2), 1e-12) with BOTH operations correctly rounded, through fp64: a 53-bit square root / quotient of fp32
+// operands rounds to the correctly rounded fp32 result (53 >= 2 * 24 + 2).  Not __fsqrt_rn / __fdiv_rn: hipcc lowered
+// __fsqrt_rn to the bare v_sqrt_f32 (1 ulp) in one kernel of this file and to the refined sequence in another -- the
+// reciprocal norms of 13 % of the pixels came out one ulp apart between the two k-means forms.
+__device__ inline float rinv_norm(float n2) {
+  const float n = fmaxf((float)sqrt((double)n2), 1e-12f);
+  return (float)(1.0 / (double)n);
+}
 
 constexpr int KM_MAXK = 64;
 constexpr int KM_CHUNK = 64;
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void normalize_rows_kernel(const fl
     float* r = tile + threadIdx.x * pitch;
     float n2 = 0.f;
     for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(r[d], r[d]));
-    const float rinv = __fdiv_rn(1.f, fmaxf(__fsqrt_rn(n2), 1e-12f));
+    const float rinv = rinv_norm(n2);
     for (int d = 0; d < C; ++d) r[d] = __fmul_rn(r[d], rinv);
   }
   __syncthreads();
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict_
   if (d == 0) {
     float n2 = 0.f;
     for (int i = 0; i < C; ++i) n2 = __fadd_rn(n2, __fmul_rn(sums[i], sums[i]));
-    nrm_s = __fdiv_rn(1.f, fmaxf(__fsqrt_rn(n2), 1e-12f));
+    nrm_s = rinv_norm(n2);
   }
   __syncthreads();
   if (d < C && cnt_s > 0) cent[((size_t)b * K + k) * C + d] = __fmul_rn(sums[d], nrm_s);
@@ -240,21 +249,11 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
 //   rinv    : lane = pixel; the block's two source code rows in LDS
 //   assign  : lane = pixel, x[C] in registers, centroids through the scalar cache (uniform addresses), four independent
 //             dot-product chains in flight
-//   partial : one 128-lane workgroup per group of KM_SUPER chunks, lane = channel.  Per pixel everything but the four code
-//             values is wave-uniform (tap tables, label, reciprocal norm: scalar loads); a cluster's running sum of the
-//             current chunk stays in a register while consecutive pixels carry the same label (the usual case) and is parked
-//             in LDS when the label changes -- the addition order is exactly the sequential one.
+//   partial : one 128-lane workgroup per group of KM_SUPER chunks, lane = channel; the values of 16 pixels are fetched and
+//             interpolated together, then added in pixel order; a cluster's running sum of the current chunk stays in a
+//             register while consecutive pixels carry the same label (the usual case) and is parked in LDS when the label
+//             changes -- the addition order is exactly the sequential one.
 // ---------------------------------------------------------------------------------------------------------------------------
-struct PixTabs { const int* i0; const int* i1; const float* w0; const float* w1; };   // [H] each
-
-__global__ void km_pix_tables_kernel(int* __restrict__ i0, int* __restrict__ i1, float* __restrict__ w0, float* __restrict__ w1,
-                                     int G, int H) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= H) return;
-  const LerpTap t = lerp_tap(o, G, lerp_scale(G, H));
-  i0[o] = t.i0; i1[o] = t.i1; w0[o] = t.w0; w1[o] = t.w1;
-}
-
 // stage code rows y0 / y1 of frame b ([G][C] each) into LDS: rows[0][G*C], rows[1][G*C]
 __device__ inline void pix_stage_rows(const float* __restrict__ code, int b, int G, int C, int y0, int y1, float* rows) {
   const int n = G * C;   // contiguous in memory
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(256) void km_pix_rinv_kernel(const float* __restric
     float n2 = 0.f;
 #pragma unroll
     for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(v[d], v[d]));
-    rinv[(size_t)b * H * H + (size_t)y * H + x] = __fdiv_rn(1.f, fmaxf(__fsqrt_rn(n2), 1e-12f));
+    rinv[(size_t)b * H * H + (size_t)y * H + x] = rinv_norm(n2);
   }
 }
 
@@ -361,14 +360,21 @@ __global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restr
 }
 
 // part[b][group][k][d] = the group's partial (chunk partials added in ascending chunk order), pcnt[b][group][k] = member count
+//
+// Lane = channel (two waves cover C <= 128).  The additions of a (cluster, channel) pair are a dependent chain in pixel order, but
+// the VALUES are not: per batch of PB pixels the wave first fetches and interpolates all PB values (4 * PB independent coalesced
+// loads in flight -- one pixel at a time the kernel was a chain of three memory round trips per pixel, 4.5 ms per launch), then
+// walks the batch in order.  Per-pixel parameters (tap offsets and weights, label, reciprocal norm) are computed ONCE per chunk,
+// pixel j by lane j, and handed to all lanes through v_readlane.
+constexpr int PB = 16;
 __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
-                                                             const int* __restrict__ labels, PixTabs tb, float* __restrict__ part,
+                                                             const int* __restrict__ labels, float* __restrict__ part,
                                                              int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup) {
   extern __shared__ float lds[];   // tab[K][C] (current chunk), grp[K][C] (group so far), cnt[K]
   float* tab = lds;
   float* grp = lds + K * C;
   int* cn = (int*)(grp + K * C);
-  const int g = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const int g = blockIdx.x, b = blockIdx.y, d = threadIdx.x, lane = threadIdx.x & 63;
   const long long P = (long long)H * H;
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) { tab[i] = 0.f; grp[i] = 0.f; }
   for (int i = threadIdx.x; i < K; i += blockDim.x) cn[i] = 0;
@@ -377,30 +383,49 @@ __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __rest
   const int* __restrict__ lab = labels + (size_t)b * P;
   const float* __restrict__ rv = rinv + (size_t)b * P;
   const long long g0 = (long long)g * KM_SUPER * KM_CHUNK;
+  const float scale = lerp_scale(G, H);
   const bool act = d < C;
+  const int dd = act ? d : 0;   // (inactive lanes of the second wave read channel 0 and drop the result)
   for (int c = 0; c < KM_SUPER; ++c) {
     const long long p0 = g0 + (long long)c * KM_CHUNK;
     if (p0 >= P) break;                                  // (uniform)
-    const int p1 = (int)min(P, p0 + KM_CHUNK);
-    int y = (int)(p0 / H), x = (int)(p0 - (long long)y * H);
+    const int n = (int)min((long long)KM_CHUNK, P - p0);
+    // ---- per-pixel parameters: lane j <-> pixel p0 + j ----
+    const long long pj = min(p0 + lane, P - 1);
+    const int yj = (int)(pj / H), xj = (int)(pj - (long long)yj * H);
+    const LerpTap ty = lerp_tap(yj, G, scale), tx = lerp_tap(xj, G, scale);
+    const int o00 = (ty.i0 * G + tx.i0) * C, o01 = (ty.i0 * G + tx.i1) * C, o10 = (ty.i1 * G + tx.i0) * C, o11 = (ty.i1 * G + tx.i1) * C;
+    const float rj = rv[pj];
+    const int kj = lab[pj];
     int kcur = -1;
     float acc = 0.f;
-    for (int p = (int)p0; p < p1; ++p) {
-      const int k = __builtin_amdgcn_readfirstlane(lab[p]);   // uniform: scalar compare / branch below
-      if (k != kcur) {                                    // park the running sum of the previous label, fetch this label's
-        if (act && kcur >= 0) tab[kcur * C + d] = acc;
-        if (act) acc = tab[k * C + d];
-        kcur = k;
+    for (int j0 = 0; j0 < n; j0 += PB) {
+      float val[PB];
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {                     // no branches here: all 4 * PB loads go out before the first is needed
+        const int j = min(j0 + u, n - 1);
+        const int a00 = __builtin_amdgcn_readlane(o00, j), a01 = __builtin_amdgcn_readlane(o01, j);
+        const int a10 = __builtin_amdgcn_readlane(o10, j), a11 = __builtin_amdgcn_readlane(o11, j);
+        const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), j));
+        const float wx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w1), j));
+        const float wy0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w0), j));
+        const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), j));
+        const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), j));
+        val[u] = __fmul_rn(bilerp_fixed(cb[a00 + dd], cb[a01 + dd], cb[a10 + dd], cb[a11 + dd], wx0, wx1, wy0, wy1), ri);
       }
-      if (act) {
-        const int y0 = tb.i0[y], y1 = tb.i1[y], x0 = tb.i0[x], x1 = tb.i1[x];
-        const float v = bilerp_fixed(cb[((size_t)y0 * G + x0) * C + d], cb[((size_t)y0 * G + x1) * C + d],
-                                     cb[((size_t)y1 * G + x0) * C + d], cb[((size_t)y1 * G + x1) * C + d], tb.w0[x], tb.w1[x],
-                                     tb.w0[y], tb.w1[y]);
-        acc = __fadd_rn(acc, __fmul_rn(v, rv[p]));
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        if (j0 + u < n) {                                // (uniform)
+          const int k = __builtin_amdgcn_readlane(kj, j0 + u);
+          if (k != kcur) {                               // park the running sum of the previous label, fetch this label's
+            if (act && kcur >= 0) tab[kcur * C + d] = acc;
+            if (act) acc = tab[k * C + d];
+            kcur = k;
+          }
+          acc = __fadd_rn(acc, val[u]);
+          if (d == 0) cn[k] += 1;
+        }
       }
-      if (d == 0) cn[k] += 1;
-      if (++x == H) { x = 0; ++y; }
     }
     if (act && kcur >= 0) tab[kcur * C + d] = acc;
     // fold the chunk into the group partial (ascending chunk order) and clear the chunk table: lane d owns column d
@@ -416,7 +441,7 @@ __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __rest
   for (int i = threadIdx.x; i < K; i += blockDim.x) pcnt[((size_t)b * ngroup + g) * K + i] = cn[i];
 }
 
-struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; int* i0; int* i1; float* w0; float* w1; size_t floats; };
+struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; size_t floats; };
 PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
   const size_t P = (size_t)H * H, ngroup = (P + (size_t)KM_SUPER * KM_CHUNK - 1) / ((size_t)KM_SUPER * KM_CHUNK);
   PixScratch s;
@@ -426,7 +451,6 @@ PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
   s.part = take((size_t)B * ngroup * K * C);
   s.pcnt = (int*)take((size_t)B * ngroup * K);
   s.rinv = take((size_t)B * P);
-  s.i0 = (int*)take(H); s.i1 = (int*)take(H); s.w0 = take(H); s.w1 = take(H);
   s.floats = off;
   return s;
 }
@@ -440,17 +464,15 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   const size_t shm_rows = (size_t)2 * G * C * sizeof(float);
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C>)) return rc;
-  hipLaunchKernelGGL(km_pix_tables_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, st, s.i0, s.i1, s.w0, s.w1, G, H);
   hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(H, B), dim3(256), shm_rows, st, code, s.rinv, G, H);
   hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K);
   WVN_LAUNCH_CHECK();
-  const PixTabs tb{s.i0, s.i1, s.w0, s.w1};
   for (int it = 0; it <= iters; ++it) {
     hipLaunchKernelGGL((km_pix_assign_kernel<C>), dim3(H, B), dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
     hipLaunchKernelGGL(km_pix_partial_kernel, dim3(ngroup, B), dim3(128), (size_t)(2 * K * C + K) * sizeof(float), st, code, s.rinv,
-                       labels, tb, s.part, s.pcnt, G, H, C, K, ngroup);
+                       labels, s.part, s.pcnt, G, H, C, K, ngroup);
     WVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1);
     WVN_LAUNCH_CHECK();

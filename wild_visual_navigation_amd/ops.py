@@ -252,8 +252,8 @@ def seg_adjacency(seg: torch.Tensor, n_seg: int) -> torch.Tensor:
     return edges[: int(count.item())]  # the edge count fixes the output shape: one host sync, as in the reference
 
 
-def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = True):
-    """code [B,P,C] fp32 (any row stride) -> (labels [B,P] int32, n_segments [B] int32)."""
+def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = True, return_centroids: bool = False):
+    """code [B,P,C] fp32 (any row stride) -> (labels [B,P] int32, n_segments [B] int32[, final centroids [B,K,C]])."""
     require_cuda(code, "code")
     B, P, Cc = code.shape
     if code.stride(2) != 1 or code.stride(0) != P * code.stride(1):
@@ -266,10 +266,13 @@ def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = T
     scratch = torch.empty(lib().wvn_kmeans_scratch_bytes(B, P, Cc, K), dtype=torch.uint8, device=dev)
     check(lib().wvn_kmeans_cosine(ptr(xn), ptr(labels), ptr(nseg), ptr(scratch), B, P, Cc, K, iters, int(relabel),
                                   stream()), "wvn_kmeans_cosine")
+    if return_centroids:   # (the centroids are the first B*K*C floats of the scratch area, include/wvn_hip.h)
+        return labels, nseg, scratch.view(torch.float32)[: B * K * Cc].reshape(B, K, Cc).clone()
     return labels, nseg
 
 
-def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int = 10, relabel: bool = True):
+def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int = 10, relabel: bool = True,
+                         return_centroids: bool = False):
     """code [B, G*G, C] fp32 patch codes -> (labels [B, H*H] int32, n_segments [B] int32): the k-means of ``kmeans_cosine`` over
     the H x H bilinearly up-sampled, normalised code pixels, interpolated on the fly (the [B, H*H, C] array is never built)."""
     require_cuda(code, "code")
@@ -283,6 +286,8 @@ def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int 
     scratch = torch.empty(lib().wvn_kmeans_pixels_scratch_bytes(B, G, H, Cc, K), dtype=torch.uint8, device=dev)
     check(lib().wvn_kmeans_cosine_pixels(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters, int(relabel),
                                          stream()), "wvn_kmeans_cosine_pixels")
+    if return_centroids:
+        return labels, nseg, scratch.view(torch.float32)[: B * K * Cc].reshape(B, K, Cc).clone()
     return labels, nseg
 
 
