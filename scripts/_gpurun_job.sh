@@ -1,6 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python scripts/debug_pixel_kmeans3.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/debug_pix3.log
-timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/gputest.log | tail -30
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log
-timeout 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-300
+timeout 900 python -m pytest tests/test_gpu_stego_pixels.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -3
+bash scripts/ab_lib.sh "b64 libwvn_hip.so" "b62 libwvn_hip.so --batch 62 --chunk 62" "b60 libwvn_hip.so --batch 60 --chunk 60" "b64_again libwvn_hip.so" 2>&1 | tee gpurun_out/ab_batch.log
+timeout 300 python bench.py --stego-reading upstream --no-cpu-baseline --steps 12 --warmup 3 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('upstream', d['value'], d['ms_per_step'])"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_up4 -o up -- python $GRAFT_REPO_ROOT/bench.py --stego-reading upstream --no-cpu-baseline --no-overlap --steps 4 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_up4.log 2>&1
+cd $GRAFT_REPO_ROOT; python scripts/summarize_profile.py db gpurun_out/prof_up4/up_results.db 2>&1 | head -12

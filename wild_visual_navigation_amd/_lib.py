@@ -11,7 +11,8 @@ import threading
 import torch  # noqa: F401  (must be imported first: its bundled libamdhip64.so.7 is the one HIP runtime of the process)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwvn_hip.so")
+# WVN_LIB_PATH: load another build of the same library (same-box A/B runs of compiler flags, scripts/ab_lib.sh); never a fallback
+LIB_PATH = os.environ.get("WVN_LIB_PATH") or os.path.join(_HERE, "lib", "libwvn_hip.so")
 
 WVN_MAX_DEPTH = 32
 PREC_F32, PREC_BF16, PREC_X3, PREC_FP8, PREC_F16 = 0, 1, 2, 3, 4

@@ -341,10 +341,16 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
         const int t = ks >> 1, h8 = (ks & 1) * 8;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const uint32_t pk = pack_op2(__builtin_amdgcn_exp2f(st[t][h8 + 2 * e]), __builtin_amdgcn_exp2f(st[t][h8 + 2 * e + 1]));
+          const float e0 = __builtin_amdgcn_exp2f(st[t][h8 + 2 * e]), e1 = __builtin_amdgcn_exp2f(st[t][h8 + 2 * e + 1]);
+          const uint32_t pk = pack_op2(e0, e1);
           pfu[ks][e] = pk;
-          if (e & 1) s1 = dot2_ones_op(pk, s1);
-          else s0 = dot2_ones_op(pk, s0);
+          if constexpr (SUM == 0) {   // row sums of the ROUNDED P: one v_dot2c per pair
+            if (e & 1) s1 = dot2_ones_op(pk, s1);
+            else s0 = dot2_ones_op(pk, s0);
+          } else {                    // plain fp32 adds on the unrounded P (this file is compiled with -fno-slp-vectorize: packed
+            s0 += e0;                 // v_pk_add_f32 beside MFMAs costs more than two scalar adds, MI355X_MICROARCH.md)
+            s1 += e1;
+          }
         }
       }
     };
@@ -463,6 +469,15 @@ void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16
   // 3 workgroups and 13.2 for 4 stages / 2); row sums by v_dot2c_f32_bf16 on the packed P (plain fp32 adds, which hipcc packs
   // into v_pk_add_f32, measured 12.0 ms per step against 11.7).  The same arithmetic with and without the XCD block order:
   // results must not depend on the batch size (tests/test_gpu_attention_xcd.py).
+  if (g_attn_variant == 2) {   // lazy max, row sums by scalar fp32 adds
+    if (xcd)
+      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+    else
+      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+    return;
+  }
   if (g_attn_variant == 1) {
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,

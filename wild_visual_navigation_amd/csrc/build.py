@@ -28,8 +28,9 @@ HEADERS = ["common.h", "operand.h", "wvn_internal.h", os.path.join("..", "..", "
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall",
          "-Wno-unused-function"]
 # bit-exact integer outputs need un-fused multiply/add in the k-means kernels (see stego.hip)
-EXTRA = {"stego.hip": ["-ffp-contract=off"], "supervision.hip": ["-ffp-contract=off"], "attention_bf16.hip": ["-fno-honor-nans"],
-         "attention_x3.hip": ["-fno-honor-nans"]}
+EXTRA = {"stego.hip": ["-ffp-contract=off"], "supervision.hip": ["-ffp-contract=off"],
+         "attention_bf16.hip": ["-fno-honor-nans"] + os.environ.get("WVN_ATTN_FLAGS", "").split(),
+         "attention_x3.hip": ["-fno-honor-nans"], "mlp_fused.hip": os.environ.get("WVN_MLP_FLAGS", "").split()}
 
 
 def _hipcc():

@@ -42,7 +42,19 @@ constexpr int B1_OFF = B2_OFF + KD * 4;               // 151,040
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 // the fc1 epilogue GELU of gemm_a384.hip (x * sigmoid(g(x)), g fitted to logit Phi(x): within 0.25 bf16 ulp of erf GELU)
+#ifndef WVN_GELU_SCALAR
+#define WVN_GELU_SCALAR 0   // 1: the same arithmetic on scalar VALU instructions (A/B of packed-f32 VALU beside MFMAs, scripts/ab_lib.sh)
+#endif
+__device__ inline float gelu_fast1(float x) {
+  const float x2 = x * x;
+  float t = x2 * -1.285982656e-05f + 1.435476415e-03f;
+  t = t * x2 + -1.096917929e-01f;
+  t = t * x2 + -2.296416554e+00f;
+  const float e = __builtin_amdgcn_exp2f(t * x) + 1.f;
+  return x * __builtin_amdgcn_rcpf(e);
+}
 __device__ inline f32x2_t gelu_fast2(f32x2_t x) {
+  if constexpr (WVN_GELU_SCALAR != 0) return f32x2_t{gelu_fast1(x[0]), gelu_fast1(x[1])};
   const f32x2_t k3 = {-1.285982656e-05f, -1.285982656e-05f}, k2 = {1.435476415e-03f, 1.435476415e-03f},
                 k1 = {-1.096917929e-01f, -1.096917929e-01f}, k0 = {-2.296416554e+00f, -2.296416554e+00f}, one = {1.f, 1.f};
   const f32x2_t x2 = x * x;
@@ -501,7 +513,7 @@ static int mlp_fused_launch_impl(const op16_t* xn, int lda, const float* ln_g, c
   const dim3 grid(nrb < ncu ? nrb : ncu);
   p.dbg = WVN_OPSYM(g_mlp_fused_dbg);
   if (proj) hipLaunchKernelGGL((mlp_fused_kernel<true, false, true>), grid, dim3(256), lds, st, p);
-  else if (lnf && g_mlp_fused_dbg) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
+  else if (lnf && WVN_OPSYM(g_mlp_fused_dbg)) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
   else if (lnf) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();

@@ -249,11 +249,11 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
 //   rinv    : lane = pixel; the block's two source code rows in LDS
 //   assign  : lane = pixel, x[C] in registers, centroids through the scalar cache (uniform addresses), four independent
 //             dot-product chains in flight
-//   partial : one 128-lane workgroup per group of KM_SUPER chunks, lane = channel; the values of 16 pixels are fetched and
-//             interpolated together, then added in pixel order; a cluster's running sum of the current chunk stays in a
-//             register while consecutive pixels carry the same label (the usual case) and is parked in LDS when the label
-//             changes -- the addition order is exactly the sequential one.
+//   partial : one 128-lane workgroup per group of KM_SUPER chunks, lane = channel; the four code values of a pixel's cell stay
+//             in registers while consecutive pixels share it (the next cell's are prefetched); running sums in an LDS table
+//             indexed by the uniform label -- the addition order is exactly the sequential one.
 // ---------------------------------------------------------------------------------------------------------------------------
+constexpr int PIX_RPB = 4;   // image rows per workgroup of the lane-per-pixel kernels (the two staged code rows serve P of them)
 // stage code rows y0 / y1 of frame b ([G][C] each) into LDS: rows[0][G*C], rows[1][G*C]
 __device__ inline void pix_stage_rows(const float* __restrict__ code, int b, int G, int C, int y0, int y1, float* rows) {
   const int n = G * C;   // contiguous in memory
@@ -276,19 +276,26 @@ __device__ inline void pix_row(const float* rows, int G, const LerpTap& tx, cons
 template <int C>
 __global__ __launch_bounds__(256) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H) {
   extern __shared__ float rows[];  // [2][G][C]
-  const int y = blockIdx.x, b = blockIdx.y;
+  const int b = blockIdx.y;
   const float scale = lerp_scale(G, H);
-  const LerpTap ty = lerp_tap(y, G, scale);
-  pix_stage_rows(code, b, G, C, ty.i0, ty.i1, rows);
-  __syncthreads();
-  for (int x = threadIdx.x; x < H; x += blockDim.x) {
-    const LerpTap tx = lerp_tap(x, G, scale);
-    float v[C];
-    pix_row<C>(rows, G, tx, ty, v);
-    float n2 = 0.f;
+  int s0 = -1, s1 = -1;            // the code rows staged in LDS
+  for (int y = blockIdx.x * PIX_RPB; y < min(H, (blockIdx.x + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
+    const LerpTap ty = lerp_tap(y, G, scale);
+    if (ty.i0 != s0 || ty.i1 != s1) {
+      __syncthreads();
+      pix_stage_rows(code, b, G, C, ty.i0, ty.i1, rows);
+      __syncthreads();
+      s0 = ty.i0; s1 = ty.i1;
+    }
+    for (int x = threadIdx.x; x < H; x += blockDim.x) {
+      const LerpTap tx = lerp_tap(x, G, scale);
+      float v[C];
+      pix_row<C>(rows, G, tx, ty, v);
+      float n2 = 0.f;
 #pragma unroll
-    for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(v[d], v[d]));
-    rinv[(size_t)b * H * H + (size_t)y * H + x] = rinv_norm(n2);
+      for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(v[d], v[d]));
+      rinv[(size_t)b * H * H + (size_t)y * H + x] = rinv_norm(n2);
+    }
   }
 }
 
@@ -316,12 +323,18 @@ __global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restr
                                                             const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
                                                             int K) {
   extern __shared__ float rows[];  // [2][G][C]
-  const int y = blockIdx.x, b = blockIdx.y;
+  const int b = blockIdx.y;
   const float scale = lerp_scale(G, H);
-  const LerpTap ty = lerp_tap(y, G, scale);
-  pix_stage_rows(code, b, G, C, ty.i0, ty.i1, rows);
-  __syncthreads();
   const float* __restrict__ cb = cent + (size_t)b * K * C;   // uniform addresses: served by the scalar cache
+  int s0 = -1, s1 = -1;            // the code rows staged in LDS
+  for (int y = blockIdx.x * PIX_RPB; y < min(H, (blockIdx.x + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
+  const LerpTap ty = lerp_tap(y, G, scale);
+  if (ty.i0 != s0 || ty.i1 != s1) {
+    __syncthreads();
+    pix_stage_rows(code, b, G, C, ty.i0, ty.i1, rows);
+    __syncthreads();
+    s0 = ty.i0; s1 = ty.i1;
+  }
   for (int x = threadIdx.x; x < H; x += blockDim.x) {
     const LerpTap tx = lerp_tap(x, G, scale);
     const size_t p = (size_t)b * H * H + (size_t)y * H + x;
@@ -357,27 +370,29 @@ __global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restr
     }
     labels[p] = best;
   }
+  }
 }
 
 // part[b][group][k][d] = the group's partial (chunk partials added in ascending chunk order), pcnt[b][group][k] = member count
 //
-// Lane = channel (two waves cover C <= 128).  The additions of a (cluster, channel) pair are a dependent chain in pixel order, but
-// the VALUES are not: per batch of PB pixels the wave first fetches and interpolates all PB values (4 * PB independent coalesced
-// loads in flight -- one pixel at a time the kernel was a chain of three memory round trips per pixel, 4.5 ms per launch), then
-// walks the batch in order.  Per-pixel parameters (tap offsets and weights, label, reciprocal norm) are computed ONCE per chunk,
-// pixel j by lane j, and handed to all lanes through v_readlane.
-constexpr int PB = 16;
+// Lane = channel (two waves cover C <= 128).  Consecutive pixels of an image row share their four source patches for about P
+// pixels (8.1 at 448 / 56): the chunk is walked cell by cell -- a cell = a run of pixels with the same four taps -- with the NEXT
+// cell's four code values already on their way while the current cell's pixels are added (half a load per pixel, none of them
+// waited for; fetching the taps of every pixel made the kernel L1-throughput-bound, 2.1 ms per launch; one pixel at a time with
+// dependent scalar loads it was a chain of three memory round trips per pixel, 4.5 ms).  Per-pixel parameters (tap offsets and
+// weights, label, reciprocal norm) are computed ONCE per chunk, pixel j by lane j, and handed to all lanes through v_readlane.
+// A cluster's running sum of the current chunk stays in a register while consecutive pixels carry the same label (the usual
+// case: a dependent chain of one v_add per pixel) and is parked in the LDS table tab[k][d] when the label changes -- the addition
+// order per (cluster, channel) is exactly the pixel order; member counts come from ballots.
 __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                              const int* __restrict__ labels, float* __restrict__ part,
                                                              int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup) {
-  extern __shared__ float lds[];   // tab[K][C] (current chunk), grp[K][C] (group so far), cnt[K]
+  extern __shared__ float lds[];   // tab[K][C] (current chunk), grp[K][C] (group so far)
   float* tab = lds;
   float* grp = lds + K * C;
-  int* cn = (int*)(grp + K * C);
   const int g = blockIdx.x, b = blockIdx.y, d = threadIdx.x, lane = threadIdx.x & 63;
   const long long P = (long long)H * H;
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) { tab[i] = 0.f; grp[i] = 0.f; }
-  for (int i = threadIdx.x; i < K; i += blockDim.x) cn[i] = 0;
   __syncthreads();
   const float* __restrict__ cb = code + (size_t)b * G * G * C;
   const int* __restrict__ lab = labels + (size_t)b * P;
@@ -386,10 +401,12 @@ __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __rest
   const float scale = lerp_scale(G, H);
   const bool act = d < C;
   const int dd = act ? d : 0;   // (inactive lanes of the second wave read channel 0 and drop the result)
+  int mycnt = 0;                // wave 0, lane k: members of cluster k in this group
   for (int c = 0; c < KM_SUPER; ++c) {
     const long long p0 = g0 + (long long)c * KM_CHUNK;
     if (p0 >= P) break;                                  // (uniform)
     const int n = (int)min((long long)KM_CHUNK, P - p0);
+    const unsigned long long valid = n == 64 ? ~0ull : ((1ull << n) - 1);
     // ---- per-pixel parameters: lane j <-> pixel p0 + j ----
     const long long pj = min(p0 + lane, P - 1);
     const int yj = (int)(pj / H), xj = (int)(pj - (long long)yj * H);
@@ -397,35 +414,43 @@ __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __rest
     const int o00 = (ty.i0 * G + tx.i0) * C, o01 = (ty.i0 * G + tx.i1) * C, o10 = (ty.i1 * G + tx.i0) * C, o11 = (ty.i1 * G + tx.i1) * C;
     const float rj = rv[pj];
     const int kj = lab[pj];
-    int kcur = -1;
+    if (threadIdx.x < 64)
+      for (int k = 0; k < K; ++k) {                      // (uniform loop) member counts by ballot
+        const int m = __builtin_popcountll(__ballot(kj == k) & valid);
+        if (lane == k) mycnt += m;
+      }
+    // ---- cells ----
+    int j = 0;
+    float n00 = cb[__builtin_amdgcn_readlane(o00, 0) + dd], n01 = cb[__builtin_amdgcn_readlane(o01, 0) + dd];
+    float n10 = cb[__builtin_amdgcn_readlane(o10, 0) + dd], n11 = cb[__builtin_amdgcn_readlane(o11, 0) + dd];
+    int kcur = -1;     // the cluster whose running sum of this chunk is in `acc` (the others are parked in tab)
     float acc = 0.f;
-    for (int j0 = 0; j0 < n; j0 += PB) {
-      float val[PB];
-#pragma unroll
-      for (int u = 0; u < PB; ++u) {                     // no branches here: all 4 * PB loads go out before the first is needed
-        const int j = min(j0 + u, n - 1);
-        const int a00 = __builtin_amdgcn_readlane(o00, j), a01 = __builtin_amdgcn_readlane(o01, j);
-        const int a10 = __builtin_amdgcn_readlane(o10, j), a11 = __builtin_amdgcn_readlane(o11, j);
-        const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), j));
-        const float wx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w1), j));
-        const float wy0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w0), j));
-        const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), j));
-        const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), j));
-        val[u] = __fmul_rn(bilerp_fixed(cb[a00 + dd], cb[a01 + dd], cb[a10 + dd], cb[a11 + dd], wx0, wx1, wy0, wy1), ri);
+    while (j < n) {                                      // (uniform)
+      const float v00 = n00, v01 = n01, v10 = n10, v11 = n11;
+      const int a00 = __builtin_amdgcn_readlane(o00, j), a10 = __builtin_amdgcn_readlane(o10, j);
+      const unsigned long long same = __ballot(o00 == a00 && o10 == a10) & valid;
+      const unsigned long long rest = ~same & valid & ~((2ull << j) - 1);   // pixels after j that are not in j's cell
+      const int jend = rest ? __builtin_ctzll(rest) : n;                    // cells are contiguous runs along x
+      if (jend < n) {                                    // the next cell's values: in flight during this cell's additions
+        n00 = cb[__builtin_amdgcn_readlane(o00, jend) + dd]; n01 = cb[__builtin_amdgcn_readlane(o01, jend) + dd];
+        n10 = cb[__builtin_amdgcn_readlane(o10, jend) + dd]; n11 = cb[__builtin_amdgcn_readlane(o11, jend) + dd];
       }
-#pragma unroll
-      for (int u = 0; u < PB; ++u) {
-        if (j0 + u < n) {                                // (uniform)
-          const int k = __builtin_amdgcn_readlane(kj, j0 + u);
-          if (k != kcur) {                               // park the running sum of the previous label, fetch this label's
-            if (act && kcur >= 0) tab[kcur * C + d] = acc;
-            if (act) acc = tab[k * C + d];
-            kcur = k;
-          }
-          acc = __fadd_rn(acc, val[u]);
-          if (d == 0) cn[k] += 1;
+      for (int jj = j; jj < jend; ++jj) {
+        const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), jj));
+        const float wx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w1), jj));
+        const float wy0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w0), jj));
+        const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), jj));
+        const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), jj));
+        const int k = __builtin_amdgcn_readlane(kj, jj);
+        const float val = __fmul_rn(bilerp_fixed(v00, v01, v10, v11, wx0, wx1, wy0, wy1), ri);
+        if (k != kcur) {                                 // (uniform, rare: labels are spatially coherent) park / fetch
+          if (act && kcur >= 0) tab[kcur * C + d] = acc;
+          if (act) acc = tab[k * C + d];
+          kcur = k;
         }
+        acc = __fadd_rn(acc, val);
       }
+      j = jend;
     }
     if (act && kcur >= 0) tab[kcur * C + d] = acc;
     // fold the chunk into the group partial (ascending chunk order) and clear the chunk table: lane d owns column d
@@ -438,7 +463,7 @@ __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __rest
   __syncthreads();
   float* dst = part + ((size_t)b * ngroup + g) * K * C;
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) dst[i] = grp[i];
-  for (int i = threadIdx.x; i < K; i += blockDim.x) pcnt[((size_t)b * ngroup + g) * K + i] = cn[i];
+  if (threadIdx.x < K) pcnt[((size_t)b * ngroup + g) * K + threadIdx.x] = mycnt;
 }
 
 struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; size_t floats; };
@@ -464,14 +489,14 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   const size_t shm_rows = (size_t)2 * G * C * sizeof(float);
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C>)) return rc;
-  hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(H, B), dim3(256), shm_rows, st, code, s.rinv, G, H);
+  hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(256), shm_rows, st, code, s.rinv, G, H);
   hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K);
   WVN_LAUNCH_CHECK();
   for (int it = 0; it <= iters; ++it) {
-    hipLaunchKernelGGL((km_pix_assign_kernel<C>), dim3(H, B), dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
+    hipLaunchKernelGGL((km_pix_assign_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
-    hipLaunchKernelGGL(km_pix_partial_kernel, dim3(ngroup, B), dim3(128), (size_t)(2 * K * C + K) * sizeof(float), st, code, s.rinv,
+    hipLaunchKernelGGL(km_pix_partial_kernel, dim3(ngroup, B), dim3(128), (size_t)(2 * K * C) * sizeof(float), st, code, s.rinv,
                        labels, s.part, s.pcnt, G, H, C, K, ngroup);
     WVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1);
