@@ -374,12 +374,19 @@ int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* gra
  * the batch from nodes that all exist; a batched extractor has to drop the ids a frame did not produce). */
 int wvn_compact_segment_rows(const float* feat, int D, const float* side, int Dside, const int* nseg, int B, int S, float* x_out,
                              float* side_out, int* rows_dev, void* stream);
+/* sync_word (phase A) != NULL and fused (phase B) != 0 select the FOUR-LAUNCH step for the SimpleMLP geometry (H1 = 256, H2 = 32, R <=
+ * 8192; csrc/mlp_train.hip): phase A = one launch (all three layers, row losses, statistic -- the last row tile to arrive folds the
+ * per-tile partials in tile order; sync_word: a device word that is ZERO on first use and is left at zero), phase B = two launches
+ * (gradient seed + dL/dh2 + dL/dh1; the three weight / bias gradients and the loss sums), phase C = one launch (Adam + losses)
+ * against 17-20 launches of the general path.  Both phases of a step must take the same path and the same workspace; other
+ * geometries fall back to the general path whatever the flags say.  Fixed summation orders: bit-reproducible. */
 int wvn_mlp_train_phase_a_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const unsigned char* y_valid,
-                               int R, const int* rows_dev, double* stats, void* workspace, size_t workspace_bytes, void* stream);
+                               int R, const int* rows_dev, double* stats, void* workspace, size_t workspace_bytes,
+                               unsigned int* sync_word, void* stream);
 int wvn_mlp_train_phase_b_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
                                const unsigned char* y_valid, int R, const int* rows_dev, const double* stats, float std_factor,
                                float w_trav, float w_reco, float* grads, float* confidence_out, void* workspace,
-                               size_t workspace_bytes, void* stream);
+                               size_t workspace_bytes, int fused, void* stream);
 /* quick_start.py:194-210 / loss.py:162-164: trav[r] = out[r][0], conf[r] = confidence(mse(out[r][1:], x[r])) */
 int wvn_mlp_confidence(const float* out, int ldo, const float* x, int ldx, float mean, float std, float std_factor,
                        float* trav, float* conf, int R, int D, void* stream);

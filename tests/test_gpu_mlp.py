@@ -32,12 +32,14 @@ def test_forward_matches_reference(dev, golden, case):
     assert list(m.state_dict()) == list(c["sd0"])
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("case", ["graph_pt_D90", "synthetic_D384"])
-def test_ten_adam_steps_match_reference_trajectory(dev, golden, case):
+def test_ten_adam_steps_match_reference_trajectory(dev, golden, case, fused):
+    """fused: the four-launch step of csrc/mlp_train.hip (what the trainer runs at these sizes); not fused: the general path."""
     c = golden("mlp_train.pt")[case]
     x, y, yv = c["x"].to(dev), c["y"].to(dev), c["y_valid"].to(dev)
     m = _model(c["sd0"], x.shape[1], dev)
-    tr = MlpTrainer(m, lr=1e-3, std_factor=0.5, w_trav=0.03, w_reco=0.5)
+    tr = MlpTrainer(m, lr=1e-3, std_factor=0.5, w_trav=0.03, w_reco=0.5, fused=fused)
     traj = []
     for step in range(10):
         losses = tr.train_step(x, y, yv, want_confidence=(step == 0))
@@ -69,6 +71,65 @@ def test_large_batch_step_matches_oracle(dev):
     assert abs(got[3].item() - want["mean"]) < 2e-6 and abs(got[4].item() - want["std"]) < 2e-6
     for k in st.sd:
         assert torch.allclose(m.state_dict()[k].cpu(), st.sd[k], atol=2e-5), k
+
+
+@pytest.mark.parametrize("R,D", [(1280, 90), (1280, 384), (77, 384), (800, 91), (33, 90)])
+def test_four_launch_step_equals_general_path_and_oracle(dev, R, D):
+    """The bench / live-node sizes through both paths and the CPU oracle (three steps), ragged last row tile, odd D; then a
+    compacted batch whose row count lives on the device (rows_dev): both paths ignore the rows behind it; and bit-reproducible."""
+    g = torch.Generator().manual_seed(R + D)
+    x = torch.randn(R, D, generator=g)
+    yv = torch.rand(R, generator=g) < 0.16
+    yv[:2] = True
+    y = yv.float() * (0.5 + 0.5 * torch.rand(R, generator=g))
+    sd0 = OM.make_mlp_state_dict(D, seed=42)
+    ma, mb = _model(sd0, D, dev), _model(sd0, D, dev)
+    ta, tb = MlpTrainer(ma, fused=True), MlpTrainer(mb, fused=False)
+    st = OM.TrainState(sd0)
+    for _ in range(3):
+        la = ta.train_step(x.to(dev), y.to(dev), yv.to(dev), want_confidence=True).cpu()
+        lb = tb.train_step(x.to(dev), y.to(dev), yv.to(dev), want_confidence=True).cpu()
+        want = OM.train_step(st, x, y, yv)
+        assert torch.allclose(ta.last_confidence, tb.last_confidence, atol=1e-5)
+    assert torch.allclose(la, lb, rtol=1e-5, atol=2e-6), (la, lb)
+    assert abs(la[0].item() - want["loss_total"]) < 2e-6 and abs(la[2].item() - want["loss_reco"]) < 2e-6
+    for k in st.sd:
+        assert torch.allclose(ma.state_dict()[k].cpu(), st.sd[k], atol=2e-5), k
+        assert torch.allclose(ma.state_dict()[k], mb.state_dict()[k], atol=1e-5), k
+    assert int(ta.sync_word.item()) == 0                                      # the arrival counter is back at zero
+    # rows_dev: the first n rows are real, garbage behind them
+    n = R - R // 3
+    rows_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    xg = x.clone()
+    xg[n:] = 1e6
+    mc, md, me = _model(sd0, D, dev), _model(sd0, D, dev), _model(sd0, D, dev)
+    lc = MlpTrainer(mc, fused=True).train_step(xg.to(dev), y.to(dev), yv.to(dev), rows_dev=rows_dev).cpu()
+    ld = MlpTrainer(md, fused=True).train_step(x[:n].to(dev), y[:n].to(dev), yv[:n].to(dev)).cpu()
+    le = MlpTrainer(me, fused=False).train_step(xg.to(dev), y.to(dev), yv.to(dev), rows_dev=rows_dev).cpu()
+    assert torch.equal(lc, ld)                                                # the fused path walks the same tiles: identical bits
+    assert torch.allclose(lc, le, rtol=1e-5, atol=2e-6)
+    for k in st.sd:
+        assert torch.equal(mc.state_dict()[k], md.state_dict()[k]), k
+        assert torch.allclose(mc.state_dict()[k], me.state_dict()[k], atol=1e-5), k
+    mf = _model(sd0, D, dev)
+    lf = MlpTrainer(mf, fused=True).train_step(xg.to(dev), y.to(dev), yv.to(dev), rows_dev=rows_dev).cpu()
+    assert torch.equal(lc, lf) and all(torch.equal(mc.state_dict()[k], mf.state_dict()[k]) for k in st.sd)
+
+
+def test_compact_segment_rows(dev):
+    """ops.compact_segment_rows: rows (b, s < nseg[b]) front to back, zeros behind, count on the device."""
+    B, S, D = 5, 7, 12
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(B, S, D, generator=g)
+    side = torch.rand(B, S, 2, generator=g)
+    nseg = torch.tensor([7, 0, 3, 5, 1], dtype=torch.int32)
+    feat[1] = float("nan")
+    x, so, cnt = ops.compact_segment_rows(feat.to(dev), nseg.to(dev), side.to(dev))
+    keep = (torch.arange(S)[None] < nseg[:, None]).reshape(-1)
+    n = int(keep.sum())
+    assert int(cnt.item()) == n == 16
+    assert torch.equal(x[:n].cpu(), feat.reshape(B * S, D)[keep]) and torch.equal(so[:n].cpu(), side.reshape(B * S, 2)[keep])
+    assert (x[n:] == 0).all() and (so[n:] == 0).all()
 
 
 def test_single_labelled_row_gives_nan_std_like_reference(dev):

@@ -119,8 +119,8 @@ _SIGNATURES = {
     "wvn_mlp_train_phase_a": ([_p, _p, _p, _i, _p, _i, _p, _p, _sz, _p], _i),
     "wvn_mlp_train_phase_b": ([_p, _p, _p, _i, _p, _p, _i, _p, _f, _f, _f, _p, _p, _p, _sz, _p], _i),
     "wvn_compact_segment_rows": ([_p, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p], _i),
-    "wvn_mlp_train_phase_a_rows": ([_p, _p, _p, _i, _p, _i, _p, _p, _p, _sz, _p], _i),
-    "wvn_mlp_train_phase_b_rows": ([_p, _p, _p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _p, _p, _p, _sz, _p], _i),
+    "wvn_mlp_train_phase_a_rows": ([_p, _p, _p, _i, _p, _i, _p, _p, _p, _sz, _p, _p], _i),
+    "wvn_mlp_train_phase_b_rows": ([_p, _p, _p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _p, _p, _p, _sz, _i, _p], _i),
     "wvn_mlp_train_phase_c": ([_p, _p, _p, _p, _p, _i, _f, _p, _f, _f, _p, _p], _i),
     "wvn_mlp_confidence": ([_p, _i, _p, _i, _f, _f, _f, _p, _p, _i, _i, _p], _i),
     "wvn_pixel_mlp_pack_bytes": ([_p], _sz),

@@ -604,7 +604,7 @@ MlpOff mlp_off(const wvn_mlp_desc* d) {
   return o;
 }
 int mlp_splitk(int R) { int s = (R + 511) / 512; return s < 1 ? 1 : (s > 32 ? 32 : s); }
-struct MlpWs { float *h1, *h2, *out, *lr, *g_out, *g_h2, *g_h1, *trav_w, *trav_raw, *part; size_t total; };
+struct MlpWs { float *h1, *h2, *out, *lr, *g_out, *g_h2, *g_h1, *trav_w, *trav_raw, *part; void* fused; size_t total; };
 MlpWs mlp_carve(const wvn_mlp_desc* d, int R, void* base) {
   MlpWs w;
   size_t off = 0;
@@ -617,6 +617,7 @@ MlpWs mlp_carve(const wvn_mlp_desc* d, int R, void* base) {
   if ((size_t)d->H2 * d->H1 > mx) mx = (size_t)d->H2 * d->H1;
   if ((size_t)O * d->H2 > mx) mx = (size_t)O * d->H2;
   w.part = take(mx * mlp_splitk(R));
+  w.fused = take(wvn_mlp_train_fused_scratch_bytes(R) / sizeof(float) + 1);   // per-tile partials of the four-launch step
   w.total = off;
   return w;
 }
@@ -672,18 +673,24 @@ int wvn_compact_segment_rows(const float* feat, int D, const float* side, int Ds
 
 int wvn_mlp_train_phase_a_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx,
                                const unsigned char* y_valid, int R, const int* rows_dev, double* stats, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, unsigned int* sync_word, void* stream) {
   if (!d || !params || !x || !y_valid || !stats || !workspace || R <= 0) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   MlpWs w = mlp_carve(d, R, workspace);
   if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
+  if (sync_word && wvn_mlp_train_fused_ok(d->D, d->H1, d->H2, R)) {   // the four-launch step (mlp_train.hip): forward + statistic
+    const MlpOff o = mlp_off(d);
+    const size_t off[6] = {o.W1, o.b1, o.W2, o.b2, o.W3, o.b3};
+    return wvn_mlp_train_fwd_launch(params, off, o.total, x, ldx, y_valid, R, d->D, rows_dev, w.h1, w.h2, w.out, w.lr, stats, w.fused,
+                                    sync_word, st);
+  }
   RET_IF(mlp_fwd(d, params, x, ldx, R, w.out, w.h1, w.h2, st));
   return wvn_mlp_rowloss_stats_launch(w.out, 1 + d->D, x, ldx, y_valid, w.lr, stats, R, d->D, st, rows_dev);
 }
 int wvn_mlp_train_phase_a(const wvn_mlp_desc* d, const float* params, const float* x, int ldx,
                           const unsigned char* y_valid, int R, double* stats, void* workspace, size_t workspace_bytes,
                           void* stream) {
-  return wvn_mlp_train_phase_a_rows(d, params, x, ldx, y_valid, R, nullptr, stats, workspace, workspace_bytes, stream);
+  return wvn_mlp_train_phase_a_rows(d, params, x, ldx, y_valid, R, nullptr, stats, workspace, workspace_bytes, nullptr, stream);
 }
 
 int wvn_mlp_train_phase_b(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
@@ -691,19 +698,24 @@ int wvn_mlp_train_phase_b(const wvn_mlp_desc* d, const float* params, const floa
                           float w_reco, float* grads, float* confidence_out, void* workspace, size_t workspace_bytes,
                           void* stream) {
   return wvn_mlp_train_phase_b_rows(d, params, x, ldx, y, y_valid, R, nullptr, stats, std_factor, w_trav, w_reco, grads,
-                                    confidence_out, workspace, workspace_bytes, stream);
+                                    confidence_out, workspace, workspace_bytes, 0, stream);
 }
 
 int wvn_mlp_train_phase_b_rows(const wvn_mlp_desc* d, const float* params, const float* x, int ldx, const float* y,
                                const unsigned char* y_valid, int R, const int* rows_dev, const double* stats, float std_factor,
                                float w_trav, float w_reco, float* grads, float* confidence_out, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, int fused, void* stream) {
   if (!d || !params || !x || !y || !y_valid || !stats || !grads || !workspace || R <= 0) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   MlpWs w = mlp_carve(d, R, workspace);
   if (w.total > workspace_bytes) return WVN_ERR_WORKSPACE;
   const MlpOff o = mlp_off(d);
   const int O = o.O;
+  if (fused && wvn_mlp_train_fused_ok(d->D, d->H1, d->H2, R)) {   // (phase A of this step ran the fused forward on this workspace)
+    const size_t off[6] = {o.W1, o.b1, o.W2, o.b2, o.W3, o.b3};
+    return wvn_mlp_train_bwd_launch(params, off, o.total, x, ldx, y, y_valid, R, d->D, rows_dev, w.h1, w.h2, w.out, w.lr, w.g_out, w.g_h2,
+                                    w.g_h1, stats, std_factor, w_trav, w_reco, confidence_out, grads, w.fused, st);
+  }
   RET_IF(wvn_mlp_gradout_launch(w.out, O, x, ldx, y, y_valid, w.lr, stats, std_factor, w_trav, w_reco, w.g_out, O,
                                 w.trav_w, w.trav_raw, confidence_out, grads + o.total, R, d->D, st, rows_dev));
   // layer 3
@@ -736,9 +748,9 @@ int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* gra
   if (!d || !params || !grads || !adam_m || !adam_v || !stats || step <= 0) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const MlpOff o = mlp_off(d);
-  RET_IF(wvn_adam_launch(params, grads, adam_m, adam_v, (int)o.total, step, lr, 0.9f, 0.999f, 1e-8f, st));
-  if (losses) RET_IF(wvn_mlp_losses_launch(stats, grads + o.total, w_trav, w_reco, losses, st));
-  return WVN_OK;
+  // Adam and the step's losses in ONE launch
+  return wvn_adam_launch(params, grads, adam_m, adam_v, (int)o.total, step, lr, 0.9f, 0.999f, 1e-8f, st, stats, grads + o.total, w_trav,
+                         w_reco, losses);
 }
 
 // fused per-pixel inference (pixel_mlp.hip)

@@ -6,6 +6,7 @@
 // All cross-row reductions have a fixed order (single-workgroup trees, fp64 accumulators for the
 // confidence statistic) so that a 1-GPU and an N-GPU run see bit-identical local contributions.
 #include "common.h"
+#include "mlp_device.h"
 #include "wvn_internal.h"
 
 namespace {
@@ -49,27 +50,6 @@ __global__ __launch_bounds__(1024) void mlp_stats_kernel(const float* __restrict
     for (int i = 0; i < 16; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; }
     stats[0] = a; stats[1] = b; stats[2] = c; stats[3] = (double)R;
   }
-}
-
-struct ConfStats { float mean, std; };
-__device__ inline ConfStats conf_stats(const double* st) {
-  const double n = st[0];
-  const double mean = st[1] / n;
-  const double var = (st[2] - st[1] * st[1] / n) / (n - 1.0);  // unbiased (torch.std); NaN for n < 2
-  ConfStats c;
-  c.mean = (float)mean;
-  c.std = (float)sqrt(var > 0.0 || !(var == var) ? var : 0.0);
-  return c;
-}
-// confidence_generator.py:182-193
-__device__ inline float confidence_of(float x, float mean, float std, float f) {
-  const float shifted = mean + std * f;
-  float lo = shifted - std;
-  lo = (lo > 0.f || isnan(lo)) ? lo : 0.f;  // python max(lo, 0): NaN stays NaN
-  const float hi = shifted + std;
-  float xc = fminf(fmaxf(x, lo), hi);
-  if (isnan(lo) || isnan(hi)) xc = NAN;
-  return 1.f - (xc - lo) / (hi - lo);
 }
 
 // gradient seed wrt the pre-sigmoid / linear outputs + per-row loss terms.  One wave per row.
@@ -155,10 +135,25 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 }
 
 // torch.optim.Adam single-tensor update (no amsgrad / weight decay / maximize)
+__device__ inline void write_losses(const double* __restrict__ stats, const float* __restrict__ extra, float w_trav, float w_reco,
+                                    float* __restrict__ losses) {
+  const ConfStats cs = conf_stats(stats);
+  const float Rtot = (float)stats[3];
+  const float reco = (float)(stats[1] / stats[0]);
+  const float trav_conf = extra[0] / Rtot;
+  losses[0] = w_trav * trav_conf + w_reco * reco;
+  losses[1] = extra[1] / Rtot;
+  losses[2] = reco;
+  losses[3] = cs.mean;
+  losses[4] = cs.std;
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt) {
+                            float bc2_sqrt, const double* __restrict__ stats, const float* __restrict__ extra, float w_trav,
+                            float w_reco, float* __restrict__ losses) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (losses && i == 0) write_losses(stats, extra, w_trav, w_reco, losses);   // (the step's losses ride along: one launch fewer)
   if (i >= n) return;
   const float gi = g[i];
   const float mi = m[i] * b1 + (1.f - b1) * gi;
@@ -173,15 +168,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 __global__ void mlp_losses_kernel(const double* __restrict__ stats, const float* __restrict__ extra, float w_trav,
                                   float w_reco, float* __restrict__ losses) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const ConfStats cs = conf_stats(stats);
-  const float Rtot = (float)stats[3];
-  const float reco = (float)(stats[1] / stats[0]);
-  const float trav_conf = extra[0] / Rtot;
-  losses[0] = w_trav * trav_conf + w_reco * reco;
-  losses[1] = extra[1] / Rtot;
-  losses[2] = reco;
-  losses[3] = cs.mean;
-  losses[4] = cs.std;
+  write_losses(stats, extra, w_trav, w_reco, losses);
 }
 
 // per-row reconstruction confidence for inference (quick_start.py:207-210, loss.py:162-164)
@@ -269,10 +256,11 @@ int wvn_colsum_launch(const float* A, int lda, int R, int N, float* outv, hipStr
 }
 
 int wvn_adam_launch(float* p, const float* g, float* m, float* v, int n, int step, float lr, float b1, float b2,
-                    float eps, hipStream_t st) {
+                    float eps, hipStream_t st, const double* stats, const float* extra, float w_trav, float w_reco, float* losses) {
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
-  hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2s);
+  hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2s, stats, extra,
+                     w_trav, w_reco, losses);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

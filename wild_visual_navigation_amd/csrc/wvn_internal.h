@@ -179,13 +179,26 @@ int wvn_mlp_rowloss_stats_launch(const float* out, int ldo, const float* x, int 
                                  float* lr, double* stats, int R, int D, hipStream_t st, const int* rows_dev = nullptr);
 int wvn_compact_segment_rows_launch(const float* feat, int D, const float* side, int Ds, const int* nseg, int B, int S, float* x,
                                     float* side_out, int* count, hipStream_t st);
+// mlp_train.hip: the four-launch optimisation step (fwd | bwd + wgrad | adam).  off: {W1, b1, W2, b2, W3, b3} offsets into the flat
+// parameter / gradient vectors; scratch: wvn_mlp_train_fused_scratch_bytes(R); sync_word: a zero device word, left at zero
+bool wvn_mlp_train_fused_ok(int D, int H1, int H2, int R);
+size_t wvn_mlp_train_fused_scratch_bytes(int R);
+int wvn_mlp_train_fwd_launch(const float* P, const size_t* off, size_t ntotal, const float* x, int ldx, const unsigned char* valid, int R,
+                             int D, const int* rows_dev, float* h1, float* h2, float* out, float* lr, double* stats, void* scratch,
+                             unsigned* sync_word, hipStream_t st);
+int wvn_mlp_train_bwd_launch(const float* P, const size_t* off, size_t ntotal, const float* x, int ldx, const float* y,
+                             const unsigned char* valid, int R, int D, const int* rows_dev, float* h1, float* h2, float* out, float* lr,
+                             float* g_out, float* g_h2, float* g_h1, const double* stats, float std_factor, float w_trav, float w_reco,
+                             float* conf_out, float* grads, void* scratch, hipStream_t st);
 int wvn_mlp_gradout_launch(const float* out, int ldo, const float* x, int ldx, const float* y,
                            const unsigned char* valid, const float* lr, const double* stats, float std_factor,
                            float w_trav, float w_reco, float* g, int ldg, float* trav_w, float* trav_raw,
                            float* conf_out, float* extra, int R, int D, hipStream_t st, const int* rows_dev = nullptr);
 int wvn_colsum_launch(const float* A, int lda, int R, int N, float* outv, hipStream_t st);
+// stats / extra / losses non-null: the same launch also writes the step's losses (block 0)
 int wvn_adam_launch(float* p, const float* g, float* m, float* v, int n, int step, float lr, float b1, float b2,
-                    float eps, hipStream_t st);
+                    float eps, hipStream_t st, const double* stats = nullptr, const float* extra = nullptr, float w_trav = 0.f,
+                    float w_reco = 0.f, float* losses = nullptr);
 int wvn_mlp_losses_launch(const double* stats, const float* extra, float w_trav, float w_reco, float* losses,
                           hipStream_t st);
 int wvn_mlp_confidence_launch(const float* out, int ldo, const float* x, int ldx, float mean, float std,

@@ -25,7 +25,7 @@ from ..model.simple_mlp import SimpleMLP
 
 class MlpTrainer:
     def __init__(self, model: SimpleMLP, lr: float = 1e-3, std_factor: float = 0.5, w_trav: float = 0.03,
-                 w_reco: float = 0.5, process_group=None):
+                 w_reco: float = 0.5, process_group=None, fused: bool = True):
         self.model = model
         self.lr, self.std_factor, self.w_trav, self.w_reco = lr, std_factor, w_trav, w_reco
         self.group = process_group
@@ -33,6 +33,9 @@ class MlpTrainer:
         self._state_dev = None
         self.last_confidence: Optional[torch.Tensor] = None
         self.comm_events = None   # set to [] to collect (start, end) CUDA-event pairs around the two all-reduces of every step
+        # True: the four-launch step of csrc/mlp_train.hip where its geometry applies (256 / 32 hidden units, <= 8192 rows);
+        # False: the general path (one kernel per stage, 17-20 launches).  Same arithmetic, other summation orders.
+        self.fused = fused
 
     def _state(self, dev):
         if self._state_dev != dev:
@@ -45,6 +48,7 @@ class MlpTrainer:
                 self.v = torch.zeros(n, dtype=torch.float32, device=dev)
             self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
             self.losses = torch.zeros(5, dtype=torch.float32, device=dev)
+            self.sync_word = torch.zeros(1, dtype=torch.int32, device=dev)   # arrival counter of the fused forward (zero between steps)
             self._state_dev = dev
 
     # Adam moments in torch.optim.Adam.state_dict() shape, for save/load_checkpoint compatibility
@@ -118,7 +122,8 @@ class MlpTrainer:
         rd = _lib.ptr(rows_dev)
         if R > 0:
             _lib.check(lib.wvn_mlp_train_phase_a_rows(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), yv.data_ptr(), R, rd,
-                                                      self.stats.data_ptr(), ws.data_ptr(), ws.numel(), st), "phase_a")
+                                                      self.stats.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                      self.sync_word.data_ptr() if self.fused else 0, st), "phase_a")
         else:
             self.stats.zero_()
         self._timed_allreduce(self.stats)
@@ -126,7 +131,7 @@ class MlpTrainer:
             _lib.check(lib.wvn_mlp_train_phase_b_rows(C.byref(d), flat.data_ptr(), x.data_ptr(), x.stride(0), y.data_ptr(),
                                                       yv.data_ptr(), R, rd, self.stats.data_ptr(), self.std_factor, self.w_trav,
                                                       self.w_reco, self.grads.data_ptr(), _lib.ptr(conf), ws.data_ptr(),
-                                                      ws.numel(), st), "phase_b")
+                                                      ws.numel(), int(self.fused), st), "phase_b")
         else:
             self.grads.zero_()
         self._timed_allreduce(self.grads)
