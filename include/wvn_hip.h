@@ -375,7 +375,7 @@ int wvn_mlp_train_phase_c(const wvn_mlp_desc* d, float* params, const float* gra
 int wvn_compact_segment_rows(const float* feat, int D, const float* side, int Dside, const int* nseg, int B, int S, float* x_out,
                              float* side_out, int* rows_dev, void* stream);
 /* sync_word (phase A) != NULL and fused (phase B) != 0 select the FOUR-LAUNCH step for the SimpleMLP geometry (H1 = 256, H2 = 32, R <=
- * 8192; csrc/mlp_train.hip): phase A = one launch (all three layers, row losses, statistic -- the last row tile to arrive folds the
+ * 2048; csrc/mlp_train.hip): phase A = one launch (all three layers, row losses, statistic -- the last row tile to arrive folds the
  * per-tile partials in tile order; sync_word: a device word that is ZERO on first use and is left at zero), phase B = two launches
  * (gradient seed + dL/dh2 + dL/dh1; the three weight / bias gradients and the loss sums), phase C = one launch (Adam + losses)
  * against 17-20 launches of the general path.  Both phases of a step must take the same path and the same workspace; other

@@ -97,13 +97,31 @@ def stego_code_tokens(head: Dict[str, torch.Tensor], tok: torch.Tensor) -> torch
     return lin + F.linear(hid, head["cluster2.2.weight"], head["cluster2.2.bias"])
 
 
+def _fma32(a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """Correctly rounded fp32 fused multiply-add of fp32 arrays.  The product of two fp32 values is exact in fp64; the fp64 sum
+    with c can carry a rounding error, which matters only when the fp64 sum lands exactly on an fp32 rounding midpoint -- the
+    error term of the addition (TwoSum) then decides the direction."""
+    a64, b64, c64 = a.astype(np.float64), b.astype(np.float64), np.broadcast_to(c, np.broadcast_shapes(a.shape, b.shape, np.shape(c))).astype(np.float64)
+    p = a64 * b64
+    s = p + c64
+    bb = s - p
+    err = (p - (s - bb)) + (c64 - bb)
+    r = s.astype(np.float32)
+    r64 = r.astype(np.float64)
+    other = np.where(s > r64, np.nextafter(r, np.float32(np.inf)), np.nextafter(r, np.float32(-np.inf))).astype(np.float32)
+    tie = (s != r64) & (np.abs(s - r64) == np.abs(other.astype(np.float64) - s))
+    # on a tie numpy rounded to even; the true value s + err lies on err's side of the midpoint
+    want_other = tie & (((err > 0) & (other.astype(np.float64) > r64)) | ((err < 0) & (other.astype(np.float64) < r64)))
+    return np.where(want_other, other, r).astype(np.float32)
+
+
 def _seq_dot_f32(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """sum_d a[..., d] * b[..., d] accumulated strictly in index order, one fp32 rounding per
-    multiply and per add (no FMA) -- the exact order the HIP k-means kernel uses, so integer
-    outputs can be compared bit-for-bit."""
+    """sum_d a[..., d] * b[..., d] as a FUSED multiply-add chain over the index, acc = fma(a_d, b_d, acc) from +0: one fp32
+    rounding per step -- the exact order and rounding of the HIP k-means kernels (v_fma_f32), so integer outputs can be compared
+    bit for bit.  (Round 2 defined it with separate multiply / add roundings: twice the instructions on the GPU for no benefit.)"""
     acc = np.zeros(np.broadcast_shapes(a.shape[:-1], b.shape[:-1]), dtype=np.float32)
     for d in range(a.shape[-1]):
-        acc = (acc + (a[..., d] * b[..., d]).astype(np.float32)).astype(np.float32)
+        acc = _fma32(np.broadcast_to(a[..., d], acc.shape), np.broadcast_to(b[..., d], acc.shape), acc)
     return acc
 
 
@@ -117,7 +135,41 @@ def _normalize_rows_f32(x: np.ndarray) -> np.ndarray:
     return (x * rinv[..., None]).astype(np.float32)
 
 
-def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) -> np.ndarray:
+_ORACLE_LIB = None
+
+
+def _oracle_lib():
+    """oracle/_build/libwvn_oracle.so (oracle/kmeans_ref.c, built by __graft_entry__.build() / oracle.build_oracle), or None."""
+    global _ORACLE_LIB
+    if _ORACLE_LIB is None:
+        import ctypes
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libwvn_oracle.so")
+        _ORACLE_LIB = False
+        if os.path.exists(path):
+            h = ctypes.CDLL(path)
+            h.wvn_oracle_kmeans_cosine.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            h.wvn_oracle_kmeans_cosine.restype = ctypes.c_int
+            _ORACLE_LIB = h
+    return _ORACLE_LIB or None
+
+
+def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS, force_numpy: bool = False) -> np.ndarray:
+    """The k-means below through its C restatement (oracle/kmeans_ref.c: the same operations with libm's fmaf, seconds instead of
+    minutes at 448 x 448 pixels) when that library has been built, else -- and with ``force_numpy`` -- the numpy statement
+    itself; tests/test_oracle_stego.py holds the two against each other."""
+    h = None if force_numpy else _oracle_lib()
+    if h is None:
+        return kmeans_cosine_labels_numpy(code, K, iters)
+    code = np.ascontiguousarray(code, dtype=np.float32)
+    labels = np.empty(code.shape[0], dtype=np.int32)
+    if h.wvn_oracle_kmeans_cosine(code.ctypes.data, code.shape[0], code.shape[1], K, iters, labels.ctypes.data) != 0:
+        raise MemoryError("oracle k-means")
+    return labels
+
+
+def kmeans_cosine_labels_numpy(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) -> np.ndarray:
     """Deterministic cosine k-means over one image's code vectors.
 
     code: [P, C] fp32.  Returns int32 labels [P] in 0..K-1 (not yet compacted).
@@ -127,7 +179,8 @@ def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) ->
       repeat ``iters`` times: label_p = argmax_k <x_p, c_k> (lowest k wins ties);
                               c_k = normalise(sum of its x_p in ascending p); empty cluster keeps c_k.
       final labels = one more assignment against the last centroids.
-    All arithmetic fp32, accumulation strictly sequential (see _seq_dot_f32).
+    All arithmetic fp32; norms and similarities are fma chains over the channel index (see _seq_dot_f32), centroid sums plain
+    additions in the order given below.
     """
     code = np.ascontiguousarray(code, dtype=np.float32)
     P, C = code.shape
@@ -157,24 +210,6 @@ def kmeans_cosine_labels(code: np.ndarray, K: int, iters: int = KMEANS_ITERS) ->
         new = _normalize_rows_f32(sums)
         cent = np.where((cnt > 0)[:, None], new, cent).astype(np.float32)
     return assign(cent)
-
-
-def _fma32(a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
-    """Correctly rounded fp32 fused multiply-add of fp32 arrays.  The product of two fp32 values is exact in fp64; the fp64 sum
-    with c can carry a rounding error, which matters only when the fp64 sum lands exactly on an fp32 rounding midpoint -- the
-    error term of the addition (TwoSum) then decides the direction."""
-    a64, b64, c64 = a.astype(np.float64), b.astype(np.float64), np.broadcast_to(c, np.broadcast_shapes(a.shape, b.shape, np.shape(c))).astype(np.float64)
-    p = a64 * b64
-    s = p + c64
-    bb = s - p
-    err = (p - (s - bb)) + (c64 - bb)
-    r = s.astype(np.float32)
-    r64 = r.astype(np.float64)
-    other = np.where(s > r64, np.nextafter(r, np.float32(np.inf)), np.nextafter(r, np.float32(-np.inf))).astype(np.float32)
-    tie = (s != r64) & (np.abs(s - r64) == np.abs(other.astype(np.float64) - s))
-    # on a tie numpy rounded to even; the true value s + err lies on err's side of the midpoint
-    want_other = tie & (((err > 0) & (other.astype(np.float64) > r64)) | ((err < 0) & (other.astype(np.float64) < r64)))
-    return np.where(want_other, other, r).astype(np.float32)
 
 
 def upsample_bilinear_fixed(code: np.ndarray, H: int) -> np.ndarray:

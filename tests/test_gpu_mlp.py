@@ -73,7 +73,7 @@ def test_large_batch_step_matches_oracle(dev):
         assert torch.allclose(m.state_dict()[k].cpu(), st.sd[k], atol=2e-5), k
 
 
-@pytest.mark.parametrize("R,D", [(1280, 90), (1280, 384), (77, 384), (800, 91), (33, 90)])
+@pytest.mark.parametrize("R,D", [(1280, 90), (2048, 384), (77, 384), (800, 91), (33, 90)])
 def test_four_launch_step_equals_general_path_and_oracle(dev, R, D):
     """The bench / live-node sizes through both paths and the CPU oracle (three steps), ragged last row tile, odd D; then a
     compacted batch whose row count lives on the device (rows_dev): both paths ignore the rows behind it; and bit-reproducible."""

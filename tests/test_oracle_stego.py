@@ -39,15 +39,32 @@ def test_fixed_order_upsampling_is_atens_up_to_rounding():
 def test_kmeans_group_fold_degenerates_for_short_inputs():
     """Up to KMEANS_SUPER chunks (512 points) the three-level order IS the flat chunk order (0 + x = x exactly)."""
     code = np.random.default_rng(1).standard_normal((500, 16)).astype(np.float32)
-    lab = OI.kmeans_cosine_labels(code, 4, iters=3)
+    lab = OI.kmeans_cosine_labels_numpy(code, 4, iters=3)
     keep = OI.KMEANS_SUPER
     try:
         OI.KMEANS_SUPER = 10 ** 6          # one group = the flat order
-        assert np.array_equal(OI.kmeans_cosine_labels(code, 4, iters=3), lab)
+        assert np.array_equal(OI.kmeans_cosine_labels_numpy(code, 4, iters=3), lab)
     finally:
         OI.KMEANS_SUPER = keep
     lab_pix = OI.kmeans_cosine_labels_pixels(code[:49], 7, 20, 3, iters=2)
     assert lab_pix.shape == (400,) and lab_pix.min() >= 0 and lab_pix.max() < 3
+
+
+def test_c_restatement_of_the_kmeans_equals_the_numpy_statement():
+    """oracle/kmeans_ref.c (fmaf chains, built by oracle.build_oracle) against the numpy definition (exact fp32 fma emulation):
+    ragged sizes, more than one group of chunks, near-parallel rows (many close similarities), an empty cluster."""
+    from oracle import build_oracle
+
+    build_oracle.build()
+    assert OI._oracle_lib() is not None
+    rng = np.random.default_rng(5)
+    for P, C, K, it in ((700, 16, 5, 4), (1500, 90, 20, 3), (64, 90, 3, 10), (1100, 33, 7, 2)):
+        code = (rng.standard_normal((P, C)) + 3.0 * rng.standard_normal(C)).astype(np.float32)      # a strong common component
+        a = OI.kmeans_cosine_labels(code, K, it)
+        b = OI.kmeans_cosine_labels_numpy(code, K, it)
+        assert a.dtype == np.int32 and np.array_equal(a, b), (P, C, K)
+    code = np.tile(rng.standard_normal((1, 16)).astype(np.float32), (200, 1))                       # identical rows: clusters 1.. stay empty
+    assert np.array_equal(OI.kmeans_cosine_labels(code, 4, 3), OI.kmeans_cosine_labels_numpy(code, 4, 3))
 
 
 def test_supervision_oracle_nan_scan_lines_and_raw_projection():

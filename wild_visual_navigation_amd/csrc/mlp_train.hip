@@ -333,10 +333,12 @@ size_t bwd_lds(int D) { return (size_t)(TR * (D + 1) + TR * H2 + 2 * TR) * sizeo
 
 }  // namespace
 
-// Eligibility of the four-launch step: the SimpleMLP geometry (256, 32), any D whose row tiles fit the LDS (<= 460), at most 8192 rows (the wgrad
+// Eligibility of the four-launch step: the SimpleMLP geometry (256, 32), any D whose row tiles fit the LDS (<= 460), at most 2048 rows (the wgrad
 // launch walks the rows without split-K).  The scratch behind the MLP workspace: part [ceil(R / 32)][4] doubles + one ticket.
 bool wvn_mlp_train_fused_ok(int D, int H1_, int H2_, int R) {
-  return H1_ == H1 && H2_ == H2 && D > 0 && fwd_lds(D) <= FUSED_LDS_MAX && R > 0 && R <= 8192;   // D <= 460
+  // measured (MI355X, D = 384 / 90): 75 vs 152 us per step at 160 rows, 196 vs 312 at 800, 185 vs 251 at 1280; the un-split weight
+  // gradients lose from about 3000 rows on (792 vs 504 us at 6400), where the general path's split-K GEMMs take over
+  return H1_ == H1 && H2_ == H2 && D > 0 && fwd_lds(D) <= FUSED_LDS_MAX && R > 0 && R <= 2048;   // D <= 460
 }
 size_t wvn_mlp_train_fused_scratch_bytes(int R) { return (size_t)ceil_div(R, TR) * 4 * sizeof(double); }
 

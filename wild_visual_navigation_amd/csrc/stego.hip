@@ -3,9 +3,9 @@
 //
 // Integer outputs (segment-index maps) must be bit-exact against the oracle given the same fp32
 // code, so every floating-point reduction here has a FIXED, documented order and uses the
-// non-fused multiply / add (__fmul_rn / __fadd_rn are plain operators: this file is compiled with
-// -ffp-contract=off) and square roots / reciprocals formed in fp64 (rinv_norm below):
-//   * dot products / norms : strictly sequential over the channel index
+// explicitly fused (__fmaf_rn) or explicitly separate (__fmul_rn / __fadd_rn are plain operators: this file is compiled
+// with -ffp-contract=off) operations, and square roots / reciprocals formed in fp64 (rinv_norm below):
+//   * dot products / norms : fused multiply-add chains over the channel index, acc = fma(a_d, b_d, acc) from +0
 //   * centroid sums        : points are cut into chunks of KM_CHUNK (64) consecutive indices; inside a
 //                            chunk the members of a cluster are added in ascending point order starting
 //                            from 0; the chunk partials are added in ascending chunk order inside groups
@@ -34,6 +34,7 @@ __device__ inline float rinv_norm(float n2) {
   return (float)(1.0 / (double)n);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
 constexpr int KM_MAXK = 64;
 constexpr int KM_CHUNK = 64;
 constexpr int KM_SUPER = 8;   // chunk partials are folded in groups of 8 consecutive chunks (512 points)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK) void normalize_rows_kernel(const fl
   if (p < rows) {
     float* r = tile + threadIdx.x * pitch;
     float n2 = 0.f;
-    for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(r[d], r[d]));
+    for (int d = 0; d < C; ++d) n2 = __fmaf_rn(r[d], r[d], n2);
     const float rinv = rinv_norm(n2);
     for (int d = 0; d < C; ++d) r[d] = __fmul_rn(r[d], rinv);
   }
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void km_assign_kernel(const float* __restrict_
     const float* c = cs + k * C;
     float acc = 0.f;
 #pragma unroll
-    for (int d = 0; d < C; ++d) acc = __fadd_rn(acc, __fmul_rn(x[d], c[d]));
+    for (int d = 0; d < C; ++d) acc = __fmaf_rn(x[d], c[d], acc);
     if (acc > bv) { bv = acc; best = k; }
   }
   labels[(size_t)b * P + p] = best;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict_
   __syncthreads();
   if (d == 0) {
     float n2 = 0.f;
-    for (int i = 0; i < C; ++i) n2 = __fadd_rn(n2, __fmul_rn(sums[i], sums[i]));
+    for (int i = 0; i < C; ++i) n2 = __fmaf_rn(sums[i], sums[i], n2);
     nrm_s = rinv_norm(n2);
   }
   __syncthreads();
@@ -249,9 +250,9 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
 //   rinv    : lane = pixel; the block's two source code rows in LDS
 //   assign  : lane = pixel, x[C] in registers, centroids through the scalar cache (uniform addresses), four independent
 //             dot-product chains in flight
-//   partial : one 128-lane workgroup per group of KM_SUPER chunks, lane = channel; the four code values of a pixel's cell stay
-//             in registers while consecutive pixels share it (the next cell's are prefetched); running sums in an LDS table
-//             indexed by the uniform label -- the addition order is exactly the sequential one.
+//   partial : one wave per group of KM_SUPER chunks, a lane owns two channels; the code values of a pixel's cell stay in
+//             registers while consecutive pixels share it (the next cell's are prefetched); a cluster's running sums stay in
+//             registers while the label repeats -- the addition order is exactly the sequential one.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int PIX_RPB = 4;   // image rows per workgroup of the lane-per-pixel kernels (the two staged code rows serve P of them)
 // stage code rows y0 / y1 of frame b ([G][C] each) into LDS: rows[0][G*C], rows[1][G*C]
@@ -269,7 +270,9 @@ __device__ inline void pix_row(const float* rows, int G, const LerpTap& tx, cons
   const float* b0 = rows + G * C + tx.i0 * C;
   const float* b1 = rows + G * C + tx.i1 * C;
 #pragma unroll
-  for (int d = 0; d < C; ++d) v[d] = bilerp_fixed(a0[d], a1[d], b0[d], b1[d], tx.w0, tx.w1, ty.w0, ty.w1);
+  for (int d = 0; d < C; ++d) {
+    v[d] = bilerp_fixed(a0[d], a1[d], b0[d], b1[d], tx.w0, tx.w1, ty.w0, ty.w1);
+  }
 }
 
 // rinv[b][y*H + x] = 1 / max(||v||, 1e-12), v = the interpolated code row of pixel (y, x)
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void km_pix_rinv_kernel(const float* __restric
       pix_row<C>(rows, G, tx, ty, v);
       float n2 = 0.f;
 #pragma unroll
-      for (int d = 0; d < C; ++d) n2 = __fadd_rn(n2, __fmul_rn(v[d], v[d]));
+      for (int d = 0; d < C; ++d) n2 = __fmaf_rn(v[d], v[d], n2);
       rinv[(size_t)b * H * H + (size_t)y * H + x] = rinv_norm(n2);
     }
   }
@@ -318,6 +321,10 @@ __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* 
   }
 }
 
+// (Measured and not kept: two pixels per lane as packed pairs -- every centroid value feeding one v_pk_fma_f32 -- with the centroids
+// through the scalar cache, 24.2 ms per 64-frame k-means against 22.5 for this form, and with the centroids in LDS, 33.5 ms:
+// at 250 registers only two waves per SIMD are left to cover the operand fetches.  Multiply + add against fma in the dot
+// products: no difference, the kernel waits for its centroid operands, not for the VALU.)
 template <int C>
 __global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
@@ -351,10 +358,10 @@ __global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restr
       const float* c0 = cb + (size_t)k * C;
 #pragma unroll
       for (int d = 0; d < C; ++d) {
-        a0 = __fadd_rn(a0, __fmul_rn(v[d], c0[d]));
-        a1 = __fadd_rn(a1, __fmul_rn(v[d], c0[C + d]));
-        a2 = __fadd_rn(a2, __fmul_rn(v[d], c0[2 * C + d]));
-        a3 = __fadd_rn(a3, __fmul_rn(v[d], c0[3 * C + d]));
+        a0 = __fmaf_rn(v[d], c0[d], a0);
+        a1 = __fmaf_rn(v[d], c0[C + d], a1);
+        a2 = __fmaf_rn(v[d], c0[2 * C + d], a2);
+        a3 = __fmaf_rn(v[d], c0[3 * C + d], a3);
       }
       if (a0 > bv) { bv = a0; best = k; }
       if (a1 > bv) { bv = a1; best = k + 1; }
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restr
       float a0 = 0.f;
       const float* c0 = cb + (size_t)k * C;
 #pragma unroll
-      for (int d = 0; d < C; ++d) a0 = __fadd_rn(a0, __fmul_rn(v[d], c0[d]));
+      for (int d = 0; d < C; ++d) a0 = __fmaf_rn(v[d], c0[d], a0);
       if (a0 > bv) { bv = a0; best = k; }
     }
     labels[p] = best;
@@ -375,65 +382,68 @@ __global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restr
 
 // part[b][group][k][d] = the group's partial (chunk partials added in ascending chunk order), pcnt[b][group][k] = member count
 //
-// Lane = channel (two waves cover C <= 128).  Consecutive pixels of an image row share their four source patches for about P
-// pixels (8.1 at 448 / 56): the chunk is walked cell by cell -- a cell = a run of pixels with the same four taps -- with the NEXT
-// cell's four code values already on their way while the current cell's pixels are added (half a load per pixel, none of them
-// waited for; fetching the taps of every pixel made the kernel L1-throughput-bound, 2.1 ms per launch; one pixel at a time with
-// dependent scalar loads it was a chain of three memory round trips per pixel, 4.5 ms).  Per-pixel parameters (tap offsets and
-// weights, label, reciprocal norm) are computed ONCE per chunk, pixel j by lane j, and handed to all lanes through v_readlane.
-// A cluster's running sum of the current chunk stays in a register while consecutive pixels carry the same label (the usual
-// case: a dependent chain of one v_add per pixel) and is parked in the LDS table tab[k][d] when the label changes -- the addition
-// order per (cluster, channel) is exactly the pixel order; member counts come from ballots.
-__global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
-                                                             const int* __restrict__ labels, float* __restrict__ part,
-                                                             int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup) {
-  extern __shared__ float lds[];   // tab[K][C] (current chunk), grp[K][C] (group so far)
-  float* tab = lds;
-  float* grp = lds + K * C;
-  const int g = blockIdx.x, b = blockIdx.y, d = threadIdx.x, lane = threadIdx.x & 63;
+// ONE wave per group; lane l owns channels 2 l and 2 l + 1 (C even, <= 128).  The kernel is bound by instruction issue, not by
+// memory: per pixel there is a handful of arithmetic and a dozen wave-uniform moves, so everything that is per WAVE is paid once
+// (two waves with lane = channel paid it twice, the second for 26 of its 64 lanes).  Consecutive pixels of an image row share their
+// four source patches for about P pixels (8.1 at 448 / 56): the chunk is walked cell by cell -- a cell = a run of pixels with the
+// same four taps -- with the NEXT cell's code values already on their way while the current cell's pixels are added (fetching the
+// taps of every pixel: L1-throughput-bound, 2.1 ms per launch; one pixel at a time with dependent scalar loads: three memory round
+// trips per pixel, 4.5 ms).  Per-pixel parameters (tap offsets and weights, label, reciprocal norm) are computed once per chunk,
+// pixel j by lane j, and handed to all lanes through v_readlane.  A cluster's running sum of the current chunk stays in registers
+// while consecutive pixels carry the same label (the usual case: a dependent chain of one v_add per pixel) and is parked in the
+// LDS table tab[k][c] when the label changes -- the addition order per (cluster, channel) is exactly the pixel order.  The group
+// partial lives in registers (KMAX x 2 per lane); member counts come from ballots.
+template <int KMAX>
+__global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+                                                            const int* __restrict__ labels, float* __restrict__ part,
+                                                            int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup) {
+  extern __shared__ __attribute__((aligned(8))) float tab[];   // [K][C]: the current chunk's parked sums
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const long long P = (long long)H * H;
-  for (int i = threadIdx.x; i < K * C; i += blockDim.x) { tab[i] = 0.f; grp[i] = 0.f; }
-  __syncthreads();
+  const bool act = 2 * lane < C;
+  const int c2 = act ? 2 * lane : 0;   // (inactive lanes read channels 0, 1 and drop the result)
+  for (int i = lane; i < K * C; i += 64) tab[i] = 0.f;
+  f32x2v_t grp[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) grp[k] = f32x2v_t{0.f, 0.f};
   const float* __restrict__ cb = code + (size_t)b * G * G * C;
   const int* __restrict__ lab = labels + (size_t)b * P;
   const float* __restrict__ rv = rinv + (size_t)b * P;
   const long long g0 = (long long)g * KM_SUPER * KM_CHUNK;
   const float scale = lerp_scale(G, H);
-  const bool act = d < C;
-  const int dd = act ? d : 0;   // (inactive lanes of the second wave read channel 0 and drop the result)
-  int mycnt = 0;                // wave 0, lane k: members of cluster k in this group
+  int mycnt = 0;                       // lane k: members of cluster k in this group
+  auto tap = [&](int off) -> f32x2v_t { return *(const f32x2v_t*)(cb + off + c2); };
   for (int c = 0; c < KM_SUPER; ++c) {
     const long long p0 = g0 + (long long)c * KM_CHUNK;
     if (p0 >= P) break;                                  // (uniform)
     const int n = (int)min((long long)KM_CHUNK, P - p0);
     const unsigned long long valid = n == 64 ? ~0ull : ((1ull << n) - 1);
     // ---- per-pixel parameters: lane j <-> pixel p0 + j ----
-    const long long pj = min(p0 + lane, P - 1);
-    const int yj = (int)(pj / H), xj = (int)(pj - (long long)yj * H);
+    const int pj = (int)min(p0 + lane, P - 1);
+    const int yj = pj / H, xj = pj - yj * H;
     const LerpTap ty = lerp_tap(yj, G, scale), tx = lerp_tap(xj, G, scale);
     const int o00 = (ty.i0 * G + tx.i0) * C, o01 = (ty.i0 * G + tx.i1) * C, o10 = (ty.i1 * G + tx.i0) * C, o11 = (ty.i1 * G + tx.i1) * C;
     const float rj = rv[pj];
     const int kj = lab[pj];
-    if (threadIdx.x < 64)
-      for (int k = 0; k < K; ++k) {                      // (uniform loop) member counts by ballot
-        const int m = __builtin_popcountll(__ballot(kj == k) & valid);
-        if (lane == k) mycnt += m;
-      }
+    for (int k = 0; k < K; ++k) {                        // (uniform loop) member counts by ballot
+      const int m = __builtin_popcountll(__ballot(kj == k) & valid);
+      if (lane == k) mycnt += m;
+    }
     // ---- cells ----
     int j = 0;
-    float n00 = cb[__builtin_amdgcn_readlane(o00, 0) + dd], n01 = cb[__builtin_amdgcn_readlane(o01, 0) + dd];
-    float n10 = cb[__builtin_amdgcn_readlane(o10, 0) + dd], n11 = cb[__builtin_amdgcn_readlane(o11, 0) + dd];
-    int kcur = -1;     // the cluster whose running sum of this chunk is in `acc` (the others are parked in tab)
-    float acc = 0.f;
+    f32x2v_t n00 = tap(__builtin_amdgcn_readlane(o00, 0)), n01 = tap(__builtin_amdgcn_readlane(o01, 0));
+    f32x2v_t n10 = tap(__builtin_amdgcn_readlane(o10, 0)), n11 = tap(__builtin_amdgcn_readlane(o11, 0));
+    int kcur = -1;     // the cluster whose running sums of this chunk are in `acc` (the others are parked in tab)
+    f32x2v_t acc = {0.f, 0.f};
     while (j < n) {                                      // (uniform)
-      const float v00 = n00, v01 = n01, v10 = n10, v11 = n11;
+      const f32x2v_t v00 = n00, v01 = n01, v10 = n10, v11 = n11;
       const int a00 = __builtin_amdgcn_readlane(o00, j), a10 = __builtin_amdgcn_readlane(o10, j);
       const unsigned long long same = __ballot(o00 == a00 && o10 == a10) & valid;
       const unsigned long long rest = ~same & valid & ~((2ull << j) - 1);   // pixels after j that are not in j's cell
       const int jend = rest ? __builtin_ctzll(rest) : n;                    // cells are contiguous runs along x
       if (jend < n) {                                    // the next cell's values: in flight during this cell's additions
-        n00 = cb[__builtin_amdgcn_readlane(o00, jend) + dd]; n01 = cb[__builtin_amdgcn_readlane(o01, jend) + dd];
-        n10 = cb[__builtin_amdgcn_readlane(o10, jend) + dd]; n11 = cb[__builtin_amdgcn_readlane(o11, jend) + dd];
+        n00 = tap(__builtin_amdgcn_readlane(o00, jend)); n01 = tap(__builtin_amdgcn_readlane(o01, jend));
+        n10 = tap(__builtin_amdgcn_readlane(o10, jend)); n11 = tap(__builtin_amdgcn_readlane(o11, jend));
       }
       for (int jj = j; jj < jend; ++jj) {
         const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), jj));
@@ -442,28 +452,36 @@ __global__ __launch_bounds__(128) void km_pix_partial_kernel(const float* __rest
         const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), jj));
         const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), jj));
         const int k = __builtin_amdgcn_readlane(kj, jj);
-        const float val = __fmul_rn(bilerp_fixed(v00, v01, v10, v11, wx0, wx1, wy0, wy1), ri);
+        const float val0 = __fmul_rn(bilerp_fixed(v00[0], v01[0], v10[0], v11[0], wx0, wx1, wy0, wy1), ri);
+        const float val1 = __fmul_rn(bilerp_fixed(v00[1], v01[1], v10[1], v11[1], wx0, wx1, wy0, wy1), ri);
         if (k != kcur) {                                 // (uniform, rare: labels are spatially coherent) park / fetch
-          if (act && kcur >= 0) tab[kcur * C + d] = acc;
-          if (act) acc = tab[k * C + d];
+          if (kcur >= 0) *(f32x2v_t*)(tab + kcur * C + c2) = acc;
+          acc = *(const f32x2v_t*)(tab + k * C + c2);
           kcur = k;
         }
-        acc = __fadd_rn(acc, val);
+        acc[0] = __fadd_rn(acc[0], val0);
+        acc[1] = __fadd_rn(acc[1], val1);
       }
       j = jend;
     }
-    if (act && kcur >= 0) tab[kcur * C + d] = acc;
-    // fold the chunk into the group partial (ascending chunk order) and clear the chunk table: lane d owns column d
-    if (act)
-      for (int k = 0; k < K; ++k) {
-        grp[k * C + d] = __fadd_rn(grp[k * C + d], tab[k * C + d]);
-        tab[k * C + d] = 0.f;
+    if (kcur >= 0) *(f32x2v_t*)(tab + kcur * C + c2) = acc;
+    // fold the chunk into the group partial (ascending chunk order) and clear the chunk table: a lane owns its two columns
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        const f32x2v_t t = *(const f32x2v_t*)(tab + k * C + c2);
+        grp[k][0] = __fadd_rn(grp[k][0], t[0]);
+        grp[k][1] = __fadd_rn(grp[k][1], t[1]);
+        *(f32x2v_t*)(tab + k * C + c2) = f32x2v_t{0.f, 0.f};
       }
   }
-  __syncthreads();
   float* dst = part + ((size_t)b * ngroup + g) * K * C;
-  for (int i = threadIdx.x; i < K * C; i += blockDim.x) dst[i] = grp[i];
-  if (threadIdx.x < K) pcnt[((size_t)b * ngroup + g) * K + threadIdx.x] = mycnt;
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) *(f32x2v_t*)(dst + k * C + c2) = grp[k];
+  }
+  if (lane < K) pcnt[((size_t)b * ngroup + g) * K + lane] = mycnt;
 }
 
 struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; size_t floats; };
@@ -496,8 +514,12 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
     hipLaunchKernelGGL((km_pix_assign_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
-    hipLaunchKernelGGL(km_pix_partial_kernel, dim3(ngroup, B), dim3(128), (size_t)(2 * K * C) * sizeof(float), st, code, s.rinv,
-                       labels, s.part, s.pcnt, G, H, C, K, ngroup);
+    if (K <= 32)
+      hipLaunchKernelGGL(km_pix_partial_kernel<32>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
+                         s.part, s.pcnt, G, H, C, K, ngroup);
+    else
+      hipLaunchKernelGGL(km_pix_partial_kernel<KM_MAXK>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv,
+                         labels, s.part, s.pcnt, G, H, C, K, ngroup);
     WVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1);
     WVN_LAUNCH_CHECK();
@@ -573,7 +595,7 @@ size_t wvn_kmeans_pixels_scratch_floats(int B, int G, int H, int C, int K) { ret
 int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K, int iters,
                              int relabel, hipStream_t st) {
   if (!code || !labels || !nseg || !scratch || K <= 0 || K > KM_MAXK || G <= 0 || H <= 0 || B <= 0) return WVN_ERR_ARG;
-  if ((size_t)2 * G * C * sizeof(float) > 96 * 1024 || (size_t)(2 * K * C + K) * sizeof(float) > 60 * 1024) return WVN_ERR_ARG;
+  if ((size_t)2 * G * C * sizeof(float) > 96 * 1024 || (size_t)K * C * sizeof(float) > 60 * 1024 || (C & 1) || C > 128) return WVN_ERR_ARG;
   if (C == 90) return run_kmeans_pixels<90>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st);
   if (C == 16) return run_kmeans_pixels<16>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st);
   return WVN_ERR_ARG;

@@ -33,7 +33,7 @@ class MlpTrainer:
         self._state_dev = None
         self.last_confidence: Optional[torch.Tensor] = None
         self.comm_events = None   # set to [] to collect (start, end) CUDA-event pairs around the two all-reduces of every step
-        # True: the four-launch step of csrc/mlp_train.hip where its geometry applies (256 / 32 hidden units, <= 8192 rows);
+        # True: the four-launch step of csrc/mlp_train.hip where its geometry applies (256 / 32 hidden units, <= 2048 rows);
         # False: the general path (one kernel per stage, 17-20 launches).  Same arithmetic, other summation orders.
         self.fused = fused
 
