@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 500 python -m pytest tests/test_gpu_stego_pixels.py tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -3
-timeout 120 python scripts/bench_pixel_kmeans.py 2>&1 | tail -1
-timeout 300 python bench.py --stego-reading upstream --no-cpu-baseline --steps 20 --warmup 4 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('upstream', d['value'], d['ms_per_step'])"
+timeout 1000 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/gputest.log | tail -12
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
+timeout 400 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log > gpurun_out/bench_r03_default.json; cut -c1-160 gpurun_out/bench_r03_default.json
+bash scripts/profile_job.sh r03_f16 1
+bash scripts/profile_job.sh r03_exact 0 --precision exact
+bash scripts/profile_job.sh r03_upstream 0 --stego-reading upstream
+bash scripts/profile_job.sh r03_dinov2_fp8 1 --mode dinov2
