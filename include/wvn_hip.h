@@ -71,6 +71,10 @@ typedef struct wvn_vit_layer {
   const float *ls1, *ls2; /* [D] LayerScale of the attention / MLP branch (DINOv2 blocks.i.ls{1,2}.gamma); NULL = none (DINO) */
   const float *qkv_s, *proj_s, *fc1_s, *fc2_s; /* WVN_PREC_FP8: per-output-channel scale of each e4m3 weight row (w = q * s) */
   const void* fc2_w_fused;                     /* WVN_VIT_MLP_FUSED: fc2.weight with the permuted hidden index (see above); else NULL */
+  const void* fc1_w_fused; /* optional with WVN_VIT_MLP_FUSED: fc1.weight with its COLUMN (input) index permuted the same way,
+                            * fc1_w_fused[f][k] = fc1.weight[f][swap23(k)].  With it (and no LayerScale) the block's projection + MLP
+                            * kernel keeps the residual rows in its accumulator registers: one read and one write of the residual
+                            * stream per block instead of two and two (wvn_proj_mlp_resident).  NULL: the form without it */
 } wvn_vit_layer;
 
 typedef struct wvn_vit_model {
@@ -141,6 +145,14 @@ int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b,
 int wvn_proj_mlp_fused(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
                        const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
                        const float* ls2, float* x, int ldx, int M, int F, void* stream);
+/* The same result (no LayerScale) with the residual rows RESIDENT in the accumulator registers of the kernel for the whole block:
+ * x is read once and written once (wvn_proj_mlp_fused: twice and twice), the LayerNorm reads the rows where the projection MFMAs
+ * left them, and fc2 accumulates on top of them.  W1p = fc1.weight with bits 2 and 3 of its column index swapped inside every
+ * aligned group of 16 (wvn_vit_layer.fc1_w_fused), W2p as above.  Differs from wvn_proj_mlp_fused by fp32 summation order only
+ * (the products are accumulated onto x + bias instead of being added to it at the end). */
+int wvn_proj_mlp_resident(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
+                          float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx, int M,
+                          int F, void* stream);
 /* Block MLP in one launch: x [M,ldx] fp32 += gelu(xn [M,lda] bf16 * W1[F,384]^T + b1) * W2[384,F]^T + b2  (optionally
  * times LayerScale ls [384]).  W2p = W2 with the hidden index permuted as WVN_VIT_MLP_FUSED describes.  xn == NULL: the kernel
  * computes xn = LayerNorm(x; ln_g, ln_b, ln_eps) itself (what wvn_vit_forward uses: blocks.i.norm2 never touches memory).
@@ -161,6 +173,9 @@ int wvn_qkv_fused_f16(const float* x, int ldx, const float* ln_g, const float* l
 int wvn_proj_mlp_fused_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
                            const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
                            const float* ls2, float* x, int ldx, int M, int F, void* stream);
+int wvn_proj_mlp_resident_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
+                              float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx,
+                              int M, int F, void* stream);
 int wvn_mlp_fused_f16(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
                       const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream);
 int wvn_attention_f16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad, float scale,

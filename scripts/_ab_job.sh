@@ -1,0 +1,4 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}
+export PYTHONPATH=$PWD
+for l in "$@"; do WVN_LIB_PATH=$PWD/wild_visual_navigation_amd/lib/libwvn_$l.so timeout 120 python scripts/mlp_fused_ab.py $l 2>&1 | grep -v amdgpu.ids | tail -2; done

@@ -115,6 +115,46 @@ def test_projection_in_the_prologue(dev, M, scaled):
     assert torch.equal(got, again), "run-to-run difference (pipeline race)"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 100, 128 * 3 + 5, 128 * 300 + 17, 128 * 600])
+def test_resident_form_matches_fused(dev, M, dtype):
+    """wvn_proj_mlp_resident (the residual rows stay in the accumulators: x read once and written once, the LayerNorm reads the
+    accumulators, fc1.weight with swapped column bits) against wvn_proj_mlp_fused on the same operands: same rounding points;
+    the products are accumulated onto x + bias instead of being added to it at the end, and the projection bias enters as two
+    operand-format terms (bf16: exact to 2^-17 relative)."""
+    Fh = 1536
+    _, w1, b1, w2, b2, x, _ = make(M, Fh, dev)
+    x = x * 2.0 + 0.4
+    attn = (torch.randn(M, 384, generator=g(11)) * 1.5).to(dtype).to(dev)
+    wp = (torch.randn(384, 384, generator=g(12)) * 0.05).to(dtype).to(dev)
+    bp = (torch.randn(384, generator=g(13)) * 0.3).to(dev)
+    gam = (torch.rand(384, generator=g(8)) + 0.5).to(dev)
+    bet = (torch.randn(384, generator=g(9)) * 0.2).to(dev)
+    w1, w2 = w1.to(dtype), w2.to(dtype)
+    w2p = w2[:, ops.vt_token_order(Fh, device=dev)].contiguous()
+    w1p = w1[:, ops.vt_token_order(384, device=dev)].contiguous()
+    if dtype == torch.bfloat16:
+        want = ops.proj_mlp_fused(attn, wp, bp, (gam, bet, 1e-6), w1, b1, w2p, b2, x.clone())
+    else:   # fp16 operands: the separate fp16 kernels
+        want = x.clone()
+        ops.gemm_bf16(attn, wp, bp, _lib.EPI_RESID_F32, out=want)
+        xn = F.layer_norm(want, (384,), gam, bet, 1e-6).to(dtype)
+        hid = ops.gemm_bf16(xn, w1, b1, _lib.EPI_GELU_BF16)
+        ops.gemm_bf16(hid, w2, b2, _lib.EPI_RESID_F32, out=want)
+    got = ops.proj_mlp_resident(attn, wp, bp, (gam, bet, 1e-6), w1p, b1, w2p, b2, x.clone())
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= (1e-2 if dtype == torch.bfloat16 else 4e-3)
+    assert (got - want).abs().mean().item() <= 1e-4
+    # the residual stream itself is exact to fp32 rounding where the MLP contributes nothing
+    z = ops.proj_mlp_resident(attn * 0, wp, bp * 0, (gam, bet, 1e-6), w1p * 0, b1 * 0, w2p * 0, b2 * 0, x.clone())
+    assert torch.equal(z, x)
+    zb = ops.proj_mlp_resident(attn * 0, wp, bp, (gam, bet, 1e-6), w1p * 0, b1 * 0, w2p * 0, b2, x.clone())
+    assert (zb - (x + bp + b2)).abs().max().item() <= 2e-5
+    again = ops.proj_mlp_resident(attn, wp, bp, (gam, bet, 1e-6), w1p, b1, w2p, b2, x.clone())
+    assert torch.equal(got, again), "run-to-run difference (pipeline race)"
+
+
 def test_fused_layerscale(dev):
     M, Fh = 515, 1536
     xn, w1, b1, w2, b2, x, gam = make(M, Fh, dev, ls=True)

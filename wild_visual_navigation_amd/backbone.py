@@ -8,6 +8,7 @@ upstream DINO state-dict layout, so released DINO checkpoints load unchanged; wi
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -185,12 +186,21 @@ class VitBackbone:
                 if self.fuse_mlp:
                     # proj.weight, fc1.weight and the fused kernel's own copy of fc2.weight (hidden index in the order the fc1
                     # accumulators hand it over, wvn_hip.h), one allocation per layer
+                    # ... and, where the block has no LayerScale, fc1.weight with its column index in the order the projection
+                    # accumulators hand the residual rows over (the kernel then keeps the rows in registers for the whole block)
                     k = torch.arange(self.mlp_dim)
-                    parts = [sd[p + "attn.proj.weight"], sd[p + "mlp.fc1.weight"], w2[:, (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)]]
+                    swap23 = lambda i: (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)   # noqa: E731
+                    w1 = sd[p + "mlp.fc1.weight"]
+                    parts = [sd[p + "attn.proj.weight"], w1, w2[:, swap23(k)]]
+                    resident = (p + "ls1.gamma") not in sd and self.dim == 384 and not os.environ.get("WVN_NO_RESIDENT")   # (env: A/B runs)
+                    if resident:
+                        parts.append(w1[:, swap23(torch.arange(self.dim))])
                     pack = torch.cat([t.detach().float().reshape(-1) for t in parts]).to(self.device).to(self._lowp16).contiguous()
                     self._keep.append(pack)
-                    n0, n1 = parts[0].numel(), parts[1].numel()
+                    n0, n1, n2 = parts[0].numel(), parts[1].numel(), parts[2].numel()
                     L.proj_w, L.fc1_w, L.fc2_w_fused = pack.data_ptr(), pack.data_ptr() + 2 * n0, pack.data_ptr() + 2 * (n0 + n1)
+                    if resident:
+                        L.fc1_w_fused = pack.data_ptr() + 2 * (n0 + n1 + n2)
                 else:
                     L.fc1_w = mat(sd[p + "mlp.fc1.weight"])
             L.qkv_b, L.proj_b = vec(sd[p + "attn.qkv.bias"]), vec(sd[p + "attn.proj.bias"])

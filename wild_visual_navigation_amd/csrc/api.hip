@@ -326,7 +326,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       if (!L.fc2_w_fused) return WVN_ERR_ARG;
       const int rc = opk.proj_mlp_fused((const bf16_t*)w.xn, d.D, (const bf16_t*)L.proj_w, L.proj_b, L.ls1, L.ln2_g, L.ln2_b, 1e-6f,
                                                (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b, L.ls2, w.x, d.D, M,
-                                               d.F, st);
+                                               d.F, st, (const bf16_t*)L.fc1_w_fused);
       if (rc == WVN_OK) continue;
       if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
@@ -380,7 +380,14 @@ int wvn_proj_mlp_fused_f16(const void* attn, int lda, const void* Wp, const floa
                            const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
                            const float* ls2, float* x, int ldx, int M, int F, void* stream) {
   return wvn_proj_mlp_fused_launch_f16((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, ls1, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1,
-                                       (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream);
+                                       (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream, nullptr);
+}
+int wvn_proj_mlp_resident_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
+                              float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx,
+                              int M, int F, void* stream) {
+  if (!W1p) return WVN_ERR_ARG;
+  return wvn_proj_mlp_fused_launch_f16((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, nullptr, ln_g, ln_b, ln_eps, nullptr, b1,
+                                       (const bf16_t*)W2p, b2, nullptr, x, ldx, M, F, (hipStream_t)stream, (const bf16_t*)W1p);
 }
 int wvn_mlp_fused_f16(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
                       const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream) {
@@ -403,7 +410,14 @@ int wvn_proj_mlp_fused(const void* attn, int lda, const void* Wp, const float* b
                        const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
                        const float* ls2, float* x, int ldx, int M, int F, void* stream) {
   return wvn_proj_mlp_fused_launch((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, ls1, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1,
-                                   (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream);
+                                   (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream, nullptr);
+}
+int wvn_proj_mlp_resident(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
+                          float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx, int M,
+                          int F, void* stream) {
+  if (!W1p) return WVN_ERR_ARG;
+  return wvn_proj_mlp_fused_launch((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, nullptr, ln_g, ln_b, ln_eps, nullptr, b1,
+                                   (const bf16_t*)W2p, b2, nullptr, x, ldx, M, F, (hipStream_t)stream, (const bf16_t*)W1p);
 }
 
 int wvn_mlp_fused(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,

@@ -41,6 +41,12 @@ constexpr int B1_OFF = B2_OFF + KD * 4;               // 151,040
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
+// Timing experiments (scripts/build_variant.sh ... -DWVN_MLP_EXP=<bits>; results are WRONG with any bit set): 1 no DMA after the
+// prologue, 2 no barrier, 4 no fragment reads, 8 no vmcnt waits -- what each ingredient of the slice loop costs.
+#ifndef WVN_MLP_EXP
+#define WVN_MLP_EXP 0
+#endif
+
 // the fc1 epilogue GELU of gemm_a384.hip (x * sigmoid(g(x)), g fitted to logit Phi(x): within 0.25 bf16 ulp of erf GELU)
 #ifndef WVN_GELU_SCALAR
 #define WVN_GELU_SCALAR 0   // 1: the same arithmetic on scalar VALU instructions (A/B of packed-f32 VALU beside MFMAs, scripts/ab_lib.sh)
@@ -98,8 +104,16 @@ __device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool LNF, bool TIMING = false, bool PROJ = false>
+// ACC (with PROJ, no LayerScale): the residual rows live in the ACCUMULATOR registers for the whole row block.  `out` starts as
+// x + bp (loaded in the accumulator layout: lane = row, 4 consecutive columns per register group), the projection MFMAs add to
+// it, the LayerNorm reads it where it lies -- the lane pair (l, l ^ 32) holds one row; and because a lane's 8 values of every 16
+// columns are the k-slots {4 hi .. + 3, 8 + 4 hi .. + 3}, they ARE the fc1 operand fragment once fc1.weight is stored with the same
+// bit-2 <-> bit-3 swap of its column index as W2's hidden index (p.W1 = that copy) -- and fc2 accumulates on top.  One read and one
+// write of the residual stream per block instead of two and two, no LDS transposes except the final store, and the next row
+// block's rows are fetched into the accumulator registers as the store phase frees them.
+template <bool LNF, bool TIMING = false, bool PROJ = false, bool ACC = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
+  static_assert(!ACC || (PROJ && LNF && !TIMING), "ACC is a form of the projection + LayerNorm + MLP kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,10 +204,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   auto open_next = [&](auto issue_fn) {   // issue_fn(slot): the DMA of slice si + 4, whose kind the caller knows statically
     __builtin_amdgcn_sched_barrier(0);
     if (si + 1 < total) {
-      if (si + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (si + 4 < total) issue_fn(rslot == 0 ? NS - 1 : rslot - 1);   // into the slot of slice si - 1
+      if constexpr (!(WVN_MLP_EXP & 8)) {
+        if (si + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if constexpr (!(WVN_MLP_EXP & 2)) __builtin_amdgcn_s_barrier();
+      if constexpr (!(WVN_MLP_EXP & 1))
+        if (si + 4 < total) issue_fn(rslot == 0 ? NS - 1 : rslot - 1);   // into the slot of slice si - 1
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -223,10 +240,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
     return 0;
   };
   const long long t_begin = now();
+  f32x16_t out[12];
+  // ACC: the residual rows of row block rbn in the accumulator layout, tiles t0 .. t0 + 3 (rows past M read as zero: descriptor bounds)
+  const unsigned avoff = (unsigned)((l31 * p.ldx + 4 * hi) * 4);
+  auto load_xacc = [&](int rbn, int t0) {
+#pragma unroll
+    for (int t = t0; t < t0 + 4; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned so = __builtin_amdgcn_readfirstlane(((rbn * BM + wave * 32) * p.ldx + 32 * t + 8 * g) * 4);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, avoff, so, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[t][4 * g + e] = __uint_as_float(v[e]);
+      }
+  };
+  if constexpr (ACC) { load_xacc(blockIdx.x, 0); load_xacc(blockIdx.x, 4); load_xacc(blockIdx.x, 8); }
   for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     const int m0w = rb * BM + wave * 32;
     const long long c_p0 = now();
-    f32x16_t out[12];
     f32x4_t xq[KD / 8];   // the wave's rows in the fragment layout (lane = row l31, columns 16 k + 8 hi .. + 7), fp32: LayerNorm input
     // keep_tag: also hand the updated rows over in xq (the LayerNorm that follows then needs no memory at all)
     auto residual_update = [&](const float* bias_tab, const float* ls_vec, auto keep_tag) {
@@ -294,10 +325,26 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
 #pragma unroll
         for (int s = 0; s < KD / 16; ++s) af[s] = *(const opx8_t*)(ap + s * 16);
       }
+      if constexpr (ACC) {
+        // out = x (in flight since the previous store phase) + bp.  The bias joins through the matrix pipe -- one MFMA per column
+        // tile whose only non-zero k-slots are 0 and 1: bp split into two operand-format terms (hi + lo, exact to 2^-17 / 2^-22
+        // relative) against ones -- so that no VALU instruction ever writes an accumulator (see the LayerNorm below).
+        union { u32x4_t u; opx8_t v; } ones;
+        ones.u = u32x4_t{hi == 0 ? WVN_OP_ONE2 : 0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int t = 0; t < 12; ++t)
+        for (int t = 0; t < 12; ++t) {
+          const float bv = bp_l[32 * t + l31];
+          const float bh = op_to_f32(f32_to_op(bv));
+          union { u32x4_t u; opx8_t v; } bf;
+          bf.u = u32x4_t{hi == 0 ? pack_op2(bh, bv - bh) : 0u, 0u, 0u, 0u};
+          out[t] = wvn_mfma_32x32x16(bf.v, ones.v, out[t], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+      }
       // one slice of Wp: rows (output columns) 64 cp .. + 63, k 128 ks .. + 127: 16 MFMAs on out[2 cp], out[2 cp + 1]
       auto pslice = [&](auto CPc, auto KSc) {
         constexpr int cp = decltype(CPc)::value, ks = decltype(KSc)::value;
@@ -326,11 +373,64 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       pslice(I3{}, I0{}); pslice(I3{}, I1{}); pslice(I3{}, I2{});
       pslice(I4{}, I0{}); pslice(I4{}, I1{}); pslice(I4{}, I2{});
       pslice(I5{}, I0{}); pslice(I5{}, I1{}); pslice(I5{}, I2{});
-      residual_update(bp_l, p.ls1, std::true_type{});   // ... and the updated rows stay in registers for the LayerNorm below
+      if constexpr (!ACC) residual_update(bp_l, p.ls1, std::true_type{});   // ... and the updated rows stay in registers for the LayerNorm below
     }
     // ---- A rows -> registers (MFMA operand layout: row l31, k = 16 s + 8 hi .. + 7); rows past M are clamped ----
     opx8_t xf[KD / 16];
-    if constexpr (LNF) {
+    if constexpr (ACC) {
+      // LayerNorm where the rows lie: lane (l31, hi) holds the columns 32 t + 8 g + 4 hi + e of row l31.  The accumulators are only
+      // ever READ here, by explicit accumulator reads: an ordinary VALU use of an accumulator value would tie all 192 of them to the
+      // 256 architectural VGPRs for the whole kernel, and there is no room for that beside the operand fragments.
+      auto rd4 = [&](int t, int g) -> f32x4_t {
+        f32x4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float r;
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(out[t][4 * g + e]));
+          v[e] = r;
+        }
+        return v;
+      };
+      float sm = 0.f;
+#pragma unroll
+      for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t v = rd4(t, g);
+          sm += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm / 384.f;
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t v = rd4(t, g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+        }
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = 1.0f / sqrtf(q / 384.f + p.ln_eps);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) {   // k-step s = columns 16 s .. + 15: this lane's slots are 16 s + 4 hi + e and 16 s + 8 + 4 hi + e
+        union { u32x4_t u; opx8_t v; } o;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x4_t g4 = *(const f32x4_t*)(lng_l + 16 * s + 8 * h2 + 4 * hi);
+          const f32x4_t b4 = *(const f32x4_t*)(lng_l + KD + 16 * s + 8 * h2 + 4 * hi);
+          const f32x4_t v = rd4(s >> 1, 2 * (s & 1) + h2);
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * g4[e] + b4[e];
+          o.u[2 * h2] = pack_op2(y[0], y[1]);
+          o.u[2 * h2 + 1] = pack_op2(y[2], y[3]);
+        }
+        asm volatile("" : "+v"(o.u));   // pins the arithmetic between the accumulator reads of this step and of the next: code sinking
+        xf[s] = o.v;                    // would otherwise park all 192 read values (and the table rows) until the first use of xf
+      }
+    } else if constexpr (LNF) {
       // LayerNorm of the wave's 32 residual rows, once per row block: a lane holds half a row (the k-slots it feeds the MFMAs),
       // its partner lane ^ 32 the other half
       // The rows come in coalesced (an instruction = 4 rows x 256 contiguous bytes = 8 whole lines; the fragment layout would
@@ -390,10 +490,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       for (int s = 0; s < KD / 16; ++s) xf[s] = *(const opx8_t*)(ap + s * 16);
     }
     if constexpr (TIMING) tm[0] += now() - c_p0;
+    if constexpr (!ACC) {
 #pragma unroll
-    for (int t = 0; t < 12; ++t)
+      for (int t = 0; t < 12; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) out[t][r] = 0.f;
+    }
 
     for (int j = 0; j < NTL; ++j) {
       const int jn = j + 1 == NTL ? 0 : j + 1;
@@ -417,7 +519,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
         auto step = [&](int i) {
           if constexpr (Q < 3) hacc[i & 1] = wvn_mfma_32x32x16(wf[i & 3], xf[Q * 8 + (i >> 1)], hacc[i & 1], 0, 0, 0);
           else out[4 * (Q - 3) + (i & 3)] = wvn_mfma_32x32x16(wf[i & 3], hf[i >> 2], out[4 * (Q - 3) + (i & 3)], 0, 0, 0);
-          if (i + 4 < 16) wf[i & 3] = frag(Qc, rslot, i + 4);
+          if constexpr (WVN_MLP_EXP & 4) asm volatile("" : "+v"(wf[i & 3]));
+          else if (i + 4 < 16) wf[i & 3] = frag(Qc, rslot, i + 4);
           else wf[i & 3] = frag(std::integral_constant<int, QN>{}, nslot, i + 4 - 16);
         };
 #pragma unroll
@@ -460,6 +563,35 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
       if constexpr (TIMING) { tm[1] += c1 - c0; tm[2] += c2 - c1; tm[3] += now() - c2; }
     }
     const long long c_e0 = now();
+    if constexpr (ACC) {
+      // ---- store phase: out (+ b2) -> the wave's LDS image -> whole 512-byte row pieces; the registers of a staged chunk take the
+      //      next row block's rows at once (their latency hides behind the stores and the first projection slices) ----
+      const int rbn = rb + (int)gridDim.x;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16_t& a = out[4 * c + tt];
+            const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+            *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rbn < nrb) load_xacc(rbn, 4 * c);
+        const f32x4_t b4 = *(const f32x4_t*)(b2_l + 128 * c + (lane & 31) * 4);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldx + 128 * c) * 4);
+          const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
+          u32x4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e] + b4[e]);
+          store_b128_guarded(o, rs_x, cvoff, so);  // rows >= M fall outside num_records: dropped
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
     residual_update(b2_l, p.ls, std::false_type{});
     if constexpr (TIMING) tm[4] += now() - c_e0;
   }
@@ -492,8 +624,11 @@ long long* WVN_OPSYM(g_mlp_fused_dbg) = nullptr;   // wvn_debug_mlp_fused_timing
 
 static int mlp_fused_launch_impl(const op16_t* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const op16_t* W1, const float* b1,
                                  const op16_t* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, const op16_t* attn,
-                                 int lda_attn, const op16_t* Wp, const float* bp, const float* ls1, hipStream_t st) {
+                                 int lda_attn, const op16_t* Wp, const float* bp, const float* ls1, hipStream_t st,
+                                 const op16_t* W1p = nullptr) {
   const bool lnf = xn == nullptr, proj = attn != nullptr;
+  const bool acc = proj && W1p && !ls && !ls1;   // the residual rows stay in the accumulators (W1p: fc1.weight with the swapped column bits)
+  if (acc) W1 = W1p;
   if (!W1 || !W2p || !x || M <= 0 || F <= 0 || (F % HT) != 0 || (ldx % 4) != 0) return WVN_ERR_ARG;
   if (lnf ? (!ln_g || !ln_b) : ((lda % 8) != 0 || ((uintptr_t)xn & 15) != 0)) return WVN_ERR_ARG;
   if ((((uintptr_t)W1 | (uintptr_t)W2p | (uintptr_t)x) & 15) != 0) return WVN_ERR_ARG;
@@ -503,7 +638,7 @@ static int mlp_fused_launch_impl(const op16_t* xn, int lda, const float* ln_g, c
   if ((size_t)M * ldx * 4 >= (1ull << 32)) return WVN_ERR_ARG;
   if ((size_t)F * KD * 2 >= (1ull << 32)) return WVN_ERR_ARG;
   static LdsOptIn lds_opt_in;   // per device (common.h)
-  if (const int rc = lds_opt_in(160 * 1024, (const void*)mlp_fused_kernel<false>, (const void*)mlp_fused_kernel<true>, (const void*)mlp_fused_kernel<true, true>, (const void*)mlp_fused_kernel<true, false, true>)) return rc;
+  if (const int rc = lds_opt_in(160 * 1024, (const void*)mlp_fused_kernel<false>, (const void*)mlp_fused_kernel<true>, (const void*)mlp_fused_kernel<true, true>, (const void*)mlp_fused_kernel<true, false, true>, (const void*)mlp_fused_kernel<true, false, true, true>)) return rc;
   MlpFusedParams p{};
   p.A = xn; p.lda = lda; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.W1 = W1; p.W2 = W2p; p.b1 = b1; p.b2 = b2; p.ls = ls;
   p.X = x; p.ldx = ldx; p.M = M; p.F = F;
@@ -512,7 +647,8 @@ static int mlp_fused_launch_impl(const op16_t* xn, int lda, const float* ln_g, c
   const int nrb = ceil_div(M, BM), ncu = mlp_fused_num_cus();
   const dim3 grid(nrb < ncu ? nrb : ncu);
   p.dbg = WVN_OPSYM(g_mlp_fused_dbg);
-  if (proj) hipLaunchKernelGGL((mlp_fused_kernel<true, false, true>), grid, dim3(256), lds, st, p);
+  if (acc) hipLaunchKernelGGL((mlp_fused_kernel<true, false, true, true>), grid, dim3(256), lds, st, p);
+  else if (proj) hipLaunchKernelGGL((mlp_fused_kernel<true, false, true>), grid, dim3(256), lds, st, p);
   else if (lnf && WVN_OPSYM(g_mlp_fused_dbg)) hipLaunchKernelGGL((mlp_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
   else if (lnf) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(256), lds, st, p);
@@ -527,9 +663,13 @@ int WVN_OPSYM(wvn_mlp_fused_launch)(const op16_t* xn, int lda, const float* ln_g
 }
 
 // The same with the attention output projection of the block in front: x += (attn Wp^T + bp) (* ls1); x += MLP(LayerNorm(x)).
+// W1p (optional): fc1.weight with bits 2 and 3 of its COLUMN index swapped inside every aligned group of 16 -- with it, and
+// without LayerScale, the kernel keeps the residual rows in its accumulators (ACC above).  W1 may then be nullptr.
 int WVN_OPSYM(wvn_proj_mlp_fused_launch)(const op16_t* attn, int lda_attn, const op16_t* Wp, const float* bp, const float* ls1, const float* ln_g,
                               const float* ln_b, float ln_eps, const op16_t* W1, const float* b1, const op16_t* W2p, const float* b2,
-                              const float* ls2, float* x, int ldx, int M, int F, hipStream_t st) {
-  if (!attn) return WVN_ERR_ARG;
-  return mlp_fused_launch_impl(nullptr, 0, ln_g, ln_b, ln_eps, W1, b1, W2p, b2, ls2, x, ldx, M, F, attn, lda_attn, Wp, bp, ls1, st);
+                              const float* ls2, float* x, int ldx, int M, int F, hipStream_t st, const op16_t* W1p) {
+  if (!attn || (!W1 && !W1p)) return WVN_ERR_ARG;
+  if (!W1 && (ls1 || ls2)) return WVN_ERR_ARG;   // the LayerScale form needs fc1.weight in its own column order
+  return mlp_fused_launch_impl(nullptr, 0, ln_g, ln_b, ln_eps, W1 ? W1 : W1p, b1, W2p, b2, ls2, x, ldx, M, F, attn, lda_attn, Wp, bp, ls1, st,
+                               W1p);
 }

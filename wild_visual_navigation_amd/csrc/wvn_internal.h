@@ -52,7 +52,7 @@ struct GemmBf16Params {
   int wvn_proj_mlp_fused_launch##SFX(const bf16_t* attn, int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1,         \
                                      const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1,         \
                                      const bf16_t* W2p, const float* b2, const float* ls2, float* x, int ldx, int M, int F,         \
-                                     hipStream_t st);                                                                               \
+                                     hipStream_t st, const bf16_t* W1p);                                                            \
   /* qkv_fused.hip: LayerNorm(x) -> q | k | v^T in the layouts of attention_bf16.hip (D = 384, heads = 6), one launch */            \
   int wvn_qkv_fused_launch##SFX(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W,       \
                                 const float* bias, bf16_t* q, bf16_t* k, bf16_t* vt, int heads, int npad, int ntok_s,               \

@@ -486,6 +486,19 @@ def proj_mlp_fused(attn: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tens
     return x
 
 
+def proj_mlp_resident(attn: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tensor], ln: Tuple[torch.Tensor, torch.Tensor, float],
+                      w1p: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """``proj_mlp_fused`` without LayerScale, the residual rows resident in the kernel's accumulators (x read once, written once).
+    ``w1p`` = fc1.weight with its column index in the fused order: ``w1[:, vt_token_order(384)]``; bf16 or fp16 operands."""
+    M, F = x.shape[0], w1p.shape[0]
+    g, b, eps = ln
+    f16 = attn.dtype == torch.float16
+    fn = lib().wvn_proj_mlp_resident_f16 if f16 else lib().wvn_proj_mlp_resident
+    check(fn(ptr(attn), attn.stride(0), ptr(wp), ptr(bp), ptr(g), ptr(b), float(eps), ptr(w1p), ptr(b1), ptr(w2p), ptr(b2), ptr(x),
+             x.stride(0), M, F, stream()), "wvn_proj_mlp_resident")
+    return x
+
+
 def mlp_fused(xn: Optional[torch.Tensor], w1: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor],
               x: torch.Tensor, ls: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
     """x [M,384] fp32 += gelu(xn [M,384] bf16 @ w1[F,384]^T + b1) @ w2^T + b2 in ONE launch, in place.  ``w2p`` is fc2.weight
