@@ -61,6 +61,10 @@ int wvn_version(void);
 #define WVN_VIT_FUSE_ANY_SIZE 4
 /* keep the attention projection a separate kernel where the fused MLP kernel runs (A/B runs; default: it is folded into that kernel) */
 #define WVN_VIT_NO_PROJ_IN_MLP 8
+/* A/B runs: do not let the projection + MLP kernel of a block apply the NEXT block's norm1 (default where fc1_w_fused and the next
+ * layer's qkv_w_fused are given: the rows leave that kernel a second time as LayerNorm'ed operand fragments and the next QKV
+ * kernel starts from those -- no second pass over the fp32 residual stream, no statistics, half the bytes) */
+#define WVN_VIT_NO_LN_HANDOVER 16
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
@@ -75,6 +79,8 @@ typedef struct wvn_vit_layer {
                             * fc1_w_fused[f][k] = fc1.weight[f][swap23(k)].  With it (and no LayerScale) the block's projection + MLP
                             * kernel keeps the residual rows in its accumulator registers: one read and one write of the residual
                             * stream per block instead of two and two (wvn_proj_mlp_resident).  NULL: the form without it */
+  const void* qkv_w_fused; /* optional with WVN_VIT_QKV_FUSED: qkv.weight with its column index permuted the same way: the QKV kernel
+                            * of this block can then start from the fragments the previous block's kernel left (wvn_qkv_prenorm) */
 } wvn_vit_layer;
 
 typedef struct wvn_vit_model {
@@ -152,7 +158,15 @@ int wvn_proj_mlp_fused(const void* attn, int lda, const void* Wp, const float* b
  * (the products are accumulated onto x + bias instead of being added to it at the end). */
 int wvn_proj_mlp_resident(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
                           float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx, int M,
-                          int F, void* stream);
+                          int F, const float* next_ln_g, const float* next_ln_b, float next_ln_eps, void* xn_next, void* stream);
+/* xn_next != NULL: the kernel also applies LayerNorm(next_ln_g, next_ln_b, next_ln_eps) -- blocks.(i+1).norm1 -- to the finished rows
+ * and writes the result as MFMA operand fragments: fragment (32-row group R, k-step s) = 1 KB at xn_next + (R * 24 + s) * 1024
+ * bytes, lane l's 16 bytes at l * 16 = the 8 values of row 32 R + (l & 31) at columns 16 s + 4 (l >> 5) + {0..3} and
+ * 16 s + 8 + 4 (l >> 5) + {0..3}; (M + 31) / 32 * 24 KB.  wvn_qkv_prenorm is the QKV projection that starts from them (Wperm =
+ * qkv.weight with bits 2 and 3 of its column index swapped, wvn_vit_layer.qkv_w_fused): = wvn_qkv_fused on the same rows up to
+ * fp32 summation order.  b2 then joins the rows as two operand-format terms through the matrix pipe, like bp. */
+int wvn_qkv_prenorm(const void* xn_frag, const void* Wperm, const float* bias, void* q, void* k, void* vt, int heads, int npad, int ntok_s,
+                    float q_scale, int M, void* stream);
 /* Block MLP in one launch: x [M,ldx] fp32 += gelu(xn [M,lda] bf16 * W1[F,384]^T + b1) * W2[384,F]^T + b2  (optionally
  * times LayerScale ls [384]).  W2p = W2 with the hidden index permuted as WVN_VIT_MLP_FUSED describes.  xn == NULL: the kernel
  * computes xn = LayerNorm(x; ln_g, ln_b, ln_eps) itself (what wvn_vit_forward uses: blocks.i.norm2 never touches memory).
@@ -175,7 +189,10 @@ int wvn_proj_mlp_fused_f16(const void* attn, int lda, const void* Wp, const floa
                            const float* ls2, float* x, int ldx, int M, int F, void* stream);
 int wvn_proj_mlp_resident_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
                               float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx,
-                              int M, int F, void* stream);
+                              int M, int F, const float* next_ln_g, const float* next_ln_b, float next_ln_eps, void* xn_next,
+                              void* stream);
+int wvn_qkv_prenorm_f16(const void* xn_frag, const void* Wperm, const float* bias, void* q, void* k, void* vt, int heads, int npad,
+                        int ntok_s, float q_scale, int M, void* stream);
 int wvn_mlp_fused_f16(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
                       const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream);
 int wvn_attention_f16(const void* q, const void* k, const void* vt, void* out, int B, int heads, int ntok, int npad, float scale,

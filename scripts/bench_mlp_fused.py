@@ -43,14 +43,23 @@ x.normal_()
 t = timeit(lambda: ops.mlp_fused(None, w1, b1, w2p * 0, b2 * 0, x, ln=(gam, bet, 1e-6)))
 print("fused (LayerNorm inside): %.1f us  (%.0f TFLOP/s)" % (t, fl / t / 1e6))
 import ctypes
-dbg = torch.zeros(256 * 4 * 6, dtype=torch.int64, device=dev)
-_lib.lib().wvn_debug_mlp_fused_timing(ctypes.c_void_p(dbg.data_ptr()))
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record(); ops.mlp_fused(None, w1, b1, w2p * 0, b2 * 0, x, ln=(gam, bet, 1e-6)); b.record(); torch.cuda.synchronize()
-_lib.lib().wvn_debug_mlp_fused_timing(ctypes.c_void_p(0))
-d = dbg.cpu().view(256, 4, 6).double()
-tot = d[..., 5].mean()
-names = ["LayerNorm prologue", "fc1 slices", "GELU + pack", "fc2 slices", "epilogue"]
-print("instrumented launch %.1f us; per wave cycles: total %.0f (max %.0f); " % (a.elapsed_time(b) * 1e3, tot, d[..., 5].max()) +
-      " | ".join("%s %.0f (%.1f%%)" % (n, d[..., i].mean(), 100 * d[..., i].mean() / tot) for i, n in enumerate(names)))
-print("MFMA floor per wave: %.0f cycles" % (M / 128 / 256 * 24 * 96 * 32))
+attn = torch.randn(M, 384, generator=g).to(torch.bfloat16).to(dev)
+wp = (torch.randn(384, 384, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+bp = torch.randn(384, generator=g).to(dev)
+w1p = w1[:, ops.vt_token_order(384, device=dev)].contiguous()
+t = timeit(lambda: ops.proj_mlp_resident(attn, wp * 0, bp * 0, (gam, bet, 1e-6), w1p, b1, w2p * 0, b2 * 0, x))
+print("projection + MLP, resident rows: %.1f us  (%.0f TFLOP/s)" % (t, (fl + 2.0 * M * 384 * 384) / t / 1e6))
+names = ["prologue (rows, projection, LayerNorm)", "fc1 slices", "GELU + pack", "fc2 slices", "epilogue", "projection slices"]
+for label, fn in (("LayerNorm + MLP", lambda: ops.mlp_fused(None, w1, b1, w2p * 0, b2 * 0, x, ln=(gam, bet, 1e-6))),
+                  ("resident", lambda: ops.proj_mlp_resident(attn, wp * 0, bp * 0, (gam, bet, 1e-6), w1p, b1, w2p * 0, b2 * 0, x))):
+    dbg = torch.zeros(256 * 4 * 12, dtype=torch.int64, device=dev)
+    _lib.lib().wvn_debug_mlp_fused_timing(ctypes.c_void_p(dbg.data_ptr()))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record(); torch.cuda.synchronize()
+    _lib.lib().wvn_debug_mlp_fused_timing(ctypes.c_void_p(0))
+    d = dbg.cpu().view(256, 4, 12).double()
+    tot = d[..., 7].mean()
+    print("%s: instrumented launch %.1f us; per wave cycles: total %.0f (max %.0f); " % (label, a.elapsed_time(b) * 1e3, tot, d[..., 7].max()) +
+          " | ".join("%s %.0f (%.1f%%)" % (n, d[..., i].mean(), 100 * d[..., i].mean() / tot) for i, n in enumerate(names)) +
+          " || inside the slices: " + " | ".join("%s %.0f (%.1f%%)" % (n, d[..., i].mean(), 100 * d[..., i].mean() / tot) for i, n in ((8, "wait for the next slice"), (9, "barrier"), (10, "DMA issue"))))
+print("MFMA floor per wave: %.0f cycles (+ %.0f projection)" % (M / 128 / 256 * 24 * 96 * 32, M / 128 / 256 * 288 * 32))

@@ -43,3 +43,33 @@ print("instrumented launch %.1f us; per wave cycles: total mean %.0f max %.0f | 
     a.elapsed_time(b) * 1e3, tot.mean(), tot.max(), d[..., 0].mean(), 100 * d[..., 0].mean() / tot.mean(), d[..., 1].mean(), 100 * d[..., 1].mean() / tot.mean(),
     d[..., 2].mean(), 100 * d[..., 2].mean() / tot.mean()))
 print("MFMA floor per wave: %.0f cycles" % (3.08 * 18 * 96 * 32))
+
+# the PRE form: rows already normalised, as operand fragments (what the resident projection + MLP kernel leaves)
+frag = (torch.randn((M + 31) // 32 * 24 * 512, generator=g) * 1.0).to(torch.bfloat16).to(dev)
+wperm = w[:, ops.vt_token_order(384, device=dev)].contiguous()
+
+
+def run_pre():
+    _lib.check(L.wvn_qkv_prenorm(frag.data_ptr(), wperm.data_ptr(), bias.data_ptr(), q.data_ptr(), k.data_ptr(), vt.data_ptr(), 6, npad, ntok_s,
+                                 0.18, M, torch.cuda.current_stream().cuda_stream))
+
+
+for _ in range(3):
+    run_pre()
+torch.cuda.synchronize()
+a.record()
+for _ in range(20):
+    run_pre()
+b.record()
+torch.cuda.synchronize()
+t = a.elapsed_time(b) / 20 * 1e3
+print("qkv_prenorm: %.1f us (%.0f TFLOP/s)" % (t, 2.0 * M * 384 * 1152 / t / 1e6))
+dbg.zero_()
+L.wvn_debug_qkv_fused_timing(ctypes.c_void_p(dbg.data_ptr()))
+a.record(); run_pre(); b.record(); torch.cuda.synchronize()
+L.wvn_debug_qkv_fused_timing(ctypes.c_void_p(0))
+d = dbg.cpu().view(256, 4, 4).double()
+tot = d[..., 3]
+print("instrumented launch %.1f us; per wave cycles: total mean %.0f max %.0f | fragment loads %.0f (%.1f%%) | slices %.0f (%.1f%%) | epilogues %.0f (%.1f%%)" % (
+    a.elapsed_time(b) * 1e3, tot.mean(), tot.max(), d[..., 0].mean(), 100 * d[..., 0].mean() / tot.mean(), d[..., 1].mean(), 100 * d[..., 1].mean() / tot.mean(),
+    d[..., 2].mean(), 100 * d[..., 2].mean() / tot.mean()))

@@ -155,6 +155,56 @@ def test_resident_form_matches_fused(dev, M, dtype):
     assert torch.equal(got, again), "run-to-run difference (pipeline race)"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("frames,ntok_s", [(1, 144), (3, 3152), (2, 784)])
+def test_resident_form_hands_next_layernorm_to_qkv(dev, frames, ntok_s, dtype):
+    """wvn_proj_mlp_resident with xn_next: the rows it stores are the rows of the plain call (b2 joins as two operand-format
+    terms instead of an fp32 add), the fragments it leaves are LayerNorm(next)(those rows) in the operand format, and
+    wvn_qkv_prenorm on them equals wvn_qkv_fused on the stored rows up to the operand ulps of rows that round the other way."""
+    M, Fh, npad = frames * ntok_s, 1536, (ntok_s + 127) // 128 * 128
+    _, w1, b1, w2, b2, x, _ = make(M, Fh, dev)
+    x = x * 2.0 + 0.4
+    x[:, 7] *= 12.0
+    attn = (torch.randn(M, 384, generator=g(11)) * 1.5).to(dtype).to(dev)
+    wp = (torch.randn(384, 384, generator=g(12)) * 0.05).to(dtype).to(dev)
+    bp = (torch.randn(384, generator=g(13)) * 0.3).to(dev)
+    gam = (torch.rand(384, generator=g(8)) + 0.5).to(dev)
+    bet = (torch.randn(384, generator=g(9)) * 0.2).to(dev)
+    ngam = (torch.rand(384, generator=g(18)) + 0.5).to(dev)
+    nbet = (torch.randn(384, generator=g(19)) * 0.2).to(dev)
+    wq = (torch.randn(1152, 384, generator=g(20)) * 0.05).to(dtype).to(dev)
+    bq = (torch.randn(1152, generator=g(21)) * 0.3).to(dev)
+    w1, w2 = w1.to(dtype), w2.to(dtype)
+    perm = ops.vt_token_order(384, device=dev)
+    w2p = w2[:, ops.vt_token_order(Fh, device=dev)].contiguous()
+    w1p, wqp = w1[:, perm].contiguous(), wq[:, perm].contiguous()
+    plain = ops.proj_mlp_resident(attn, wp, bp, (gam, bet, 1e-6), w1p, b1, w2p, b2, x.clone())
+    got, frag = ops.proj_mlp_resident(attn, wp, bp, (gam, bet, 1e-6), w1p, b1, w2p, b2, x.clone(), next_ln=(ngam, nbet, 1e-6))
+    torch.cuda.synchronize()
+    assert (got - plain).abs().max().item() <= 3e-5 * max(1.0, b2.abs().max().item())
+    xn = ops.unpack_row_fragments(frag, M).float()
+    want_xn = F.layer_norm(got, (384,), ngam, nbet, 1e-6)
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    assert ((xn - want_xn).abs() <= ulp * want_xn.abs() + 1e-3).all()
+    assert torch.equal(ops.unpack_row_fragments(frag, M), want_xn.to(dtype)) or ((xn - want_xn.to(dtype).float()) != 0).float().mean().item() < 0.02
+    QS = 0.125 * 1.4426950408889634
+    q1 = ops.qkv_prenorm(frag, wqp, bq, M, frames, ntok_s, npad, QS)
+    if dtype == torch.bfloat16:
+        q0 = ops.qkv_fused(got, (ngam, nbet, 1e-6), wq, bq, frames, ntok_s, npad, QS)
+        for name, a, b in zip("q k vt".split(), q1, q0):
+            err = (a.float() - b.float()).abs()
+            assert (err <= 1.6e-2 * b.float().abs() + 2e-2).all(), (name, err.max().item())
+            assert err.mean().item() <= 1e-3, name
+    else:   # fp16 operands: fp32 math on the fragments' own values
+        y = xn @ wq.float().T + bq
+        qh = (y[:, :384] * QS).view(frames, ntok_s, 6, 64).permute(0, 2, 1, 3).reshape(frames * 6, ntok_s, 64)
+        err = (q1[0][:, :ntok_s].float() - qh).abs()
+        assert (err <= 2e-3 * qh.abs() + 4e-3).all(), err.max().item()
+    again = ops.qkv_prenorm(frag, wqp, bq, M, frames, ntok_s, npad, QS)
+    for a, b in zip(q1, again):
+        assert torch.equal(a, b), "run-to-run difference (pipeline race)"
+
+
 def test_fused_layerscale(dev):
     M, Fh = 515, 1536
     xn, w1, b1, w2, b2, x, gam = make(M, Fh, dev, ls=True)

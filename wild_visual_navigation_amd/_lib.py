@@ -20,6 +20,7 @@ VIT_MLP_FUSED = 1
 VIT_QKV_FUSED = 2
 VIT_FUSE_ANY_SIZE = 4
 VIT_NO_PROJ_IN_MLP = 8
+VIT_NO_LN_HANDOVER = 16
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -33,7 +34,7 @@ class WvnError(RuntimeError):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s", "fc2_w_fused", "fc1_w_fused")]
+        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s", "fc2_w_fused", "fc1_w_fused", "qkv_w_fused")]
 
 
 class VitModel(C.Structure):
@@ -72,8 +73,10 @@ _SIGNATURES = {
     "wvn_mlp_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_gemm_f16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_qkv_fused_f16": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),
-    "wvn_proj_mlp_resident": ([_p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
-    "wvn_proj_mlp_resident_f16": ([_p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "wvn_proj_mlp_resident": ([_p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p], _i),
+    "wvn_proj_mlp_resident_f16": ([_p, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p], _i),
+    "wvn_qkv_prenorm": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),
+    "wvn_qkv_prenorm_f16": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),
     "wvn_proj_mlp_fused_f16": ([_p, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_mlp_fused_f16": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "wvn_attention_f16": ([_p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),

@@ -159,7 +159,7 @@ class VitBackbone:
         # None: the library decides by size (the fused kernels pay from about half a chip of row blocks on); True: always
         m.flags = ((_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
                    | (_lib.VIT_FUSE_ANY_SIZE if (fuse_mlp is True or fuse_qkv is True) else 0)
-                   | (0 if fuse_proj else _lib.VIT_NO_PROJ_IN_MLP))
+                   | (0 if fuse_proj else _lib.VIT_NO_PROJ_IN_MLP) | (_lib.VIT_NO_LN_HANDOVER if os.environ.get("WVN_NO_HANDOVER") else 0))
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
@@ -179,6 +179,11 @@ class VitBackbone:
                 L.fc2_w, L.fc2_s = mat8(sd[p + "mlp.fc2.weight"])
             else:
                 L.qkv_w = mat(sd[p + "attn.qkv.weight"])
+                if self.fuse_qkv and self.fuse_mlp and (p + "ls1.gamma") not in sd and self.dim == 384 and not os.environ.get("WVN_NO_RESIDENT"):
+                    # the copy the QKV kernel multiplies with when the previous block's kernel hands the normalised rows over as
+                    # operand fragments (include/wvn_hip.h: qkv_w_fused)
+                    kk = torch.arange(self.dim)
+                    L.qkv_w_fused = mat(sd[p + "attn.qkv.weight"][:, (kk & ~12) | ((kk & 4) << 1) | ((kk & 8) >> 1)])
                 if not self.fuse_mlp:
                     L.proj_w = mat(sd[p + "attn.proj.weight"])
                 w2 = sd[p + "mlp.fc2.weight"]

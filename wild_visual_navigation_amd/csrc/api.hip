@@ -267,8 +267,10 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
                  p.ntok_s = extra->ntok_s; p.q_scale = extra->q_scale; }
     return wvn_gemm_fp8_launch(p, epi, st);
   };
+  bool pre_qkv = false;   // this block's norm1 has been applied by the previous block's projection + MLP kernel (fragments in w.hid)
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
+    if (l == 0) pre_qkv = false;
     if (fp8) {
       if (!L.qkv_s || !L.proj_s || !L.fc1_s || !L.fc2_s) return WVN_ERR_ARG;
       { Span s(2, st); RET_IF(wvn_layernorm_fp8_launch(w.x, L.ln1_g, L.ln1_b, w.xq, d.D, w.sa, M, d.D, 1e-6f, st)); }
@@ -297,8 +299,12 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     bool qkv_done = false;
     if (qkv_fused) {  // LayerNorm 1 + QKV projection: one launch, no xn round trip
       Span s(3, st);
-      const int rc = opk.qkv_fused(w.x, d.D, L.ln1_g, L.ln1_b, 1e-6f, (const bf16_t*)L.qkv_w, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
-                                   (bf16_t*)w.v, d.H, d.npad, d.ntok_s, scale * 1.44269504088896340736f, M, st);
+      // (pre_qkv: the previous block's projection + MLP kernel has already applied this block's norm1 to the rows as they left it,
+      //  and parked the result as operand fragments in w.hid)
+      const int rc = pre_qkv ? opk.qkv_fused(nullptr, 0, nullptr, nullptr, 0.f, (const bf16_t*)L.qkv_w_fused, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
+                                             (bf16_t*)w.v, d.H, d.npad, d.ntok_s, scale * 1.44269504088896340736f, M, st, (const bf16_t*)w.hid)
+                             : opk.qkv_fused(w.x, d.D, L.ln1_g, L.ln1_b, 1e-6f, (const bf16_t*)L.qkv_w, L.qkv_b, (bf16_t*)w.q, (bf16_t*)w.k,
+                                             (bf16_t*)w.v, d.H, d.npad, d.ntok_s, scale * 1.44269504088896340736f, M, st, nullptr);
       if (rc != WVN_OK && rc != WVN_ERR_ARG) return rc;   // WVN_ERR_ARG: not eligible (e.g. q / k / v beyond the 2 GB a buffer
       qkv_done = rc == WVN_OK;                            // descriptor spans) -- the separate kernels below, as proj_mlp does
     }
@@ -324,9 +330,22 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     if (mlp_fused && proj_in_mlp) {  // attention projection + LayerNorm 2 + fc1 + GELU + fc2 + both residual updates: one launch
       Span s(6, st);
       if (!L.fc2_w_fused) return WVN_ERR_ARG;
-      const int rc = opk.proj_mlp_fused((const bf16_t*)w.xn, d.D, (const bf16_t*)L.proj_w, L.proj_b, L.ls1, L.ln2_g, L.ln2_b, 1e-6f,
-                                               (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b, L.ls2, w.x, d.D, M,
-                                               d.F, st, (const bf16_t*)L.fc1_w_fused);
+      // the resident form may also apply the NEXT block's norm1 and hand the rows to its QKV kernel as operand fragments
+      const bool last = l + 1 == m->depth;
+      bool hand_over = qkv_fused && !last && L.fc1_w_fused && m->layers[last ? l : l + 1].qkv_w_fused && !(m->flags & WVN_VIT_NO_LN_HANDOVER);
+      const wvn_vit_layer& Ln = m->layers[last ? l : l + 1];
+      int rc = WVN_ERR_ARG;
+      if (hand_over)
+        rc = opk.proj_mlp_fused((const bf16_t*)w.xn, d.D, (const bf16_t*)L.proj_w, L.proj_b, L.ls1, L.ln2_g, L.ln2_b, 1e-6f,
+                                (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b, L.ls2, w.x, d.D, M, d.F, st,
+                                (const bf16_t*)L.fc1_w_fused, Ln.ln1_g, Ln.ln1_b, 1e-6f, (bf16_t*)w.hid);
+      if (rc == WVN_ERR_ARG) {
+        hand_over = false;
+        rc = opk.proj_mlp_fused((const bf16_t*)w.xn, d.D, (const bf16_t*)L.proj_w, L.proj_b, L.ls1, L.ln2_g, L.ln2_b, 1e-6f,
+                                (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b, L.ls2, w.x, d.D, M, d.F, st,
+                                (const bf16_t*)L.fc1_w_fused, nullptr, nullptr, 0.f, nullptr);
+      }
+      pre_qkv = rc == WVN_OK && hand_over;
       if (rc == WVN_OK) continue;
       if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
@@ -374,20 +393,28 @@ int wvn_gemm_f16(const void* A, int lda, const void* W, int ldw, const float* bi
 int wvn_qkv_fused_f16(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
                       void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream) {
   return wvn_qkv_fused_launch_f16(x, ldx, ln_g, ln_b, ln_eps, (const bf16_t*)W, bias, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, heads, npad,
-                                  ntok_s, q_scale, M, (hipStream_t)stream);
+                                  ntok_s, q_scale, M, (hipStream_t)stream, nullptr);
+}
+int wvn_qkv_prenorm_f16(const void* xn_frag, const void* Wperm, const float* bias, void* q, void* k, void* vt, int heads, int npad,
+                        int ntok_s, float q_scale, int M, void* stream) {
+  if (!xn_frag) return WVN_ERR_ARG;
+  return wvn_qkv_fused_launch_f16(nullptr, 0, nullptr, nullptr, 0.f, (const bf16_t*)Wperm, bias, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, heads,
+                                  npad, ntok_s, q_scale, M, (hipStream_t)stream, (const bf16_t*)xn_frag);
 }
 int wvn_proj_mlp_fused_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
                            const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
                            const float* ls2, float* x, int ldx, int M, int F, void* stream) {
   return wvn_proj_mlp_fused_launch_f16((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, ls1, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1,
-                                       (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream, nullptr);
+                                       (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream, nullptr, nullptr, nullptr, 0.f, nullptr);
 }
 int wvn_proj_mlp_resident_f16(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
                               float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx,
-                              int M, int F, void* stream) {
+                              int M, int F, const float* next_ln_g, const float* next_ln_b, float next_ln_eps, void* xn_next,
+                              void* stream) {
   if (!W1p) return WVN_ERR_ARG;
   return wvn_proj_mlp_fused_launch_f16((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, nullptr, ln_g, ln_b, ln_eps, nullptr, b1,
-                                       (const bf16_t*)W2p, b2, nullptr, x, ldx, M, F, (hipStream_t)stream, (const bf16_t*)W1p);
+                                       (const bf16_t*)W2p, b2, nullptr, x, ldx, M, F, (hipStream_t)stream, (const bf16_t*)W1p, next_ln_g, next_ln_b,
+                                   next_ln_eps, (bf16_t*)xn_next);
 }
 int wvn_mlp_fused_f16(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,
                       const void* W2p, const float* b2, const float* ls, float* x, int ldx, int M, int F, void* stream) {
@@ -403,21 +430,28 @@ int wvn_attention_f16(const void* q, const void* k, const void* vt, void* out, i
 int wvn_qkv_fused(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const void* W, const float* bias,
                   void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, void* stream) {
   return wvn_qkv_fused_launch(x, ldx, ln_g, ln_b, ln_eps, (const bf16_t*)W, bias, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, heads, npad, ntok_s,
-                              q_scale, M, (hipStream_t)stream);
+                              q_scale, M, (hipStream_t)stream, nullptr);
+}
+int wvn_qkv_prenorm(const void* xn_frag, const void* Wperm, const float* bias, void* q, void* k, void* vt, int heads, int npad, int ntok_s,
+                    float q_scale, int M, void* stream) {
+  if (!xn_frag) return WVN_ERR_ARG;
+  return wvn_qkv_fused_launch(nullptr, 0, nullptr, nullptr, 0.f, (const bf16_t*)Wperm, bias, (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, heads, npad,
+                              ntok_s, q_scale, M, (hipStream_t)stream, (const bf16_t*)xn_frag);
 }
 
 int wvn_proj_mlp_fused(const void* attn, int lda, const void* Wp, const float* bp, const float* ls1, const float* ln_g,
                        const float* ln_b, float ln_eps, const void* W1, const float* b1, const void* W2p, const float* b2,
                        const float* ls2, float* x, int ldx, int M, int F, void* stream) {
   return wvn_proj_mlp_fused_launch((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, ls1, ln_g, ln_b, ln_eps, (const bf16_t*)W1, b1,
-                                   (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream, nullptr);
+                                   (const bf16_t*)W2p, b2, ls2, x, ldx, M, F, (hipStream_t)stream, nullptr, nullptr, nullptr, 0.f, nullptr);
 }
 int wvn_proj_mlp_resident(const void* attn, int lda, const void* Wp, const float* bp, const float* ln_g, const float* ln_b,
                           float ln_eps, const void* W1p, const float* b1, const void* W2p, const float* b2, float* x, int ldx, int M,
-                          int F, void* stream) {
+                          int F, const float* next_ln_g, const float* next_ln_b, float next_ln_eps, void* xn_next, void* stream) {
   if (!W1p) return WVN_ERR_ARG;
   return wvn_proj_mlp_fused_launch((const bf16_t*)attn, lda, (const bf16_t*)Wp, bp, nullptr, ln_g, ln_b, ln_eps, nullptr, b1,
-                                   (const bf16_t*)W2p, b2, nullptr, x, ldx, M, F, (hipStream_t)stream, (const bf16_t*)W1p);
+                                   (const bf16_t*)W2p, b2, nullptr, x, ldx, M, F, (hipStream_t)stream, (const bf16_t*)W1p, next_ln_g, next_ln_b,
+                                   next_ln_eps, (bf16_t*)xn_next);
 }
 
 int wvn_mlp_fused(const void* xn, int lda, const float* ln_g, const float* ln_b, float ln_eps, const void* W1, const float* b1,

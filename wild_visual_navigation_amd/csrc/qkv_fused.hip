@@ -41,6 +41,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 struct QkvFusedParams {
   const float* X; int ldx;       // residual stream [M][384] fp32
+  const op16_t* XN;              // PRE: the rows already normalised, as operand fragments (layout below); X / ln_* unused
   const float *ln_g, *ln_b; float ln_eps;
   const op16_t* W;               // [3 * heads * 64][384]
   const float* bias;             // [3 * heads * 64]
@@ -60,7 +61,12 @@ __device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool TIMING>
+// PRE: the LayerNorm has been applied by the kernel that produced the rows (mlp_fused.hip, resident form with NXT), which left them
+// as ready-made operand fragments: fragment (32-row group R, k-step s) = 1 KB at XN + (R * 24 + s) * 1024, lane l's 16 bytes at
+// l * 16 -- one fully coalesced load per fragment, no LDS pass, no statistics, half the bytes of the fp32 rows.  The k-slots of a
+// lane are the ones the accumulator layout hands over (columns 16 s + {4 hi .. + 3, 8 + 4 hi .. + 3}), so W is the copy of
+// qkv.weight with bits 2 and 3 of its column index swapped.
+template <bool TIMING, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -87,8 +93,10 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
   float* bias_l = (float*)(smem + TAB_OFF);
   float* lng_l = bias_l + N;
   for (int i = tid; i < N; i += 256) bias_l[i] = p.bias ? p.bias[i] : 0.f;
-  for (int i = tid; i < KD; i += 256) { lng_l[i] = p.ln_g[i]; lng_l[KD + i] = p.ln_b[i]; }
+  if constexpr (!PRE)
+    for (int i = tid; i < KD; i += 256) { lng_l[i] = p.ln_g[i]; lng_l[KD + i] = p.ln_b[i]; }
   if (total == 0) return;
+  const __amdgpu_buffer_rsrc_t rs_xn = __builtin_amdgcn_make_buffer_rsrc((void*)(PRE ? p.XN : p.W), 0, (unsigned)((size_t)((p.M + 31) / 32) * 24 * 1024), 0x00020000);
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)N * KD * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.base, 0, p.bytes, 0x00020000);
@@ -176,6 +184,17 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
     // ---- LayerNorm of the wave's 64 rows -> MFMA operand fragments xf[row sub-tile][k-step] (row l31, k = 16 s + 8 hi .. + 7) ----
     opx8_t xf[2][KD / 16];
     int dep = 0;   // serialises the two 32-row passes (384 fp32 values in flight at once would not fit the register file)
+    if constexpr (PRE) {
+#pragma unroll
+      for (int k = 0; k < KD / 16; ++k)     // in the order the slices consume them: loads retire in order, the first slice starts after 16 of the 48
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs) {
+          const unsigned so = __builtin_amdgcn_readfirstlane(((m0w >> 5) + rs) * 24 + k) * 1024u;   // groups past M: zeros (bounds)
+          union { u32x4_t u; opx8_t v; } a;
+          a.u = __builtin_amdgcn_raw_buffer_load_b128(rs_xn, lane * 16, so, 0);
+          xf[rs][k] = a.v;
+        }
+    } else
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) {
       // The rows come in COALESCED (an instruction = 4 rows x 256 contiguous bytes = 8 whole lines) and are turned into the fragment
@@ -381,9 +400,13 @@ int qkv_fused_num_cus() {
 // Eligibility: D == 384 (heads == 6), ntok_s % 16 == 0, M % 16 == 0, npad % 16 == 0, q / k / v^T within 2 GB of each other.
 long long* WVN_OPSYM(g_qkv_fused_dbg) = nullptr;   // wvn_debug_qkv_fused_timing (scripts/bench_qkv_fused.py)
 
+// xn_frag != nullptr: the PRE form (x, ln_* unused; W = the column-swapped copy of qkv.weight; (M + 31) / 32 * 24 KB of fragments).
 int WVN_OPSYM(wvn_qkv_fused_launch)(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const op16_t* W, const float* bias,
-                         op16_t* q, op16_t* k, op16_t* vt, int heads, int npad, int ntok_s, float q_scale, int M, hipStream_t st) {
-  if (!x || !ln_g || !ln_b || !W || !q || !k || !vt || M <= 0 || heads * 64 != KD || (ldx % 4) != 0) return WVN_ERR_ARG;
+                         op16_t* q, op16_t* k, op16_t* vt, int heads, int npad, int ntok_s, float q_scale, int M, hipStream_t st,
+                         const op16_t* xn_frag) {
+  const bool pre = xn_frag != nullptr;
+  if (pre) { if (((uintptr_t)xn_frag & 15) != 0) return WVN_ERR_ARG; x = (const float*)xn_frag; ldx = 4; }
+  if (!x || (!pre && (!ln_g || !ln_b)) || !W || !q || !k || !vt || M <= 0 || heads * 64 != KD || (ldx % 4) != 0) return WVN_ERR_ARG;
   if ((ntok_s % 16) || (M % 16) || (npad % 16)) return WVN_ERR_ARG;
   if ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) != 0) return WVN_ERR_ARG;
   const uintptr_t lo = std::min({(uintptr_t)q, (uintptr_t)k, (uintptr_t)vt}), hi = std::max({(uintptr_t)q, (uintptr_t)k, (uintptr_t)vt});
@@ -391,16 +414,20 @@ int WVN_OPSYM(wvn_qkv_fused_launch)(const float* x, int ldx, const float* ln_g, 
   if (hi - lo + one >= (1ull << 31)) return WVN_ERR_ARG;
   const int N = 3 * heads * 64, lds = TAB_OFF + (N + 2 * KD) * 4;
   static LdsOptIn lds_opt_in;   // per device (common.h)
-  if (const int rc = lds_opt_in(160 * 1024, (const void*)qkv_fused_kernel<false>, (const void*)qkv_fused_kernel<true>)) return rc;
+  if (const int rc = lds_opt_in(160 * 1024, (const void*)qkv_fused_kernel<false>, (const void*)qkv_fused_kernel<true>, (const void*)qkv_fused_kernel<false, true>, (const void*)qkv_fused_kernel<true, true>)) return rc;
   QkvFusedParams p{};
+  p.XN = xn_frag;
   p.X = x; p.ldx = ldx; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.W = W; p.bias = bias;
   p.base = (op16_t*)lo; p.q_off = (unsigned)((uintptr_t)q - lo); p.k_off = (unsigned)((uintptr_t)k - lo); p.v_off = (unsigned)((uintptr_t)vt - lo);
   p.bytes = (unsigned)(hi - lo + one);
   p.heads = heads; p.npad = npad; p.ntok_s = ntok_s; p.q_scale = q_scale != 0.f ? q_scale : 1.f; p.M = M;
   const int nrb = ceil_div(M, BM), ncu = qkv_fused_num_cus();
   p.dbg = WVN_OPSYM(g_qkv_fused_dbg);
-  if (g_qkv_fused_dbg) hipLaunchKernelGGL(qkv_fused_kernel<true>, dim3(nrb < ncu ? nrb : ncu), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(qkv_fused_kernel<false>, dim3(nrb < ncu ? nrb : ncu), dim3(256), lds, st, p);
+  const dim3 grid(nrb < ncu ? nrb : ncu);
+  if (pre && p.dbg) hipLaunchKernelGGL((qkv_fused_kernel<true, true>), grid, dim3(256), lds, st, p);
+  else if (pre) hipLaunchKernelGGL((qkv_fused_kernel<false, true>), grid, dim3(256), lds, st, p);
+  else if (p.dbg) hipLaunchKernelGGL(qkv_fused_kernel<true>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(qkv_fused_kernel<false>, grid, dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

@@ -52,11 +52,12 @@ struct GemmBf16Params {
   int wvn_proj_mlp_fused_launch##SFX(const bf16_t* attn, int lda_attn, const bf16_t* Wp, const float* bp, const float* ls1,         \
                                      const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W1, const float* b1,         \
                                      const bf16_t* W2p, const float* b2, const float* ls2, float* x, int ldx, int M, int F,         \
-                                     hipStream_t st, const bf16_t* W1p);                                                            \
+                                     hipStream_t st, const bf16_t* W1p, const float* nx_g, const float* nx_b, float nx_eps,         \
+                                     bf16_t* xn_next);                                                                              \
   /* qkv_fused.hip: LayerNorm(x) -> q | k | v^T in the layouts of attention_bf16.hip (D = 384, heads = 6), one launch */            \
   int wvn_qkv_fused_launch##SFX(const float* x, int ldx, const float* ln_g, const float* ln_b, float ln_eps, const bf16_t* W,       \
                                 const float* bias, bf16_t* q, bf16_t* k, bf16_t* vt, int heads, int npad, int ntok_s,               \
-                                float q_scale, int M, hipStream_t st);                                                              \
+                                float q_scale, int M, hipStream_t st, const bf16_t* xn_frag);                                       \
   /* row-panel kernel for N == 384 residual updates with long K (gemm_n384.hip); WVN_ERR_ARG when not eligible */                   \
   int wvn_gemm_n384_launch##SFX(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done, int force = 0);                   \
   /* attention_bf16.hip */                                                                                                          \

@@ -474,6 +474,28 @@ def qkv_fused(x: torch.Tensor, ln: Tuple[torch.Tensor, torch.Tensor, float], w: 
     return q, k, vt
 
 
+def qkv_prenorm(xn_frag: torch.Tensor, w_perm: torch.Tensor, bias: Optional[torch.Tensor], M: int, frames: int, ntok_s: int, npad: int,
+                q_scale: float = 0.0):
+    """The QKV projection of ``qkv_fused`` from rows that are already normalised and laid out as operand fragments
+    (``proj_mlp_resident(..., next_ln=...)`` writes them; include/wvn_hip.h).  ``w_perm = w[:, vt_token_order(384)]``."""
+    heads = 6
+    n = frames * heads * npad * 64
+    buf = torch.zeros(3 * n, dtype=w_perm.dtype, device=w_perm.device)
+    q, k, vt = buf[:n].view(frames * heads, npad, 64), buf[n:2 * n].view(frames * heads, npad, 64), buf[2 * n:].view(frames * heads, 64, npad)
+    fn = lib().wvn_qkv_prenorm_f16 if w_perm.dtype == torch.float16 else lib().wvn_qkv_prenorm
+    check(fn(ptr(xn_frag), ptr(w_perm), ptr(bias), ptr(q), ptr(k), ptr(vt), heads, npad, ntok_s, float(q_scale), M, stream()), "wvn_qkv_prenorm")
+    return q, k, vt
+
+
+def unpack_row_fragments(frag: torch.Tensor, M: int) -> torch.Tensor:
+    """[M, 384] rows from the fragment layout of ``proj_mlp_resident(next_ln=...)`` (tests): fragment (R, s) holds, for lane l, row
+    32 R + (l & 31), columns 16 s + 4 (l >> 5) + {0..3} and 16 s + 8 + 4 (l >> 5) + {0..3}."""
+    G = (M + 31) // 32
+    f = frag.view(G, 24, 2, 32, 2, 4)          # [R, s, hi, row, half, e]
+    rows = f.permute(0, 3, 1, 4, 2, 5)          # [R, row, s, half, hi, e]: column = 16 s + 8 half + 4 hi + e
+    return rows.reshape(G * 32, 384)[:M]
+
+
 def proj_mlp_fused(attn: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tensor], ln: Tuple[torch.Tensor, torch.Tensor, float], w1: torch.Tensor,
                    b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor], x: torch.Tensor,
                    ls1: Optional[torch.Tensor] = None, ls2: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -487,16 +509,23 @@ def proj_mlp_fused(attn: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tens
 
 
 def proj_mlp_resident(attn: torch.Tensor, wp: torch.Tensor, bp: Optional[torch.Tensor], ln: Tuple[torch.Tensor, torch.Tensor, float],
-                      w1p: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+                      w1p: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor], x: torch.Tensor,
+                      next_ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None):
     """``proj_mlp_fused`` without LayerScale, the residual rows resident in the kernel's accumulators (x read once, written once).
-    ``w1p`` = fc1.weight with its column index in the fused order: ``w1[:, vt_token_order(384)]``; bf16 or fp16 operands."""
+    ``w1p`` = fc1.weight with its column index in the fused order: ``w1[:, vt_token_order(384)]``; bf16 or fp16 operands.
+    ``next_ln=(gamma, beta, eps)``: also returns LayerNorm(x_new) as operand fragments for ``qkv_prenorm`` (x, fragments)."""
     M, F = x.shape[0], w1p.shape[0]
     g, b, eps = ln
     f16 = attn.dtype == torch.float16
     fn = lib().wvn_proj_mlp_resident_f16 if f16 else lib().wvn_proj_mlp_resident
+    frag = None
+    ng, nb, ne = (None, None, 0.0)
+    if next_ln is not None:
+        ng, nb, ne = next_ln
+        frag = torch.zeros((M + 31) // 32 * 24 * 512, dtype=attn.dtype, device=x.device)
     check(fn(ptr(attn), attn.stride(0), ptr(wp), ptr(bp), ptr(g), ptr(b), float(eps), ptr(w1p), ptr(b1), ptr(w2p), ptr(b2), ptr(x),
-             x.stride(0), M, F, stream()), "wvn_proj_mlp_resident")
-    return x
+             x.stride(0), M, F, ptr(ng), ptr(nb), float(ne), ptr(frag), stream()), "wvn_proj_mlp_resident")
+    return x if next_ln is None else (x, frag)
 
 
 def mlp_fused(xn: Optional[torch.Tensor], w1: torch.Tensor, b1: Optional[torch.Tensor], w2p: torch.Tensor, b2: Optional[torch.Tensor],
