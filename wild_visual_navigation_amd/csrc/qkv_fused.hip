@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
 
   int si = 0, rslot = 0;   // slice being multiplied (workgroup-local index) and its ring slot
   bool stored = false;     // a tile epilogue has run (wave-uniform)
+  int pf_slack = 0;        // PRE: open_next calls whose slice was issued BEFORE the latest prefetch (see prefetch below)
   // "slice si + 1 is readable" (runs in the middle of slice si; see mlp_fused.hip open_next).  The wave's VM queue behind the DMA
   // of slice si + 1 (issued three slices ago): the DMAs of si + 2 and si + 3 (4 each) and -- tile epilogues come every three
   // slices -- the 8 stores of exactly one epilogue, once there has been one.  Vector memory operations retire in order (the
@@ -145,7 +146,11 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
     __builtin_amdgcn_sched_barrier(0);
     if (si + 1 < total) {
       if (si + 3 < total) {
-        if (stored) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (pf_slack > 0) {   // PRE: the NPF = 36 prefetch loads of the next segment sit behind slice si + 1 in the queue, too
+          --pf_slack;
+          if (stored) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+        } else if (stored) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -178,6 +183,8 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
   };
   const long long t_begin = now();
   constexpr unsigned OOB = 0x80000000u;
+  constexpr int NPF = PRE ? 36 : 1;   // PRE: fragments of the next segment fetched ahead (k-steps 0 .. 17 of both row sub-tiles: 144 registers)
+  u32x4_t pf[NPF];
   for (int s = 0; s < nseg; ++s) {
     const int m0w = seg_rb(s) * BM + wave * RW;
     const long long c_ln0 = now();
@@ -185,15 +192,20 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
     opx8_t xf[2][KD / 16];
     int dep = 0;   // serialises the two 32-row passes (384 fp32 values in flight at once would not fit the register file)
     if constexpr (PRE) {
+      // fragment (rs, k) of the segment's rows; in the order the slices consume them (k-major): loads retire in order.  From the
+      // second segment on, the first NPF of the 48 are already here: they were fetched while the previous segment was being multiplied
+      // (all 256 workgroups pulling 192 KB each at the same moment is a 50 MB burst at HBM speed: 19 % of the kernel without this)
 #pragma unroll
-      for (int k = 0; k < KD / 16; ++k)     // in the order the slices consume them: loads retire in order, the first slice starts after 16 of the 48
-#pragma unroll
-        for (int rs = 0; rs < 2; ++rs) {
+      for (int i = 0; i < 48; ++i) {
+        const int k = i >> 1, rs = i & 1;
+        union { u32x4_t u; opx8_t v; } a;
+        if (i < NPF && s > 0) a.u = pf[i < NPF ? i : 0];
+        else {
           const unsigned so = __builtin_amdgcn_readfirstlane(((m0w >> 5) + rs) * 24 + k) * 1024u;   // groups past M: zeros (bounds)
-          union { u32x4_t u; opx8_t v; } a;
           a.u = __builtin_amdgcn_raw_buffer_load_b128(rs_xn, lane * 16, so, 0);
-          xf[rs][k] = a.v;
         }
+        xf[rs][k] = a.v;
+      }
     } else
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs) {
@@ -373,8 +385,27 @@ __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
       __builtin_amdgcn_sched_barrier(0);
     };
     const int t0 = seg_t0(s), t1 = seg_t1(s);
-    for (int j = t0; j < t1 && j < NQK; ++j) tile(j, std::true_type{});
-    for (int j = t0 > NQK ? t0 : NQK; j < t1; ++j) tile(j, std::false_type{});
+    bool pf_done = false;
+    auto prefetch = [&](int j) {
+      if constexpr (PRE) {
+        // Once per segment, after a tile that differs from workgroup to workgroup: 256 workgroups fetching together are a 37 MB
+        // burst that takes ~10 us, and vector memory operations retire in order -- the weight slices issued after the prefetch
+        // cannot be used before it has landed; spread over the tiles, a prefetch is back within the three slices that are in flight
+        // ahead of it.  (No branch around the loads themselves: past the last segment they re-read this segment's fragments.)
+        if (j != t0 + (int)((blockIdx.x * 5u) % 12u) && !(j == t1 - 1 && !pf_done)) return;
+        if (pf_done) return;
+        pf_done = true;
+        pf_slack = 3;
+        const int m0n = seg_rb(s + 1 < nseg ? s + 1 : s) * BM + wave * RW;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+          const unsigned so = __builtin_amdgcn_readfirstlane(((m0n >> 5) + (i & 1)) * 24 + (i >> 1)) * 1024u;
+          pf[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_xn, lane * 16, so, 0);
+        }
+      }
+    };
+    for (int j = t0; j < t1 && j < NQK; ++j) { tile(j, std::true_type{}); prefetch(j); }
+    for (int j = t0 > NQK ? t0 : NQK; j < t1; ++j) { tile(j, std::false_type{}); prefetch(j); }
   }
   if constexpr (TIMING) {
     if (lane == 0 && p.dbg) {
