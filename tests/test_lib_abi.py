@@ -31,8 +31,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.VitLayer) == 19 * 8
-    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 19 * 8
+    assert C.sizeof(_lib.VitLayer) == 21 * 8
+    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 21 * 8
     assert C.sizeof(_lib.MlpDesc) == 16
 
 
