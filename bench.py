@@ -523,7 +523,7 @@ def main():
         else:
             metric = "frames/sec (448x448 DINO-ViT-S/8 + seg + MLP train-step)"
             segdesc = ("grid segmentation (32-pixel cells)" if args.segmentation != "stego" else
-                       "STEGO head + per-image cosine k-means (20 clusters, at patch resolution, single pass: no flip TTA)"
+                       "STEGO head + per-image cosine k-means (20 clusters, at patch resolution, single pass: no flip TTA -- the opt-in fast form of StegoInterface; its defaults, flip TTA + k-means over the code pixels, are the stego_upstream leg of this line)"
                        if args.stego_reading == "patch" else
                        "STEGO head with flip TTA (two backbone passes per frame) + per-image cosine k-means over the 448x448 "
                        "up-sampled code pixels (20 clusters)")

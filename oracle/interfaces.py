@@ -64,9 +64,10 @@ def dino_inference(sd, img: torch.Tensor, input_size: int, patch: int, heads: in
 # package (stego_interface.py:14,43,91,94-100) -> PARITY UNPINNED; the definition below is the one
 # this build documents (DESIGN.md "STEGO definition"): published STEGO segmentation head
 # (1x1 conv D->C linear branch + 1x1 conv D->D, ReLU, 1x1 conv D->C non-linear branch, summed),
-# single pass (no flip TTA), and, for run_clustering=True, a deterministic per-image cosine
-# k-means on the patch-resolution code (n_image_clusters centroids, fixed iteration count,
-# lowest-index tie-break) whose labels are then nearest-upsampled by stego_interface.py:108.
+# averaged with the flipped-back code of the mirrored frame, and, for run_clustering=True, a deterministic
+# per-image cosine k-means (n_image_clusters centroids, fixed iteration count, lowest-index tie-break)
+# over the code up-sampled to the input size; the single-pass / patch-resolution forms (labels then
+# nearest-upsampled by stego_interface.py:108) are the documented cheap options.
 # ----------------------------------------------------------------------------------------------
 STEGO_CODE_DIM = 90
 KMEANS_ITERS = 10
@@ -267,17 +268,28 @@ def upsample_nearest(lab: torch.Tensor, out: int) -> torch.Tensor:
 
 
 def stego_inference(
-    sd, head, img: torch.Tensor, input_size: int, patch: int, heads: int, n_image_clusters: int
+    sd, head, img: torch.Tensor, input_size: int, patch: int, heads: int, n_image_clusters: int,
+    flip_tta: bool = True, cluster_resolution: str = "pixel",
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """StegoInterface.inference as used by FeatureExtractor (run_clustering=True, run_crf=False).
-    Returns (code [B,C,H,H] fp32, cluster_pred [1,B,H,H] int32)."""
+    Returns (code [B,C,H,H] fp32, cluster_pred [1,B,H,H] int32).  Defaults = the upstream behaviour as this build reads it (the code
+    averaged with the flipped-back code of the mirrored frame, k-means over the H x H up-sampled code pixels); flip_tta=False /
+    cluster_resolution="patch" are the cheap forms (single pass, k-means over the patch codes, labels nearest-upsampled)."""
     x = dino_transform(img, input_size)
     tok = vit.vit_tokens(sd, x, patch, heads)[:, 1:]
     B, P, D = tok.shape
     G = input_size // patch
-    code = stego_code_tokens(head, tok)  # [B, P, C]
-    labels = np.stack([kmeans_cosine_labels(code[b].numpy(), n_image_clusters) for b in range(B)])
-    labels = torch.from_numpy(labels).reshape(B, G, G)
+    if flip_tta:
+        tok_m = vit.vit_tokens(sd, x.flip(-1), patch, heads)[:, 1:]
+        code = stego_code_flip_average(head, tok, tok_m, G)
+    else:
+        code = stego_code_tokens(head, tok)  # [B, P, C]
     code_map = code.reshape(B, G, G, -1).permute(0, 3, 1, 2)
     H = img.shape[2]
+    if cluster_resolution == "pixel":
+        labels = np.stack([kmeans_cosine_labels_pixels(code[b].numpy(), G, input_size, n_image_clusters) for b in range(B)])
+        labels = torch.from_numpy(labels).reshape(B, input_size, input_size)
+    else:
+        labels = np.stack([kmeans_cosine_labels(code[b].numpy(), n_image_clusters) for b in range(B)])
+        labels = torch.from_numpy(labels).reshape(B, G, G)
     return upsample_bilinear_ac(code_map, H), upsample_nearest(labels, H)

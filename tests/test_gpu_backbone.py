@@ -184,26 +184,37 @@ def test_feature_extractor_grid_and_random(dev, prec, tol):
     assert (f2.cpu() - dense[0].reshape(384, -1)[:, idx].T).abs().max().item() < tol
 
 
-def test_feature_extractor_stego_pipeline(dev):
-    """feature_type = segmentation_type = 'stego' (the reference's ROS default): code, k-means
-    segment map (bit-exact given the GPU's own fp32 code), relabel, pooled 90-d features."""
+@pytest.mark.parametrize("reading", ["upstream", "cheap"])
+def test_feature_extractor_stego_pipeline(dev, reading):
+    """feature_type = segmentation_type = 'stego' (the reference's ROS default): code, k-means segment map (bit-exact given the
+    GPU's own fp32 code), relabel, pooled 90-d features -- under the class DEFAULTS (the upstream reading: flip-averaged code,
+    k-means over the code pixels) and under the documented cheap options (single pass, k-means over the patch codes)."""
     S, K = 224, 20
+    G = S // 8
     sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=7, depth=2)
     head = OI.make_stego_head_state_dict(384, 90, seed=0)
     img = torch.rand(1, 3, S, S, generator=g(8))
     tok = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
-    code_ref = OI.stego_code_tokens(head, tok)  # [1, P, 90]
+    if reading == "upstream":
+        code_ref = OI.stego_code_flip_average(head, tok, OV.vit_tokens(sd, OI.normalize(img).flip(-1), 8, 6)[:, 1:], G)
+        opts = {}
+    else:
+        code_ref = OI.stego_code_tokens(head, tok)  # [1, P, 90]
+        opts = dict(flip_tta=False, cluster_resolution="patch")
     for prec, tol in (("fp32", 1e-3), ("bf16", 0.25)):
         fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=S,
                               backbone_type="vit_small", patch_size=8, pretrained_weights=sd, head_weights=head,
-                              n_image_clusters=K, precision=prec)
+                              n_image_clusters=K, precision=prec, **opts)
         edges, feat, seg, center, dense = fe.extract(img.to(dev), return_dense_features=True)
         code = fe._extractor.feature_tokens.cpu()
         assert (code - code_ref).abs().max().item() < tol, prec
         # integer outputs: oracle clustering of the SAME fp32 code must agree bit-for-bit
-        lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), K))
-        G = S // 8
-        want_seg = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), S)[0, 0].long()
+        if reading == "upstream":
+            lab = OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(code[0].numpy(), G, S, K))
+            want_seg = torch.from_numpy(lab).reshape(S, S).long()
+        else:
+            lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), K))
+            want_seg = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), S)[0, 0].long()
         assert torch.equal(seg.cpu(), want_seg), prec
         n_seg = int(want_seg.max()) + 1
         assert feat.shape == (n_seg, 90) and center.shape == (n_seg, 2)
@@ -261,7 +272,8 @@ def test_stego_checkpoint_probes_flip_tta_and_pixel_clustering(dev, tmp_path, la
     code = OI.stego_code_tokens(head, tok)                                      # [2, G*G, 90]
     tol = {"fp32": 1e-4, "exact": 1e-4, "bf16": 0.15}[prec]
 
-    si = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=False, precision=prec)
+    si = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=False, precision=prec,
+                        flip_tta=False, cluster_resolution="patch")   # (the probes at patch resolution: labels comparable patch by patch)
     lin, clu = si.inference(img.to(dev))
     assert (si.feature_tokens.cpu() - code).abs().max().item() < tol
     assert lin.shape == clu.shape == (1, 2, S, S) and lin.dtype == torch.int32
@@ -271,8 +283,7 @@ def test_stego_checkpoint_probes_flip_tta_and_pixel_clustering(dev, tmp_path, la
     thr = 0.999 if prec != "bf16" else 0.9
     assert agree(clu, want_clu) >= thr and agree(lin, want_lin) >= thr
 
-    flip = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=True, precision=prec,
-                          flip_tta=True)
+    flip = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=True, precision=prec)   # (the default)
     tok_f = OV.vit_tokens(sd, OI.normalize(img.flip(-1)), P, 6)[:, 1:]
     code_f = OI.stego_code_tokens(head, tok_f).reshape(2, G, G, 90).flip(2).reshape(2, G * G, 90)
     assert (flip.code_tokens(img.to(dev)).cpu() - 0.5 * (code + code_f)).abs().max().item() < tol

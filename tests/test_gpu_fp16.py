@@ -145,7 +145,7 @@ def test_fp16_stego_extract_batch_and_per_pixel(dev, golden):
     head = OI.make_stego_head_state_dict(384, 90, seed=2)
     img = torch.rand(3, 3, S, S, generator=g(12))
     fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=S, pretrained_weights=sd, head_weights=head,
-                          n_image_clusters=5, precision="fp16")
+                          n_image_clusters=5, precision="fp16", flip_tta=False, cluster_resolution="patch")
     feat, seg, nseg = fe.extract_batch(img.to(dev))
     tok = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
     code = OI.stego_code_tokens(head, tok)

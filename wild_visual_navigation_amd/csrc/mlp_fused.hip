@@ -54,7 +54,8 @@ constexpr int B1_OFF = B2_OFF + KD * 4;               // 151,040
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 // Timing experiments (scripts/build_variant.sh ... -DWVN_MLP_EXP=<bits>; results are WRONG with any bit set): 1 no DMA after the
-// prologue, 2 no barrier, 4 no fragment reads, 8 no vmcnt waits -- what each ingredient of the slice loop costs.
+// prologue, 2 no barrier, 4 no fragment reads, 8 no vmcnt waits, 16 fragment reads at compile-time slot offsets -- what each
+// ingredient of the slice loop costs.
 #ifndef WVN_MLP_EXP
 #define WVN_MLP_EXP 0
 #endif
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
   for (int sg = 0; sg < 4; ++sg) off2[sg] = l31 * 128 + (((2 * sg + hi) ^ ((l31 >> 1) & 7)) << 4);  // W2 slice: row l31, k-step sg
   auto frag = [&](auto Qc, int slot, int i) -> opx8_t {
     constexpr int Q = decltype(Qc)::value;
+    if constexpr (WVN_MLP_EXP & 16) slot = Q % NS;   // (timing experiment: what compile-time slot offsets would buy -- a ring of six)
     if constexpr (Q < 3) return *(const opx8_t*)(smem + slot * SLICE + off1[i >> 1] + (i & 1) * 8192);   // sub-tile t = i & 1
     else return *(const opx8_t*)(smem + slot * SLICE + off2[i >> 2] + (i & 3) * 4096);                    // column tile T = i & 3
   };

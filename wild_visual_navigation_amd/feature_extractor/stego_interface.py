@@ -9,11 +9,14 @@ either the upstream STEGO (``net.model.* / net.cluster1.* / cluster_probe.cluste
 self_supervised_segmentation (``backbone.* / segmentation_head.*``) key layout is loaded (``load_stego_checkpoint``); without
 one, seeded synthetic weights are used and a warning says so.  ``run_crf=True`` (pydensecrf, CPU) is not available.
 
-Two knobs make the definition explicit instead of implicit (both default to the cheap form; bench.py names what it ran):
-  flip_tta            False | True : average the code with the code of the horizontally flipped frame (upstream get_code does;
-                                     doubles the backbone work)
-  cluster_resolution  "patch" | "pixel": k-means over the G x G patch codes (labels then nearest-upsampled: segments are
-                                     patch-aligned) or over the H x H bilinearly up-sampled code pixels
+Two knobs make the definition explicit instead of implicit.  Their DEFAULTS are the upstream behaviour as published (Stego.get_code
+averages the code with the flipped-back code of the mirrored frame; postprocess clusters the code up-sampled to the image size);
+the cheap forms are opt-in, and bench.py names which one each of its legs ran:
+  flip_tta            True | False : average the code with the code of the horizontally flipped frame (a second backbone pass; the
+                                     mirror is a reversed column table of the fused ingest, no flipped frame exists)
+  cluster_resolution  "pixel" | "patch": k-means over the H x H bilinearly up-sampled code pixels (interpolated on the fly, the
+                                     dense code never exists) or over the G x G patch codes (labels then nearest-upsampled:
+                                     segments are patch-aligned; 2.8x the frames/s of the default pair)
 """
 import re
 import warnings
@@ -104,8 +107,8 @@ class StegoInterface:
         head_weights: Optional[Dict[str, torch.Tensor]] = None,
         probe_weights: Optional[Dict[str, torch.Tensor]] = None,
         max_chunk: int = 16,
-        flip_tta: bool = False,
-        cluster_resolution: str = "patch",
+        flip_tta: bool = True,
+        cluster_resolution: str = "pixel",
         allow_synthetic: bool = False,
         fuse_mlp: Optional[bool] = None,
         fuse_qkv: Optional[bool] = None,
