@@ -77,6 +77,35 @@ def test_fused_block_kernels_agree_with_separate_kernels(dev, S, B, fuse_mlp, fu
         VitBackbone(sd, S, 8, 6, device=dev, precision="fp32", fuse_mlp=True)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_layernorm_handover_between_blocks(dev, monkeypatch, prec):
+    """Where the block kernels run, block i's projection + MLP kernel keeps the residual rows in its accumulators and hands block
+    i + 1 its norm1 output as operand fragments (include/wvn_hip.h: fc1_w_fused / qkv_w_fused).  Same rounding points as the forms
+    without it (WVN_NO_HANDOVER: LayerNorm inside the QKV kernel; WVN_NO_RESIDENT: rows through memory twice per block), other
+    summation orders; all three inside the oracle tolerance, and the chunked call (state per launch sequence) equals the whole one."""
+    S, B = 224, 5
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=3, depth=12)
+    img = torch.rand(B, 3, S, S, generator=g(17))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    kw = dict(device=dev, precision=prec, fuse_mlp=True, fuse_qkv=True)
+    a = VitBackbone(sd, S, 8, 6, max_chunk=8, **kw).forward_tokens(img.to(dev)).cpu()
+    chunked = VitBackbone(sd, S, 8, 6, max_chunk=2, **kw).forward_tokens(img.to(dev)).cpu()     # 2 + 2 + 1 frames
+    monkeypatch.setenv("WVN_NO_HANDOVER", "1")
+    b = VitBackbone(sd, S, 8, 6, max_chunk=8, **kw).forward_tokens(img.to(dev)).cpu()
+    monkeypatch.setenv("WVN_NO_RESIDENT", "1")
+    c = VitBackbone(sd, S, 8, 6, max_chunk=8, **kw).forward_tokens(img.to(dev)).cpu()
+    gate = 2.5e-2 if prec == "bf16" else 3e-3
+    for t in (a, b, c, chunked):
+        assert torch.isfinite(t).all() and rel_l2(t, want) < gate
+    assert not torch.equal(a, b) and not torch.equal(b, c)      # three different kernel sequences did run
+    assert rel_l2(a, b) < gate and rel_l2(a, c) < gate
+    assert rel_l2(a, chunked) < gate * 0.5
+    monkeypatch.delenv("WVN_NO_HANDOVER")
+    monkeypatch.delenv("WVN_NO_RESIDENT")
+    a2 = VitBackbone(sd, S, 8, 6, max_chunk=8, **kw).forward_tokens(img.to(dev)).cpu()
+    assert torch.equal(a, a2), "run-to-run difference"
+
+
 def test_fused_kernels_take_over_at_batch_size(dev):
     """From about half a chip of row blocks on wvn_vit_forward switches to the single-kernel block stages by itself: a 12-frame
     448^2 batch runs them (same tokens as forcing them), a 2-frame batch does not (same tokens as forbidding them)."""
