@@ -64,7 +64,7 @@ def test_pixel_kmeans_at_448_against_oracle(dev):
 
 
 def test_upstream_reading_end_to_end(dev):
-    """flip TTA + pixel clustering + general pooling through FeatureExtractor.extract_batch (what bench.py's stego_upstream leg
+    """flip TTA + pixel clustering + general pooling through FeatureExtractor.extract_batch (what bench.py's headline leg
     runs), exact precision: code within 1e-3 of the CPU oracle's flip-averaged code, labels bit-exact given the GPU's code,
     pooled features == per-segment means of the explicitly up-sampled code."""
     S, G, K = 64, 8, 5
