@@ -321,12 +321,113 @@ __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* 
   }
 }
 
-// (Measured and not kept: two pixels per lane as packed pairs -- every centroid value feeding one v_pk_fma_f32 -- with the centroids
-// through the scalar cache, 24.2 ms per 64-frame k-means against 22.5 for this form, and with the centroids in LDS, 33.5 ms:
-// at 250 registers only two waves per SIMD are left to cover the operand fetches.  Multiply + add against fma in the dot
-// products: no difference, the kernel waits for its centroid operands, not for the VALU.)
+// Lane = pixel.  The K dot products of a pixel advance TOGETHER, sixteen channels at a time: K accumulators in registers, the
+// pixel's interpolated values only for the current channel block (each dot product is still one fma chain strictly in channel
+// order: blocks ascending, channels ascending within a block -- the bits of the sequential definition).  ~60 registers instead of
+// the 138 of the pixel-vector-resident form, i.e. 8 waves per SIMD instead of 3: the centroid values come through the scalar
+// cache (uniform addresses), and it takes that many waves to cover their latency -- the old form ran at a third of the fp32 rate
+// this chip sustains (scripts/ubench/valu_rate.hip: 147 TFLOP/s of plain v_fma_f32 at 8 waves per SIMD, 95 at one).  The staged
+// code rows are padded to a multiple of 4 floats so that a block's taps are ds_read_b128s.
+// (Measured earlier and not kept: two pixels per lane as packed pairs, 24.2 ms per 64-frame k-means against 22.5 for the
+// pixel-vector-resident form; centroids in LDS, 33.5 ms.)
+__device__ inline f32x16_t km_sload16(const float* p) {   // 16 consecutive floats at a wave-uniform address -> SGPRs
+  f32x16_t r;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p));
+  return r;
+}
+// the same, issued BEFORE the users of `busy` (the previous request's result): without the tie hipcc moves the sixteen fmas that read
+// `busy` above the request, into the same scalar registers, and the wave waits out every request's full latency
+__device__ inline f32x16_t km_sload16_before(const float* p, f32x16_t& busy) {
+  f32x16_t r;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=&s"(r), "+s"(busy) : "s"(p));
+  return r;
+}
+__device__ inline void km_swait(f32x16_t& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }   // (ties the users of r to the wait)
+
+template <int C, int KMAX, bool EXACTK>
+__global__ __launch_bounds__(512) void km_pix_assign_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+                                                            const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
+                                                            int K) {
+  constexpr int CP = (C + 3) & ~3;   // padded row pitch in LDS
+  constexpr int DB = 16;             // channels per block
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [2][G][CP]
+  const int b = blockIdx.y;
+  const float scale = lerp_scale(G, H);
+  const float* __restrict__ cb = cent + (size_t)b * K * C;   // uniform addresses: served by the scalar cache
+  int s0 = -1, s1 = -1;            // the code rows staged in LDS
+  for (int y = blockIdx.x * PIX_RPB; y < min(H, (blockIdx.x + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
+    const LerpTap ty = lerp_tap(y, G, scale);
+    if (ty.i0 != s0 || ty.i1 != s1) {
+      __syncthreads();
+      const float* r0 = code + ((size_t)b * G * G + (size_t)ty.i0 * G) * C;
+      const float* r1 = code + ((size_t)b * G * G + (size_t)ty.i1 * G) * C;
+      for (int i = threadIdx.x; i < G * C; i += blockDim.x) {
+        const int g = i / C, d = i - g * C;
+        rows[g * CP + d] = r0[i];
+        rows[(G + g) * CP + d] = r1[i];
+      }
+      __syncthreads();
+      s0 = ty.i0; s1 = ty.i1;
+    }
+    for (int x = threadIdx.x; x < H; x += blockDim.x) {
+      const LerpTap tx = lerp_tap(x, G, scale);
+      const size_t p = (size_t)b * H * H + (size_t)y * H + x;
+      const float ri = rinv[p];
+      const float* a0 = rows + tx.i0 * CP;
+      const float* a1 = rows + tx.i1 * CP;
+      const float* b0 = rows + (G + tx.i0) * CP;
+      const float* b1 = rows + (G + tx.i1) * CP;
+      float acc[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int d0 = 0; d0 < C; d0 += DB) {
+        constexpr int dummy = 0; (void)dummy;
+        const int n = C - d0 < DB ? C - d0 : DB;   // (compile-time after unrolling)
+        float v[DB];
+#pragma unroll
+        for (int j = 0; j < DB; ++j)
+          if (j < n)
+            v[j] = __fmul_rn(bilerp_fixed(a0[d0 + j], a1[d0 + j], b0[d0 + j], b1[d0 + j], tx.w0, tx.w1, ty.w0, ty.w1), ri);
+        // The centroid values are wave-uniform: sixteen of them arrive in SGPRs by ONE scalar load, issued by hand -- centroid
+        // k + 1's while centroid k's are being used (left to hipcc, all K x 16 loads of a block are requested at once and 300 - 1400
+        // scalar registers spilled, whatever the source order).  Scalar loads return out of order, so each wait is for all of them:
+        // the one in flight has had sixteen fmas (x 8 waves) of cover by then.  (The last block of a 90-channel row reads 6 floats
+        // past it: the next centroid's, or -- for the last centroid -- the first bytes of the partial-sum area behind `cent`.)
+        f32x16_t cq[2];
+        const float* pk = cb + d0;   // ONE running address (120 precomputed ones cost more scalar registers than there are)
+        cq[0] = km_sload16(pk);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          {   // (every k < KMAX is computed: for K < KMAX the extra rows read whatever follows the centroids -- finite or not, they are
+              //  never compared -- which keeps the loop free of branches and the scalar registers of merges)
+            km_swait(cq[k & 1]);
+            if (k + 1 < KMAX) {
+              pk += C;
+              asm volatile("" : "+s"(pk));
+              cq[(k + 1) & 1] = km_sload16_before(pk, cq[k & 1]);
+            }
+#pragma unroll
+            for (int j = 0; j < DB; ++j)
+              if (j < n) acc[k] = __fmaf_rn(v[j], cq[k & 1][j], acc[k]);
+            asm volatile("" : "+v"(acc[k]));   // (the chain is finished here: its sixteen scalars are dead before the next request)
+          }
+        }
+      }
+      int best = 0;
+      float bv = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if ((EXACTK || k < K) && acc[k] > bv) { bv = acc[k]; best = k; }
+      labels[p] = best;
+    }
+  }
+}
+
+// The pixel-vector-resident form (x[C] in registers, four dot-product chains in flight, centroids through the scalar cache at
+// hipcc's discretion): any K; what runs for K > 32, where the accumulator-resident form above has no registers left.
 template <int C>
-__global__ __launch_bounds__(256) void km_pix_assign_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+__global__ __launch_bounds__(256) void km_pix_assign_wide_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
                                                             int K) {
   extern __shared__ float rows[];  // [2][G][C]
@@ -504,14 +605,20 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   const size_t P = (size_t)H * H;
   const int ngroup = (int)((P + (size_t)KM_SUPER * KM_CHUNK - 1) / ((size_t)KM_SUPER * KM_CHUNK));
   const PixScratch s = pix_carve(scratch, B, G, H, C, K);
-  const size_t shm_rows = (size_t)2 * G * C * sizeof(float);
+  const size_t shm_rows = (size_t)2 * G * C * sizeof(float), shm_rows_pad = (size_t)2 * G * ((C + 3) & ~3) * sizeof(float);
   static LdsOptIn lds_opt_in;
-  if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C>)) return rc;
+  if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C, 20, true>,
+                                (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>)) return rc;
   hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(256), shm_rows, st, code, s.rinv, G, H);
   hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K);
   WVN_LAUNCH_CHECK();
   for (int it = 0; it <= iters; ++it) {
-    hipLaunchKernelGGL((km_pix_assign_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
+    const dim3 ga(ceil_div(H, PIX_RPB), B);
+    // (512 threads: the two staged code rows are 41 KB at C = 90 -- three workgroups per CU -- and it takes 6 waves per SIMD to cover
+    //  the scalar loads; at 448 pixels per image row the eighth wave of a workgroup only helps with the staging)
+    if (K == 20) hipLaunchKernelGGL((km_pix_assign_kernel<C, 20, true>), ga, dim3(512), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
+    else if (K <= 32) hipLaunchKernelGGL((km_pix_assign_kernel<C, 32, false>), ga, dim3(512), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
+    else hipLaunchKernelGGL((km_pix_assign_wide_kernel<C>), ga, dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
     if (K <= 32)
