@@ -72,7 +72,15 @@ def dino_inference(sd, img: torch.Tensor, input_size: int, patch: int, heads: in
 STEGO_CODE_DIM = 90
 KMEANS_ITERS = 10
 KMEANS_CHUNK = 64
-KMEANS_SUPER = 8   # chunk partials are folded in groups of 8 consecutive chunks
+KMEANS_SUPER = None  # (tests) overrides kmeans_super() when set
+
+
+def kmeans_super(P: int) -> int:
+    """Chunk partials are folded in groups of this many consecutive chunks: 8 (512 points) up to 8192 points, 32 above (the
+    pixel-resolution clustering of a 448 x 448 frame then folds 98 group partials instead of 392; csrc/stego.hip: km_super)."""
+    if KMEANS_SUPER is not None:
+        return KMEANS_SUPER
+    return 32 if P > 8192 else 8
 
 
 def make_stego_head_state_dict(D: int = 384, C: int = STEGO_CODE_DIM, seed: int = 0) -> Dict[str, torch.Tensor]:
@@ -197,12 +205,13 @@ def kmeans_cosine_labels_numpy(code: np.ndarray, K: int, iters: int = KMEANS_ITE
         lab = assign(cent)
         # centroid sums in the kernel's fixed order: chunks of KMEANS_CHUNK consecutive points, members of a
         # cluster added in ascending point order inside a chunk (from 0); chunk partials added in ascending
-        # chunk order inside groups of KMEANS_SUPER consecutive chunks (from 0); group partials added in
+        # chunk order inside groups of kmeans_super(P) consecutive chunks (from 0); group partials added in
         # ascending group order (from 0) -- one fp32 rounding per addition
         sums = np.zeros((K, C), dtype=np.float32)
-        for g0 in range(0, P, KMEANS_CHUNK * KMEANS_SUPER):
+        sup = kmeans_super(P)
+        for g0 in range(0, P, KMEANS_CHUNK * sup):
             grp = np.zeros((K, C), dtype=np.float32)
-            for p0 in range(g0, min(P, g0 + KMEANS_CHUNK * KMEANS_SUPER), KMEANS_CHUNK):
+            for p0 in range(g0, min(P, g0 + KMEANS_CHUNK * sup), KMEANS_CHUNK):
                 part = np.zeros((K, C), dtype=np.float32)
                 np.add.at(part, lab[p0:p0 + KMEANS_CHUNK], x[p0:p0 + KMEANS_CHUNK])  # unbuffered: ascending order
                 grp = (grp + part).astype(np.float32)

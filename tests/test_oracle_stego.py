@@ -37,7 +37,7 @@ def test_fixed_order_upsampling_is_atens_up_to_rounding():
 
 
 def test_kmeans_group_fold_degenerates_for_short_inputs():
-    """Up to KMEANS_SUPER chunks (512 points) the three-level order IS the flat chunk order (0 + x = x exactly)."""
+    """Up to kmeans_super(P) chunks (512 points) the three-level order IS the flat chunk order (0 + x = x exactly)."""
     code = np.random.default_rng(1).standard_normal((500, 16)).astype(np.float32)
     lab = OI.kmeans_cosine_labels_numpy(code, 4, iters=3)
     keep = OI.KMEANS_SUPER
@@ -58,7 +58,8 @@ def test_c_restatement_of_the_kmeans_equals_the_numpy_statement():
     build_oracle.build()
     assert OI._oracle_lib() is not None
     rng = np.random.default_rng(5)
-    for P, C, K, it in ((700, 16, 5, 4), (1500, 90, 20, 3), (64, 90, 3, 10), (1100, 33, 7, 2)):
+    # (9300 points: above 8192 the chunk partials fold in groups of 32 chunks instead of 8 -- kmeans_super)
+    for P, C, K, it in ((700, 16, 5, 4), (1500, 90, 20, 3), (64, 90, 3, 10), (1100, 33, 7, 2), (9300, 16, 6, 2)):
         code = (rng.standard_normal((P, C)) + 3.0 * rng.standard_normal(C)).astype(np.float32)      # a strong common component
         a = OI.kmeans_cosine_labels(code, K, it)
         b = OI.kmeans_cosine_labels_numpy(code, K, it)

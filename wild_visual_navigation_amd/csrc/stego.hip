@@ -9,7 +9,7 @@
 //   * centroid sums        : points are cut into chunks of KM_CHUNK (64) consecutive indices; inside a
 //                            chunk the members of a cluster are added in ascending point order starting
 //                            from 0; the chunk partials are added in ascending chunk order inside groups
-//                            of KM_SUPER (8) consecutive chunks, and the group partials in ascending group
+//                            of km_super(P) (8; 32 above 8192 points) consecutive chunks, and the group partials in ascending group
 //                            order (the three-level order lets the pixel-resolution form keep a group's
 //                            running sums on chip; at every level an addition chain starts from +0)
 //   * argmax               : first maximum (lowest cluster id wins ties)
@@ -37,7 +37,9 @@ __device__ inline float rinv_norm(float n2) {
 typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
 constexpr int KM_MAXK = 64;
 constexpr int KM_CHUNK = 64;
-constexpr int KM_SUPER = 8;   // chunk partials are folded in groups of 8 consecutive chunks (512 points)
+// chunk partials are folded in groups of km_super(P) consecutive chunks: 8 (512 points) for up to 8192 points, 32 (2048 points) for
+// more -- the pixel-resolution clustering of a 448 x 448 frame then folds 98 group partials per centroid value instead of 392
+__host__ __device__ inline int km_super(long long P) { return P > 8192 ? 32 : 8; }
 
 // Rows of [rows][C] (C <= 128) are staged through LDS so that global traffic is coalesced (a row is 360 B at
 // C = 90; one thread walking its own row touches 64 cache lines per load instruction) while each thread still
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict_
   const int k = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   if (d < C) {
     float s = 0.f;
-    for (int c0 = 0; c0 < nchunk; c0 += group) {   // group = KM_SUPER for chunk partials, 1 when `part` holds group partials
+    for (int c0 = 0; c0 < nchunk; c0 += group) {   // group = km_super(P) for chunk partials, 1 when `part` holds group partials
       float gsum = 0.f;
       const int c1 = min(nchunk, c0 + group);
       for (int c = c0; c < c1; ++c) gsum = __fadd_rn(gsum, part[(((size_t)b * nchunk + c) * K + k) * C + d]);
@@ -231,7 +233,7 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
     hipLaunchKernelGGL(km_partial_kernel, dim3(nchunk, B), dim3(threads_c), shm_kc + K * sizeof(int), st, xn, labels,
                        part, pcnt, P, C, K, nchunk);
     WVN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, part, pcnt, cent, C, K, nchunk, KM_SUPER);
+    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, part, pcnt, cent, C, K, nchunk, km_super(P));
     WVN_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(km_relabel_kernel, dim3(B), dim3(1024), 0, st, labels, nseg, P, K, relabel);
@@ -250,7 +252,7 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
 //   rinv    : lane = pixel; the block's two source code rows in LDS
 //   assign  : lane = pixel, x[C] in registers, centroids through the scalar cache (uniform addresses), four independent
 //             dot-product chains in flight
-//   partial : one wave per group of KM_SUPER chunks, a lane owns two channels; the code values of a pixel's cell stay in
+//   partial : one wave per group of km_super(P) chunks, a lane owns two channels; the code values of a pixel's cell stay in
 //             registers while consecutive pixels share it (the next cell's are prefetched); a cluster's running sums stay in
 //             registers while the label repeats -- the addition order is exactly the sequential one.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(256) void km_pix_assign_wide_kernel(const float* __
 template <int KMAX>
 __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const int* __restrict__ labels, float* __restrict__ part,
-                                                            int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup) {
+                                                            int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup, int nsup) {
   extern __shared__ __attribute__((aligned(8))) float tab[];   // [K][C]: the current chunk's parked sums
   const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const long long P = (long long)H * H;
@@ -510,11 +512,11 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
   const float* __restrict__ cb = code + (size_t)b * G * G * C;
   const int* __restrict__ lab = labels + (size_t)b * P;
   const float* __restrict__ rv = rinv + (size_t)b * P;
-  const long long g0 = (long long)g * KM_SUPER * KM_CHUNK;
+  const long long g0 = (long long)g * nsup * KM_CHUNK;
   const float scale = lerp_scale(G, H);
   int mycnt = 0;                       // lane k: members of cluster k in this group
   auto tap = [&](int off) -> f32x2v_t { return *(const f32x2v_t*)(cb + off + c2); };
-  for (int c = 0; c < KM_SUPER; ++c) {
+  for (int c = 0; c < nsup; ++c) {
     const long long p0 = g0 + (long long)c * KM_CHUNK;
     if (p0 >= P) break;                                  // (uniform)
     const int n = (int)min((long long)KM_CHUNK, P - p0);
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
 
 struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; size_t floats; };
 PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
-  const size_t P = (size_t)H * H, ngroup = (P + (size_t)KM_SUPER * KM_CHUNK - 1) / ((size_t)KM_SUPER * KM_CHUNK);
+  const size_t P = (size_t)H * H, ngroup = (P + (size_t)km_super(P) * KM_CHUNK - 1) / ((size_t)km_super(P) * KM_CHUNK);
   PixScratch s;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return base ? base + o : (float*)nullptr; };
@@ -603,7 +605,7 @@ template <int C>
 int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int K, int iters, int relabel,
                       hipStream_t st) {
   const size_t P = (size_t)H * H;
-  const int ngroup = (int)((P + (size_t)KM_SUPER * KM_CHUNK - 1) / ((size_t)KM_SUPER * KM_CHUNK));
+  const int nsup = km_super((long long)P), ngroup = (int)((P + (size_t)nsup * KM_CHUNK - 1) / ((size_t)nsup * KM_CHUNK));
   const PixScratch s = pix_carve(scratch, B, G, H, C, K);
   const size_t shm_rows = (size_t)2 * G * C * sizeof(float), shm_rows_pad = (size_t)2 * G * ((C + 3) & ~3) * sizeof(float);
   static LdsOptIn lds_opt_in;
@@ -623,10 +625,10 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
     if (it == iters) break;
     if (K <= 32)
       hipLaunchKernelGGL(km_pix_partial_kernel<32>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
-                         s.part, s.pcnt, G, H, C, K, ngroup);
+                         s.part, s.pcnt, G, H, C, K, ngroup, nsup);
     else
       hipLaunchKernelGGL(km_pix_partial_kernel<KM_MAXK>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv,
-                         labels, s.part, s.pcnt, G, H, C, K, ngroup);
+                         labels, s.part, s.pcnt, G, H, C, K, ngroup, nsup);
     WVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1);
     WVN_LAUNCH_CHECK();
