@@ -20,6 +20,8 @@
 //   partial : one workgroup per (chunk, image), lane = channel: LDS table part[K][C] indexed by label
 //             (each lane owns its column, so no atomics and a fixed order)
 //   update  : one workgroup per image: ordered sum over chunks, sequential norm, divide
+#include <stdlib.h>
+
 #include "common.h"
 #include "wvn_internal.h"
 
@@ -330,8 +332,9 @@ __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* 
 // cache (uniform addresses), and it takes that many waves to cover their latency -- the old form ran at a third of the fp32 rate
 // this chip sustains (scripts/ubench/valu_rate.hip: 147 TFLOP/s of plain v_fma_f32 at 8 waves per SIMD, 95 at one).  The staged
 // code rows are padded to a multiple of 4 floats so that a block's taps are ds_read_b128s.
-// (Measured earlier and not kept: two pixels per lane as packed pairs, 24.2 ms per 64-frame k-means against 22.5 for the
-// pixel-vector-resident form; centroids in LDS, 33.5 ms.)
+// (Measured and not kept: two pixels per lane -- (y, x) and (y + 1, x), three staged code rows, every scalar load feeding 32 fmas per
+// lane -- 21.0 ms per 64-frame k-means against 20.4 for this form: four waves per SIMD cover less than six; earlier, on the
+// pixel-vector-resident form: packed pairs 24.2 ms against 22.5, centroids in LDS 33.5 ms.)
 __device__ inline f32x16_t km_sload16(const float* p) {   // 16 consecutive floats at a wave-uniform address -> SGPRs
   f32x16_t r;
   asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p));
