@@ -236,7 +236,7 @@ def _blobs(H, W, S, seed):
     return ((ys[..., None] - cy) ** 2 + (xs[..., None] - cx) ** 2).argmin(-1)
 
 
-@pytest.mark.parametrize("G,H,S,D", [(8, 64, 7, 24), (28, 224, 50, 90), (56, 448, 100, 384)])
+@pytest.mark.parametrize("G,H,S,D", [(8, 64, 7, 24), (28, 224, 50, 90), (56, 448, 100, 384), (56, 448, 20, 90)])
 def test_segpool_fused_matches_dense_reference(dev, G, H, S, D):
     B = 2
     tok = torch.randn(B, G * G, D, generator=g(1))
