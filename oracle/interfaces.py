@@ -76,11 +76,11 @@ KMEANS_SUPER = None  # (tests) overrides kmeans_super() when set
 
 
 def kmeans_super(P: int) -> int:
-    """Chunk partials are folded in groups of this many consecutive chunks: 8 (512 points) up to 8192 points, 32 above (the
-    pixel-resolution clustering of a 448 x 448 frame then folds 98 group partials instead of 392; csrc/stego.hip: km_super)."""
+    """Chunk partials are folded in groups of this many consecutive chunks: 8 (512 points) up to 8192 points, 16 above (the
+    pixel-resolution clustering of a 448 x 448 frame then folds 196 group partials instead of 392; csrc/stego.hip: km_super)."""
     if KMEANS_SUPER is not None:
         return KMEANS_SUPER
-    return 32 if P > 8192 else 8
+    return 16 if P > 8192 else 8
 
 
 def make_stego_head_state_dict(D: int = 384, C: int = STEGO_CODE_DIM, seed: int = 0) -> Dict[str, torch.Tensor]:

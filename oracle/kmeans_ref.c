@@ -17,8 +17,8 @@
 #include <string.h>
 
 #define CHUNK 64
-/* chunk partials are folded in groups of SUPER consecutive chunks: 8 up to 8192 points, 32 above (csrc/stego.hip: km_super) */
-#define SUPER (P > 8192 ? 32 : 8)
+/* chunk partials are folded in groups of SUPER consecutive chunks: 8 up to 8192 points, 16 above (csrc/stego.hip: km_super) */
+#define SUPER (P > 8192 ? 16 : 8)
 
 static float rinv_norm(float n2) {
   float n = sqrtf(n2); /* correctly rounded (IEEE) */

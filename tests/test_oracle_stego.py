@@ -58,7 +58,7 @@ def test_c_restatement_of_the_kmeans_equals_the_numpy_statement():
     build_oracle.build()
     assert OI._oracle_lib() is not None
     rng = np.random.default_rng(5)
-    # (9300 points: above 8192 the chunk partials fold in groups of 32 chunks instead of 8 -- kmeans_super)
+    # (9300 points: above 8192 the chunk partials fold in groups of 16 chunks instead of 8 -- kmeans_super)
     for P, C, K, it in ((700, 16, 5, 4), (1500, 90, 20, 3), (64, 90, 3, 10), (1100, 33, 7, 2), (9300, 16, 6, 2)):
         code = (rng.standard_normal((P, C)) + 3.0 * rng.standard_normal(C)).astype(np.float32)      # a strong common component
         a = OI.kmeans_cosine_labels(code, K, it)

@@ -9,7 +9,7 @@
 //   * centroid sums        : points are cut into chunks of KM_CHUNK (64) consecutive indices; inside a
 //                            chunk the members of a cluster are added in ascending point order starting
 //                            from 0; the chunk partials are added in ascending chunk order inside groups
-//                            of km_super(P) (8; 32 above 8192 points) consecutive chunks, and the group partials in ascending group
+//                            of km_super(P) (8; 16 above 8192 points) consecutive chunks, and the group partials in ascending group
 //                            order (the three-level order lets the pixel-resolution form keep a group's
 //                            running sums on chip; at every level an addition chain starts from +0)
 //   * argmax               : first maximum (lowest cluster id wins ties)
@@ -39,9 +39,12 @@ __device__ inline float rinv_norm(float n2) {
 typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
 constexpr int KM_MAXK = 64;
 constexpr int KM_CHUNK = 64;
-// chunk partials are folded in groups of km_super(P) consecutive chunks: 8 (512 points) for up to 8192 points, 32 (2048 points) for
-// more -- the pixel-resolution clustering of a 448 x 448 frame then folds 98 group partials per centroid value instead of 392
-__host__ __device__ inline int km_super(long long P) { return P > 8192 ? 32 : 8; }
+// chunk partials are folded in groups of km_super(P) consecutive chunks: 8 (512 points) for up to 8192 points, 16 (1024 points) for
+// more -- the pixel-resolution clustering of a 448 x 448 frame then folds 196 group partials per centroid value instead of 392
+#ifndef WVN_KM_SUPER_BIG
+#define WVN_KM_SUPER_BIG 16   // (timing experiments only: the oracles state 16; measured 8 / 16 / 24 / 32 / 48: 20.6 / 19.6 / 19.6 / 20.0 / 20.7 ms per 64-frame k-means)
+#endif
+__host__ __device__ inline int km_super(long long P) { return P > 8192 ? WVN_KM_SUPER_BIG : 8; }
 
 // Rows of [rows][C] (C <= 128) are staged through LDS so that global traffic is coalesced (a row is 360 B at
 // C = 90; one thread walking its own row touches 64 cache lines per load instruction) while each thread still
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(512) void km_pix_assign_kernel(const float* __restr
         // scalar registers spilled, whatever the source order).  Scalar loads return out of order, so each wait is for all of them:
         // the one in flight has had sixteen fmas (x 8 waves) of cover by then.  (The last block of a 90-channel row reads 6 floats
         // past it: the next centroid's, or -- for the last centroid -- the first bytes of the partial-sum area behind `cent`.)
+        // (Pairs of centroids -- two requests in flight, one wait per 32 fmas -- measured the same: 19.70 against 19.64 ms.)
         f32x16_t cq[2];
         const float* pk = cb + d0;   // ONE running address (120 precomputed ones cost more scalar registers than there are)
         cq[0] = km_sload16(pk);
@@ -626,7 +630,10 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
     else hipLaunchKernelGGL((km_pix_assign_wide_kernel<C>), ga, dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
-    if (K <= 32)
+    if (K <= 20)   // (fewer group-partial registers: 5 waves per SIMD instead of 4)
+      hipLaunchKernelGGL(km_pix_partial_kernel<20>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
+                         s.part, s.pcnt, G, H, C, K, ngroup, nsup);
+    else if (K <= 32)
       hipLaunchKernelGGL(km_pix_partial_kernel<32>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
                          s.part, s.pcnt, G, H, C, K, ngroup, nsup);
     else
