@@ -126,6 +126,13 @@ int wvn_vit_forward_u8(const wvn_vit_model* m, const unsigned char* img, int bat
 int wvn_vit_forward_frames(const wvn_vit_model* m, const void* frames, int frames_u8, int src_h, int src_w, const int* rows,
                            const int* cols, int batch, float* tokens_f32, void* tokens_lowp, int ld_lowp, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* The same for the frames AND their mirror images in ONE launch sequence of 2 * batch frames (the flip pass of the upstream
+ * Stego.get_code, stego_interface.py:91): frame batch + i of the outputs is frame i gathered through cols_mirror (the reversed
+ * column table).  tokens_f32 [2 * batch, G*G, D]; the workspace is that of wvn_vit_workspace_bytes(m, 2 * batch).  Bit-identical to two
+ * calls of wvn_vit_forward_frames, and faster than them where the persistent block kernels run: twice the rows per launch. */
+int wvn_vit_forward_frames_pair(const wvn_vit_model* m, const void* frames, int frames_u8, int src_h, int src_w, const int* rows,
+                                const int* cols, const int* cols_mirror, int batch, float* tokens_f32, void* tokens_lowp, int ld_lowp,
+                                void* workspace, size_t workspace_bytes, void* stream);
 /* The same gather as an image op (ImageProjector.resize_image, image_projector.py:199-200, whose result the callers also
  * display): out [planes, out_h, out_w] = in [planes, src_h, src_w][.., rows[y], cols[x]]; elem_bytes 1 (uint8) or 4 (fp32, int32). */
 int wvn_resize_nearest_crop(const void* in, void* out, long long planes, int src_h, int src_w, const int* rows, const int* cols,

@@ -94,3 +94,27 @@ def test_image_projector_resize_image(dev, golden):
     seg = torch.arange(224 * 299, dtype=torch.int32).reshape(1, 224, 299).to(dev)
     t = ingest_tables(224, 299, 160, dev)
     assert torch.equal(ops.resize_nearest_crop(seg, t).cpu(), resize_nearest_center_crop(seg.cpu().float()[None], 160)[0].to(torch.int32))
+
+
+@pytest.mark.parametrize("prec", ["fp16", "exact"])
+def test_mirrored_pair_forward_is_the_two_separate_passes(dev, prec):
+    """wvn_vit_forward_frames_pair (the frames and their mirror images in one launch sequence of 2 B frames) against
+    forward_tokens(img) and forward_tokens(img, flip=True): bit-identical, chunked or not, camera-sized uint8 frames included."""
+    from oracle import vit as OV
+    from wild_visual_navigation_amd.backbone import VitBackbone
+
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=5, depth=2)
+    for shape, dtype in (((5, 3, 64, 64), torch.float32), ((3, 3, 60, 91), torch.uint8)):
+        gen = torch.Generator().manual_seed(3)
+        img = torch.rand(shape, generator=gen) if dtype == torch.float32 else (torch.rand(shape, generator=gen) * 255).to(torch.uint8)
+        img = img.to(dev)
+        for chunk in (8, 2):
+            bb = VitBackbone(sd, 64, 8, 6, device=dev, precision=prec, max_chunk=chunk, fuse_mlp=True if prec == "fp16" else None,
+                             fuse_qkv=True if prec == "fp16" else None)
+            a, m = bb.forward_tokens(img), bb.forward_tokens(img, flip=True)
+            both, ck = bb.forward_tokens_pair(img)
+            B = shape[0]
+            for b0 in range(0, B, ck):
+                nb = min(ck, B - b0)
+                assert torch.equal(both[2 * b0:2 * b0 + nb], a[b0:b0 + nb]), (prec, chunk)
+                assert torch.equal(both[2 * b0 + nb:2 * b0 + 2 * nb], m[b0:b0 + nb]), (prec, chunk)

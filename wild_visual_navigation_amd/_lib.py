@@ -61,6 +61,7 @@ _SIGNATURES = {
     "wvn_vit_forward": ([_p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
     "wvn_vit_forward_u8": ([_p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
     "wvn_vit_forward_frames": ([_p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
+    "wvn_vit_forward_frames_pair": ([_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _sz, _p], _i),
     "wvn_resize_nearest_crop": ([_p, _p, _ll, _i, _i, _p, _p, _i, _i, _i, _p], _i),
     "wvn_prof_enable": ([_i], _i),
     "wvn_prof_collect": ([_p, _p], _i),

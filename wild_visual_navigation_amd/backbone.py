@@ -295,6 +295,42 @@ class VitBackbone:
                            "wvn_vit_forward")
         return out
 
+    def forward_tokens_pair(self, img: torch.Tensor, lowp_out: Optional[torch.Tensor] = None):
+        """The frames AND their horizontal mirror images through the network in one launch sequence per chunk
+        (``wvn_vit_forward_frames_pair``: twice the rows per launch; bit-identical to ``forward_tokens(img)`` and
+        ``forward_tokens(img, flip=True)``).  Returns (tokens [2B, G*G, D] fp32, chunk): rows are laid out chunk by chunk,
+        [chunk's frames | chunk's mirrors]; ``lowp_out`` ([2B*G*G, ld]) likewise."""
+        _lib.require_cuda(img, "img")
+        B, Cc, Hs, Ws = img.shape
+        if Cc != 3:
+            raise _lib.WvnError(f"expected [B,3,H,W], got {tuple(img.shape)}")
+        if lowp_out is not None and self.precision == _lib.PREC_X3:
+            raise _lib.WvnError("precision 'exact' returns fp32 tokens only (split them with ops.split_planes)")
+        if img.dtype != torch.uint8:
+            img = img.float()
+        img = img.contiguous()
+        from .feature_extractor.transforms import ingest_tables
+        tab = ingest_tables(Hs, Ws, self.img_size, self.device, flip=False)
+        tabm = ingest_tables(Hs, Ws, self.img_size, self.device, flip=True)
+        P = self.grid * self.grid
+        out = torch.empty(2 * B, P, self.dim, dtype=torch.float32, device=self.device)
+        chunk = min(self.max_chunk, B)
+        ws = self._workspace(2 * chunk)
+        st = _lib.stream()
+        esz = 2 if self._lowp16 is not None else 4
+        frame_bytes = 3 * Hs * Ws * img.element_size()
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            lp, ld = 0, 0
+            if lowp_out is not None:
+                ld = lowp_out.stride(0)
+                lp = lowp_out.data_ptr() + 2 * b0 * P * ld * esz
+            rc = self.lib.wvn_vit_forward_frames_pair(C.byref(self.model), img.data_ptr() + b0 * frame_bytes, int(img.dtype == torch.uint8),
+                                                      Hs, Ws, tab.rows.data_ptr(), tab.cols.data_ptr(), tabm.cols.data_ptr(), nb,
+                                                      out[2 * b0:].data_ptr(), lp, ld, ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "wvn_vit_forward_frames_pair")
+        return out, chunk
+
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         """What get_backbone's module returns: per-patch features [B, D, G, G] (a permuted view of the
         token tensor; no copy)."""

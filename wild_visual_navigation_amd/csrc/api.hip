@@ -127,7 +127,8 @@ size_t wvn_vit_workspace_bytes(const wvn_vit_model* m, int batch) {
 }
 
 static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, const WvnIngest* ing, int batch, float* tokens_f32,
-                            void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream);
+                            void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream,
+                            const int* cols_mirror = nullptr);
 
 int wvn_vit_forward(const wvn_vit_model* m, const float* img, int batch, float* tokens_f32, void* tokens_lowp,
                     int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
@@ -148,6 +149,15 @@ int wvn_vit_forward_frames(const wvn_vit_model* m, const void* frames, int frame
   return vit_forward_impl(m, frames, frames_u8 != 0, &ing, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream);
 }
 
+int wvn_vit_forward_frames_pair(const wvn_vit_model* m, const void* frames, int frames_u8, int src_h, int src_w, const int* rows,
+                                const int* cols, const int* cols_mirror, int batch, float* tokens_f32, void* tokens_lowp, int ld_lowp,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!rows || !cols || !cols_mirror || src_h <= 0 || src_w <= 0) return WVN_ERR_ARG;
+  const WvnIngest ing{rows, cols, src_h, src_w};
+  return vit_forward_impl(m, frames, frames_u8 != 0, &ing, batch, tokens_f32, tokens_lowp, ld_lowp, workspace, workspace_bytes, stream,
+                          cols_mirror);
+}
+
 int wvn_resize_nearest_crop(const void* in, void* out, long long planes, int src_h, int src_w, const int* rows, const int* cols,
                             int out_h, int out_w, int elem_bytes, void* stream) {
   const WvnIngest ing{rows, cols, src_h, src_w};
@@ -156,9 +166,15 @@ int wvn_resize_nearest_crop(const void* in, void* out, long long planes, int src
 
 }  // extern "C"
 
+// cols_mirror (with ing): the `batch` frames go through the network TWICE in one launch sequence of 2 * batch frames -- frame
+// batch + i is frame i gathered through the second column table (its mirror image: the flip pass of the upstream Stego.get_code).
+// Twice the rows per launch: the persistent block kernels end on a thinner partial round (6.2 -> 12.3 rounds of row blocks).
 static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8, const WvnIngest* ing, int batch, float* tokens_f32,
-                            void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!m || !img || !workspace || batch <= 0) return WVN_ERR_ARG;
+                            void* tokens_lowp, int ld_lowp, void* workspace, size_t workspace_bytes, void* stream,
+                            const int* cols_mirror) {
+  if (!m || !img || !workspace || batch <= 0 || (cols_mirror && !ing)) return WVN_ERR_ARG;
+  const int frames_in = batch;
+  if (cols_mirror) batch *= 2;
   if (m->dim != m->heads * 64 || m->depth <= 0 || m->depth > WVN_MAX_DEPTH || m->img_size % m->patch) return WVN_ERR_ARG;
   if (m->dim % 128 || m->mlp_dim % 128) return WVN_ERR_ARG;
   if (m->precision < WVN_PREC_F32 || m->precision > WVN_PREC_F16) return WVN_ERR_ARG;
@@ -223,8 +239,16 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
 
   {
     Span s(0, st);
-    RET_IF(wvn_patchify_launch(img, img_u8, w.patches, x3 ? lo(w.patches, pl_pat) : nullptr, f32 ? 0 : (x3 ? 2 : (f16 ? 3 : 1)), d.KPs, d.B,
-                               d.S, d.P, st, ing));
+    RET_IF(wvn_patchify_launch(img, img_u8, w.patches, x3 ? lo(w.patches, pl_pat) : nullptr, f32 ? 0 : (x3 ? 2 : (f16 ? 3 : 1)), d.KPs,
+                               frames_in, d.S, d.P, st, ing));
+    if (cols_mirror) {   // the mirror images' patch rows behind the frames'
+      WvnIngest ing2 = *ing;
+      ing2.cols = cols_mirror;
+      const size_t off = (size_t)frames_in * d.npatch * d.KPs;   // elements
+      void* p2 = (char*)w.patches + off * (f32 ? 4 : 2);
+      RET_IF(wvn_patchify_launch(img, img_u8, p2, x3 ? lo(w.patches, pl_pat) + off : nullptr, f32 ? 0 : (x3 ? 2 : (f16 ? 3 : 1)), d.KPs,
+                                 frames_in, d.S, d.P, st, &ing2));
+    }
     if (d.KPs != d.KP) {  // zero the K padding of the patch rows (weights are zero there too, but NaN * 0 must not happen)
       RET_IF(wvn_pad_zero_launch(w.patches, (long long)Mp * (x3 ? 2 : 1), (long long)d.KPs * 2, (long long)d.KP * 2,
                                  (long long)(d.KPs - d.KP) * 2, st));

@@ -227,15 +227,46 @@ class StegoInterface:
             ops.gemm_f32(hid, self._w_nl, self._b_nl, _lib.F32_RESID, out=code)
         return code.reshape(B, P, self._C)
 
+    def _code_pair(self, img: torch.Tensor):
+        """``_code_once`` for the frames and their mirrors together: (code [2B, P, C], chunk) in the layout of
+        ``VitBackbone.forward_tokens_pair``."""
+        B = img.shape[0]
+        P, D = self._bb.grid ** 2, self._D
+        if self._precision in ("bf16", "fp8", "fp16"):
+            cat = torch.empty(2 * B * P, 2 * D, dtype=self._bb.lowp_dtype, device=self._device)  # [tok | hid]
+            _, chunk = self._bb.forward_tokens_pair(img, lowp_out=cat)
+            ops.gemm_bf16(cat[:, :D], self._w_hid, self._b_hid, _lib.EPI_RELU_BF16, out=cat[:, D:])
+            code = ops.gemm_bf16(cat, self._w_code, self._b_code, _lib.EPI_F32)
+        elif self._precision == "exact":
+            tok32, chunk = self._bb.forward_tokens_pair(img)
+            tok = ops.split_planes(tok32.reshape(2 * B * P, D))
+            hid = ops.gemm_x3(tok, self._w_hid, self._b_hid, _lib.EPI_RELU_BF16)
+            code = ops.gemm_x3(tok, self._w_lin, self._b_lin, _lib.EPI_F32)
+            ops.gemm_x3(hid, self._w_nl, self._b_nl, _lib.EPI_RESID_F32, out=code)
+        else:
+            tok32, chunk = self._bb.forward_tokens_pair(img)
+            tok = tok32.reshape(2 * B * P, D)
+            hid = ops.gemm_f32(tok, self._w_hid, self._b_hid, _lib.F32_RELU)
+            code = ops.gemm_f32(tok, self._w_lin, self._b_lin, _lib.F32_NONE)
+            ops.gemm_f32(hid, self._w_nl, self._b_nl, _lib.F32_RESID, out=code)
+        return code.reshape(2 * B, P, self._C), chunk
+
     @torch.no_grad()
     def code_tokens(self, img: torch.Tensor) -> torch.Tensor:
         """[B,3,H,W] in [0,1] -> STEGO code [B, G*G, 90] fp32 (patch resolution)."""
         # T.Resize(NEAREST) + T.CenterCrop + T.Normalize (stego_interface.py:51-58, 87) happen inside the backbone's patch gather
         img = img.to(self._device)
-        code = self._code_once(img)
-        if self._flip_tta:  # code averaged with the flipped-back code of the mirrored frame (the mirror is a reversed column table)
-            code = ops.flip_average(code, self._code_once(img, flip=True), self._bb.grid)
-        return code
+        if not self._flip_tta:
+            return self._code_once(img)
+        # code averaged with the flipped-back code of the mirrored frame.  The mirror is a reversed column table of the fused ingest, and
+        # both passes go through the network in ONE launch sequence per chunk (twice the rows per kernel launch)
+        B, P = img.shape[0], self._bb.grid ** 2
+        code2, chunk = self._code_pair(img)                      # [2B, P, C], chunk by chunk [frames | mirrors]
+        out = torch.empty(B, P, self._C, dtype=torch.float32, device=self._device)
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            ops.flip_average(code2[2 * b0:2 * b0 + nb], code2[2 * b0 + nb:2 * b0 + 2 * nb], self._bb.grid, out=out[b0:b0 + nb])
+        return out
 
     @torch.no_grad()
     def inference(self, img: torch.Tensor, code: torch.Tensor = None):

@@ -291,14 +291,17 @@ def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int 
     return labels, nseg
 
 
-def flip_average(code: torch.Tensor, mirrored: torch.Tensor, G: int) -> torch.Tensor:
-    """0.5 * (code + flip_x(mirrored)) on [B, G*G, C] fp32 patch maps (in place on ``code``)."""
+def flip_average(code: torch.Tensor, mirrored: torch.Tensor, G: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """0.5 * (code + flip_x(mirrored)) on [B, G*G, C] fp32 patch maps (in place on ``code`` unless ``out`` is given)."""
     require_cuda(code, "code")
     B, P, Cc = code.shape
     if not (code.is_contiguous() and mirrored.is_contiguous()) or mirrored.shape != code.shape or P != G * G:
         raise _lib.WvnError("flip_average: contiguous [B, G*G, C] fp32 pairs expected")
-    check(lib().wvn_flip_average(ptr(code), ptr(mirrored), ptr(code), B, G, Cc, stream()), "wvn_flip_average")
-    return code
+    dst = code if out is None else out
+    if out is not None and (not out.is_contiguous() or out.shape != code.shape or out.dtype != torch.float32):
+        raise _lib.WvnError("flip_average: out must be a contiguous fp32 tensor of the inputs' shape")
+    check(lib().wvn_flip_average(ptr(code), ptr(mirrored), ptr(dst), B, G, Cc, stream()), "wvn_flip_average")
+    return dst
 
 
 def cast_rows_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
