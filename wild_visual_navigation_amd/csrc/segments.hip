@@ -136,8 +136,9 @@ __global__ void segpool_reduce_kernel(const unsigned long long* __restrict__ W, 
                                       const float* __restrict__ F, int ldf, float* __restrict__ feat, int P, int S,
                                       int D) {
   __shared__ float wch[256];
+  __shared__ unsigned long long nz[4];   // per 64 staged weights: which are non-zero (a segment touches ~1 patch in 15)
   const int s = blockIdx.x, b = blockIdx.y;
-  const int d = threadIdx.x;
+  const int d = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
   const unsigned long long* Wr = W + ((size_t)b * S + s) * P;
   const float* Fb = F + (size_t)b * P * ldf;
   float acc = 0.f;
@@ -145,10 +146,19 @@ __global__ void segpool_reduce_kernel(const unsigned long long* __restrict__ W, 
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += blockDim.x) wch[i] = (p0 + i < P) ? (float)((double)Wr[p0 + i] * (1.0 / WFIX)) : 0.f;
     __syncthreads();
-    const int n = min(256, P - p0);
-    for (int i = 0; i < n; ++i) {
-      const float w = wch[i];
-      if (w != 0.f && d < D) acc = fmaf(w, Fb[(size_t)(p0 + i) * ldf + d], acc);
+    for (int sc = wave; sc < 4; sc += nwave) {
+      const unsigned long long m = __ballot(wch[sc * 64 + lane] != 0.f);
+      if (lane == 0) nz[sc] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sc = 0; sc < 4; ++sc) {
+      unsigned long long m = nz[sc];                       // (uniform) ascending p: the accumulation order is fixed
+      while (m) {
+        const int i = sc * 64 + __builtin_ctzll(m);
+        m &= m - 1;
+        if (d < D) acc = fmaf(wch[i], Fb[(size_t)(p0 + i) * ldf + d], acc);
+      }
     }
   }
   if (d < D) feat[((size_t)b * S + s) * D + d] = acc / (float)cnt[(size_t)b * S + s];
