@@ -555,22 +555,26 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
         n00 = tap(__builtin_amdgcn_readlane(o00, jend)); n01 = tap(__builtin_amdgcn_readlane(o01, jend));
         n10 = tap(__builtin_amdgcn_readlane(o10, jend)); n11 = tap(__builtin_amdgcn_readlane(o11, jend));
       }
+      // (a cell lies in one image row: its row weights are fetched once; the lane's two channels go through the interpolation as
+      //  one packed pair -- v_pk_mul / v_pk_fma are two independent correctly rounded operations, the bits of bilerp_fixed)
+      const float wy0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w0), j));
+      const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), j));
+      const f32x2v_t Y0 = {wy0, wy0}, Y1 = {wy1, wy1};
       for (int jj = j; jj < jend; ++jj) {
         const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), jj));
         const float wx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w1), jj));
-        const float wy0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w0), jj));
-        const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), jj));
         const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), jj));
         const int k = __builtin_amdgcn_readlane(kj, jj);
-        const float val0 = __fmul_rn(bilerp_fixed(v00[0], v01[0], v10[0], v11[0], wx0, wx1, wy0, wy1), ri);
-        const float val1 = __fmul_rn(bilerp_fixed(v00[1], v01[1], v10[1], v11[1], wx0, wx1, wy0, wy1), ri);
+        const f32x2v_t X0 = {wx0, wx0}, X1 = {wx1, wx1}, R = {ri, ri};
+        const f32x2v_t t0 = __builtin_elementwise_fma(X1, v01, X0 * v00);
+        const f32x2v_t t1 = __builtin_elementwise_fma(X1, v11, X0 * v10);
+        const f32x2v_t val = __builtin_elementwise_fma(Y1, t1, Y0 * t0) * R;
         if (k != kcur) {                                 // (uniform, rare: labels are spatially coherent) park / fetch
           if (kcur >= 0) *(f32x2v_t*)(tab + kcur * C + c2) = acc;
           acc = *(const f32x2v_t*)(tab + k * C + c2);
           kcur = k;
         }
-        acc[0] = __fadd_rn(acc[0], val0);
-        acc[1] = __fadd_rn(acc[1], val1);
+        acc = acc + val;
       }
       j = jend;
     }
