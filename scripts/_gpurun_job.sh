@@ -2,8 +2,14 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 1000 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/gputest.log | tail -12
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
-timeout 500 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log > gpurun_out/bench_default.json; cut -c1-160 gpurun_out/bench_default.json
-bash scripts/profile_job.sh r03d_f16 1
-bash scripts/profile_job.sh r03d_exact 0 --precision exact
-bash scripts/profile_job.sh r03d_upstream 0 --stego-reading upstream
-bash scripts/profile_job.sh r03d_dinov2_fp8 0 --mode dinov2
+timeout 900 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log > gpurun_out/bench_default.json; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_default.json').read())
+print(d['value'], d['ms_per_step'], d['dtype']); print(d['parity']); print(d['cpu_baseline'])
+print('parity_mode', d['parity_mode']['value'], d['parity_mode']['ms_per_step'], d['parity_mode']['parity'])
+print('fast', d['stego_fast']['value'], d['stego_fast']['ms_per_step'], d['stego_fast'].get('parity'))
+print('roofline', d['roofline'])
+PY
+bash scripts/profile_job.sh r03e_headline 1
+bash scripts/profile_job.sh r03e_exact 0 --precision exact
+bash scripts/profile_job.sh r03e_fast 0 --stego-reading patch
