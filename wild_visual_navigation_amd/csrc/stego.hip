@@ -560,21 +560,26 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
       const float wy0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w0), j));
       const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), j));
       const f32x2v_t Y0 = {wy0, wy0}, Y1 = {wy1, wy1};
-      for (int jj = j; jj < jend; ++jj) {
-        const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), jj));
-        const float wx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w1), jj));
-        const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), jj));
+      int jj = j;
+      while (jj < jend) {                                // runs of one label inside the cell (labels are spatially coherent: usually one)
         const int k = __builtin_amdgcn_readlane(kj, jj);
-        const f32x2v_t X0 = {wx0, wx0}, X1 = {wx1, wx1}, R = {ri, ri};
-        const f32x2v_t t0 = __builtin_elementwise_fma(X1, v01, X0 * v00);
-        const f32x2v_t t1 = __builtin_elementwise_fma(X1, v11, X0 * v10);
-        const f32x2v_t val = __builtin_elementwise_fma(Y1, t1, Y0 * t0) * R;
-        if (k != kcur) {                                 // (uniform, rare: labels are spatially coherent) park / fetch
+        const unsigned long long other = __ballot(kj != k) & valid & ~((2ull << jj) - 1);
+        const int jr = other ? min(jend, (int)__builtin_ctzll(other)) : jend;
+        if (k != kcur) {                                 // park / fetch the running sums
           if (kcur >= 0) *(f32x2v_t*)(tab + kcur * C + c2) = acc;
           acc = *(const f32x2v_t*)(tab + k * C + c2);
           kcur = k;
         }
-        acc = acc + val;
+        for (int q = jj; q < jr; ++q) {                  // the additions, in pixel order
+          const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), q));
+          const float wx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w1), q));
+          const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), q));
+          const f32x2v_t X0 = {wx0, wx0}, X1 = {wx1, wx1}, R = {ri, ri};
+          const f32x2v_t t0 = __builtin_elementwise_fma(X1, v01, X0 * v00);
+          const f32x2v_t t1 = __builtin_elementwise_fma(X1, v11, X0 * v10);
+          acc = acc + __builtin_elementwise_fma(Y1, t1, Y0 * t0) * R;
+        }
+        jj = jr;
       }
       j = jend;
     }
