@@ -333,8 +333,7 @@ __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* 
 // order: blocks ascending, channels ascending within a block -- the bits of the sequential definition).  ~60 registers instead of
 // the 138 of the pixel-vector-resident form, i.e. 8 waves per SIMD instead of 3: the centroid values come through the scalar
 // cache (uniform addresses), and it takes that many waves to cover their latency -- the old form ran at a third of the fp32 rate
-// this chip sustains (scripts/ubench/valu_rate.hip: 147 TFLOP/s of plain v_fma_f32 at 8 waves per SIMD, 95 at one).  The staged
-// code rows are padded to a multiple of 4 floats so that a block's taps are ds_read_b128s.
+// this chip sustains (scripts/ubench/valu_rate.hip: 147 TFLOP/s of plain v_fma_f32 at 8 waves per SIMD, 95 at one).
 // (Measured and not kept: two pixels per lane -- (y, x) and (y + 1, x), three staged code rows, every scalar load feeding 32 fmas per
 // lane -- 21.0 ms per 64-frame k-means against 20.4 for this form: four waves per SIMD cover less than six; earlier, on the
 // pixel-vector-resident form: packed pairs 24.2 ms against 22.5, centroids in LDS 33.5 ms.)
@@ -353,10 +352,14 @@ __device__ inline f32x16_t km_sload16_before(const float* p, f32x16_t& busy) {
 __device__ inline void km_swait(f32x16_t& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }   // (ties the users of r to the wait)
 
 template <int C, int KMAX, bool EXACTK>
-__global__ __launch_bounds__(512) void km_pix_assign_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void km_pix_assign_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
                                                             int K) {
-  constexpr int CP = (C + 3) & ~3;   // padded row pitch in LDS
+  // LDS row pitch = C, unpadded: at C = 90 and G = 56 the two staged code rows are 40,320 bytes -- FOUR workgroups per CU (padding
+  // the rows to 16-byte multiples for ds_read_b128 taps costs 41,216: three).  With one wave per 64 pixels of an image row (448
+  // threads at 448 pixels: seven waves, none idle) and <= 72 registers that is 28 waves per CU against 21, and 7168 workgroups
+  // are exactly seven rounds of 1024.
+  constexpr int CP = C;
   constexpr int DB = 16;             // channels per block
   extern __shared__ __attribute__((aligned(16))) float rows[];  // [2][G][CP]
   const int b = blockIdx.y;
@@ -623,7 +626,8 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   const size_t P = (size_t)H * H;
   const int nsup = km_super((long long)P), ngroup = (int)((P + (size_t)nsup * KM_CHUNK - 1) / ((size_t)nsup * KM_CHUNK));
   const PixScratch s = pix_carve(scratch, B, G, H, C, K);
-  const size_t shm_rows = (size_t)2 * G * C * sizeof(float), shm_rows_pad = (size_t)2 * G * ((C + 3) & ~3) * sizeof(float);
+  const size_t shm_rows = (size_t)2 * G * C * sizeof(float), shm_rows_pad = shm_rows;
+  const int assign_threads = H >= 512 ? 512 : (H + 63) / 64 * 64;   // one wave per 64 pixels of an image row
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C, 20, true>,
                                 (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>)) return rc;
@@ -632,10 +636,8 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   WVN_LAUNCH_CHECK();
   for (int it = 0; it <= iters; ++it) {
     const dim3 ga(ceil_div(H, PIX_RPB), B);
-    // (512 threads: the two staged code rows are 41 KB at C = 90 -- three workgroups per CU -- and it takes 6 waves per SIMD to cover
-    //  the scalar loads; at 448 pixels per image row the eighth wave of a workgroup only helps with the staging)
-    if (K == 20) hipLaunchKernelGGL((km_pix_assign_kernel<C, 20, true>), ga, dim3(512), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
-    else if (K <= 32) hipLaunchKernelGGL((km_pix_assign_kernel<C, 32, false>), ga, dim3(512), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
+    if (K == 20) hipLaunchKernelGGL((km_pix_assign_kernel<C, 20, true>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
+    else if (K <= 32) hipLaunchKernelGGL((km_pix_assign_kernel<C, 32, false>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
     else hipLaunchKernelGGL((km_pix_assign_wide_kernel<C>), ga, dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
