@@ -5,11 +5,9 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; 
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log > gpurun_out/bench_default.json; python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/bench_default.json').read())
-print(d['value'], d['ms_per_step'], d['dtype']); print(d['parity']); print(d['cpu_baseline'])
+print(d['value'], d['ms_per_step'], d['dtype'], d['step_ms']); print(d['parity']); print(d['cpu_baseline'])
 print('parity_mode', d['parity_mode']['value'], d['parity_mode']['ms_per_step'], d['parity_mode']['parity'])
 print('fast', d['stego_fast']['value'], d['stego_fast']['ms_per_step'], d['stego_fast'].get('parity'))
 print('roofline', d['roofline'])
 PY
-bash scripts/profile_job.sh r03e_headline 1
-bash scripts/profile_job.sh r03e_exact 0 --precision exact
-bash scripts/profile_job.sh r03e_fast 0 --stego-reading patch
+bash scripts/profile_job.sh r03f_headline 0
