@@ -334,7 +334,8 @@ __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* 
 // the 138 of the pixel-vector-resident form, i.e. 8 waves per SIMD instead of 3: the centroid values come through the scalar
 // cache (uniform addresses), and it takes that many waves to cover their latency -- the old form ran at a third of the fp32 rate
 // this chip sustains (scripts/ubench/valu_rate.hip: 147 TFLOP/s of plain v_fma_f32 at 8 waves per SIMD, 95 at one).
-// (Measured and not kept: two pixels per lane -- (y, x) and (y + 1, x), three staged code rows, every scalar load feeding 32 fmas per
+// (Measured and not kept: the interpolation on channel PAIRS with v_pk_mul / v_pk_fma -- half its instructions, 70 registers, 21
+// spilled scalars -- 17.6 ms per 64-frame k-means against 16.8; two pixels per lane -- (y, x) and (y + 1, x), three staged code rows, every scalar load feeding 32 fmas per
 // lane -- 21.0 ms per 64-frame k-means against 20.4 for this form: four waves per SIMD cover less than six; earlier, on the
 // pixel-vector-resident form: packed pairs 24.2 ms against 22.5, centroids in LDS 33.5 ms.)
 __device__ inline f32x16_t km_sload16(const float* p) {   // 16 consecutive floats at a wave-uniform address -> SGPRs
