@@ -282,9 +282,11 @@ __device__ inline void pix_row(const float* rows, int G, const LerpTap& tx, cons
   }
 }
 
-// rinv[b][y*H + x] = 1 / max(||v||, 1e-12), v = the interpolated code row of pixel (y, x)
+// rinv[b][y*H + x] = 1 / max(||v||, 1e-12), v = the interpolated code row of pixel (y, x).  The squared norm is one fma chain in
+// channel order; the row is interpolated sixteen channels at a time (nothing but the chain's accumulator lives across the blocks:
+// ~30 registers, and with one wave per 64 pixels of an image row the kernel fills the CU like the assign kernel does).
 template <int C>
-__global__ __launch_bounds__(256) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H) {
+__global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H) {
   extern __shared__ float rows[];  // [2][G][C]
   const int b = blockIdx.y;
   const float scale = lerp_scale(G, H);
@@ -299,11 +301,21 @@ __global__ __launch_bounds__(256) void km_pix_rinv_kernel(const float* __restric
     }
     for (int x = threadIdx.x; x < H; x += blockDim.x) {
       const LerpTap tx = lerp_tap(x, G, scale);
-      float v[C];
-      pix_row<C>(rows, G, tx, ty, v);
+      const float* a0 = rows + tx.i0 * C;
+      const float* a1 = rows + tx.i1 * C;
+      const float* b0 = rows + G * C + tx.i0 * C;
+      const float* b1 = rows + G * C + tx.i1 * C;
       float n2 = 0.f;
 #pragma unroll
-      for (int d = 0; d < C; ++d) n2 = __fmaf_rn(v[d], v[d], n2);
+      for (int d0 = 0; d0 < C; d0 += 16) {
+        asm volatile("" ::: "memory");   // (one block's taps in flight at a time)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (d0 + j < C) {
+            const float v = bilerp_fixed(a0[d0 + j], a1[d0 + j], b0[d0 + j], b1[d0 + j], tx.w0, tx.w1, ty.w0, ty.w1);
+            n2 = __fmaf_rn(v, v, n2);
+          }
+      }
       rinv[(size_t)b * H * H + (size_t)y * H + x] = rinv_norm(n2);
     }
   }
@@ -632,7 +644,8 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C, 20, true>,
                                 (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>)) return rc;
-  hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(256), shm_rows, st, code, s.rinv, G, H);
+  hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
+                     s.rinv, G, H);
   hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K);
   WVN_LAUNCH_CHECK();
   for (int it = 0; it <= iters; ++it) {
