@@ -82,3 +82,28 @@ def test_supervision_oracle_nan_scan_lines_and_raw_projection():
     uv, z = OSV.project_points_raw(K, T, pts)
     assert np.isfinite(uv).all() and z.tolist() == [2.0, -2.0]                  # ImageProjector.project: finite behind the camera too
     assert np.isnan(OSV.project_points(K, T, pts)[1]).all() and np.isfinite(OSV.project_points(K, T, pts)[0]).all()
+
+
+def test_stego_inference_defaults_are_the_upstream_reading_and_flip_equivariant():
+    """oracle.interfaces.stego_inference: the defaults are flip-averaged code + k-means over the code pixels; the flip-averaged
+    code of a mirrored frame is the mirrored code of the frame, bit for bit (a + b = b + a); the cheap options are explicit."""
+    from oracle import vit as OV
+
+    S, P = 32, 8
+    sd = OV.make_vit_state_dict("vit_small", P, pretrain_grid=28, seed=2, depth=1)
+    head = OI.make_stego_head_state_dict(384, 90, seed=1)
+    img = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(4))
+    code, seg = OI.stego_inference(sd, head, img, S, P, 6, 4)
+    assert code.shape == (1, 90, S, S) and seg.shape == (1, 1, S, S) and seg.dtype == torch.int32
+    code_m, _ = OI.stego_inference(sd, head, img.flip(-1), S, P, 6, 4)
+    assert torch.allclose(code_m, code.flip(-1), atol=2e-6)        # (the up-sampling weights w / 1 - w swap roles: not bit for bit)
+    G = S // P
+    x = OI.dino_transform(img, S)
+    t, tm = OV.vit_tokens(sd, x, P, 6)[:, 1:], OV.vit_tokens(sd, x.flip(-1), P, 6)[:, 1:]
+    c, cm = OI.stego_code_flip_average(head, t, tm, G), OI.stego_code_flip_average(head, tm, t, G)
+    assert torch.equal(cm.reshape(1, G, G, 90), c.reshape(1, G, G, 90).flip(2))   # at patch resolution: bit for bit
+    code_1, seg_1 = OI.stego_inference(sd, head, img, S, P, 6, 4, flip_tta=False, cluster_resolution="patch")
+    assert not torch.equal(code_1, code)
+    assert torch.equal(seg_1[0, 0], seg_1[0, 0].reshape(G, P, G, P)[:, :1, :, :1].expand(G, P, G, P).reshape(S, S))   # patch-aligned labels
+    tok = OV.vit_tokens(sd, OI.dino_transform(img, S), P, 6)[:, 1:]
+    assert torch.equal(OI.upsample_bilinear_ac(OI.stego_code_tokens(head, tok).reshape(1, G, G, 90).permute(0, 3, 1, 2), S), code_1)
