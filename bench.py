@@ -184,13 +184,16 @@ def hot_path_step(fe, trainer, img, labels_u, args, backbone_out=None):
     return trainer.train_step(x, y, y_valid, rows_dev=rows_dev), (rows_dev if rows_dev is not None else x.shape[0])
 
 
+CU_SPLIT_DEFAULT = "none"   # "<a_hi>,<b_lo>[,rr|lin]" or "none": see TwoStreamPipeline
+
+
 class TwoStreamPipeline:
     """Steps are independent through the backbone, so a throughput pipeline skews them by one: stream A runs the backbone
     (+ STEGO head) of step i+1 while stream B runs clustering, pooling and the MLP optimisation step (and, multi-GPU, its two
     all-reduces) of step i.  Every step still trains on its own frames' features; only the schedule changes.  A runs at most
     one step ahead of B."""
 
-    def __init__(self, fe, trainer, args, dev):
+    def __init__(self, fe, trainer, args, dev, streams=None):
         import torch
 
         self.torch = torch
@@ -199,7 +202,22 @@ class TwoStreamPipeline:
         # persistent backbone kernels of stream A release CUs, instead of queueing behind whole launches (measured in one call: equal
         # priorities 987 - 1004 frames/s, backbone first 1017, tail first 1039).  WVN_BENCH_STREAM_PRIO = ab | a | b for A/B runs.
         pa, pb = {"ab": (0, 0), "a": (-1, 0), "b": (0, -1)}[os.environ.get("WVN_BENCH_STREAM_PRIO", "b")]
-        self.a, self.b = torch.cuda.Stream(device=dev, priority=pa), torch.cuda.Stream(device=dev, priority=pb)
+        split = streams if streams is not None else os.environ.get("WVN_BENCH_CU_SPLIT", CU_SPLIT_DEFAULT)
+        self.masked = []
+        if split and split != "none":
+            # PARTITION the chip instead: "<a_hi>,<b_lo>[,layout]" -- stream A (backbone) on CUs [0, a_hi) of every
+            # XCD, stream B (clustering / pooling / learner) on CUs [b_lo, 32); scripts/ab_cu_mask.py measured the table in
+            # profiles/r04*_ab_cu_mask.txt
+            from wild_visual_navigation_amd import ops
+            parts = split.split(",")
+            a_hi, b_lo, layout = int(parts[0]), int(parts[1]), (parts[2] if len(parts) > 2 else "rr")
+            ma = ops.MaskedStream(ops.cu_mask_words(0, a_hi, layout), dev) if a_hi < 32 else None
+            mb = ops.MaskedStream(ops.cu_mask_words(b_lo, 32, layout), dev) if b_lo > 0 else None
+            self.masked = [m for m in (ma, mb) if m is not None]
+            self.a = ma.stream if ma else torch.cuda.Stream(device=dev, priority=pa)
+            self.b = mb.stream if mb else torch.cuda.Stream(device=dev, priority=pb)
+        else:
+            self.a, self.b = torch.cuda.Stream(device=dev, priority=pa), torch.cuda.Stream(device=dev, priority=pb)
         self.pending = None     # (tokens, event) of a backbone stage already enqueued for the next step
         self.tail_done = None   # event: the previous step's tail has finished
         self.marks = []         # per-step end events (timing on), recorded on stream B

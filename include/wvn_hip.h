@@ -501,6 +501,10 @@ int wvn_debug_attention_timing(long long* dbg);
  * per-tile max; the row sums raise the alarm and the tile is redone exactly -- the default), < 0 = back to the default.  Same
  * results within the kernel's tolerance; tests/test_gpu_attention_lazy.py runs both, bench.py --attn-variant A/Bs them. */
 int wvn_debug_attention_variant(int variant);
+/* which assignment kernel subsequent wvn_kmeans_cosine_pixels calls use: -1 / 0 = the VALU form (default), 1 = the fp32-MFMA form
+ * (v_mfma_f32_4x4x1_16b_f32) where it is eligible (K <= 20): measured no faster, kept as an opt-in.  Bit-identical labels and
+ * centroids; tests/test_gpu_stego_pixels.py runs both, scripts/bench_pixel_kmeans.py A/Bs them. */
+int wvn_debug_kmeans_assign_form(int form);
 /* subsequent wvn_qkv_fused launches write dbg[(workgroup * 4 + wave) * 4 + {0 LayerNorm prologue, 1 MFMA slices, 2 tile epilogues,
  * 3 total}] in shader cycles (scripts/bench_qkv_fused.py); NULL switches the instrumented build off again. */
 int wvn_debug_qkv_fused_timing(long long* dbg);
@@ -511,6 +515,17 @@ int wvn_debug_mlp_fused_timing(long long* dbg);
  * 0.75 x #CU row blocks of 256 on); tests */
 int wvn_debug_gemm_n384(const void* A, int lda, const void* W, int ldw, const float* bias, float* C, int ldc, int M, int K,
                         void* stream);
+
+
+/* ---- step scheduling (no reference counterpart: the reference runs one frame at a time on one CUDA stream,
+ * wild_visual_navigation_ros/scripts/wvn_feature_extractor_node.py:319-363) ----
+ * A HIP stream whose kernels may only occupy the compute units named by `mask` (bit i of the `words` 32-bit words = CU i in the
+ * driver's numbering, which interleaves the 8 XCDs of an MI355X: bit i lies on XCD i mod 8), so that the persistent backbone
+ * kernels and the many small kernels of clustering / pooling / the learner PARTITION the chip instead of sharing every CU
+ * (bench.py's two-stream schedule; scripts/ab_cu_mask.py measures the split).  The handle is a hipStream_t: pass it wherever this
+ * header takes `void* stream` (PyTorch: torch.cuda.ExternalStream(handle)).  wvn_stream_destroy releases it. */
+int wvn_stream_create_cu_mask(void** stream, const unsigned int* mask, int words);
+int wvn_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -160,6 +160,9 @@ def _oracle_lib():
             h = ctypes.CDLL(path)
             h.wvn_oracle_kmeans_cosine.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
             h.wvn_oracle_kmeans_cosine.restype = ctypes.c_int
+            h.wvn_oracle_kmeans_cosine_ex.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                      ctypes.c_void_p, ctypes.c_void_p]
+            h.wvn_oracle_kmeans_cosine_ex.restype = ctypes.c_int
             _ORACLE_LIB = h
     return _ORACLE_LIB or None
 

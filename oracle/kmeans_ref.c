@@ -55,8 +55,10 @@ static void normalize_rows(const float* code, float* x, long P, int C) {
   }
 }
 
-/* code [P][C] fp32 -> labels [P] int32 (not compacted); returns 0, or 1 when out of memory */
-int wvn_oracle_kmeans_cosine(const float* code, long P, int C, int K, int iters, int* labels) {
+/* code [P][C] fp32 -> labels [P] int32 (not compacted), and -- when the pointers are not NULL -- the final centroids [K][C] and the
+ * normalised rows [P][C] the labels were assigned from (tolerance analysis of end-to-end segment maps, oracle/segmap_agreement.py);
+ * returns 0, or 1 when out of memory */
+int wvn_oracle_kmeans_cosine_ex(const float* code, long P, int C, int K, int iters, int* labels, float* cent_out, float* x_out) {
   float* x = (float*)malloc((size_t)P * C * sizeof(float));
   float* cent = (float*)malloc((size_t)K * C * sizeof(float));
   float* sums = (float*)malloc((size_t)K * C * sizeof(float));
@@ -97,6 +99,12 @@ int wvn_oracle_kmeans_cosine(const float* code, long P, int C, int K, int iters,
     }
   }
   assign_labels(x, cent, labels, P, C, K);
+  if (cent_out) memcpy(cent_out, cent, (size_t)K * C * sizeof(float));
+  if (x_out) memcpy(x_out, x, (size_t)P * C * sizeof(float));
   free(x); free(cent); free(sums); free(grp); free(part); free(cnt);
   return 0;
+}
+
+int wvn_oracle_kmeans_cosine(const float* code, long P, int C, int K, int iters, int* labels) {
+  return wvn_oracle_kmeans_cosine_ex(code, P, C, K, iters, labels, NULL, NULL);
 }

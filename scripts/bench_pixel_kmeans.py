@@ -1,23 +1,36 @@
 #!/usr/bin/env python
-"""Time the pixel-resolution k-means on its own (GPU box): 64 frames of 56 x 56 x 90 code -> 448 x 448 labels, K = 20, 10 iterations.
+"""Time the pixel-resolution k-means on its own (GPU box): 64 frames of 56 x 56 x 90 code -> 448 x 448 labels, K = 20, 10 iterations,
+with both assignment kernels (fp32 MFMA / VALU, `wvn_debug_kmeans_assign_form`), and check that they agree bit for bit.
     python scripts/bench_pixel_kmeans.py [frames]"""
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
-from wild_visual_navigation_amd import ops  # noqa: E402
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+from wild_visual_navigation_amd import _lib, ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
-code = (torch.randn(B, 56 * 56, 90, generator=torch.Generator().manual_seed(0)) * 2 + 0.3).to(dev)
-for _ in range(2):
-    ops.kmeans_cosine_pixels(code, 56, 448, 20)
-torch.cuda.synchronize()
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(5):
-    ops.kmeans_cosine_pixels(code, 56, 448, 20)
-b.record()
-torch.cuda.synchronize()
-print(f"pixel k-means, {B} frames 448^2, K = 20, 10 iterations: {a.elapsed_time(b) / 5:.2f} ms per call")
+# smooth code maps (low-pass noise) so that labels are spatially coherent like a real segmentation's
+g = torch.Generator().manual_seed(0)
+code = torch.randn(B, 90, 14, 14, generator=g)
+code = torch.nn.functional.interpolate(code, (56, 56), mode="bicubic").permute(0, 2, 3, 1).reshape(B, 56 * 56, 90).contiguous()
+code = (code * 2 + 0.3).to(dev)
+res = {}
+for form, name in ((1, "mfma"), (0, "valu")):
+    _lib.lib().wvn_debug_kmeans_assign_form(form)
+    for _ in range(2):
+        out = ops.kmeans_cosine_pixels(code, 56, 448, 20, return_centroids=True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        ops.kmeans_cosine_pixels(code, 56, 448, 20)
+    b.record()
+    torch.cuda.synchronize()
+    res[name] = out
+    print(f"pixel k-means [{name} assign], {B} frames 448^2, K = 20, 10 iterations: {a.elapsed_time(b) / 5:.2f} ms per call", flush=True)
+_lib.lib().wvn_debug_kmeans_assign_form(-1)
+same = torch.equal(res["mfma"][0], res["valu"][0]) and torch.equal(res["mfma"][2], res["valu"][2])
+print("labels and centroids identical between the two forms:", same)
+sys.exit(0 if same else 1)

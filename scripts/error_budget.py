@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Per-kernel-family error budget of the 16-bit speed path (VERDICT r3 "Next round" item 1).
+
+CPU emulation (torch fp32): the oracle's ViT (`oracle/vit.py`) with the OPERANDS of one kernel family at a time rounded the way the
+HIP kernels round them (fp16 / bf16 significands, fp32 accumulation), everything else exact.  Reports, per configuration, the
+max-abs / rms error of the final-LayerNorm'ed tokens at 448 x 448 x 12 blocks against the all-fp32 oracle, i.e. what
+`bench.py`'s `max_abs_tokens` measures on the GPU.  The emulation is validated against the GPU's own numbers: "all fp16" must land
+near the 4.5e-3 / 7.4e-4 the fp16 kernels measure (`profiles/r03g_bench_default.json`), "all split" near the exact mode's 5e-5.
+
+Families (= the operand pairs of one MFMA product):
+  patch  patch-embedding GEMM                       (pixels, conv weight)
+  qkv    LayerNorm 1 -> QKV linear                  (normalised rows, qkv.weight)
+  qk     S = Q K^T                                  (q pre-scaled by scale * log2 e as the QKV epilogue stores it, k)
+  pv     O = P V                                    (probabilities relative to the row maximum, v)
+  proj   attention projection                       (attention rows, proj.weight)
+  fc1    LayerNorm 2 -> fc1                         (normalised rows, fc1.weight)
+  fc2    GELU -> fc2                                (hidden activations, fc2.weight)
+
+Operand modes per family:
+  f32    exact
+  h      one 16-bit value per operand ("fp16" | "bf16")
+  a      activation operand split hi + lo (2 MFMAs), weight single 16-bit
+  w      weight operand split, activation single
+  x3     both split, hi*hi + hi*lo + lo*hi (3 MFMAs)  -- the shipped exact mode uses bf16 planes
+  c8/c6/c4  hi*hi in fp16 + the two correction products (a_lo * w, a * w_lo) with BOTH operands in an MX format (e4m3 / e2m3 /
+         e2m1 elements, one power-of-two scale per 32 elements along K) -- `v_mfma_scale_f32_32x32x64_f8f6f4` runs those at 2x / 4x /
+         4x the fp16 rate, so the product costs 2 / 1.5 / 1.5 fp16 MFMAs instead of 3.
+
+Usage:  python scripts/error_budget.py [--frames 2] [--size 448] [--out profiles/r04a_error_budget.md] [--weights synthetic|peaked]
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import vit as ovit  # noqa: E402
+
+FAMILIES = ["patch", "qkv", "qk", "pv", "proj", "fc1", "fc2"]
+MFMA_COST = {"f32": None, "h": 1.0, "a": 2.0, "w": 2.0, "x3": 3.0, "c8": 2.0, "c6": 1.5, "c4": 1.5}
+# share of the backbone's multiply-adds per family at 448^2 (315.1 GFLOP per frame)
+FLOP_SHARE = {"patch": 0.0015, "qkv": 0.1057, "qk": 0.2878, "pv": 0.2878, "proj": 0.0352, "fc1": 0.141, "fc2": 0.141}
+
+
+def r16(x, fmt):
+    return x.to(torch.float16 if fmt == "fp16" else torch.bfloat16).float()
+
+
+def mx_quant(x, ebits, mbits, block=32):
+    """Round to an MX element format (sign, ebits, mbits; no inf / nan) with one power-of-two scale per `block` elements of the
+    last dimension (the K dimension of the product), scale = 2^(floor(log2 amax) - emax_elem): the OCP MX rule."""
+    shp = x.shape
+    K = shp[-1]
+    pad = (-K) % block
+    if pad:
+        x = F.pad(x, (0, pad))
+    xb = x.reshape(-1, block)
+    amax = xb.abs().amax(dim=1, keepdim=True).clamp_min(1e-38)
+    if (ebits, mbits) == (4, 3):
+        emax, vmax = 8, 448.0
+    elif (ebits, mbits) == (2, 3):
+        emax, vmax = 2, 7.5
+    elif (ebits, mbits) == (2, 1):
+        emax, vmax = 2, 6.0
+    else:
+        raise ValueError
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - emax)
+    y = xb / scale
+    # element rounding: exponent of |y| clamped to the format's normal range, mantissa to mbits (round to nearest even)
+    bias = (1 << (ebits - 1)) - 1
+    emin = 1 - bias
+    e = torch.floor(torch.log2(y.abs().clamp_min(1e-38))).clamp_min(emin)
+    q = torch.exp2(e - mbits)
+    y = (torch.round(y / q) * q).clamp(-vmax, vmax)
+    out = (y * scale).reshape(*shp[:-1], K + pad)
+    return out[..., :K] if pad else out
+
+
+MX = {"c8": (4, 3), "c6": (2, 3), "c4": (2, 1)}
+
+
+def product(a, w, mode, fmt, kdim_last_w=True):
+    """a [..., K] x w [N, K]^T with the operand handling of `mode`; fp32 accumulation (torch's, order differs from the MFMA's:
+    ~1e-7 relative, far below what is measured here)."""
+    if mode == "f32":
+        return a @ w.transpose(-1, -2)
+    ah, wh = r16(a, fmt), r16(w, fmt)
+    if mode == "h":
+        return ah @ wh.transpose(-1, -2)
+    al, wl = r16(a - ah, fmt), r16(w - wh, fmt)
+    if mode == "a":
+        return ah @ wh.transpose(-1, -2) + al @ wh.transpose(-1, -2)
+    if mode == "w":
+        return ah @ wh.transpose(-1, -2) + ah @ wl.transpose(-1, -2)
+    if mode == "x3":
+        return ah @ wh.transpose(-1, -2) + (al @ wh.transpose(-1, -2) + ah @ wl.transpose(-1, -2))
+    if mode in MX:
+        eb, mb = MX[mode]
+        a_lo, w_lo = a - ah, w - wh  # the fp32 residues the kernel has in registers / the weight prep has offline
+        corr = mx_quant(a_lo, eb, mb) @ mx_quant(w, eb, mb).transpose(-1, -2) + mx_quant(a, eb, mb) @ mx_quant(w_lo, eb, mb).transpose(-1, -2)
+        return ah @ wh.transpose(-1, -2) + corr
+    raise ValueError(mode)
+
+
+def vit_tokens_emulated(sd, img, patch, heads, modes, fmt):
+    """oracle.vit.vit_tokens with per-family operand modes (dict family -> mode)."""
+    B, _, S, _ = img.shape
+    G = S // patch
+    D = sd["patch_embed.proj.weight"].shape[0]
+    cols = F.unfold(img, kernel_size=patch, stride=patch).transpose(1, 2)  # [B, G*G, 3*P*P], (c, py, px) like conv weight
+    wpe = sd["patch_embed.proj.weight"].reshape(D, -1)
+    x = product(cols, wpe, modes["patch"], fmt) + sd["patch_embed.proj.bias"]
+    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1)
+    x = x + ovit.interpolate_pos_embed(sd["pos_embed"], G)
+    dh = D // heads
+    qscale = dh**-0.5 * math.log2(math.e)
+    for i in range(ovit.vit_depth(sd)):
+        p = f"blocks.{i}."
+        y = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
+        qkv = product(y, sd[p + "attn.qkv.weight"], modes["qkv"], fmt) + sd[p + "attn.qkv.bias"]
+        qkv = qkv.reshape(B, -1, 3, heads, dh).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * qscale, qkv[1], qkv[2]
+        outs = []
+        for b in range(B):  # per frame: the [h, N, N] score block is 236 MB at 448^2
+            s = product(q[b], k[b], modes["qk"], fmt)  # log2 domain
+            pr = torch.exp2(s - s.amax(dim=-1, keepdim=True))
+            m = modes["pv"]
+            if m == "f32":
+                o = pr @ v[b]
+                den = pr.sum(-1, keepdim=True)
+            else:
+                # the kernel's row sums add the ROUNDED probabilities (v_dot2c on the packed pairs): numerator and denominator see
+                # the same values
+                o = product(pr, v[b].transpose(-1, -2), m, fmt)
+                den = (r16(pr, fmt) if m in ("h", "w") else pr).sum(-1, keepdim=True)
+            outs.append((o / den).transpose(0, 1).reshape(-1, D))
+        y = torch.stack(outs)
+        y = product(y, sd[p + "attn.proj.weight"], modes["proj"], fmt) + sd[p + "attn.proj.bias"]
+        x = x + y
+        y = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
+        hdn = F.gelu(product(y, sd[p + "mlp.fc1.weight"], modes["fc1"], fmt) + sd[p + "mlp.fc1.bias"])
+        y = product(hdn, sd[p + "mlp.fc2.weight"], modes["fc2"], fmt) + sd[p + "mlp.fc2.bias"]
+        x = x + y
+    return F.layer_norm(x, (D,), sd["norm.weight"], sd["norm.bias"], eps=1e-6)
+
+
+def peaked(sd, gain=6.0):
+    """A second synthetic weight set whose attention is NOT nearly uniform (trunc-normal sigma .02 - .06 weights give softmax rows
+    close to 1 / N: the attention branch then hardly reaches the tokens and its rounding looks free).  q / k weights scaled by
+    `gain`: score spread grows by gain^2."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    D = sd["norm.weight"].shape[0]
+    for i in range(ovit.vit_depth(sd)):
+        sd[f"blocks.{i}.attn.qkv.weight"][: 2 * D] *= gain
+    return sd
+
+
+def cost(modes):
+    c = 0.0
+    for f in FAMILIES:
+        c += FLOP_SHARE[f] * (MFMA_COST[modes[f]] or 8.0)
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=2)
+    ap.add_argument("--size", type=int, default=448)
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--fmt", default="fp16")
+    ap.add_argument("--weights", default="synthetic", choices=["synthetic", "peaked"])
+    ap.add_argument("--out", default="")
+    ap.add_argument("--configs", default="")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    sd = ovit.make_vit_state_dict("vit_small", 8, 28, seed=0, depth=args.depth)
+    if args.weights == "peaked":
+        sd = peaked(sd)
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(args.frames, 3, args.size, args.size, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    img = (img - mean) / std
+    with torch.no_grad():
+        t0 = time.time()
+        ref = ovit.vit_tokens(sd, img, 8, 6)
+        print(f"fp32 oracle: {time.time() - t0:.1f} s; token rms {ref.pow(2).mean().sqrt():.3f}, max {ref.abs().max():.2f}", flush=True)
+        # attention entropy as a witness of how peaked the rows are is not needed here; the table is the result
+        allh = {f: "h" for f in FAMILIES}
+        configs = [("emulation self-check: all f32", {f: "f32" for f in FAMILIES}), ("all single " + args.fmt, dict(allh))]
+        for f in FAMILIES:  # one family exact, the rest single 16-bit
+            m = dict(allh)
+            m[f] = "f32"
+            configs.append((f"all {args.fmt}, {f} exact", m))
+        for f in FAMILIES:  # one family single 16-bit, the rest exact: the family's own contribution
+            m = {ff: "f32" for ff in FAMILIES}
+            m[f] = "h"
+            configs.append((f"only {f} in {args.fmt}", m))
+        for mode in ("a", "w", "x3", "c8", "c6", "c4"):
+            configs.append((f"all {mode}", {f: mode for f in FAMILIES}))
+        # mixes: the linears compensated, attention products single
+        for mode in ("x3", "c8", "c4"):
+            m = {f: mode for f in FAMILIES}
+            m["qk"] = "h"
+            m["pv"] = "h"
+            configs.append((f"linears {mode}, attention single", m))
+            m = dict(m)
+            m["qk"] = mode
+            configs.append((f"linears + qk {mode}, pv single", m))
+        if args.configs:
+            keep = set(args.configs.split(","))
+            configs = [c for c in configs if c[0] in keep]
+        rows = []
+        for name, modes in configs:
+            t0 = time.time()
+            tok = vit_tokens_emulated(sd, img, 8, 6, modes, args.fmt)
+            err = (tok - ref)
+            mx, rms = err.abs().max().item(), err.pow(2).mean().sqrt().item()
+            rel = rms / ref.pow(2).mean().sqrt().item()
+            rows.append((name, mx, rms, rel, cost(modes)))
+            print(f"{name:44s} max {mx:.2e}  rms {rms:.2e}  rel-L2 {rel:.2e}  mfma cost {cost(modes):.2f}  ({time.time() - t0:.0f} s)", flush=True)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(f"# Error budget of the 16-bit path by kernel family ({args.weights} weights, {args.frames} frames at {args.size}^2, "
+                    f"{args.depth} blocks, operand format {args.fmt})\n\n")
+            f.write("CPU emulation (`scripts/error_budget.py`): operands of the named products rounded as the kernels round them, fp32 "
+                    "accumulation; error of the final-LayerNorm'ed tokens against the fp32 oracle.  `mfma cost` = matrix-pipe work "
+                    "relative to the all-single-16-bit path (FLOP shares of DESIGN section 4).\n\n")
+            f.write("| configuration | max abs | rms | rel-L2 | mfma cost |\n|---|---|---|---|---|\n")
+            for name, mx, rms, rel, c in rows:
+                f.write(f"| {name} | {mx:.2e} | {rms:.2e} | {rel:.2e} | {c:.2f} |\n")
+
+
+if __name__ == "__main__":
+    main()

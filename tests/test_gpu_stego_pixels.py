@@ -29,9 +29,22 @@ def test_upsample_kernel_matches_fixed_order_oracle(dev):
     assert (got - aten).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("G,H,C,K,B", [(8, 64, 90, 5, 2), (7, 50, 16, 4, 3), (28, 224, 90, 20, 1), (5, 33, 90, 6, 2)])
-def test_pixel_kmeans_bit_exact(dev, G, H, C, K, B):
-    """(7, 50) and (5, 33): chunks straddle image rows, the last group is ragged; (28, 224): the live node's default size."""
+@pytest.fixture
+def assign_form(request):
+    """Both assignment kernels of the pixel k-means: the VALU form (default) and the opt-in fp32-MFMA form (K <= 20)."""
+    from wild_visual_navigation_amd import _lib
+    _lib.lib().wvn_debug_kmeans_assign_form(request.param)
+    yield request.param
+    _lib.lib().wvn_debug_kmeans_assign_form(-1)
+
+
+@pytest.mark.parametrize("assign_form", [1, 0], indirect=True, ids=["mfma", "valu"])
+@pytest.mark.parametrize("G,H,C,K,B", [(8, 64, 90, 5, 2), (7, 50, 16, 4, 3), (28, 224, 90, 20, 1), (5, 33, 90, 6, 2), (28, 224, 90, 20, 16),
+                                       (9, 70, 90, 17, 9)])
+def test_pixel_kmeans_bit_exact(dev, assign_form, G, H, C, K, B):
+    """(7, 50) and (5, 33): chunks straddle image rows, the last group is ragged; (28, 224): the live node's default size; B = 16: the
+    frame -> XCD mapping of whole multiples of 8 frames; (9, 70, K = 17): two 64-pixel groups per row with a ragged second one, a
+    partial last centroid block."""
     code = torch.randn(B, G * G, C, generator=g(G * H)) * (1.0 + torch.rand(B, G * G, 1, generator=g(1)))
     lab, nseg, cent = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=False, return_centroids=True)
     lab2, nseg2 = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=True)
@@ -47,7 +60,8 @@ def test_pixel_kmeans_bit_exact(dev, G, H, C, K, B):
         assert int(nseg[b]) == len(np.unique(want)) == int(nseg2[b])
 
 
-def test_pixel_kmeans_at_448_against_oracle(dev):
+@pytest.mark.parametrize("assign_form", [1, 0], indirect=True, ids=["mfma", "valu"])
+def test_pixel_kmeans_at_448_against_oracle(dev, assign_form):
     """BASELINE size: one 448^2 frame, 56 x 56 x 90 code, K = 20: 200 704 points x 11 assignment passes, labels bit-exact."""
     G, H, C, K = 56, 448, 90, 20
     sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=2, depth=1)

@@ -13,6 +13,10 @@ import torch  # noqa: F401  (must be imported first: its bundled libamdhip64.so.
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # WVN_LIB_PATH: load another build of the same library (same-box A/B runs of compiler flags, scripts/ab_lib.sh); never a fallback
 LIB_PATH = os.environ.get("WVN_LIB_PATH") or os.path.join(_HERE, "lib", "libwvn_hip.so")
+if os.environ.get("WVN_LIB_PATH"):
+    import sys as _sys
+
+    print(f"[wild_visual_navigation_amd] WVN_LIB_PATH is set: loading {LIB_PATH} instead of the in-tree build", file=_sys.stderr)
 
 WVN_MAX_DEPTH = 32
 PREC_F32, PREC_BF16, PREC_X3, PREC_FP8, PREC_F16 = 0, 1, 2, 3, 4
@@ -67,6 +71,9 @@ _SIGNATURES = {
     "wvn_prof_collect": ([_p, _p], _i),
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_debug_attention_variant": ([_i], _i),
+    "wvn_debug_kmeans_assign_form": ([_i], _i),
+    "wvn_stream_create_cu_mask": ([_p, _p, _i], _i),
+    "wvn_stream_destroy": ([_p], _i),
     "wvn_debug_qkv_fused_timing": ([_p], _i),
     "wvn_debug_mlp_fused_timing": ([_p], _i),
     "wvn_qkv_fused": ([_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p], _i),

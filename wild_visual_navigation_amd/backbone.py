@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from . import _lib
 
 ARCH = {"vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}
+PRECISIONS = ("fp16", "bf16", "exact", "fp32", "fp8")   # names VitBackbone(precision=...) accepts in this build
 
 
 def synthetic_vit_state_dict(arch="vit_small", patch=8, pretrain_grid=28, seed=0, depth=None, dinov2=False) -> Dict[str, torch.Tensor]:

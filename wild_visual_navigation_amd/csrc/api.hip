@@ -522,6 +522,21 @@ int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const
 int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
 int wvn_debug_mlp_fused_timing(long long* dbg) { g_mlp_fused_dbg = dbg; return WVN_OK; }
 int wvn_debug_qkv_fused_timing(long long* dbg) { g_qkv_fused_dbg = dbg; return WVN_OK; }
+int wvn_stream_create_cu_mask(void** stream, const unsigned int* mask, int words) {
+  if (!stream || !mask || words <= 0) return WVN_ERR_ARG;
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+  if (e != hipSuccess) return (int)e;
+  *stream = (void*)st;
+  return WVN_OK;
+}
+int wvn_stream_destroy(void* stream) {
+  if (!stream) return WVN_ERR_ARG;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? WVN_OK : (int)e;
+}
+
+int wvn_debug_kmeans_assign_form(int form) { wvn_kmeans_pixels_set_assign_form(form); return WVN_OK; }
 int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); wvn_attention_bf16_set_variant_f16(v); return WVN_OK; }
 
 int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,

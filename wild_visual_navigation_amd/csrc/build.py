@@ -47,6 +47,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _cmd_changed(obj, cmd):
+    """The full compile command is part of the staleness key (WVN_ATTN_FLAGS / WVN_MLP_FLAGS builds were reused by a
+    later normal build and the reverse): it is kept beside the object and compared."""
+    stamp = obj + ".cmd"
+    line = " ".join(cmd)
+    try:
+        with open(stamp) as f:
+            if f.read() == line:
+                return False
+    except OSError:
+        pass
+    return True
+
+
+def _write_cmd(obj, cmd):
+    with open(obj + ".cmd", "w") as f:
+        f.write(" ".join(cmd))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -58,12 +77,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s, o, defs in units:
         src = os.path.join(HERE, s)
         obj = os.path.join(OBJ, o)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append((o, [hipcc] + FLAGS + EXTRA.get(s, []) + defs + ["-c", src, "-o", obj]))
+        cmd = [hipcc] + FLAGS + EXTRA.get(s, []) + defs + ["-c", src, "-o", obj]
+        if force or _stale(obj, [src] + hdrs) or _cmd_changed(obj, cmd):
+            jobs.append((o, cmd))
 
     def run(job):
         name, cmd = job
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            _write_cmd(cmd[-1], cmd)
         return name, r.returncode, r.stdout + r.stderr
 
     if jobs:

@@ -361,6 +361,9 @@ int wvn_mlp_train_fwd_launch(const float* P, const size_t* off, size_t ntotal, c
   if (fwd_lds(D) > FUSED_LDS_MAX) return WVN_ERR_ARG;
   static LdsOptIn lds_opt_in;   // (the kernels also hold a few bytes of static LDS: the dynamic limit must stay below 160 KB)
   if (const int rc = lds_opt_in((int)FUSED_LDS_MAX, (const void*)mlp_train_fwd_kernel, (const void*)mlp_train_bwd_kernel)) return rc;
+  // the arrival counter is zeroed on the stream in front of every launch (a count left over by an aborted launch, or a
+  // sync word the caller shares, would leave no tile "last" and the step would train on stale statistics without an error)
+  if (const hipError_t e = hipMemsetAsync(sync_word, 0, sizeof(unsigned), st); e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(mlp_train_fwd_kernel, dim3(ceil_div(R, TR)), dim3(256), fwd_lds(D), st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;

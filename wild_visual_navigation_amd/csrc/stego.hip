@@ -262,6 +262,21 @@ int run_kmeans(const float* xn, int* labels, int* nseg, float* scratch, int B, i
 //             registers while the label repeats -- the addition order is exactly the sequential one.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int PIX_RPB = 4;   // image rows per workgroup of the lane-per-pixel kernels (the two staged code rows serve P of them)
+// Workgroup -> (part ix of the frame, frame b) for 1-D grids of nx * B workgroups.  Consecutive workgroup ids land on consecutive
+// XCDs (guide: block i runs on XCD i mod 8), each with its own 4 MB L2: with whole multiples of 8 frames, every frame is worked on
+// by ONE XCD (frame b on XCD b mod 8), so its 1.1 MB of patch codes, its labels and its reciprocal norms are fetched into one L2
+// instead of eight (round 3 PMC: the partial-sum kernel read 1376 MB per launch against 175 MB algorithmic, the assign kernel 467).
+__host__ __device__ inline int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
+__device__ inline void km_frame_map(int id, int nx, int B, int& ix, int& b) {
+  if ((B & 7) == 0) {
+    const int xcd = id & 7, s = id >> 3, f = s / nx;
+    b = f * 8 + xcd;
+    ix = s - f * nx;
+  } else {
+    b = id / nx;
+    ix = id - b * nx;
+  }
+}
 // stage code rows y0 / y1 of frame b ([G][C] each) into LDS: rows[0][G*C], rows[1][G*C]
 __device__ inline void pix_stage_rows(const float* __restrict__ code, int b, int G, int C, int y0, int y1, float* rows) {
   const int n = G * C;   // contiguous in memory
@@ -286,12 +301,13 @@ __device__ inline void pix_row(const float* rows, int G, const LerpTap& tx, cons
 // channel order; the row is interpolated sixteen channels at a time (nothing but the chain's accumulator lives across the blocks:
 // ~30 registers, and with one wave per 64 pixels of an image row the kernel fills the CU like the assign kernel does).
 template <int C>
-__global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H) {
+__global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H, int B) {
   extern __shared__ float rows[];  // [2][G][C]
-  const int b = blockIdx.y;
+  int bx, b;
+  km_frame_map(blockIdx.x, ceil_div_dev(H, PIX_RPB), B, bx, b);
   const float scale = lerp_scale(G, H);
   int s0 = -1, s1 = -1;            // the code rows staged in LDS
-  for (int y = blockIdx.x * PIX_RPB; y < min(H, (blockIdx.x + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
+  for (int y = bx * PIX_RPB; y < min(H, (bx + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
     const LerpTap ty = lerp_tap(y, G, scale);
     if (ty.i0 != s0 || ty.i1 != s1) {
       __syncthreads();
@@ -367,7 +383,7 @@ __device__ inline void km_swait(f32x16_t& r) { asm volatile("s_waitcnt lgkmcnt(0
 template <int C, int KMAX, bool EXACTK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void km_pix_assign_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
-                                                            int K) {
+                                                            int K, int B) {
   // LDS row pitch = C, unpadded: at C = 90 and G = 56 the two staged code rows are 40,320 bytes -- FOUR workgroups per CU (padding
   // the rows to 16-byte multiples for ds_read_b128 taps costs 41,216: three).  With one wave per 64 pixels of an image row (448
   // threads at 448 pixels: seven waves, none idle) and <= 72 registers that is 28 waves per CU against 21, and 7168 workgroups
@@ -375,11 +391,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   constexpr int CP = C;
   constexpr int DB = 16;             // channels per block
   extern __shared__ __attribute__((aligned(16))) float rows[];  // [2][G][CP]
-  const int b = blockIdx.y;
+  int bx, b;
+  km_frame_map(blockIdx.x, ceil_div_dev(H, PIX_RPB), B, bx, b);
   const float scale = lerp_scale(G, H);
   const float* __restrict__ cb = cent + (size_t)b * K * C;   // uniform addresses: served by the scalar cache
   int s0 = -1, s1 = -1;            // the code rows staged in LDS
-  for (int y = blockIdx.x * PIX_RPB; y < min(H, (blockIdx.x + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
+  for (int y = bx * PIX_RPB; y < min(H, (bx + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
     const LerpTap ty = lerp_tap(y, G, scale);
     if (ty.i0 != s0 || ty.i1 != s1) {
       __syncthreads();
@@ -449,18 +466,178 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
 }
 
+
+// ---- the assignment pass on the matrix pipe (round 4) ----------------------------------------------------------------------
+// The K x C similarity products of a pixel are an fp32 GEMM, and gfx950 has an fp32-input MFMA whose result is, bit for bit, the
+// k-ordered fmaf chain of the definition (MI355X guide: "exact f32 == an fmaf chain, bitwise").  The form used is
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products per instruction, K = 1, 8 cycles --
+//     D[blk][i][j] += A[blk][i] * B[blk][j]       A: lane 4 blk + i, B: lane 4 blk + j, D: lane 4 blk + j, register i
+// With B = the lane's OWN pixel value of one channel (lane = pixel, exactly the layout the interpolation produces) and
+// A = centroid (4 m + (lane & 3)) of that channel, one instruction advances centroids 4 m .. 4 m + 3 of all 64 pixels by one
+// channel: accumulator (m, i) of a lane IS acc_{4 m + i} of the definition, one fma per channel in ascending channel order.
+// K = 20 is five such instructions per channel and 64 pixels = 40 matrix-pipe cycles with no padded rows (the 32 x 32 x 2 and
+// 16 x 16 x 4 forms would run 32 centroid slots for 20), against 20 v_fma_f32 = 80 cycles on the VALU.
+//
+// What the first version of this kernel taught (scripts/ablate_pixel_kmeans.py, 64 frames): MFMAs, VALU and LDS reads of a wave do
+// NOT hide behind each other here -- an 8-cycle MFMA leaves no issue slot to fill -- so the kernel costs their sum, and the LDS
+// reads (13 ds_read_b128 per channel quad and image-row pair) were the largest term: 350 of 814 us.  Hence the work split:
+//   * a workgroup owns one RUN of image rows: the rows whose two source code rows (i0, i0 + 1) are the same (8 or 9 rows at
+//     448 / 56).  Only those two code rows are staged (2 x G x CP floats).
+//   * a wave item is FOUR image rows x 64 pixels of the run with the same x: all four rows read the SAME four taps, so a quad of
+//     channels costs 4 tap reads + 5 centroid-fragment reads for 256 pixels (2.25 per row instead of 6.5), and the horizontal half
+//     of the interpolation -- t0 = fma(wx1, v01, wx0 v00), t1 likewise: the values do not depend on the image row -- is computed
+//     once for the four rows (4 + 4 x 3 VALU instructions per channel instead of 4 x 7; the same operations on the same values,
+//     so the same bits).
+//   * the twenty MFMAs of a channel go to twenty different accumulators (hipcc's own order is accumulator-major, which makes every
+//     other MFMA wait out its predecessor); sched_barrier keeps the channel groups apart, each group carries the next channel's
+//     interpolation and a share of the next quad's LDS reads.
+// Labels and therefore centroids are bit-identical to the VALU form (tests/test_gpu_stego_pixels.py runs both).
+//
+// MEASURED (64 frames at 448^2, one pass): 805 us against 779 us for the VALU form -- NOT faster, so the VALU form stays the default
+// and this kernel is opt-in (wvn_debug_kmeans_assign_form(1)).  Why: the 4x4x1 instruction issues once per 16 cycles, not 8 (the
+// kernel with its interpolation removed runs at 16.0 cycles per MFMA; SQ_VALU_MFMA_BUSY_CYCLES still counts 8 per instruction),
+// i.e. 32 flop / clk / SIMD -- exactly the rate of v_fma_f32 -- and nothing else issues in its shadow.  The large fp32 forms
+// (16x16x4, 32x32x2) do reach 64 flop / clk, but with K = 20 centroids on 32 slots that is 1.25 x the VALU rate before the
+// cross-lane argmax they need: not worth a third kernel.  profiles/r04b_kmeans_assign_forms.md holds the numbers.
+constexpr int PIXM_G = 4;          // image rows per wave item
+constexpr int PIXM_MB = 5;         // centroid blocks of 4 (K <= 20)
+__host__ __device__ constexpr int pixm_cp(int C) { return (C + 3) / 4 * 4; }
+__host__ inline size_t pixm_lds_bytes(int G, int C) { return ((size_t)2 * G * pixm_cp(C) + (size_t)(pixm_cp(C) / 4) * 4 * PIXM_MB * 4) * sizeof(float); }
+
+template <int C, bool EXACTK>
+__global__ __launch_bounds__(256) void km_pix_assign_mfma_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+                                                                 const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
+                                                                 int K, int B) {
+  constexpr int CP = pixm_cp(C), NQ = CP / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* rows = lds;                         // [2][G][CP]: source rows i0 and min(i0 + 1, G - 1)
+  float* tabA = lds + 2 * G * CP;            // [NQ][4][PIXM_MB][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int i0, b;
+  km_frame_map(blockIdx.x, G, B, i0, b);
+  const float scale = lerp_scale(G, H);
+  // the run of image rows whose upper source row is i0: [yb, ye)
+  int yb = scale > 0.f ? max(0, (int)((float)i0 / scale) - 2) : 0;
+  while (yb < H && lerp_tap(yb, G, scale).i0 < i0) ++yb;
+  int ye = yb;
+  while (ye < H && lerp_tap(ye, G, scale).i0 == i0) ++ye;
+  if (ye == yb) return;                      // (uniform: no image row maps to this source row)
+  {
+    const float* cb = code + (size_t)b * G * G * C;
+    for (int rg = wave; rg < 2 * G; rg += 4) {          // one wave per (source row, patch column): a 4 C-byte run of global memory
+      const int r = rg / G, g = rg - r * G;
+      const float* src = cb + ((size_t)min(i0 + r, G - 1) * G + g) * C;
+      float* dst = rows + (size_t)rg * CP;
+#pragma unroll
+      for (int d = lane; d < CP; d += 64) dst[d] = d < C ? src[d] : 0.f;
+    }
+    const float* ck = cent + (size_t)b * K * C;
+    for (int i = tid; i < NQ * 4 * PIXM_MB * 4; i += 256) {
+      const int cq = i & 3, m = (i >> 2) % PIXM_MB, r = (i / (4 * PIXM_MB)) & 3, q = i / (16 * PIXM_MB);
+      const int k = 4 * m + r, ch = 4 * q + cq;
+      tabA[i] = (k < K && ch < C) ? ck[(size_t)k * C + ch] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int ngx = ceil_div_dev(H, 64), nchunk = ceil_div_dev(ye - yb, PIXM_G);
+  const f32x4_t* tA = (const f32x4_t*)tabA + (lane & 3) * PIXM_MB;
+  for (int item = wave; item < nchunk * ngx; item += 4) {
+    const int ck = item / ngx, gx = item - ck * ngx;
+    const int x = gx * 64 + lane, xc = min(x, H - 1);
+    const LerpTap tx = lerp_tap(xc, G, scale);
+    int yy[PIXM_G];
+    float wy0[PIXM_G], wy1[PIXM_G], ri[PIXM_G];
+    size_t pp[PIXM_G];
+#pragma unroll
+    for (int j = 0; j < PIXM_G; ++j) {
+      yy[j] = min(yb + ck * PIXM_G + j, ye - 1);         // (rows past the run repeat its last row; their labels are not stored)
+      const LerpTap ty = lerp_tap(yy[j], G, scale);
+      wy0[j] = ty.w0; wy1[j] = ty.w1;
+      pp[j] = (size_t)b * H * H + (size_t)yy[j] * H + xc;
+      ri[j] = rinv[pp[j]];
+    }
+    const float* p00 = rows + tx.i0 * CP;
+    const float* p01 = rows + tx.i1 * CP;
+    const float* p10 = rows + (G + tx.i0) * CP;
+    const float* p11 = rows + (G + tx.i1) * CP;
+    f32x4_t acc[PIXM_G][PIXM_MB];
+#pragma unroll
+    for (int j = 0; j < PIXM_G; ++j)
+#pragma unroll
+      for (int m = 0; m < PIXM_MB; ++m) acc[j][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    struct Quad { f32x4_t t00, t01, t10, t11, w[PIXM_MB]; };
+    auto fetch = [&](int q, Quad& t, int part) {   // part 0: the four taps, 1: the centroid fragments; < 0: both
+      if (part <= 0) {
+        t.t00 = *(const f32x4_t*)(p00 + 4 * q); t.t01 = *(const f32x4_t*)(p01 + 4 * q);
+        t.t10 = *(const f32x4_t*)(p10 + 4 * q); t.t11 = *(const f32x4_t*)(p11 + 4 * q);
+      }
+      if (part < 0 || part == 1) {
+#pragma unroll
+        for (int m = 0; m < PIXM_MB; ++m) t.w[m] = tA[q * 4 * PIXM_MB + m];
+      }
+    };
+    // v[j] of channel (quad t, position cq): bilerp_fixed's operations with the row-independent half hoisted
+    auto interp = [&](const Quad& t, int cq, float (&v)[PIXM_G]) {
+      const float h0 = __fmaf_rn(tx.w1, t.t01[cq], __fmul_rn(tx.w0, t.t00[cq]));
+      const float h1 = __fmaf_rn(tx.w1, t.t11[cq], __fmul_rn(tx.w0, t.t10[cq]));
+#pragma unroll
+      for (int j = 0; j < PIXM_G; ++j) v[j] = __fmul_rn(__fmaf_rn(wy1[j], h1, __fmul_rn(wy0[j], h0)), ri[j]);
+    };
+    Quad cur, nxt;
+    fetch(0, cur, -1);
+    float v[PIXM_G], vn[PIXM_G];
+    interp(cur, 0, v);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      constexpr int dummy = 0; (void)dummy;
+      const int nch = C - 4 * q < 4 ? C - 4 * q : 4;   // (compile-time after unrolling)
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq)
+        if (cq < nch) {
+          if (q + 1 < NQ && cq < 2) fetch(q + 1, nxt, cq);
+#pragma unroll
+          for (int j = 0; j < PIXM_G; ++j) vn[j] = 0.f;
+          if (cq + 1 < nch) interp(cur, cq + 1, vn);
+          else if (q + 1 < NQ) interp(nxt, 0, vn);
+#pragma unroll
+          for (int m = 0; m < PIXM_MB; ++m)
+#pragma unroll
+            for (int j = 0; j < PIXM_G; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_4x4x1f32(cur.w[m][cq], v[j], acc[j][m], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < PIXM_G; ++j) v[j] = vn[j];
+        }
+      if (q + 1 < NQ) cur = nxt;
+    }
+#pragma unroll
+    for (int j = 0; j < PIXM_G; ++j) {
+      int best = 0;
+      float bv = -INFINITY;
+#pragma unroll
+      for (int m = 0; m < PIXM_MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 4 * m + r;
+          if ((EXACTK || k < K) && acc[j][m][r] > bv) { bv = acc[j][m][r]; best = k; }
+        }
+      if (x < H && yb + ck * PIXM_G + j < ye) labels[pp[j]] = best;
+    }
+  }
+}
+
 // The pixel-vector-resident form (x[C] in registers, four dot-product chains in flight, centroids through the scalar cache at
 // hipcc's discretion): any K; what runs for K > 32, where the accumulator-resident form above has no registers left.
 template <int C>
 __global__ __launch_bounds__(256) void km_pix_assign_wide_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
-                                                            int K) {
+                                                            int K, int B) {
   extern __shared__ float rows[];  // [2][G][C]
-  const int b = blockIdx.y;
+  int bx, b;
+  km_frame_map(blockIdx.x, ceil_div_dev(H, PIX_RPB), B, bx, b);
   const float scale = lerp_scale(G, H);
   const float* __restrict__ cb = cent + (size_t)b * K * C;   // uniform addresses: served by the scalar cache
   int s0 = -1, s1 = -1;            // the code rows staged in LDS
-  for (int y = blockIdx.x * PIX_RPB; y < min(H, (blockIdx.x + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
+  for (int y = bx * PIX_RPB; y < min(H, (bx + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
   const LerpTap ty = lerp_tap(y, G, scale);
   if (ty.i0 != s0 || ty.i1 != s1) {
     __syncthreads();
@@ -522,9 +699,11 @@ __global__ __launch_bounds__(256) void km_pix_assign_wide_kernel(const float* __
 template <int KMAX>
 __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const int* __restrict__ labels, float* __restrict__ part,
-                                                            int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup, int nsup) {
+                                                            int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup, int nsup, int B) {
   extern __shared__ __attribute__((aligned(8))) float tab[];   // [K][C]: the current chunk's parked sums
-  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  int g, b;
+  km_frame_map(blockIdx.x, ngroup, B, g, b);
+  const int lane = threadIdx.x;
   const long long P = (long long)H * H;
   const bool act = 2 * lane < C;
   const int c2 = act ? 2 * lane : 0;   // (inactive lanes read channels 0, 1 and drop the result)
@@ -633,6 +812,10 @@ PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
   return s;
 }
 
+// the MFMA assign kernel is eligible when K <= 20 and the two staged code rows + the fragment table fit the LDS
+static bool pixm_ok(int G, int H, int C, int K) { return K <= 4 * PIXM_MB && H >= 2 && pixm_lds_bytes(G, C) <= 150 * 1024; }
+int g_km_assign_form = -1;   // -1 / 0: the VALU form (default), 1: the fp32-MFMA form where eligible (K <= 20; tests, A/B)
+
 template <int C>
 int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int K, int iters, int relabel,
                       hipStream_t st) {
@@ -644,26 +827,32 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C, 20, true>,
                                 (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>)) return rc;
-  hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(ceil_div(H, PIX_RPB), B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
-                     s.rinv, G, H);
+  static LdsOptIn lds_opt_in_m;
+  if (const int rc = lds_opt_in_m(150 * 1024, (const void*)km_pix_assign_mfma_kernel<C, true>, (const void*)km_pix_assign_mfma_kernel<C, false>)) return rc;
+  const bool mfma = g_km_assign_form == 1 && pixm_ok(G, H, C, K);
+  const int nrb = ceil_div(H, PIX_RPB);
+  hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(nrb * B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
+                     s.rinv, G, H, B);
   hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K);
   WVN_LAUNCH_CHECK();
   for (int it = 0; it <= iters; ++it) {
-    const dim3 ga(ceil_div(H, PIX_RPB), B);
-    if (K == 20) hipLaunchKernelGGL((km_pix_assign_kernel<C, 20, true>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
-    else if (K <= 32) hipLaunchKernelGGL((km_pix_assign_kernel<C, 32, false>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K);
-    else hipLaunchKernelGGL((km_pix_assign_wide_kernel<C>), ga, dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K);
+    const dim3 ga(nrb * B);
+    if (mfma && K == 20) hipLaunchKernelGGL((km_pix_assign_mfma_kernel<C, true>), dim3(G * B), dim3(256), pixm_lds_bytes(G, C), st, code, s.rinv, s.cent, labels, G, H, K, B);
+    else if (mfma) hipLaunchKernelGGL((km_pix_assign_mfma_kernel<C, false>), dim3(G * B), dim3(256), pixm_lds_bytes(G, C), st, code, s.rinv, s.cent, labels, G, H, K, B);
+    else if (K == 20) hipLaunchKernelGGL((km_pix_assign_kernel<C, 20, true>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K, B);
+    else if (K <= 32) hipLaunchKernelGGL((km_pix_assign_kernel<C, 32, false>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K, B);
+    else hipLaunchKernelGGL((km_pix_assign_wide_kernel<C>), ga, dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K, B);
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
     if (K <= 20)   // (fewer group-partial registers: 5 waves per SIMD instead of 4)
-      hipLaunchKernelGGL(km_pix_partial_kernel<20>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
-                         s.part, s.pcnt, G, H, C, K, ngroup, nsup);
+      hipLaunchKernelGGL(km_pix_partial_kernel<20>, dim3(ngroup * B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
+                         s.part, s.pcnt, G, H, C, K, ngroup, nsup, B);
     else if (K <= 32)
-      hipLaunchKernelGGL(km_pix_partial_kernel<32>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
-                         s.part, s.pcnt, G, H, C, K, ngroup, nsup);
+      hipLaunchKernelGGL(km_pix_partial_kernel<32>, dim3(ngroup * B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
+                         s.part, s.pcnt, G, H, C, K, ngroup, nsup, B);
     else
-      hipLaunchKernelGGL(km_pix_partial_kernel<KM_MAXK>, dim3(ngroup, B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv,
-                         labels, s.part, s.pcnt, G, H, C, K, ngroup, nsup);
+      hipLaunchKernelGGL(km_pix_partial_kernel<KM_MAXK>, dim3(ngroup * B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv,
+                         labels, s.part, s.pcnt, G, H, C, K, ngroup, nsup, B);
     WVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1);
     WVN_LAUNCH_CHECK();
@@ -744,6 +933,8 @@ int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* s
   if (C == 16) return run_kmeans_pixels<16>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st);
   return WVN_ERR_ARG;
 }
+
+void wvn_kmeans_pixels_set_assign_form(int form) { g_km_assign_form = form; }
 
 int wvn_flip_average_launch(const float* a, const float* mirrored, float* out, int B, int G, int C, hipStream_t st) {
   if (!a || !mirrored || !out || B <= 0 || G <= 0 || C <= 0) return WVN_ERR_ARG;

@@ -46,7 +46,7 @@ class DinoInterface:
         dropout_p: float = 0,
         pretrained_weights=None,  # path to a DINO checkpoint, or a state dict; None -> seeded synthetic
         cfg=None,
-        precision: str = "bf16",  # extension: "bf16" | "fp16" (MFMA speed path, 8 / 11 significand bits) | "exact" (<= 1e-3 parity mode on MFMA) | "fp32" (same gate, FMA)
+        precision: str = "fp16",  # extension: "fp16" | "bf16" (MFMA speed path, 11 / 8 significand bits) | "mixed" | "exact" (<= 1e-3 parity mode on MFMA) | "fp32" (same gate, FMA)
         max_chunk: int = 16,
         allow_synthetic: bool = False,
         fuse_mlp: Optional[bool] = None,

@@ -7,7 +7,9 @@ STEGO head (1x1-conv linear branch + 1x1-conv/ReLU/1x1-conv branch, summed) on t
 deterministic per-image cosine k-means for ``run_clustering=True``.  ``model_path`` is honoured: a Lightning checkpoint in
 either the upstream STEGO (``net.model.* / net.cluster1.* / cluster_probe.clusters / linear_probe.*``) or the
 self_supervised_segmentation (``backbone.* / segmentation_head.*``) key layout is loaded (``load_stego_checkpoint``); without
-one, seeded synthetic weights are used and a warning says so.  ``run_crf=True`` (pydensecrf, CPU) is not available.
+one, seeded synthetic weights are used and a warning says so.  ``run_crf=True`` -- the reference constructor's own default -- needs
+pydensecrf (CPU, external): it raises unless the caller opts in to running WITHOUT the CRF refinement (``skip_crf=True`` or the
+environment variable ``WVN_SKIP_CRF=1``), in which case a warning says that the CRF step was dropped.
 
 Two knobs make the definition explicit instead of implicit.  Their DEFAULTS are the upstream behaviour as published (Stego.get_code
 averages the code with the flipped-back code of the mirrored frame; postprocess clusters the code up-sampled to the image size);
@@ -102,7 +104,7 @@ class StegoInterface:
         cfg=None,
         backbone_type: str = None,     # extension: default = what the weights say (the released ckpt is ViT-Base), else vit_small
         patch_size: int = 8,
-        precision: str = "bf16",
+        precision: str = "fp16",       # "fp16" (default speed path) | "bf16" | "mixed" / "exact" (<= 1e-3 parity modes) | "fp32" | "fp8"
         backbone_weights=None,
         head_weights: Optional[Dict[str, torch.Tensor]] = None,
         probe_weights: Optional[Dict[str, torch.Tensor]] = None,
@@ -113,6 +115,7 @@ class StegoInterface:
         fuse_mlp: Optional[bool] = None,
         fuse_qkv: Optional[bool] = None,
         fuse_proj: bool = True,
+        skip_crf: Optional[bool] = None,  # run_crf=True without pydensecrf: None -> WVN_SKIP_CRF env, True -> warn and drop the CRF step
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(model_path=model_path, input_size=input_size, run_crf=run_crf,
@@ -120,7 +123,15 @@ class StegoInterface:
         else:
             self._cfg = _Cfg(cfg)
         if self._cfg.run_crf:
-            raise _lib.WvnError("run_crf=True needs pydensecrf (CPU, external); FeatureExtractor uses run_crf=False")
+            import os
+
+            if skip_crf is None:
+                skip_crf = os.environ.get("WVN_SKIP_CRF", "0") not in ("", "0")
+            if not skip_crf:
+                raise _lib.WvnError("run_crf=True needs pydensecrf (CPU, external); FeatureExtractor uses run_crf=False.  Pass "
+                                    "skip_crf=True (or set WVN_SKIP_CRF=1) to run the segmentation without the CRF refinement")
+            warnings.warn("StegoInterface: run_crf=True but the dense CRF (pydensecrf, CPU) is not part of the MI355X path -- the "
+                          "cluster / linear predictions are returned WITHOUT CRF refinement (skip_crf)", stacklevel=2)
         if cluster_resolution not in ("patch", "pixel"):
             raise _lib.WvnError("cluster_resolution must be 'patch' or 'pixel'")
         self._device = torch.device(device)
@@ -275,6 +286,8 @@ class StegoInterface:
         result of ``code_tokens(img)`` if the caller already ran that stage (e.g. on another stream)."""
         G = self._bb.grid
         H = img.shape[2]
+        S = self._cfg.input_size   # postprocess() works on the resized frame (stego_interface.py:87-100); the label maps are then
+        #                            nearest-resampled to the camera height (stego_interface.py:108-109)
         if code is None:
             code = self.code_tokens(img)
         B = code.shape[0]
@@ -282,14 +295,20 @@ class StegoInterface:
         self._code = None  # dense code is produced lazily (features property): 72 MB/frame at 448^2
         self._H = H
         self._labels_patch = None
-        if self._cluster_resolution == "pixel":      # cluster the H x H up-sampled code pixels
-            if self._cfg.run_clustering:   # rows interpolated on the fly from the patch codes: the dense code is never built
-                labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, H, self._cfg.n_image_clusters, KMEANS_ITERS, relabel=True)
+        if self._cluster_resolution == "pixel":      # cluster the S x S up-sampled code pixels
+            K = self._cfg.n_image_clusters
+            if self._cfg.run_clustering and ops.kmeans_cosine_pixels_supported(G, S, self._C, K):
+                # rows interpolated on the fly from the patch codes: the dense code is never built
+                labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, S, K, KMEANS_ITERS, relabel=True)
+            elif self._cfg.run_clustering:   # code dimension / cluster count outside the fused kernel's instantiations: dense rows
+                pix = ops.upsample_bilinear(code, G, S).permute(0, 2, 3, 1).reshape(B, S * S, self._C).contiguous()
+                labels, self._n_segments = ops.kmeans_cosine(pix, K, KMEANS_ITERS, relabel=True)
             else:
-                pix = self.features.permute(0, 2, 3, 1).reshape(B * H * H, self._C)   # [B, C, H, H] -> pixel rows
+                pix = ops.upsample_bilinear(code, G, S).permute(0, 2, 3, 1).reshape(B * S * S, self._C)   # [B, C, S, S] -> pixel rows
                 labels = self._probe_labels(pix, self._clusters, None, cosine=True)
                 self._n_segments = None
-            self._cluster_pred = labels.reshape(1, B, H, H)
+            labels = labels.reshape(B, S, S)
+            self._cluster_pred = (labels if H == S else ops.upsample_nearest_labels(labels, H))[None]
         else:
             if self._cfg.run_clustering:
                 labels, self._n_segments = ops.kmeans_cosine(code, self._cfg.n_image_clusters, KMEANS_ITERS, relabel=True)

@@ -271,6 +271,12 @@ def kmeans_cosine(code: torch.Tensor, K: int, iters: int = 10, relabel: bool = T
     return labels, nseg
 
 
+def kmeans_cosine_pixels_supported(G: int, H: int, C: int, K: int) -> bool:
+    """Whether ``wvn_kmeans_cosine_pixels`` has an instantiation for this shape (csrc/stego.hip: code dimension 90 or 16, up to 64
+    clusters, the two staged code rows within 96 KB of LDS); callers fall back to the dense rows + ``kmeans_cosine`` otherwise."""
+    return C in (90, 16) and 0 < K <= 64 and 2 * G * C * 4 <= 96 * 1024 and G > 0 and H > 0
+
+
 def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int = 10, relabel: bool = True,
                          return_centroids: bool = False):
     """code [B, G*G, C] fp32 patch codes -> (labels [B, H*H] int32, n_segments [B] int32): the k-means of ``kmeans_cosine`` over
@@ -570,3 +576,34 @@ def prof_collect():
     cnt = (C.c_longlong * n)()
     check(lib().wvn_prof_collect(ms, cnt), "wvn_prof_collect")
     return {c: (ms[i], cnt[i]) for i, c in enumerate(_lib.PROF_CATS)}
+
+
+def cu_mask_words(cus_per_xcd_lo: int, cus_per_xcd_hi: int, layout: str = "rr", xcds: int = 8, cus_per_xcd: int = 32):
+    """32-bit mask words selecting CUs [lo, hi) of every XCD.  ``layout``: how the driver numbers mask bits -- "rr": bit i is CU
+    i // xcds of XCD i % xcds (amdkfd spreads a queue's mask over the XCCs round-robin), "lin": bit i is CU i % cus_per_xcd of XCD
+    i // cus_per_xcd."""
+    n = xcds * cus_per_xcd
+    bits = 0
+    for i in range(n):
+        cu = i // xcds if layout == "rr" else i % cus_per_xcd
+        if cus_per_xcd_lo <= cu < cus_per_xcd_hi:
+            bits |= 1 << i
+    return [(bits >> (32 * w)) & 0xFFFFFFFF for w in range((n + 31) // 32)]
+
+
+class MaskedStream:
+    """A HIP stream restricted to a set of compute units (``wvn_stream_create_cu_mask``), usable as a torch stream."""
+
+    def __init__(self, words, device=None):
+        import ctypes as C
+        arr = (C.c_uint32 * len(words))(*words)
+        h = C.c_void_p()
+        check(lib().wvn_stream_create_cu_mask(C.byref(h), arr, len(words)), "wvn_stream_create_cu_mask")
+        self.handle = h.value
+        self.stream = torch.cuda.ExternalStream(self.handle, device=device)
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            check(lib().wvn_stream_destroy(self.handle), "wvn_stream_destroy")
+            self.handle = None
