@@ -35,6 +35,13 @@ extern "C" {
                            instead of 8 -- 8x less operand rounding; accumulation, residual stream, LayerNorm and softmax            \
                            statistics are fp32 in both.  Range: csrc/operand.h.  Weights: fp16 bits in the bf16 layouts */
 
+#define WVN_PREC_MIX 5  /* the <= 1e-3 parity mode sized by the error budget (profiles/r04a_error_budget_*.md): every LINEAR of the   \
+                           network (patch embedding, QKV, projection, fc1, fc2) exactly as in WVN_PREC_X3 -- hi + lo bf16 planes,    \
+                           three MFMAs per product, erf GELU -- because each of them alone spends a third of the 1e-3 budget at one  \
+                           16-bit value per operand; the two attention products (Q K^T, P V: 58 % of the multiply-adds, 3 % of the  \
+                           error) on the fp16-operand kernel of WVN_PREC_F16, fed fp16 q / k / v^T by the QKV epilogue and writing  \
+                           its output as hi + lo planes from its fp32 accumulators.  Weights as for WVN_PREC_X3 */
+
 int wvn_version(void);
 
 /* ---------------------------------------------------------------------------------------------

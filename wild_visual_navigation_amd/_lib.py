@@ -19,7 +19,7 @@ if os.environ.get("WVN_LIB_PATH"):
     print(f"[wild_visual_navigation_amd] WVN_LIB_PATH is set: loading {LIB_PATH} instead of the in-tree build", file=_sys.stderr)
 
 WVN_MAX_DEPTH = 32
-PREC_F32, PREC_BF16, PREC_X3, PREC_FP8, PREC_F16 = 0, 1, 2, 3, 4
+PREC_F32, PREC_BF16, PREC_X3, PREC_FP8, PREC_F16, PREC_MIX = 0, 1, 2, 3, 4, 5
 VIT_MLP_FUSED = 1
 VIT_QKV_FUSED = 2
 VIT_FUSE_ANY_SIZE = 4

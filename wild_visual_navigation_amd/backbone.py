@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import _lib
 
 ARCH = {"vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}
-PRECISIONS = ("fp16", "bf16", "exact", "fp32", "fp8")   # names VitBackbone(precision=...) accepts in this build
+PRECISIONS = ("fp16", "bf16", "mixed", "exact", "fp32", "fp8")   # names VitBackbone(precision=...) accepts in this build
 
 
 def synthetic_vit_state_dict(arch="vit_small", patch=8, pretrain_grid=28, seed=0, depth=None, dinov2=False) -> Dict[str, torch.Tensor]:
@@ -88,7 +88,8 @@ def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
 
 class VitBackbone:
     """Device-resident DINO / DINOv2 ViT.  ``precision``: "bf16" (MFMA fast path), "fp16" (the same kernels with fp16 operands:
-    same speed, 8x less operand rounding -- csrc/operand.h), "exact" (hi + lo split bf16 operands, three
+    same speed, 8x less operand rounding -- csrc/operand.h), "mixed" (the <= 1e-3 parity mode sized by the error budget: the linears as
+    in "exact", the two attention products on the fp16 kernel -- include/wvn_hip.h WVN_PREC_MIX), "exact" (hi + lo split bf16 operands, three
     MFMAs per product: fp32-class results on the matrix pipe, the <= 1e-3 parity mode) or "fp32" (the same gate on fp32 FMA
     kernels; slow, kept as the independent cross-check of "exact") or "fp8" (BASELINE configs[4]: the four linears of every block on
     e4m3 MFMA at twice the bf16 rate, per-token / per-channel scales; everything else as "bf16")."""
@@ -101,7 +102,7 @@ class VitBackbone:
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
         self.lib = _lib.lib()
         self.precision = {"bf16": _lib.PREC_BF16, "fp16": _lib.PREC_F16, "fp32": _lib.PREC_F32, "exact": _lib.PREC_X3,
-                          "fp8": _lib.PREC_FP8}[precision]
+                          "fp8": _lib.PREC_FP8, "mixed": _lib.PREC_MIX}[precision]
         self._lowp16 = {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_FP8: torch.bfloat16, _lib.PREC_F16: torch.float16}.get(self.precision)
         self.precision_name = precision
         self.img_size, self.patch, self.heads = img_size, patch, heads
@@ -132,7 +133,7 @@ class VitBackbone:
             t = t.to(self.device)
             if self._lowp16 is not None:
                 t = t.to(self._lowp16).contiguous()
-            elif self.precision == _lib.PREC_X3:  # two stacked bf16 planes: hi = bf16(w), lo = bf16(w - hi)
+            elif self.precision in (_lib.PREC_X3, _lib.PREC_MIX):  # two stacked bf16 planes: hi = bf16(w), lo = bf16(w - hi)
                 t = split_planes(t)
             else:
                 t = t.contiguous()
@@ -255,8 +256,8 @@ class VitBackbone:
         B, Cc, Hs, Ws = img.shape
         if Cc != 3:
             raise _lib.WvnError(f"expected [B,3,H,W], got {tuple(img.shape)}")
-        if lowp_out is not None and self.precision == _lib.PREC_X3:
-            raise _lib.WvnError("precision 'exact' returns fp32 tokens only (split them with ops.split_planes)")
+        if lowp_out is not None and self.precision in (_lib.PREC_X3, _lib.PREC_MIX):
+            raise _lib.WvnError("precisions 'exact' / 'mixed' return fp32 tokens only (split them with ops.split_planes)")
         if img.dtype != torch.uint8:
             img = img.float()
         img = img.contiguous()
@@ -305,8 +306,8 @@ class VitBackbone:
         B, Cc, Hs, Ws = img.shape
         if Cc != 3:
             raise _lib.WvnError(f"expected [B,3,H,W], got {tuple(img.shape)}")
-        if lowp_out is not None and self.precision == _lib.PREC_X3:
-            raise _lib.WvnError("precision 'exact' returns fp32 tokens only (split them with ops.split_planes)")
+        if lowp_out is not None and self.precision in (_lib.PREC_X3, _lib.PREC_MIX):
+            raise _lib.WvnError("precisions 'exact' / 'mixed' return fp32 tokens only (split them with ops.split_planes)")
         if img.dtype != torch.uint8:
             img = img.float()
         img = img.contiguous()

@@ -177,7 +177,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   if (cols_mirror) batch *= 2;
   if (m->dim != m->heads * 64 || m->depth <= 0 || m->depth > WVN_MAX_DEPTH || m->img_size % m->patch) return WVN_ERR_ARG;
   if (m->dim % 128 || m->mlp_dim % 128) return WVN_ERR_ARG;
-  if (m->precision < WVN_PREC_F32 || m->precision > WVN_PREC_F16) return WVN_ERR_ARG;
+  if (m->precision < WVN_PREC_F32 || m->precision > WVN_PREC_MIX) return WVN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const VitDims d = vit_dims(m, batch);
   const VitWs w = vit_carve(d, workspace);
@@ -188,7 +188,9 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   // "bf": the 16-bit-operand speed path, in either operand format (opk)
   const bool f16 = m->precision == WVN_PREC_F16;
   const OperandKernels& opk = f16 ? OPK_F16 : OPK_BF16;
-  const bool bf = m->precision == WVN_PREC_BF16 || fp8 || f16, x3 = m->precision == WVN_PREC_X3, f32 = m->precision == WVN_PREC_F32;
+  // mix (WVN_PREC_MIX): every linear as in the exact mode (x3), the two attention products on the fp16-operand kernel
+  const bool mix = m->precision == WVN_PREC_MIX;
+  const bool bf = m->precision == WVN_PREC_BF16 || fp8 || f16, x3 = m->precision == WVN_PREC_X3 || mix, f32 = m->precision == WVN_PREC_F32;
   const bool lowp16 = m->precision == WVN_PREC_BF16 || f16;   // the precisions the single-kernel block stages exist for
   // The single-kernel block stages are persistent one-workgroup-per-CU kernels (128 / 256 rows per workgroup): measured against the
   // separate kernels (scripts/small_batch_latency.py, 448^2 and 224^2 frames) they win from about half a chip of row blocks on and
@@ -267,7 +269,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     if (qkv_fused)
       RET_IF(wvn_pad_zero_launch(w.xn, d.B, (long long)d.ntok_s * d.D * 2, (long long)d.ntok * d.D * 2, (long long)(d.ntok_s - d.ntok) * d.D * 2, st));
     const long long nbh = (long long)d.B * d.H;
-    const long long tokb = f32 ? 256 : 128, npl = x3 ? 2 : 1;  // bytes per token row of q / k; planes per tensor
+    const long long tokb = f32 ? 256 : 128, npl = (x3 && !mix) ? 2 : 1;  // bytes per token row of q / k; planes per tensor
     RET_IF(wvn_pad_zero_launch(w.q, nbh * npl, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
     RET_IF(wvn_pad_zero_launch(w.k, nbh * npl, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
     if (!f32)  // V^T [B*h*64][npad] (bf16, or hi / lo planes)
@@ -305,7 +307,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
         e.q_scale = scale * 1.44269504088896340736f;
         RET_IF(linear_fp8(w.xq, d.D, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, 0, 3 * d.D, EPI_QKV, nullptr, &e));
       }
-      { Span s(4, st); RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st)); }
+      { Span s(4, st); RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr)); }
       {
         Span s(5, st);
         RET_IF(wvn_quantize_rows_fp8_launch(w.xn, 1, d.D, w.xq, d.D, w.sa, M, d.D, st));
@@ -341,13 +343,15 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       // bf16: the softmax scale is folded into q by the QKV epilogue (q leaves it as an exp2 argument) and attention takes
       // the running max as an MFMA operand (attention_bf16.hip, PRE)
       if (bf) e.q_scale = scale * 1.44269504088896340736f;
-      if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
+      if (mix) { e.qkv_f16 = 1; e.q_scale = scale * 1.44269504088896340736f; }   // one fp16 plane each, q pre-scaled: the fp16 attention kernel's operands
+      else if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
       RET_IF(linear(w.xn, pl_xn, d.D, L.qkv_w, L.qkv_b, nullptr, 0, 0, M, 3 * d.D, d.D, EPI_QKV, nullptr, &e));
     }
     }
     {
       Span s(4, st);
-      if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st));
+      if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr));
+      else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn)));
       else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
                                                                   const op16_t* __restrict__ vt,
                                                                   op16_t* __restrict__ out, int heads, int nbh,
                                                                   int nqb, int ntok, int ntok_s, int npad,
-                                                                  float c_exp, long long* dbg) {
+                                                                  float c_exp, long long* dbg, op16_t* __restrict__ out_lo) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE_BYTES];  // [stage][K | Vt][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -445,7 +445,25 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
   const float inv = 1.0f / l_tot;
   const int qi = q0 + l31;
   if (qi < ntok) {
-    op16_t* og = out + ((size_t)b * ntok_s + qi) * (heads * DH) + head * DH;
+    const size_t oo = ((size_t)b * ntok_s + qi) * (heads * DH) + head * DH;
+    op16_t* og = out + oo;
+    if (out_lo) {   // (uniform) hi / lo bf16 planes
+      op16_t* ol = out_lo + oo;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2_t oh, olo;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float a = ot[dt][4 * g + 2 * e] * inv, c = ot[dt][4 * g + 2 * e + 1] * inv;
+            oh[e] = pack_bf16x2(a, c);
+            olo[e] = pack_bf16x2(a - __uint_as_float(oh[e] << 16), c - __uint_as_float(oh[e] & 0xffff0000u));
+          }
+          *(u32x2_t*)(og + dt * 32 + 8 * g + 4 * hi) = oh;
+          *(u32x2_t*)(ol + dt * 32 + 8 * g + 4 * hi) = olo;
+        }
+    } else {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -455,6 +473,7 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
         o[1] = pack_op2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
         *(u32x2_t*)(og + dt * 32 + 8 * g + 4 * hi) = o;
       }
+    }
   }
 }
 
@@ -464,7 +483,7 @@ constexpr int ATTN_DEFAULT = 1;
 int g_attn_variant = ATTN_DEFAULT;   // 0: exact per-tile row max, 1: lazy (alarm on the row sums; what ships: -4 % attention time)
 
 void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out,
-                int heads, int nbh, int nqb, int ntok, int ntok_s, int npad) {
+                int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, op16_t* out_lo) {
   // 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for 3 stages /
   // 3 workgroups and 13.2 for 4 stages / 2); row sums by v_dot2c_f32_bf16 on the packed P (plain fp32 adds, which hipcc packs
   // into v_pk_add_f32, measured 12.0 ms per step against 11.7).  The same arithmetic with and without the XCD block order:
@@ -472,43 +491,43 @@ void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16
   if (g_attn_variant == 2) {   // lazy max, row sums by scalar fp32 adds
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
     else
       hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
     return;
   }
   if (g_attn_variant == 1) {
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
     else
       hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
     return;
   }
   if (xcd)
     hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                       nqb, ntok, ntok_s, npad, 1.f, nullptr);
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                       nqb, ntok, ntok_s, npad, 1.f, nullptr);
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
 }
 
 template <int NST, int OCC>
 void launch_v(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out,
-              int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, float c_exp) {
+              int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, float c_exp, op16_t* out_lo) {
   if (g_attn_dbg) {
     hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb,
-                       ntok, ntok_s, npad, c_exp, g_attn_dbg);
+                       ntok, ntok_s, npad, c_exp, g_attn_dbg, out_lo);
     return;
   }
   if (xcd)
     hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
-                       ntok_s, npad, c_exp, nullptr);
+                       ntok_s, npad, c_exp, nullptr, out_lo);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<NST, false, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
-                       ntok_s, npad, c_exp, nullptr);
+                       ntok_s, npad, c_exp, nullptr, out_lo);
 }
 
 }  // namespace
@@ -519,7 +538,10 @@ void WVN_OPSYM(wvn_attention_bf16_set_variant)(int v) { g_attn_variant = v < 0 ?
 // scale > 0: q holds the raw projections.  scale == 0: q is pre-multiplied by softmax_scale * log2(e) (EPI_QKV with
 // q_scale set), the kernel with the running max folded into the S^T MFMA chain runs.
 int WVN_OPSYM(wvn_attention_bf16_launch)(const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out, int B, int heads,
-                              int ntok, int ntok_s, int npad, float scale, hipStream_t st) {
+                              int ntok, int ntok_s, int npad, float scale, hipStream_t st, op16_t* out_lo) {
+  // out_lo (WVN_PREC_MIX): the normalised output leaves as two bf16 planes, hi = bf16(o) -> out, lo = bf16(o - hi) -> out_lo (the
+  // operand representation of the exact-mode projection GEMM), straight from the fp32 accumulators -- whatever this build's own
+  // operand format is
   if (!q || !k || !vt || !out || npad % QB != 0 || npad < ntok) return WVN_ERR_ARG;
   const int nqb = ceil_div(ntok, QB), nbh = B * heads;
   if ((size_t)nbh * npad * DH * 2 >= (1ull << 32)) return WVN_ERR_ARG;  // 32-bit buffer offsets
@@ -527,12 +549,12 @@ int WVN_OPSYM(wvn_attention_bf16_launch)(const op16_t* q, const op16_t* k, const
   dim3 grid(nqb * nbh);
   const bool xcd = (nbh % 8) == 0;  // the XCD decode needs whole groups of 8 (frame, head) pairs
   if (scale == 0.f && !g_attn_dbg) {
-    launch_pre(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad);
+    launch_pre(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, out_lo);
     WVN_LAUNCH_CHECK();
     return WVN_OK;
   }
   if (scale == 0.f) return WVN_ERR_ARG;
-  launch_v<3, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp);  // raw-q form: 3-stage ring, 3 workgroups / CU
+  launch_v<3, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp, out_lo);  // raw-q form: 3-stage ring, 3 workgroups / CU
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

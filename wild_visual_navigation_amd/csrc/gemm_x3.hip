@@ -185,6 +185,14 @@ __device__ inline void gemm_x3_tile(const GemmBf16Params& p, int tm, int tn, uns
             if (p.ls) v[e] *= (n0 + c + e < p.N) ? p.ls[n0 + c + e] : 0.f;  // LayerScale (DINOv2): x += ls * (acc + bias)
           }
         }
+        if constexpr (EPI == EPI_QKV) {
+          if (p.qkv_f16) {   // (uniform) WVN_PREC_MIX: ONE fp16 plane for the fp16 attention kernel; q carries scale * log2(e)
+            const float qs = (n0 < p.N / 3 && p.q_scale != 0.f) ? p.q_scale : 1.f;
+            const u32x2_t oh = {pack_f16x2(v[0] * qs, v[1] * qs), pack_f16x2(v[2] * qs, v[3] * qs)};
+            *(u32x2_t*)((bf16_t*)smem + lane_dim * CT_BF16_STRIDE + c) = oh;
+            continue;
+          }
+        }
         if constexpr (OP) {
           uint32_t h0, l0, h1, l1;
           split2(v[0], v[1], h0, l0);
@@ -207,6 +215,7 @@ __device__ inline void gemm_x3_tile(const GemmBf16Params& p, int tm, int tn, uns
     const int cbase = n0 - which * D;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
+      if (pl == 1 && p.qkv_f16) break;   // (uniform) single fp16 plane
       const bf16_t* img = (const bf16_t*)smem + pl * CT_PLANE;
       if constexpr (TR) {  // q / k : image [m][n]; dst[(b*h + head)*npad + t][d]
         bf16_t* dst = which == 0 ? (pl ? p.q_lo : p.q) : (pl ? p.k_lo : p.k);
@@ -326,7 +335,7 @@ int wvn_gemm_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st) {
       if ((p.ldc & 3) || !p.pos || p.N % 4 || !p.C) return WVN_ERR_ARG;
       return launch<EPI_PATCH>(p, st);
     case EPI_QKV:
-      if ((p.N % 3) != 0 || ((p.N / 3) % BN) != 0 || !p.q || !p.k || !p.vt || !p.q_lo || !p.k_lo || !p.vt_lo ||
+      if ((p.N % 3) != 0 || ((p.N / 3) % BN) != 0 || !p.q || !p.k || !p.vt || (!p.qkv_f16 && (!p.q_lo || !p.k_lo || !p.vt_lo)) ||
           (p.ntok_s % 16) || (p.M % 16) || (p.npad % 16))
         return WVN_ERR_ARG;
       return launch<EPI_QKV>(p, st);

@@ -190,7 +190,7 @@ class FeatureExtractor:
         G = self._grid()
         stego = self._feature_type == "stego"
         prec = self._extractor._precision
-        exact = prec in ("exact", "fp32")
+        exact = prec in ("exact", "fp32", "mixed")
         if exact:   # fp32 extractor: hi + lo split MFMA operands in the fused kernel
             tokens = self.backbone_stage(img)
             return model.forward_per_pixel_exact(tokens.reshape(B * G * G, -1), B, G, (H, H), mean, std, f, want_loss=want_loss,

@@ -177,7 +177,7 @@ class StegoInterface:
             lp = self._bb.lowp_dtype
             self._w_hid = head["cluster2.0.weight"].to(dev, lp).contiguous()
             self._w_code = torch.cat([head["cluster1.0.weight"], head["cluster2.2.weight"]], dim=1).to(dev, lp).contiguous()  # [C, 2D] acting on [tok | hid]
-        elif precision == "exact":  # hi / lo planes for the x3 MFMA GEMMs
+        elif precision in ("exact", "mixed"):  # hi / lo planes for the x3 MFMA GEMMs
             self._w_hid = split_planes(head["cluster2.0.weight"].float().to(dev))
             self._w_lin = split_planes(head["cluster1.0.weight"].float().to(dev))
             self._w_nl = split_planes(head["cluster2.2.weight"].float().to(dev))
@@ -226,7 +226,7 @@ class StegoInterface:
             self._bb.forward_tokens(img, lowp_out=cat, flip=flip)
             ops.gemm_bf16(cat[:, :D], self._w_hid, self._b_hid, _lib.EPI_RELU_BF16, out=cat[:, D:])
             code = ops.gemm_bf16(cat, self._w_code, self._b_code, _lib.EPI_F32)
-        elif self._precision == "exact":
+        elif self._precision in ("exact", "mixed"):
             tok = ops.split_planes(self._bb.forward_tokens(img, flip=flip).reshape(B * P, D))
             hid = ops.gemm_x3(tok, self._w_hid, self._b_hid, _lib.EPI_RELU_BF16)
             code = ops.gemm_x3(tok, self._w_lin, self._b_lin, _lib.EPI_F32)
@@ -248,7 +248,7 @@ class StegoInterface:
             _, chunk = self._bb.forward_tokens_pair(img, lowp_out=cat)
             ops.gemm_bf16(cat[:, :D], self._w_hid, self._b_hid, _lib.EPI_RELU_BF16, out=cat[:, D:])
             code = ops.gemm_bf16(cat, self._w_code, self._b_code, _lib.EPI_F32)
-        elif self._precision == "exact":
+        elif self._precision in ("exact", "mixed"):
             tok32, chunk = self._bb.forward_tokens_pair(img)
             tok = ops.split_planes(tok32.reshape(2 * B * P, D))
             hid = ops.gemm_x3(tok, self._w_hid, self._b_hid, _lib.EPI_RELU_BF16)
