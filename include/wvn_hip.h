@@ -72,6 +72,7 @@ int wvn_version(void);
  * layer's qkv_w_fused are given: the rows leave that kernel a second time as LayerNorm'ed operand fragments and the next QKV
  * kernel starts from those -- no second pass over the fp32 residual stream, no statistics, half the bytes) */
 #define WVN_VIT_NO_LN_HANDOVER 16
+#define WVN_VIT_NO_A384_X3 32     /* A/B and tests: the K = 384 linears of WVN_PREC_X3 / WVN_PREC_MIX on the tiled gemm_x3 kernel instead of the A-stationary one */
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
@@ -501,6 +502,19 @@ int wvn_wire_unpack(const void* in, long long* seg_i64, int* seg_i32, float* fea
  * 2 epilogue part, 3 total}] in shader cycles (K == 384 shapes only; dbg may be NULL). */
 int wvn_debug_gemm_bf16_timed(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                               int N, int K, int epi, long long* dbg, void* stream);
+/* The A-stationary split-operand GEMM for K = 384 (csrc/gemm_a384_x3.hip: what WVN_PREC_MIX / WVN_PREC_X3 run for QKV, projection
+ * and fc1 from 8192 rows on), callable on its own: A / W as hi + lo bf16 planes ([M][384], [N][384]; the lo planes at A_lo / W_lo,
+ * W_lo behind W in one allocation), epi = 1 (erf GELU, hi / lo bf16 planes C / C_lo [M][ldc]) or 4 (fp32 C [M][ldc] += result).
+ * dbg != NULL: the instrumented build writes dbg[(workgroup * 4 + wave) * 4 + {0 wait + barrier, 1 DMA issue, 2 MFMA steps with the
+ * epilogue chunks, 3 total}] in shader cycles (scripts/bench_a384_x3.py).  WVN_ERR_ARG when the shape is not eligible. */
+int wvn_debug_gemm_a384_x3(const void* A, const void* A_lo, int lda, const void* W, const void* W_lo, const float* bias, void* C,
+                           void* C_lo, int ldc, int M, int N, int epi, long long* dbg, void* stream);
+/* The row-panel split-operand GEMM for N = 384 residual updates (csrc/gemm_n384_x3.hip: fc2 and the attention projection of
+ * WVN_PREC_MIX / WVN_PREC_X3 from 8192 rows on): C [M][ldc] fp32 += (A W^T + bias) (* ls), A [M][lda] / W [384][K] as hi + lo bf16 planes
+ * (lo planes behind the hi planes in one allocation each), K % 32 == 0.  dbg != NULL: the instrumented build writes
+ * dbg[(workgroup * 4 + wave) * 4 + {0 wait + barrier, 1 k-steps, 2 epilogue, 3 total}] in shader cycles. */
+int wvn_debug_gemm_n384_x3(const void* A, const void* A_lo, int lda, const void* W, const void* W_lo, const float* bias, const float* ls,
+                           float* C, int ldc, int M, int K, long long* dbg, void* stream);
 /* subsequent wvn_attention_bf16 launches write dbg[(workgroup * 4 + wave) * 5 + {0 wait, 1 QK^T, 2 softmax, 3 PV,
  * 4 total}]; NULL switches the instrumented build off again. */
 int wvn_debug_attention_timing(long long* dbg);

@@ -25,6 +25,7 @@ VIT_QKV_FUSED = 2
 VIT_FUSE_ANY_SIZE = 4
 VIT_NO_PROJ_IN_MLP = 8
 VIT_NO_LN_HANDOVER = 16
+VIT_NO_A384_X3 = 32
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -72,6 +73,8 @@ _SIGNATURES = {
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_debug_attention_variant": ([_i], _i),
     "wvn_debug_kmeans_assign_form": ([_i], _i),
+    "wvn_debug_gemm_n384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p], _i),
+    "wvn_debug_gemm_a384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p], _i),
     "wvn_stream_create_cu_mask": ([_p, _p, _i], _i),
     "wvn_stream_destroy": ([_p], _i),
     "wvn_debug_qkv_fused_timing": ([_p], _i),

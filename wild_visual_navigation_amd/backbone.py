@@ -161,7 +161,8 @@ class VitBackbone:
         # None: the library decides by size (the fused kernels pay from about half a chip of row blocks on); True: always
         m.flags = ((_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
                    | (_lib.VIT_FUSE_ANY_SIZE if (fuse_mlp is True or fuse_qkv is True) else 0)
-                   | (0 if fuse_proj else _lib.VIT_NO_PROJ_IN_MLP) | (_lib.VIT_NO_LN_HANDOVER if os.environ.get("WVN_NO_HANDOVER") else 0))
+                   | (0 if fuse_proj else _lib.VIT_NO_PROJ_IN_MLP) | (_lib.VIT_NO_LN_HANDOVER if os.environ.get("WVN_NO_HANDOVER") else 0)
+                   | (_lib.VIT_NO_A384_X3 if os.environ.get("WVN_NO_A384_X3") else 0))
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)

@@ -234,6 +234,14 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     p.M = rows; p.N = N; p.K = K; p.ls = ls;
     if (x3) {
       p.A_lo = lo(A, a_plane); p.W_lo = lo(W, (size_t)N * K); p.C_lo = C ? lo(C, c_plane) : nullptr;
+      if (N == 384 && (epi == EPI_RESID_F32) && rows >= 64 * 128 && !(m->flags & WVN_VIT_NO_A384_X3)) {   // row panel: fc2, projection
+        const int rc = wvn_gemm_n384_x3_launch(p, epi, st);
+        if (rc != WVN_ERR_ARG) return rc;
+      }
+      if (K == 384 && rows >= 64 * 128 && !(m->flags & WVN_VIT_NO_A384_X3)) {   // the A-stationary form from about a quarter chip of row blocks on
+        const int rc = wvn_gemm_a384_x3_launch(p, epi, st);
+        if (rc != WVN_ERR_ARG) return rc;
+      }
       return wvn_gemm_x3_launch(p, epi, st);
     }
     return opk.gemm(p, epi, st);
@@ -540,6 +548,21 @@ int wvn_stream_destroy(void* stream) {
   return e == hipSuccess ? WVN_OK : (int)e;
 }
 
+int wvn_debug_gemm_a384_x3(const void* A, const void* A_lo, int lda, const void* W, const void* W_lo, const float* bias, void* C,
+                           void* C_lo, int ldc, int M, int N, int epi, long long* dbg, void* stream) {
+  if (epi != EPI_GELU_BF16 && epi != EPI_RESID_F32) return WVN_ERR_ARG;
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A; p.A_lo = (const bf16_t*)A_lo; p.lda = lda; p.W = (const bf16_t*)W; p.W_lo = (const bf16_t*)W_lo; p.ldw = 384;
+  p.bias = bias; p.C = C; p.C_lo = C_lo; p.ldc = ldc; p.M = M; p.N = N; p.K = 384; p.dbg = dbg;
+  return wvn_gemm_a384_x3_launch(p, epi, (hipStream_t)stream);
+}
+int wvn_debug_gemm_n384_x3(const void* A, const void* A_lo, int lda, const void* W, const void* W_lo, const float* bias, const float* ls,
+                           float* C, int ldc, int M, int K, long long* dbg, void* stream) {
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A; p.A_lo = (const bf16_t*)A_lo; p.lda = lda; p.W = (const bf16_t*)W; p.W_lo = (const bf16_t*)W_lo; p.ldw = K;
+  p.bias = bias; p.ls = ls; p.C = C; p.ldc = ldc; p.M = M; p.N = 384; p.K = K; p.dbg = dbg;
+  return wvn_gemm_n384_x3_launch(p, EPI_RESID_F32, (hipStream_t)stream);
+}
 int wvn_debug_kmeans_assign_form(int form) { wvn_kmeans_pixels_set_assign_form(form); return WVN_OK; }
 int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); wvn_attention_bf16_set_variant_f16(v); return WVN_OK; }
 

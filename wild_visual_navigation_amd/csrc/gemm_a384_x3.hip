@@ -1,0 +1,481 @@
+// A-stationary SPLIT-OPERAND MFMA GEMM for the K = 384 linears of the ViT (QKV, attention projection, fc1) on gfx950:
+//     C = epilogue(A[M,384] * W[N,384]^T + bias),   A and W as hi + lo bf16 planes, every product hi*hi + hi*lo + lo*hi
+// (three v_mfma_f32_32x32x16_bf16 per fragment pair, fp32 accumulation: the arithmetic of gemm_x3.hip, fp32-class results).
+// The kernel behind precisions "mixed" (WVN_PREC_MIX) and "exact" (WVN_PREC_X3) where the shape allows.
+//
+// Why: the output-tiled gemm_x3_kernel issues 320 - 580 TFLOP/s of matrix work on these shapes (profiles/r04c_*): with K = 384 a
+// 128 x 128 tile has twelve K-tiles, so its pipeline fill and its epilogue are as long as its MFMA loop.  Here -- the structure of
+// gemm_a384.hip, re-sized for two planes per operand --
+//   * a workgroup (4 waves, ONE per SIMD: the 512-entry register file) owns 128 rows of A for the whole N range; a wave keeps its
+//     32 rows x 384 of BOTH planes in registers (192 VGPRs, loaded once per row block, already in MFMA operand layout);
+//   * W streams through a 3-deep LDS ring in slices of 64 (n) x 128 (k) x 2 planes = 32 KB, written by direct-to-LDS loads
+//     (buffer_load ... lds), one s_barrier per slice, counted vmcnt; LDS rows are 256 B with the 16-byte chunks XOR-swizzled by
+//     (row & 15): conflict-free ds_read_b128;
+//   * a fragment pair read from LDS (W hi, W lo of one 32 x 16 block: two ds_read_b128) feeds THREE MFMAs, so the LDS pipe and the
+//     DMA issue cost per MFMA are two thirds / one half of the single-plane kernel's; 48 MFMAs per wave and slice;
+//   * the epilogue of column tile j - 1 rides in the slice periods of tile j, one third per slice (bias in the accumulator
+//     initialisation, activation + plane split + wave-private LDS transpose, 16-byte coalesced row stores).
+// Outputs: q | k (one fp16 plane each, q pre-scaled: the operands of the fp16 attention kernel; or hi / lo bf16 planes), v^T
+// likewise, hi / lo planes with the exact erf GELU (fc1), fp32 residual read-modify-write (projection).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+#include "wvn_internal.h"
+
+namespace {
+
+constexpr int KD = 384;
+constexpr int BNT = 64;                         // output columns per column tile
+constexpr int SLK = 128;                        // k per ring slice
+constexpr int NSL = KD / SLK;                   // slices per column tile (3)
+constexpr int NS = 3;                           // ring depth
+constexpr int PLANE_BYTES = BNT * SLK * 2;      // 16 KB: one plane of a slice
+constexpr int SLICE_BYTES = 2 * PLANE_BYTES;    // hi | lo
+constexpr int RING_BYTES = NS * SLICE_BYTES;    // 96 KB
+constexpr int IMG_BF16 = 32 * 144;              // a wave's 32 x 64 bf16 image (rows of 144 B)
+constexpr int STG_BYTES = 2 * 64 * 80;          // two V^T plane images (64 rows of 80 B each: 10240 B) >= two bf16 images (9216) >= the fp32 image (8704)
+constexpr int STG_OFF = RING_BYTES;
+constexpr int BIAS_OFF = STG_OFF + 4 * STG_BYTES;
+constexpr int BM = 128;
+constexpr int PIECES = SLICE_BYTES / 1024 / 4;  // 1 KB DMA pieces per wave and slice (8)
+static_assert(PIECES == 8, "one DMA piece per k-step of a slice");
+
+enum { X_GELU = 0, X_RESID = 1, X_QK = 2, X_V = 3, X_PLANES = 4 };
+
+struct X384Params {
+  const bf16_t* A; const bf16_t* A_lo; int lda;
+  const bf16_t* W; size_t w_plane;      // [2][N][384]: lo plane w_plane elements behind the hi plane
+  const float* bias;
+  void* C; void* C_lo; int ldc;         // planes (bf16) or fp32 (X_RESID: in/out; C_lo unused)
+  int M, N;
+  int heads, npad, ntok_s;
+  float q_scale;
+  int f16_out;                          // X_QK / X_V: 1 = ONE fp16 plane per tensor, 0 = hi / lo bf16 planes
+  bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;   // one buffer descriptor over q / k / v^T (hi planes or the fp16 planes)
+  bf16_t* qkv_base_lo;                  // the same span of the lo planes (f16_out == 0)
+  const float* ls;                      // X_RESID: optional LayerScale
+  long long* dbg;                       // TIMING builds: per wave {wait + barrier, DMA issue, MFMA steps (+ epilogue chunks), total} shader cycles
+};
+
+__device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+  lo = pack_bf16x2(a - ah, b - bh);
+}
+// exact erf GELU, erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), as gemm_x3.hip
+__device__ inline float gelu_as(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // (1 ulp: far inside the formula's own 1.5e-7)
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+template <int EPI, bool TIMING = false>
+__global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int NT = p.N / BNT;
+  // persistent, unit-balanced schedule (gemm_a384.hip): (row block, column tile) units in row-block-major order
+  const int NRB = (p.M + BM - 1) / BM;
+  const long long U = (long long)NRB * NT;
+  const int u_begin = (int)(U * blockIdx.x / gridDim.x), u_end = (int)(U * (blockIdx.x + 1) / gridDim.x);
+  const int total = (u_end - u_begin) * NSL;
+  int m0w = 0;
+  unsigned char* stg = smem + STG_OFF + wave * STG_BYTES;
+  const float* bias_l = (const float*)(smem + BIAS_OFF);
+
+  // ---- W ring producer: 32 wave-instructions of 1 KB (4 rows x 256 B of one plane) per slice, 8 per wave ----
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((p.w_plane + (size_t)p.N * KD) * 2), 0x00020000);
+  unsigned wvoff[PIECES];
+#pragma unroll
+  for (int u = 0; u < PIECES; ++u) {
+    const int piece = wave * PIECES + u, plane = piece >> 4, inst = piece & 15;
+    const int row = inst * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ (row & 15);
+    wvoff[u] = (unsigned)(plane * p.w_plane * 2 + (row * KD + chunk * 8) * 2);
+  }
+  int iss_j = u_begin % NT, iss_ks = 0;
+  unsigned iss_soff = 0;
+  auto issue_begin = [&]() { iss_soff = __builtin_amdgcn_readfirstlane((iss_j * BNT * KD + iss_ks * SLK) * 2); };
+  auto issue_piece = [&](int i, int u) {   // piece u of this wave's PIECES of slice i (u is a compile-time constant at every call site)
+    unsigned char* dst = smem + (i % NS) * SLICE_BYTES + wave * PIECES * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, wvoff[u], iss_soff, 0, 0);
+  };
+  auto issue_end = [&]() { if (++iss_ks == NSL) { iss_ks = 0; if (++iss_j == NT) iss_j = 0; } };
+  auto issue = [&](int i) {
+    issue_begin();
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) issue_piece(i, u);
+    issue_end();
+  };
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < total) issue(i);
+
+  for (int i = tid; i < p.N; i += 256) ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
+  bf16x8_t xh[KD / 16], xl[KD / 16];
+  auto load_a = [&]() {
+    const size_t ro = (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
+#pragma unroll
+    for (int s = 0; s < KD / 16; ++s) {
+      xh[s] = *(const bf16x8_t*)(p.A + ro + s * 16);
+      xl[s] = *(const bf16x8_t*)(p.A_lo + ro + s * 16);
+    }
+  };
+
+  f32x16_t acc[2], prev[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; prev[t][r] = 0.f; }
+
+  const int xorc = l31 & 15;
+  const unsigned rd_base = l31 * 256;
+
+  // ---- epilogue addressing ----
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr bool IS_QKV = EPI == X_QK || EPI == X_V;
+  using TRK = std::integral_constant<bool, EPI != X_V>;
+  unsigned voff[2] = {0, 0};
+  unsigned vt_off = 0, stg_rd = 0;
+  const unsigned c_bytes = IS_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == X_RESID ? 4 : 2));
+  const __amdgpu_buffer_rsrc_t rs_c = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base, 0, p.qkv_bytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c2 = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base_lo ? p.qkv_base_lo : p.qkv_base, 0, p.qkv_bytes, 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc(p.C_lo ? p.C_lo : p.C, 0, c_bytes, 0x00020000);
+  auto qkv_offsets = [&]() {
+#pragma unroll
+    for (int hblk = 0; hblk < 2; ++hblk) {
+      const int m = m0w + hblk * 16 + (lane >> 3);
+      const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
+      voff[hblk] = m < p.M ? (unsigned)((((size_t)b * p.heads * p.npad + tk) * 64 + (lane & 7) * 8) * 2) : OOB;
+    }
+    {
+      const int m = m0w + (lane & 3) * 8;
+      const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
+      vt_off = m < p.M ? (unsigned)((((size_t)b * p.heads * 64 + (lane >> 2)) * p.npad + tk) * 2) : OOB;
+    }
+  };
+  if constexpr (EPI == X_RESID) {
+    voff[0] = (unsigned)(((lane >> 4) * p.ldc + (lane & 15) * 4) * 4);
+    stg_rd = (lane >> 4) * 272 + (lane & 15) * 16;
+  } else if constexpr (!IS_QKV) {
+    voff[0] = (unsigned)(((lane >> 3) * p.ldc + (lane & 7) * 8) * 2);
+    stg_rd = (lane >> 3) * 144 + (lane & 7) * 16;
+  }
+
+  // ---- one k-step (16 of the slice's 128) of one ring slice: the (W hi, W lo) fragment pairs of the two column halves -> six MFMAs,
+  // alternating between the two accumulators (a filler between two MFMAs on the SAME accumulator costs ~43 cycles, between different
+  // ones ~6: MI355X guide); the four fragments of k-step s + 1 are requested during the six MFMAs of step s (192 cycles of cover) ----
+  bf16x8_t wh[2][2], wl[2][2];   // [k-step parity][column half]
+  u32x4_t resid_q[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  auto frag_read = [&](int slot, int s, int par) {
+    const unsigned char* base = smem + slot * SLICE_BYTES + rd_base;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const unsigned o = t * 8192 + (((2 * s + hi) ^ xorc) << 4);
+      wh[par][t] = *(const bf16x8_t*)(base + o);
+      wl[par][t] = *(const bf16x8_t*)(base + PLANE_BYTES + o);
+    }
+  };
+  auto mfma_step = [&](int slot, int ks, int s, auto tr_tag) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int cur = s & 1;
+    if (s + 1 < 8) frag_read(slot, s + 1, cur ^ 1);
+    const bf16x8_t ah = xh[ks * 8 + s], al = xl[ks * 8 + s];
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8_t w = term == 1 ? wl[cur][t] : wh[cur][t];
+        const bf16x8_t a = term == 0 ? al : ah;          // hi*lo, lo*hi, hi*hi
+        if constexpr (TR) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[t], 0, 0, 0);
+      }
+  };
+
+  // ---- the epilogue of column tile jp (accumulators in prev[]) in 3 x 8 chunks: part 0 / 1 = column half t of the tile (activation,
+  // plane split, wave-private LDS image), one PAIR of values per chunk; part 2 = the image(s) -> global, one 16-byte store group per
+  // chunk.  A chunk rides between the six MFMAs of one k-step.
+  // TR tiles : images [32 rows m][64 cols n] (bf16 rows of 144 B: hi image at 0, lo image at IMG_BF16; fp32 rows of 272 B)
+  // !TR tiles: images [64 rows n][32 cols m] (rows of 80 B; hi at 0, lo at 64 * 80)       -- V^T
+  auto epi_chunk = [&](int part, int jp, int s, auto tr_tag) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int n0 = jp * BNT;
+    if constexpr (EPI == X_RESID) {
+      if (part == 1 && s >= 6)   // the first two residual row groups of part 2
+        resid_q[s - 6] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, voff[0], __builtin_amdgcn_readfirstlane(((m0w + 4 * (s - 6)) * p.ldc + n0) * 4), 0);
+    }
+    if (part < 2) {
+      const int t = part, g = s >> 1, h2 = (s & 1) * 2;     // values prev[t][4 g + h2], prev[t][4 g + h2 + 1]
+      float v0 = prev[t][4 * g + h2], v1 = prev[t][4 * g + h2 + 1];
+      if constexpr (TR) {
+        const int c = 32 * t + 8 * g + 4 * hi + h2;
+        if constexpr (EPI == X_GELU) { v0 = gelu_as(v0); v1 = gelu_as(v1); }
+        if constexpr (EPI == X_RESID) {
+          if (p.ls) { v0 *= p.ls[n0 + c]; v1 *= p.ls[n0 + c + 1]; }
+          const wvn_f32x2_t o = {v0, v1};
+          *(wvn_f32x2_t*)(stg + l31 * 272 + c * 4) = o;
+        } else if (EPI == X_QK && p.f16_out) {
+          const float qs = n0 < p.heads * 64 ? p.q_scale : 1.f;
+          *(uint32_t*)(stg + l31 * 144 + c * 2) = pack_f16x2(v0 * qs, v1 * qs);
+        } else {
+          uint32_t h, l;
+          split2(v0, v1, h, l);
+          *(uint32_t*)(stg + l31 * 144 + c * 2) = h;
+          *(uint32_t*)(stg + IMG_BF16 + l31 * 144 + c * 2) = l;
+        }
+      } else {
+        // V^T: tokens 8g + 4hi + e of the wave's 32, stored with bits 2 and 3 of the token index swapped inside aligned groups of 16
+        const int mloc = 16 * (g >> 1) + 8 * hi + 4 * (g & 1) + h2;
+        if (p.f16_out) {
+          *(uint32_t*)(stg + (32 * t + l31) * 80 + mloc * 2) = pack_f16x2(v0, v1);
+        } else {
+          uint32_t h, l;
+          split2(v0, v1, h, l);
+          *(uint32_t*)(stg + (32 * t + l31) * 80 + mloc * 2) = h;
+          *(uint32_t*)(stg + 64 * 80 + (32 * t + l31) * 80 + mloc * 2) = l;
+        }
+      }
+      return;
+    }
+    // part 2: wave-private image(s) -> global, 16 bytes per lane
+    if constexpr (EPI == X_RESID) {
+      const int it = s;
+      const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 4 * it) * p.ldc + n0) * 4);
+      f32x4_t v = *(const f32x4_t*)(stg + stg_rd + it * 4 * 272);
+      // requested TWO chunks earlier: a wave alone on its SIMD has nobody to cover the round trip, and vmcnt retires in order -- the wait
+      // for these rows is also a wait for every DMA piece requested before them (one per k-step)
+      const u32x4_t r = resid_q[it & 1];
+      if (it + 2 < 8)
+        resid_q[it & 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, voff[0], __builtin_amdgcn_readfirstlane(((m0w + 4 * (it + 2)) * p.ldc + n0) * 4), 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(r[e]);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, voff[0], so, 0);
+    } else if constexpr (EPI == X_QK) {
+      const int it = s & 3, pl = s >> 2;
+      if (pl == 1 && p.f16_out) return;
+      const int D = p.heads * 64;
+      const int which = n0 / D, head = (n0 - which * D) >> 6;
+      const unsigned so = __builtin_amdgcn_readfirstlane((which == 0 ? p.q_off : p.k_off) + head * p.npad * 64 * 2);
+      const u32x4_t val = *(const u32x4_t*)(stg + pl * IMG_BF16 + ((lane >> 3) + it * 8) * 144 + (lane & 7) * 16);
+      if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, voff[it >> 1], so + (it & 1) * 1024, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(val, rs_c2, voff[it >> 1], so + (it & 1) * 1024, 0);
+    } else if constexpr (EPI == X_V) {
+      const int it = s & 3, pl = s >> 2;
+      if (pl == 1 && p.f16_out) return;
+      const int head = n0 >> 6;
+      const u32x4_t val = *(const u32x4_t*)(stg + pl * 64 * 80 + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+      const unsigned so = __builtin_amdgcn_readfirstlane(p.v_off + (head * 64 + it * 16) * p.npad * 2);
+      if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, vt_off, so, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(val, rs_c2, vt_off, so, 0);
+    } else {   // hi / lo planes [M][ldc]
+      const int it = s >> 1, pl = s & 1;
+      const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 8 * it) * p.ldc + n0) * 2);
+      const u32x4_t val = *(const u32x4_t*)(stg + pl * IMG_BF16 + stg_rd + it * 8 * 144);
+      const unsigned vo = m0w + 8 * it + (lane >> 3) < p.M ? voff[0] : OOB;
+      if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, vo, so, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(val, rs_c2, vo, so, 0);
+    }
+  };
+
+  auto init_acc = [&](int j, auto tr_tag) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int n0 = j * BNT;
+    if constexpr (TR) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t b4 = *(const f32x4_t*)(bias_l + n0 + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b4[e];
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float b = bias_l[n0 + 32 * t + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b;
+      }
+    }
+  };
+
+  // ---- one slice period ----
+  // VM queue at the boundary of slice i (oldest first): DMA(i) [requested in period i - 2], then DMA(i + 1); the stores of a tile
+  // epilogue are issued in a ks == 2 period AFTER that period's DMA request, so they are the youngest operations at the next
+  // boundary (ks == 0) only; everywhere else a wait for "all but the 8 youngest" covers them.
+  // VM operations of one part 2 per lane -- exactly, or a LOWER bound where it depends on a run-time flag (allowing more operations to
+  // stay outstanding than were issued would let DMA(i) itself slip through the wait)
+  constexpr int ST = EPI == X_RESID ? 14 : (EPI == X_GELU || EPI == X_PLANES ? 8 : 4);   // (X_RESID: 6 row fetches + 8 stores ride in the ks == 2 period)
+  long long t_wait = 0, t_iss = 0, t_mfma = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, auto epi_tag) {
+    constexpr bool do_epi = decltype(epi_tag)::value;   // (compile-time: a branch around the epilogue would end the scheduling region)
+    long long c0 = 0, c1 = 0, c2 = 0;
+    if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
+    if (i + 1 < total) {
+      if (ks == 0 && stores_in_window) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + ST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
+    // the DMA requests of slice i + 2 (into the ring slot every wave has just left): one 1 KB piece per k-step, riding with the
+    // fillers, instead of eight behind the barrier (measured: 509 cycles of a 3700-cycle period went to issuing them in a burst)
+    const bool dma = i + NS - 1 < total;   // (uniform)
+    if (dma) issue_begin();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TIMING) c2 = (long long)__builtin_amdgcn_s_memtime();
+    // Eight scheduling regions per slice: the six MFMAs of a k-step, the LDS reads of the next step's fragments and ONE chunk of the
+    // previous tile's epilogue.  This wave is alone on its SIMD, so the epilogue's VALU / LDS / store instructions must issue in the
+    // MFMAs' shadow (<= 5 slots per 32-cycle MFMA): inside a region the issue order is pinned to MFMA, LDS read, VALU..., and the
+    // regions keep the epilogue spread evenly over the slice (one region for the whole slice: the scheduler left the epilogue behind
+    // the last MFMA)
+    frag_read(i % NS, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (dma) issue_piece(i + NS - 1, s);
+      mfma_step(i % NS, ks, s, mtr);
+      if constexpr (do_epi) epi_chunk(ks, j - 1, s, etr);
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (dma) issue_end();
+    if constexpr (TIMING) { t_wait += c1 - c0; t_iss += c2 - c1; t_mfma += (long long)__builtin_amdgcn_s_memtime() - c2; }
+  };
+  int si = 0;
+  auto tile = [&](int j, int jj, int j_end, auto mtr, auto etr, auto next_tr) {
+    if (jj >= 1) {
+#pragma unroll
+      for (int ks = 0; ks < NSL; ++ks) period(si + ks, ks, j, jj >= 2, mtr, etr, std::true_type{});
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < NSL; ++ks) period(si + ks, ks, j, false, mtr, etr, std::false_type{});
+    }
+    si += NSL;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) prev[t] = acc[t];
+    if (j + 1 < j_end) init_acc(j + 1, next_tr);
+  };
+
+  __syncthreads();
+  for (int u = u_begin; u < u_end;) {
+    const int rb = u / NT, j0 = u - rb * NT, j1 = min(NT, j0 + (u_end - u));
+    m0w = rb * BM + wave * 32;
+    load_a();
+    if constexpr (IS_QKV) qkv_offsets();
+    init_acc(j0, TRK{});
+    for (int j = j0; j < j1; ++j) tile(j, j - j0, j1, TRK{}, TRK{}, TRK{});
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) epi_chunk(part, j1 - 1, c, TRK{});
+    u += j1 - j0;
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+      d[0] = t_wait; d[1] = t_iss; d[2] = t_mfma; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+    }
+  }
+}
+
+constexpr int X384_LDS_MAX = 160 * 1024;
+
+int x384_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int EPI>
+int launch(const X384Params& p, hipStream_t st) {
+  const int lds = BIAS_OFF + p.N * 4;
+  if (lds > X384_LDS_MAX) return WVN_ERR_ARG;
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(X384_LDS_MAX, (const void*)gemm_a384_x3_kernel<EPI>, (const void*)gemm_a384_x3_kernel<EPI, true>)) return rc;
+  const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
+  const int grid = (int)(units < x384_num_cus() ? units : x384_num_cus());
+  if (p.dbg) hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, true>), dim3(grid), dim3(256), lds, st, p);
+  else
+  hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI>), dim3(grid), dim3(256), lds, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+}  // namespace
+
+// Eligibility: K == 384, N % 64 == 0, stacked weight planes, 16-byte aligned operands, epilogues GELU planes / residual / QKV;
+// WVN_ERR_ARG otherwise (the caller uses the tiled gemm_x3 kernel).  Worth it from about a chip of 128-row blocks on.
+int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
+  if (g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.W || !g.W_lo || (g.lda % 8) != 0) return WVN_ERR_ARG;
+  if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.W | (uintptr_t)g.W_lo) & 15) return WVN_ERR_ARG;
+  if (g.W_lo <= g.W || (size_t)(g.W_lo - g.W) + (size_t)g.N * KD >= (1ull << 30)) return WVN_ERR_ARG;   // one descriptor over both planes
+  X384Params p{};
+  p.A = g.A; p.A_lo = g.A_lo; p.lda = g.lda; p.W = g.W; p.w_plane = (size_t)(g.W_lo - g.W); p.bias = g.bias;
+  p.C = g.C; p.C_lo = g.C_lo; p.ldc = g.ldc; p.M = g.M; p.N = g.N;
+  p.heads = g.heads; p.npad = g.npad; p.ntok_s = g.ntok_s; p.q_scale = g.q_scale != 0.f ? g.q_scale : 1.f; p.f16_out = g.qkv_f16;
+  p.ls = g.ls; p.dbg = g.dbg;
+  switch (epi) {
+    case EPI_GELU_BF16:
+      if (!g.C || !g.C_lo || (g.ldc % 8) != 0 || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return WVN_ERR_ARG;
+      return launch<X_GELU>(p, st);
+    case EPI_BF16:
+      if (!g.C || !g.C_lo || (g.ldc % 8) != 0 || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return WVN_ERR_ARG;
+      return launch<X_PLANES>(p, st);
+    case EPI_RESID_F32:
+    case EPI_ACCUM_F32:
+      if (!g.C || (g.ldc % 4) != 0 || ((uintptr_t)g.C & 15) || (size_t)g.M * g.ldc * 4 >= (1ull << 31)) return WVN_ERR_ARG;
+      return launch<X_RESID>(p, st);
+    case EPI_QKV: {
+      if (g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 16) || (g.M % 16) || (g.npad % 16)) return WVN_ERR_ARG;
+      if (!g.qkv_f16 && (!g.q_lo || !g.k_lo || !g.vt_lo)) return WVN_ERR_ARG;
+      const uintptr_t lo = std::min({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
+      const uintptr_t hi = std::max({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
+      const size_t one = (size_t)(g.M / (g.ntok_s > 0 ? g.ntok_s : 1)) * g.heads * g.npad * 64 * 2;
+      if (hi - lo + one >= (1ull << 31)) return WVN_ERR_ARG;
+      p.qkv_base = (bf16_t*)lo; p.q_off = (unsigned)((uintptr_t)g.q - lo); p.k_off = (unsigned)((uintptr_t)g.k - lo);
+      p.v_off = (unsigned)((uintptr_t)g.vt - lo); p.qkv_bytes = (unsigned)(hi - lo + one);
+      if (!g.qkv_f16) {   // the lo planes must sit at the same distances from their base
+        const uintptr_t lo2 = std::min({(uintptr_t)g.q_lo, (uintptr_t)g.k_lo, (uintptr_t)g.vt_lo});
+        if ((uintptr_t)g.q_lo - lo2 != p.q_off || (uintptr_t)g.k_lo - lo2 != p.k_off || (uintptr_t)g.vt_lo - lo2 != p.v_off) return WVN_ERR_ARG;
+        p.qkv_base_lo = (bf16_t*)lo2;
+      }
+      const int D = g.heads * 64;
+      p.N = 2 * D;
+      const int rc = launch<X_QK>(p, st);
+      if (rc != WVN_OK) return rc;
+      p.W = g.W + (size_t)2 * D * KD;
+      p.bias = g.bias ? g.bias + 2 * D : nullptr;
+      p.N = D;
+      return launch<X_V>(p, st);
+    }
+    default: return WVN_ERR_ARG;
+  }
+}

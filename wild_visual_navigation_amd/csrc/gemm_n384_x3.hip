@@ -1,0 +1,252 @@
+// Row-panel SPLIT-OPERAND MFMA GEMM for the N = 384 residual updates of the ViT (fc2: K = 1536, attention projection: K = 384):
+//     C[M,384] (fp32, in place) += (A[M,K] * W[384,K]^T + bias) (* ls),   A and W as hi + lo bf16 planes,
+// every product hi*lo + lo*hi + hi*hi (three v_mfma_f32_32x32x16_bf16 per fragment pair, fp32 accumulation): the arithmetic of
+// gemm_x3.hip in the structure of gemm_n384.hip, re-sized for two planes per operand and ONE wave per SIMD.
+//
+// A workgroup (4 waves) owns 128 rows and all 384 output columns: a wave keeps the 32 x 384 fp32 accumulator of its rows in
+// registers (12 MFMA tiles = 192 of the 512 registers), so A -- the 4x wider hidden activation in fc2 -- is read exactly once and the
+// fp32 residual read-modify-write happens once per row, after the whole K loop.  W [2 planes][384 n][16 k] (24 KB per slice, shared
+// by the 4 waves) and A [2 planes][128 m][16 k] (8 KB, every wave requests and reads only its own
+// 32 rows) arrive by buffer_load ... lds DMA -- in slices of ONE k-step (16 k: 32 KB) through a 4-deep LDS ring, three slices in flight.
+// A k-step is 36 MFMAs per wave against 26 fragment reads; the MFMAs of two column tiles alternate (hi*lo, lo*hi,
+// hi*hi of tile t interleaved with those of tile t + 1), because a filler between two MFMAs on the SAME accumulator costs ~43
+// cycles and between different ones ~6 (MI355X guide), and the 16 DMA requests of the next slice ride as fillers, two per tile
+// pair of the first k-step and one of the second's first four (a burst behind the barrier costs the lone wave ~60 cycles a piece).
+// The epilogue (once per K loop) moves the accumulators through a wave-private LDS image, 128 columns at a time, and updates C
+// with whole 512-byte rows.
+#include <type_traits>
+
+#include "common.h"
+#include "wvn_internal.h"
+
+namespace {
+
+constexpr int NN = 384;
+constexpr int NTILE = NN / 32;
+constexpr int BKS = 16;                          // k per ring slice (ONE MFMA k-step: 36 MFMAs per wave)
+constexpr int BM = 128;
+constexpr int NS = 4;                            // slices i + 1 .. i + 3 in flight while slice i is multiplied (A comes from HBM)
+constexpr int W_PLANE = NN * BKS * 2;            // 12 KB
+constexpr int A_PLANE = BM * BKS * 2;            // 4 KB
+constexpr int A_OFF = 2 * W_PLANE;
+constexpr int STAGE_BYTES = 2 * W_PLANE + 2 * A_PLANE;   // 32 KB
+constexpr int RING_BYTES = NS * STAGE_BYTES;     // 128 KB
+constexpr int STG_PITCH = 132;                   // floats per staged row (128 columns + 4)
+constexpr int STG_BYTES = 32 * STG_PITCH * 4;    // per wave: 16,896 (the four images overlap the ring's first 66 KB)
+constexpr int BIAS_OFF = RING_BYTES;
+constexpr int LS_OFF = BIAS_OFF + NN * 4;
+constexpr int LDS_BYTES = LS_OFF + NN * 4;
+constexpr int WP = 6, AP = 2;                    // DMA pieces (1 KB = 32 rows x 32 B) per wave and slice: W, A
+
+struct N384X3Params {
+  const bf16_t* A; size_t a_plane; int lda;      // [2][M][lda]: lo plane a_plane elements behind the hi plane
+  const bf16_t* W; size_t w_plane; int ldw;      // [2][384][K]
+  const float* bias; const float* ls;
+  float* C; int ldc;
+  int M, K;
+  long long* dbg;                                // TIMING builds: per wave {wait + barrier, k-steps, epilogue, total} shader cycles
+};
+
+template <bool TIMING>
+__global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nk = p.K / BKS;
+  const float* bias_l = (const float*)(smem + BIAS_OFF);
+  const float* ls_l = (const float*)(smem + LS_OFF);
+  for (int i = tid; i < NN; i += 256) {
+    ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
+    ((float*)(smem + LS_OFF))[i] = p.ls ? p.ls[i] : 1.f;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((p.w_plane + (size_t)NN * p.ldw) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((p.a_plane + (size_t)p.M * p.lda) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
+  // W: 24 wave-instructions per slice (12 per plane: 32 rows x 32 B each), 6 per wave; LDS rows are 32 B = two 16-byte chunks, chunk c
+  // of row r at position c ^ ((r >> 3) & 1): a ds_read_b128 is served 16 lanes at a time ({0-3, 12-15, 20-27}, ...), rows 8 apart
+  // share their banks, and without the swizzle half of every group collides (measured: 2235 instead of ~1400 cycles per k-step)
+  unsigned wvoff[WP];
+#pragma unroll
+  for (int u = 0; u < WP; ++u) {
+    const int piece = wave * WP + u, plane = piece / 12, idx = piece - plane * 12;
+    const int row = idx * 32 + (lane >> 1);
+    wvoff[u] = (unsigned)((plane * p.w_plane + (size_t)row * p.ldw + (((lane & 1) ^ ((row >> 3) & 1)) * 8)) * 2);
+  }
+  const unsigned rdw = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4);                         // + plane * W_PLANE + t * 1024
+  const unsigned rda = A_OFF + wave * 1024 + l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4);   // + plane * A_PLANE : this wave's 32 A rows
+
+  long long t_wait = 0, t_steps = 0, t_epi = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  const int nrb = (p.M + BM - 1) / BM;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int m0w = rb * BM + wave * 32;
+    unsigned avoff[AP];   // [plane]: rows past M are clamped (their results are dropped)
+#pragma unroll
+    for (int u = 0; u < AP; ++u) {
+      const int rl = lane >> 1, row = min(m0w + rl, p.M - 1);
+      avoff[u] = (unsigned)((u * p.a_plane + (size_t)row * p.lda + (((lane & 1) ^ ((rl >> 3) & 1)) * 8)) * 2);
+    }
+    unsigned soff = 0;
+    auto piece_w = [&](int i, int u) {
+      unsigned char* st = smem + (i % NS) * STAGE_BYTES;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(st + (wave * WP + u) * 1024), 16, wvoff[u], soff, 0, 0);
+    };
+    auto piece_a = [&](int i, int u) {
+      unsigned char* st = smem + (i % NS) * STAGE_BYTES;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(st + A_OFF + u * A_PLANE + wave * 1024), 16, avoff[u], soff, 0, 0);
+    };
+    __syncthreads();  // the previous row block's staging reads are done (and the bias table is visible) before DMA reuses the LDS
+#pragma unroll
+    for (int i0 = 0; i0 < NS - 1; ++i0)
+      if (i0 < nk) {
+        soff = (unsigned)(i0 * BKS * 2);
+#pragma unroll
+        for (int u = 0; u < AP; ++u) piece_a(i0, u);
+#pragma unroll
+        for (int u = 0; u < WP; ++u) piece_w(i0, u);
+      }
+
+    f32x16_t acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int i = 0; i < nk; ++i) {
+      long long c0 = 0, c1 = 0;
+      if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
+      // slice i landed: everything but the requests of slices i + 1 and i + 2 (8 per wave each) has retired
+      if (i + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WP + AP)) : "memory");
+      else if (i + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
+      const bool dma = i + NS - 1 < nk;   // (uniform) slice i + 3 into the stage every wave has just left
+      soff = __builtin_amdgcn_readfirstlane((i + NS - 1) * BKS * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* st = smem + (i % NS) * STAGE_BYTES;
+      {
+        const bf16x8_t ah = *(const bf16x8_t*)(st + rda), al = *(const bf16x8_t*)(st + rda + A_PLANE);
+        bf16x8_t wh[2][2], wl[2][2];   // [pair parity][tile of the pair]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          wh[0][t] = *(const bf16x8_t*)(st + rdw + t * 1024);
+          wl[0][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + t * 1024);
+        }
+#pragma unroll
+        for (int pr = 0; pr < NTILE / 2; ++pr) {
+          const int cur = pr & 1, nx = cur ^ 1;
+          if (dma) {   // the requests of slice i + 3 ride as fillers: the two A pieces (HBM) first, then the six W pieces (L2)
+            if (pr < AP) piece_a(i + NS - 1, pr);
+            piece_w(i + NS - 1, pr);
+          }
+          if (pr + 1 < NTILE / 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              wh[nx][t] = *(const bf16x8_t*)(st + rdw + (2 * pr + 2 + t) * 1024);
+              wl[nx][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + (2 * pr + 2 + t) * 1024);
+            }
+          }
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const bf16x8_t w = term == 1 ? wl[cur][t] : wh[cur][t];
+              const bf16x8_t a = term == 0 ? al : ah;          // hi*lo, lo*hi, hi*hi
+              acc[2 * pr + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc[2 * pr + t], 0, 0, 0);
+            }
+#pragma unroll
+          for (int n = 0; n < 6; ++n) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (TIMING) { t_wait += c1 - c0; t_steps += (long long)__builtin_amdgcn_s_memtime() - c1; }
+    }
+
+    // ---- epilogue: C[rows of this wave][384] += (acc + bias) * ls, 128 columns at a time through the wave's LDS image ----
+    long long e0 = 0;
+    if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
+    __syncthreads();  // every wave is done reading the ring: the staging images overlap it
+    float* stg = (float*)(smem + wave * STG_BYTES);
+    const unsigned cvoff = (unsigned)(((lane >> 5) * p.ldc + (lane & 31) * 4) * 4);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x16_t& a = acc[4 * c + tt];
+          const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+          *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
+        }
+      const f32x4_t b4 = *(const f32x4_t*)(bias_l + 128 * c + (lane & 31) * 4);
+      const f32x4_t l4 = *(const f32x4_t*)(ls_l + 128 * c + (lane & 31) * 4);
+      // a wave alone on its SIMD: the sixteen row fetches of the column group are requested together (64 registers), then added and
+      // stored -- four at a time they cost sixteen exposed round trips per row block (measured: 56 K cycles per epilogue)
+      u32x4_t r[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+        r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff, __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldc + 128 * c) * 4), 0);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldc + 128 * c) * 4);
+        const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[it][e]));
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, cvoff, so, 0);  // rows >= M fall outside num_records: dropped
+      }
+    }
+    if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+      d[0] = t_wait; d[1] = t_steps; d[2] = t_epi; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+    }
+  }
+}
+
+int n384x3_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+}  // namespace
+
+// Eligibility: N == 384, K % 32 == 0, residual epilogue (optional LayerScale), stacked planes, 16-byte aligned operands, 31-bit byte
+// offsets; WVN_ERR_ARG otherwise (the caller uses the tiled gemm_x3 kernel).
+int wvn_gemm_n384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
+  if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
+  if (g.N != NN || g.K <= 0 || (g.K % BKS) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.W || !g.W_lo || !g.C) return WVN_ERR_ARG;
+  if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 4) || g.ldw != g.K) return WVN_ERR_ARG;
+  if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.W | (uintptr_t)g.W_lo | (uintptr_t)g.C) & 15) return WVN_ERR_ARG;
+  if (g.A_lo <= g.A || g.W_lo <= g.W) return WVN_ERR_ARG;
+  const size_t a_plane = (size_t)(g.A_lo - g.A), w_plane = (size_t)(g.W_lo - g.W);
+  if ((a_plane + (size_t)g.M * g.lda) * 2 >= (1ull << 32) || (size_t)g.M * g.ldc * 4 >= (1ull << 32) || (w_plane + (size_t)NN * g.ldw) * 2 >= (1ull << 32))
+    return WVN_ERR_ARG;
+  N384X3Params p{};
+  p.A = g.A; p.a_plane = a_plane; p.lda = g.lda; p.W = g.W; p.w_plane = w_plane; p.ldw = g.ldw; p.bias = g.bias; p.ls = g.ls;
+  p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg;
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(LDS_BYTES, (const void*)gemm_n384_x3_kernel<false>, (const void*)gemm_n384_x3_kernel<true>)) return rc;
+  const int ncu = n384x3_num_cus(), nrb = ceil_div(g.M, BM);
+  const int grid = nrb < ncu ? nrb : ncu;
+  if (p.dbg) hipLaunchKernelGGL(gemm_n384_x3_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  else hipLaunchKernelGGL(gemm_n384_x3_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}

@@ -73,6 +73,10 @@ WVN_DECLARE_OPERAND_LAUNCHERS(_f16)
 // exact mode: hi/lo bf16 planes, three MFMAs per product (gemm_x3.hip); same epilogue codes, plane-typed outputs for the
 // "bf16" ones
 int wvn_gemm_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
+// the A-stationary form for K == 384 (gemm_a384_x3.hip); WVN_ERR_ARG when the shape / epilogue is not eligible
+int wvn_gemm_a384_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
+// the row-panel form for N == 384 residual updates (gemm_n384_x3.hip: fc2, attention projection); WVN_ERR_ARG when not eligible
+int wvn_gemm_n384_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 
 // ---- fp8 (e4m3) MFMA GEMM with per-row scales of both operands (gemm_fp8.hip) + the row quantisers (fp8.hip) -----------
 struct GemmFp8Params {
