@@ -82,7 +82,11 @@ typedef struct wvn_vit_layer {
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const float *ls1, *ls2; /* [D] LayerScale of the attention / MLP branch (DINOv2 blocks.i.ls{1,2}.gamma); NULL = none (DINO) */
   const float *qkv_s, *proj_s, *fc1_s, *fc2_s; /* WVN_PREC_FP8: per-output-channel scale of each e4m3 weight row (w = q * s) */
-  const void* fc2_w_fused;                     /* WVN_VIT_MLP_FUSED: fc2.weight with the permuted hidden index (see above); else NULL */
+  const void* fc2_w_fused;                     /* WVN_VIT_MLP_FUSED: fc2.weight with the permuted hidden index (see above); else NULL.
+                                                * WVN_PREC_X3 / WVN_PREC_MIX (optional, D = 384): fc2.weight packed for the fragment-major MLP
+                                                * (csrc/gemm_n384_x3.hip, AFRAG): bf16 [F / 16 k-steps][2 planes hi, lo][384 rows n][2 chunks][8],
+                                                * chunk position cp of row n holds chunk c = cp ^ ((n >> 3) & 1), element j of chunk c =
+                                                * fc2.weight[n][16 s + swap23(8 c + j)] (swap23: bits 2 and 3 exchanged); NULL: the row-major MLP */
   const void* fc1_w_fused; /* optional with WVN_VIT_MLP_FUSED: fc1.weight with its COLUMN (input) index permuted the same way,
                             * fc1_w_fused[f][k] = fc1.weight[f][swap23(k)].  With it (and no LayerScale) the block's projection + MLP
                             * kernel keeps the residual rows in its accumulator registers: one read and one write of the residual
@@ -515,6 +519,12 @@ int wvn_debug_gemm_a384_x3(const void* A, const void* A_lo, int lda, const void*
  * dbg[(workgroup * 4 + wave) * 4 + {0 wait + barrier, 1 k-steps, 2 epilogue, 3 total}] in shader cycles. */
 int wvn_debug_gemm_n384_x3(const void* A, const void* A_lo, int lda, const void* W, const void* W_lo, const float* bias, const float* ls,
                            float* C, int ldc, int M, int K, long long* dbg, void* stream);
+/* The split-operand block MLP with the fragment-major hand-over (what WVN_PREC_MIX / WVN_PREC_X3 run at D = 384 from 8192 rows on):
+ * hid = gelu(xn W1^T + b1) written by csrc/gemm_a384_x3.hip as MFMA operand fragments (hi / lo planes, ceil(M / 32) * 32 rows of F each),
+ * x [M][384] fp32 += hid W2^T + b2 by csrc/gemm_n384_x3.hip; xn / W1: hi + lo bf16 planes, W2p: wvn_vit_layer.fc2_w_fused in its
+ * WVN_PREC_X3 / WVN_PREC_MIX layout.  dbg1 / dbg2 (optional): per-wave cycle counters of the two instrumented builds. */
+int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, const void* W1_lo, const float* b1, void* hid, void* hid_lo,
+                          const void* W2p, const float* b2, float* x, int M, int F, long long* dbg1, long long* dbg2, void* stream);
 /* subsequent wvn_attention_bf16 launches write dbg[(workgroup * 4 + wave) * 5 + {0 wait, 1 QK^T, 2 softmax, 3 PV,
  * 4 total}]; NULL switches the instrumented build off again. */
 int wvn_debug_attention_timing(long long* dbg);

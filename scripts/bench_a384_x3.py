@@ -24,7 +24,7 @@ for name, N, epi in (("fc1 (GELU planes)", 1536, 1), ("proj (fp32 residual)", 38
         c = torch.zeros(M, N, dtype=torch.float32, device=dev)
         args = lambda dbg: (ap[0].data_ptr(), ap[1].data_ptr(), 384, wp[0].data_ptr(), wp[1].data_ptr(), bias.data_ptr(), c.data_ptr(), 0, N, M, N, epi, dbg, _lib.stream())
     _lib.check(lib.wvn_debug_gemm_a384_x3(*args(0)), "a384_x3")
-    rows = torch.arange(0, M, max(1, M // 512), device=dev)
+    rows = torch.cat([torch.arange(0, min(M, 4096), device=dev), torch.arange(0, M, max(1, M // 512), device=dev)])   # every row of the first blocks + a sample
     want = a[rows].double() @ w.double().T + bias.double()
     if epi == 1:
         want = torch.nn.functional.gelu(want)
@@ -61,7 +61,7 @@ for name, K in (("fc2 row panel (K = 1536)", 1536), ("proj row panel (K = 384)",
     c = torch.zeros(M, 384, dtype=torch.float32, device=dev)
     args = lambda dbg: (a2p[0].data_ptr(), a2p[1].data_ptr(), K, wp[0].data_ptr(), wp[1].data_ptr(), bias.data_ptr(), 0, c.data_ptr(), 384, M, K, dbg, _lib.stream())
     _lib.check(lib.wvn_debug_gemm_n384_x3(*args(0)), "n384_x3")
-    rows = torch.arange(0, M, max(1, M // 512), device=dev)
+    rows = torch.cat([torch.arange(0, min(M, 4096), device=dev), torch.arange(0, M, max(1, M // 512), device=dev)])
     want = a2[rows].double() @ w.double().T + bias.double()
     err = (c[rows].double() - want).abs().max().item()
     for _ in range(3):
@@ -83,3 +83,36 @@ for name, K in (("fc2 row panel (K = 1536)", 1536), ("proj row panel (K = 384)",
     print(f"{name}: {ms * 1e3:.0f} us, {tf:.0f} TFLOP/s issued, max err {err:.2e}; per slice ({slices:.0f} per wave): wait+barrier {d[0] / slices:.0f}, "
           f"k-steps {d[1] / slices:.0f} (MFMA floor 2304), epilogue {d[2] / slices:.0f}, total {d[3] / slices:.0f} cycles", flush=True)
     del a2p, c
+
+# ---- the fragment-major split-operand MLP: fc1 (EPI_GELU_FRAG) -> fc2 (AFRAG) ----
+from wild_visual_navigation_amd.backbone import pack_fc2_fragment_major  # noqa: E402
+F = 1536
+w1 = (torch.randn(F, 384, generator=g) * 0.05).to(dev); b1 = (torch.randn(F, generator=g) * 0.1).to(dev)
+w2 = (torch.randn(384, F, generator=g) * 0.03).to(dev); b2 = (torch.randn(384, generator=g) * 0.1).to(dev)
+w1p, w2p = split_planes(w1), pack_fc2_fragment_major(w2)
+Mp = (M + 31) // 32 * 32
+hid = torch.empty(2, Mp * F, dtype=torch.bfloat16, device=dev)
+x = torch.zeros(M, 384, dtype=torch.float32, device=dev)
+margs = lambda d1, d2: (ap[0].data_ptr(), ap[1].data_ptr(), w1p[0].data_ptr(), w1p[1].data_ptr(), b1.data_ptr(), hid[0].data_ptr(), hid[1].data_ptr(),
+                        w2p.data_ptr(), b2.data_ptr(), x.data_ptr(), M, F, d1, d2, _lib.stream())
+_lib.check(lib.wvn_debug_mlp_x3_frag(*margs(0, 0)), "mlp_x3_frag")
+rows = torch.cat([torch.arange(0, min(M, 4096), device=dev), torch.arange(0, M, max(1, M // 512), device=dev)])
+want = torch.nn.functional.gelu(a[rows].double() @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
+print(f"fragment-major MLP: max err {(x[rows].double() - want).abs().max().item():.2e} (|want| max {want.abs().max().item():.2f})", flush=True)
+for _ in range(2):
+    lib.wvn_debug_mlp_x3_frag(*margs(0, 0))
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    lib.wvn_debug_mlp_x3_frag(*margs(0, 0))
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+d1 = torch.zeros(256 * 16, dtype=torch.int64, device=dev); d2 = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
+lib.wvn_debug_mlp_x3_frag(*margs(d1.data_ptr(), d2.data_ptr()))
+torch.cuda.synchronize()
+t1 = d1.reshape(256, 4, 4).double().mean(dim=(0, 1)); t2 = d2.reshape(256, 4, 4).double().mean(dim=(0, 1))
+sl1 = (M / 128) * (F / 64) * 3 / 256; ks2 = (M / 128) * (F / 16) / 256
+print(f"fragment-major MLP (fc1 + fc2): {ms * 1e3:.0f} us = {2.0 * M * 384 * F * 2 * 3 / ms / 1e9:.0f} TFLOP/s issued; fc1 per slice period: wait {t1[0] / sl1:.0f}, steps {t1[2] / sl1:.0f} (floor 1536), "
+      f"total {t1[3] / sl1:.0f}; fc2 per k-step: wait+barrier {t2[0] / ks2:.0f}, steps {t2[1] / ks2:.0f} (floor 1152), epilogue {t2[2] / ks2:.0f}, total {t2[3] / ks2:.0f}", flush=True)

@@ -68,6 +68,21 @@ def split_planes(t: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo]).contiguous()
 
 
+def pack_fc2_fragment_major(w: torch.Tensor) -> torch.Tensor:
+    """fc2.weight [384][F] fp32 -> the packed operand of the fragment-major split-operand MLP (include/wvn_hip.h, wvn_vit_layer.fc2_w_fused
+    for WVN_PREC_X3 / WVN_PREC_MIX): bf16 [F / 16][2 planes][384][2 chunks][8]; k-step-major so that a k-step's 24 KB are contiguous, the
+    column order inside a k-step = the order the fc1 accumulators hand the hidden activation over (bits 2 and 3 swapped), the two
+    16-byte chunks of row n exchanged where (n >> 3) & 1 (the LDS bank swizzle, applied here because the DMA copies lane-linear)."""
+    N, K = w.shape
+    planes = split_planes(w.detach().float())                      # [2][N][K]
+    i = torch.arange(16)
+    sw = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)
+    p = planes.reshape(2, N, K // 16, 16)[..., sw.to(planes.device)].reshape(2, N, K // 16, 2, 8).clone()
+    flip = ((torch.arange(N) >> 3) & 1).bool().to(planes.device)
+    p[:, flip] = p[:, flip].flip(dims=[3])
+    return p.permute(2, 0, 1, 3, 4).contiguous()
+
+
 def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
     """DINO's position-table resampling (bicubic, scale (grid+0.1)/g; DINOv2 keeps the same rule with its default
     interpolate_offset = 0.1, antialias off), done ONCE when the model is
@@ -162,7 +177,7 @@ class VitBackbone:
         m.flags = ((_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
                    | (_lib.VIT_FUSE_ANY_SIZE if (fuse_mlp is True or fuse_qkv is True) else 0)
                    | (0 if fuse_proj else _lib.VIT_NO_PROJ_IN_MLP) | (_lib.VIT_NO_LN_HANDOVER if os.environ.get("WVN_NO_HANDOVER") else 0)
-                   | (_lib.VIT_NO_A384_X3 if os.environ.get("WVN_NO_A384_X3") else 0))
+                   | (_lib.VIT_NO_A384_X3 if os.environ.get("WVN_NO_A384_X3") else 0) | int(os.environ.get("WVN_X3_DEBUG_BITS", "0")))
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
@@ -191,6 +206,10 @@ class VitBackbone:
                     L.proj_w = mat(sd[p + "attn.proj.weight"])
                 w2 = sd[p + "mlp.fc2.weight"]
                 L.fc2_w = mat(w2)
+                if self.precision in (_lib.PREC_X3, _lib.PREC_MIX) and self.dim == 384 and self.mlp_dim % 96 == 0:
+                    t = pack_fc2_fragment_major(w2.to(self.device))
+                    self._keep.append(t)
+                    L.fc2_w_fused = t.data_ptr()
                 if self.fuse_mlp:
                     # proj.weight, fc1.weight and the fused kernel's own copy of fc2.weight (hidden index in the order the fc1
                     # accumulators hand it over, wvn_hip.h), one allocation per layer

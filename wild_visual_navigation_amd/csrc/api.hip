@@ -58,7 +58,7 @@ const OperandKernels OPK_F16 = {2, wvn_gemm_bf16_launch_f16, wvn_qkv_fused_launc
 
 struct VitDims {
   int B, S, P, G, D, H, F, KP, KPs, ntok, ntok_s, npad, npatch;
-  bool fp8;
+  bool fp8, planes;   // planes: WVN_PREC_X3 / WVN_PREC_MIX (hi + lo bf16 planes)
   size_t esz;
   long long M, Mp;
 };
@@ -70,6 +70,7 @@ VitDims vit_dims(const wvn_vit_model* m, int batch) {
   // the fp32 FMA path reads the unpadded rows
   d.KPs = m->precision == WVN_PREC_F32 ? d.KP : (d.KP + 63) / 64 * 64;
   d.fp8 = m->precision == WVN_PREC_FP8;
+  d.planes = m->precision == WVN_PREC_X3 || m->precision == WVN_PREC_MIX;
   d.ntok_s = (d.ntok + 15) / 16 * 16;  // rows per frame: 8-token (16 B) chunks and the 16-token V^T permutation groups never straddle frames
   d.npad = (d.ntok + 127) / 128 * 128;
   d.esz = (m->precision == WVN_PREC_BF16 || m->precision == WVN_PREC_FP8 || m->precision == WVN_PREC_F16) ? 2 : 4;  // exact mode (X3): two bf16 planes = 4 bytes per element
@@ -85,7 +86,7 @@ VitWs vit_carve(const VitDims& d, void* base) {
   w.xn = take((size_t)d.M * d.D * d.esz);
   size_t qkv = (size_t)d.B * d.H * d.npad * 64 * d.esz;
   w.q = take(qkv); w.k = take(qkv); w.v = take(qkv);
-  w.hid = take((size_t)d.M * d.F * d.esz);
+  w.hid = take((size_t)(d.planes ? (d.M + 31) / 32 * 32 : d.M) * d.F * d.esz);   // (planes: whole 32-row groups for the fragment-major MLP)
   w.patches = take((size_t)d.Mp * d.KPs * d.esz);
   w.xq = nullptr; w.hq = nullptr; w.sa = nullptr;
   if (d.fp8) {  // e4m3 images of the GEMM inputs + their per-row scales
@@ -234,11 +235,11 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     p.M = rows; p.N = N; p.K = K; p.ls = ls;
     if (x3) {
       p.A_lo = lo(A, a_plane); p.W_lo = lo(W, (size_t)N * K); p.C_lo = C ? lo(C, c_plane) : nullptr;
-      if (N == 384 && (epi == EPI_RESID_F32) && rows >= 64 * 128 && !(m->flags & WVN_VIT_NO_A384_X3)) {   // row panel: fc2, projection
+      if (N == 384 && (epi == EPI_RESID_F32) && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 128))) {   // row panel: fc2, projection
         const int rc = wvn_gemm_n384_x3_launch(p, epi, st);
         if (rc != WVN_ERR_ARG) return rc;
       }
-      if (K == 384 && rows >= 64 * 128 && !(m->flags & WVN_VIT_NO_A384_X3)) {   // the A-stationary form from about a quarter chip of row blocks on
+      if (K == 384 && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 64))) {   // the A-stationary form from about a quarter chip of row blocks on
         const int rc = wvn_gemm_a384_x3_launch(p, epi, st);
         if (rc != WVN_ERR_ARG) return rc;
       }
@@ -301,6 +302,8 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
                  p.ntok_s = extra->ntok_s; p.q_scale = extra->q_scale; }
     return wvn_gemm_fp8_launch(p, epi, st);
   };
+  // the split-operand block kernels (A-stationary K = 384 with the LayerNorm in its prologue, fragment-major MLP): from 8192 rows on
+  const bool x3_fast = x3 && d.D == 384 && M >= 64 * 128 && !(m->flags & WVN_VIT_NO_A384_X3);
   bool pre_qkv = false;   // this block's norm1 has been applied by the previous block's projection + MLP kernel (fragments in w.hid)
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
@@ -386,7 +389,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
     { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
-    if (!mlp_fused) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, f32 ? 0 : opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    bool ln2_done = false;
     if (mlp_fused) {  // LayerNorm 2 + fc1 + GELU + fc2 + residual: one launch, no xn / hid round trip
       Span s(6, st);
       if (!L.fc2_w_fused) return WVN_ERR_ARG;
@@ -394,6 +397,30 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
                                   L.ls2, w.x, d.D, M, d.F, st));
       continue;
     }
+    if (x3_fast && L.fc2_w_fused && !(m->flags & 256)) {
+      // the split-operand MLP with the hidden activation handed over FRAGMENT-MAJOR: fc1 (gemm_a384_x3, EPI_GELU_FRAG) writes the
+      // MFMA operand fragments of fc2 straight from its accumulators, fc2 (gemm_n384_x3, AFRAG) fetches them with one coalesced load
+      // per lane and plane -- no LDS transpose on either side, every access a contiguous kilobyte
+      const size_t pl_frag = (size_t)((d.M + 31) / 32 * 32) * d.F;
+      GemmBf16Params p1{};
+      { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, lo(w.xn, pl_xn))); }
+      ln2_done = true;
+      p1.A = (const bf16_t*)w.xn; p1.A_lo = lo(w.xn, pl_xn); p1.lda = d.D;
+      p1.W = (const bf16_t*)L.fc1_w; p1.W_lo = lo(L.fc1_w, (size_t)d.F * d.D);
+      p1.ldw = d.D; p1.bias = L.fc1_b; p1.C = w.hid; p1.C_lo = lo(w.hid, pl_frag); p1.ldc = d.F; p1.M = M; p1.N = d.F; p1.K = d.D;
+      int rc;
+      { Span s(6, st); rc = wvn_gemm_a384_x3_launch(p1, EPI_GELU_FRAG, st); }
+      if (rc == WVN_OK) {
+        GemmBf16Params p2{};
+        p2.A = (const bf16_t*)w.hid; p2.A_lo = lo(w.hid, pl_frag); p2.lda = d.F; p2.W = (const bf16_t*)L.fc2_w_fused; p2.ldw = d.F; p2.bias = L.fc2_b;
+        p2.ls = L.ls2; p2.C = w.x; p2.ldc = d.D; p2.M = M; p2.N = d.D; p2.K = d.F;
+        Span s(7, st);
+        RET_IF(wvn_gemm_n384_x3_frag_launch(p2, EPI_RESID_F32, st));
+        continue;
+      }
+      if (rc != WVN_ERR_ARG) return rc;
+    }
+    if (!mlp_fused && !ln2_done) { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, f32 ? 0 : opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
     { Span s(6, st); RET_IF(linear(w.xn, pl_xn, d.D, L.fc1_w, L.fc1_b, w.hid, pl_hid, d.F, M, d.F, d.D, EPI_GELU_BF16, nullptr, nullptr)); }
     { Span s(7, st); RET_IF(linear(w.hid, pl_hid, d.F, L.fc2_w, L.fc2_b, w.x, 0, d.D, M, d.D, d.F, EPI_RESID_F32, L.ls2, nullptr)); }
   }
@@ -562,6 +589,17 @@ int wvn_debug_gemm_n384_x3(const void* A, const void* A_lo, int lda, const void*
   p.A = (const bf16_t*)A; p.A_lo = (const bf16_t*)A_lo; p.lda = lda; p.W = (const bf16_t*)W; p.W_lo = (const bf16_t*)W_lo; p.ldw = K;
   p.bias = bias; p.ls = ls; p.C = C; p.ldc = ldc; p.M = M; p.N = 384; p.K = K; p.dbg = dbg;
   return wvn_gemm_n384_x3_launch(p, EPI_RESID_F32, (hipStream_t)stream);
+}
+int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, const void* W1_lo, const float* b1, void* hid, void* hid_lo,
+                          const void* W2p, const float* b2, float* x, int M, int F, long long* dbg1, long long* dbg2, void* stream) {
+  GemmBf16Params p1{};
+  p1.A = (const bf16_t*)xn; p1.A_lo = (const bf16_t*)xn_lo; p1.lda = 384; p1.W = (const bf16_t*)W1; p1.W_lo = (const bf16_t*)W1_lo; p1.ldw = 384;
+  p1.bias = b1; p1.C = hid; p1.C_lo = hid_lo; p1.ldc = F; p1.M = M; p1.N = F; p1.K = 384; p1.dbg = dbg1;
+  RET_IF(wvn_gemm_a384_x3_launch(p1, EPI_GELU_FRAG, (hipStream_t)stream));
+  GemmBf16Params p2{};
+  p2.A = (const bf16_t*)hid; p2.A_lo = (const bf16_t*)hid_lo; p2.lda = F; p2.W = (const bf16_t*)W2p; p2.ldw = F; p2.bias = b2; p2.C = x; p2.ldc = 384;
+  p2.M = M; p2.N = 384; p2.K = F; p2.dbg = dbg2;
+  return wvn_gemm_n384_x3_frag_launch(p2, EPI_RESID_F32, (hipStream_t)stream);
 }
 int wvn_debug_kmeans_assign_form(int form) { wvn_kmeans_pixels_set_assign_form(form); return WVN_OK; }
 int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); wvn_attention_bf16_set_variant_f16(v); return WVN_OK; }

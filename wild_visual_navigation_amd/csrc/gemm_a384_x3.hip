@@ -15,6 +15,11 @@
 //     DMA issue cost per MFMA are two thirds / one half of the single-plane kernel's; 48 MFMAs per wave and slice;
 //   * the epilogue of column tile j - 1 rides in the slice periods of tile j, one third per slice (bias in the accumulator
 //     initialisation, activation + plane split + wave-private LDS transpose, 16-byte coalesced row stores).
+// X_GELU_FRAG: the hidden activation leaves fc1 FRAGMENT-MAJOR -- for every 32-row group R and k-step s of the consumer (fc2) one 1 KB
+// block per plane at ((R * N / 16 + s) * 1024), lane-major: 16 bytes per lane = the eight values of the lane's row whose column
+// indices are 16 s + swap23(8 hi + j) (bits 2 and 3 swapped: exactly what the accumulators of a TR tile hold per lane), i.e. ready-made
+// MFMA operand fragments for a consumer whose weight has the same column permutation (gemm_n384_x3.hip, AFRAG).  No LDS transpose,
+// and every store is one contiguous kilobyte per wave.
 // Outputs: q | k (one fp16 plane each, q pre-scaled: the operands of the fp16 attention kernel; or hi / lo bf16 planes), v^T
 // likewise, hi / lo planes with the exact erf GELU (fc1), fp32 residual read-modify-write (projection).
 #include <stdlib.h>
@@ -43,7 +48,7 @@ constexpr int BM = 128;
 constexpr int PIECES = SLICE_BYTES / 1024 / 4;  // 1 KB DMA pieces per wave and slice (8)
 static_assert(PIECES == 8, "one DMA piece per k-step of a slice");
 
-enum { X_GELU = 0, X_RESID = 1, X_QK = 2, X_V = 3, X_PLANES = 4 };
+enum { X_GELU = 0, X_RESID = 1, X_QK = 2, X_V = 3, X_PLANES = 4, X_GELU_FRAG = 5, X_QK_F16 = 6, X_V_F16 = 7 };   // _F16: one fp16 plane per tensor
 
 struct X384Params {
   const bf16_t* A; const bf16_t* A_lo; int lda;
@@ -143,11 +148,12 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
 
   // ---- epilogue addressing ----
   constexpr unsigned OOB = 0x80000000u;
-  constexpr bool IS_QKV = EPI == X_QK || EPI == X_V;
-  using TRK = std::integral_constant<bool, EPI != X_V>;
+  constexpr bool IS_QK = EPI == X_QK || EPI == X_QK_F16, IS_V = EPI == X_V || EPI == X_V_F16, IS_QKV = IS_QK || IS_V;
+  constexpr bool F16OUT = EPI == X_QK_F16 || EPI == X_V_F16;   // (compile-time: a run-time flag leaves branches in the slice loop)
+  using TRK = std::integral_constant<bool, !IS_V>;
   unsigned voff[2] = {0, 0};
   unsigned vt_off = 0, stg_rd = 0;
-  const unsigned c_bytes = IS_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == X_RESID ? 4 : 2));
+  const unsigned c_bytes = IS_QKV ? 0u : (unsigned)((size_t)(EPI == X_GELU_FRAG ? (p.M + 31) / 32 * 32 : p.M) * p.ldc * (EPI == X_RESID ? 4 : 2));
   const __amdgpu_buffer_rsrc_t rs_c = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base, 0, p.qkv_bytes, 0x00020000)
                                              : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c2 = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base_lo ? p.qkv_base_lo : p.qkv_base, 0, p.qkv_bytes, 0x00020000)
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   // ones ~6: MI355X guide); the four fragments of k-step s + 1 are requested during the six MFMAs of step s (192 cycles of cover) ----
   bf16x8_t wh[2][2], wl[2][2];   // [k-step parity][column half]
   u32x4_t resid_q[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  u32x4_t fragh = {0, 0, 0, 0}, fragl = {0, 0, 0, 0};   // X_GELU_FRAG: the fragment being assembled
   auto frag_read = [&](int slot, int s, int par) {
     const unsigned char* base = smem + slot * SLICE_BYTES + rd_base;
 #pragma unroll
@@ -220,12 +227,24 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       float v0 = prev[t][4 * g + h2], v1 = prev[t][4 * g + h2 + 1];
       if constexpr (TR) {
         const int c = 32 * t + 8 * g + 4 * hi + h2;
-        if constexpr (EPI == X_GELU) { v0 = gelu_as(v0); v1 = gelu_as(v1); }
+        if constexpr (EPI == X_GELU || EPI == X_GELU_FRAG) { v0 = gelu_as(v0); v1 = gelu_as(v1); }
+        if constexpr (EPI == X_GELU_FRAG) {
+          uint32_t h, l;
+          split2(v0, v1, h, l);
+          const int e = 2 * (g & 1) + (h2 >> 1);            // dword of the lane's 16 bytes: elements j = 4 (g & 1) + h2, + 1
+          fragh[e] = h; fragl[e] = l;
+          if ((s & 3) == 3) {                                // the fragment of the consumer's k-step 4 jp + 2 t + (g >> 1) is complete
+            const unsigned so = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 4)) + 4 * jp + 2 * t + (g >> 1)) * 1024);
+            wvn_store_b128_guarded(fragh, rs_c, lane * 16, so);
+            wvn_store_b128_guarded(fragl, rs_c2, lane * 16, so);
+          }
+          return;
+        }
         if constexpr (EPI == X_RESID) {
           if (p.ls) { v0 *= p.ls[n0 + c]; v1 *= p.ls[n0 + c + 1]; }
           const wvn_f32x2_t o = {v0, v1};
           *(wvn_f32x2_t*)(stg + l31 * 272 + c * 4) = o;
-        } else if (EPI == X_QK && p.f16_out) {
+        } else if constexpr (IS_QK && F16OUT) {
           const float qs = n0 < p.heads * 64 ? p.q_scale : 1.f;
           *(uint32_t*)(stg + l31 * 144 + c * 2) = pack_f16x2(v0 * qs, v1 * qs);
         } else {
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       } else {
         // V^T: tokens 8g + 4hi + e of the wave's 32, stored with bits 2 and 3 of the token index swapped inside aligned groups of 16
         const int mloc = 16 * (g >> 1) + 8 * hi + 4 * (g & 1) + h2;
-        if (p.f16_out) {
+        if constexpr (F16OUT) {
           *(uint32_t*)(stg + (32 * t + l31) * 80 + mloc * 2) = pack_f16x2(v0, v1);
         } else {
           uint32_t h, l;
@@ -263,31 +282,33 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       u32x4_t o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
-      __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, voff[0], so, 0);
-    } else if constexpr (EPI == X_QK) {
+      wvn_store_b128_guarded(o, rs_c, voff[0], so);
+    } else if constexpr (IS_QK) {
       const int it = s & 3, pl = s >> 2;
-      if (pl == 1 && p.f16_out) return;
+      if (pl == 1 && F16OUT) return;
       const int D = p.heads * 64;
       const int which = n0 / D, head = (n0 - which * D) >> 6;
       const unsigned so = __builtin_amdgcn_readfirstlane((which == 0 ? p.q_off : p.k_off) + head * p.npad * 64 * 2);
       const u32x4_t val = *(const u32x4_t*)(stg + pl * IMG_BF16 + ((lane >> 3) + it * 8) * 144 + (lane & 7) * 16);
-      if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, voff[it >> 1], so + (it & 1) * 1024, 0);
-      else __builtin_amdgcn_raw_buffer_store_b128(val, rs_c2, voff[it >> 1], so + (it & 1) * 1024, 0);
-    } else if constexpr (EPI == X_V) {
+      if (pl == 0) wvn_store_b128_guarded(val, rs_c, voff[it >> 1], so + (it & 1) * 1024);
+      else wvn_store_b128_guarded(val, rs_c2, voff[it >> 1], so + (it & 1) * 1024);
+    } else if constexpr (IS_V) {
       const int it = s & 3, pl = s >> 2;
-      if (pl == 1 && p.f16_out) return;
+      if (pl == 1 && F16OUT) return;
       const int head = n0 >> 6;
       const u32x4_t val = *(const u32x4_t*)(stg + pl * 64 * 80 + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
       const unsigned so = __builtin_amdgcn_readfirstlane(p.v_off + (head * 64 + it * 16) * p.npad * 2);
-      if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, vt_off, so, 0);
-      else __builtin_amdgcn_raw_buffer_store_b128(val, rs_c2, vt_off, so, 0);
+      if (pl == 0) wvn_store_b128_guarded(val, rs_c, vt_off, so);
+      else wvn_store_b128_guarded(val, rs_c2, vt_off, so);
+    } else if constexpr (EPI == X_GELU_FRAG) {
+      // (nothing: the fragments left in parts 0 and 1)
     } else {   // hi / lo planes [M][ldc]
       const int it = s >> 1, pl = s & 1;
       const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 8 * it) * p.ldc + n0) * 2);
       const u32x4_t val = *(const u32x4_t*)(stg + pl * IMG_BF16 + stg_rd + it * 8 * 144);
       const unsigned vo = m0w + 8 * it + (lane >> 3) < p.M ? voff[0] : OOB;
-      if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(val, rs_c, vo, so, 0);
-      else __builtin_amdgcn_raw_buffer_store_b128(val, rs_c2, vo, so, 0);
+      if (pl == 0) wvn_store_b128_guarded(val, rs_c, vo, so);
+      else wvn_store_b128_guarded(val, rs_c2, vo, so);
     }
   };
 
@@ -319,7 +340,11 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   // boundary (ks == 0) only; everywhere else a wait for "all but the 8 youngest" covers them.
   // VM operations of one part 2 per lane -- exactly, or a LOWER bound where it depends on a run-time flag (allowing more operations to
   // stay outstanding than were issued would let DMA(i) itself slip through the wait)
-  constexpr int ST = EPI == X_RESID ? 14 : (EPI == X_GELU || EPI == X_PLANES ? 8 : 4);   // (X_RESID: 6 row fetches + 8 stores ride in the ks == 2 period)
+  // VM operations an epilogue period issues per lane, exactly, or a LOWER bound where it depends on a run-time flag (allowing more
+  // operations to stay outstanding than were issued would let DMA(i) itself slip through the wait).  ST2: the stores (and row fetches)
+  // of part 2, in a ks == 2 period; ST01: the fragment stores of X_GELU_FRAG in the ks == 0 / 1 periods.
+  constexpr int ST2 = EPI == X_RESID ? 14 : (EPI == X_GELU || EPI == X_PLANES ? 8 : (EPI == X_GELU_FRAG ? 0 : (F16OUT ? 4 : 8)));
+  constexpr int ST01 = EPI == X_GELU_FRAG ? 4 : 0;
   long long t_wait = 0, t_iss = 0, t_mfma = 0;
   const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
   auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, auto epi_tag) {
@@ -327,7 +352,8 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     long long c0 = 0, c1 = 0, c2 = 0;
     if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
     if (i + 1 < total) {
-      if (ks == 0 && stores_in_window) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + ST) : "memory");
+      if (ks == 0 && stores_in_window && ST2 > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + ST2) : "memory");
+      else if (ks != 0 && do_epi && ST01 > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + ST01) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -336,8 +362,9 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
     // the DMA requests of slice i + 2 (into the ring slot every wave has just left): one 1 KB piece per k-step, riding with the
     // fillers, instead of eight behind the barrier (measured: 509 cycles of a 3700-cycle period went to issuing them in a burst)
-    const bool dma = i + NS - 1 < total;   // (uniform)
-    if (dma) issue_begin();
+    // (requested unconditionally: past the workgroup's last slice the cursor wraps to valid W rows and the data lands in a ring slot
+    //  nobody reads again -- a uniform branch around every piece cuts each period into nine basic blocks)
+    issue_begin();
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TIMING) c2 = (long long)__builtin_amdgcn_s_memtime();
     // Eight scheduling regions per slice: the six MFMAs of a k-step, the LDS reads of the next step's fragments and ONE chunk of the
@@ -348,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     frag_read(i % NS, 0, 0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      if (dma) issue_piece(i + NS - 1, s);
+      issue_piece(i + NS - 1, s);
       mfma_step(i % NS, ks, s, mtr);
       if constexpr (do_epi) epi_chunk(ks, j - 1, s, etr);
 #pragma unroll
@@ -361,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (dma) issue_end();
+    issue_end();
     if constexpr (TIMING) { t_wait += c1 - c0; t_iss += c2 - c1; t_mfma += (long long)__builtin_amdgcn_s_memtime() - c2; }
   };
   int si = 0;
@@ -393,6 +420,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       for (int c = 0; c < 8; ++c) epi_chunk(part, j1 - 1, c, TRK{});
     u += j1 - j0;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last two periods' surplus DMA requests land before the wave ends)
   if constexpr (TIMING) {
     if (lane == 0 && p.dbg) {
       long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
@@ -423,8 +451,7 @@ int launch(const X384Params& p, hipStream_t st) {
   const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
   const int grid = (int)(units < x384_num_cus() ? units : x384_num_cus());
   if (p.dbg) hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, true>), dim3(grid), dim3(256), lds, st, p);
-  else
-  hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI>), dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI>), dim3(grid), dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -446,6 +473,9 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
     case EPI_GELU_BF16:
       if (!g.C || !g.C_lo || (g.ldc % 8) != 0 || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return WVN_ERR_ARG;
       return launch<X_GELU>(p, st);
+    case EPI_GELU_FRAG:   // fragment-major planes (see the header comment); C / C_lo hold ceil(M / 32) * 32 rows, ldc == N
+      if (!g.C || !g.C_lo || g.ldc != g.N || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || ((size_t)g.M + 32) * g.ldc * 2 >= (1ull << 31)) return WVN_ERR_ARG;
+      return launch<X_GELU_FRAG>(p, st);
     case EPI_BF16:
       if (!g.C || !g.C_lo || (g.ldc % 8) != 0 || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return WVN_ERR_ARG;
       return launch<X_PLANES>(p, st);
@@ -469,12 +499,12 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
       }
       const int D = g.heads * 64;
       p.N = 2 * D;
-      const int rc = launch<X_QK>(p, st);
+      const int rc = g.qkv_f16 ? launch<X_QK_F16>(p, st) : launch<X_QK>(p, st);
       if (rc != WVN_OK) return rc;
       p.W = g.W + (size_t)2 * D * KD;
       p.bias = g.bias ? g.bias + 2 * D : nullptr;
       p.N = D;
-      return launch<X_V>(p, st);
+      return g.qkv_f16 ? launch<X_V_F16>(p, st) : launch<X_V>(p, st);
     }
     default: return WVN_ERR_ARG;
   }

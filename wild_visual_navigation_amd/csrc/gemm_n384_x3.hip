@@ -47,6 +47,43 @@ struct N384X3Params {
   long long* dbg;                                // TIMING builds: per wave {wait + barrier, k-steps, epilogue, total} shader cycles
 };
 
+// ---- epilogue: C[rows of this wave][384] += (acc + bias) * ls, 128 columns at a time through the wave's LDS image ----
+__device__ inline void n384_epilogue(const f32x16_t (&acc)[NTILE], unsigned char* smem, int wave, int lane, int m0w, __amdgpu_buffer_rsrc_t rs_c,
+                                     int ldc, const float* bias_l, const float* ls_l) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  __syncthreads();  // every wave is done reading the ring: the staging images overlap it
+  float* stg = (float*)(smem + wave * STG_BYTES);
+  const unsigned cvoff = (unsigned)(((lane >> 5) * ldc + (lane & 31) * 4) * 4);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x16_t& a = acc[4 * c + tt];
+        const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+        *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
+      }
+    const f32x4_t b4 = *(const f32x4_t*)(bias_l + 128 * c + (lane & 31) * 4);
+    const f32x4_t l4 = *(const f32x4_t*)(ls_l + 128 * c + (lane & 31) * 4);
+    // a wave alone on its SIMD: the sixteen row fetches of the column group are requested together (64 registers), then added and
+    // stored -- four at a time they cost sixteen exposed round trips per row block (measured: 56 K cycles per epilogue)
+    u32x4_t r[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+      r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff, __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * ldc + 128 * c) * 4), 0);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * ldc + 128 * c) * 4);
+      const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[it][e]));
+      wvn_store_b128_guarded(o, rs_c, cvoff, so);  // rows >= M fall outside num_records: dropped
+    }
+  }
+}
+
 template <bool TIMING>
 __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -117,14 +154,13 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
     for (int i = 0; i < nk; ++i) {
       long long c0 = 0, c1 = 0;
       if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
-      // slice i landed: everything but the requests of slices i + 1 and i + 2 (8 per wave each) has retired
-      if (i + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WP + AP)) : "memory");
-      else if (i + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + AP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // slice i landed: everything but the requests of slices i + 1 and i + 2 (8 per wave each) has retired.  (The requests go on past
+      // the last slice -- unconditionally: a uniform branch around every piece would cut the k-step into basic blocks -- into ring stages
+      // nobody reads again; they are drained before the epilogue re-uses the ring as staging.)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WP + AP)) : "memory");
       __builtin_amdgcn_s_barrier();
       if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
-      const bool dma = i + NS - 1 < nk;   // (uniform) slice i + 3 into the stage every wave has just left
-      soff = __builtin_amdgcn_readfirstlane((i + NS - 1) * BKS * 2);
+      soff = __builtin_amdgcn_readfirstlane((i + NS - 1) * BKS * 2);   // slice i + 3 into the stage every wave has just left
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* st = smem + (i % NS) * STAGE_BYTES;
       {
@@ -138,10 +174,9 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
 #pragma unroll
         for (int pr = 0; pr < NTILE / 2; ++pr) {
           const int cur = pr & 1, nx = cur ^ 1;
-          if (dma) {   // the requests of slice i + 3 ride as fillers: the two A pieces (HBM) first, then the six W pieces (L2)
-            if (pr < AP) piece_a(i + NS - 1, pr);
-            piece_w(i + NS - 1, pr);
-          }
+          // the requests of slice i + 3 ride as fillers: the two A pieces (HBM) first, then the six W pieces (L2)
+          if (pr < AP) piece_a(i + NS - 1, pr);
+          piece_w(i + NS - 1, pr);
           if (pr + 1 < NTILE / 2) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -170,40 +205,146 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
       if constexpr (TIMING) { t_wait += c1 - c0; t_steps += (long long)__builtin_amdgcn_s_memtime() - c1; }
     }
 
-    // ---- epilogue: C[rows of this wave][384] += (acc + bias) * ls, 128 columns at a time through the wave's LDS image ----
     long long e0 = 0;
     if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
-    __syncthreads();  // every wave is done reading the ring: the staging images overlap it
-    float* stg = (float*)(smem + wave * STG_BYTES);
-    const unsigned cvoff = (unsigned)(((lane >> 5) * p.ldc + (lane & 31) * 4) * 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
+    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l);
+    if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+      d[0] = t_wait; d[1] = t_steps; d[2] = t_epi; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+    }
+  }
+}
+
+
+// ---- AFRAG: A as fragment-major planes (EPI_GELU_FRAG of gemm_a384_x3.hip), W packed (wvn_pack_n384_x3_weight) --------------------------
+// A never touches the LDS: fragment (R, s) of a plane is one contiguous kilobyte, lane-major, so a wave fetches its operand of k-step s
+// with ONE coalesced 16-byte load per lane and plane, six k-steps ahead (48 registers).  W: the 24 KB of a k-step (both planes, rows of
+// 32 B already swizzled and column-permuted by the packer) are one contiguous block: every DMA piece is one kilobyte of consecutive
+// addresses (with 32 scattered rows per piece the request cost twice as much: 2235 cycles per k-step against ~1400).
+constexpr int PD = 6;                            // k-steps of A fragments in flight
+constexpr int FW = 6;                            // W DMA pieces per wave and k-step
+constexpr int FSTAGE = 2 * W_PLANE;              // 24 KB
+constexpr int FNS = 5;                           // ring depth (120 KB)
+static_assert(FNS * FSTAGE <= RING_BYTES, "the fragment form's ring must fit in front of the bias table");
+
+template <bool TIMING>
+__global__ __launch_bounds__(256, 1) void gemm_n384_x3_frag_kernel(N384X3Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nk = p.K / BKS;                      // a multiple of PD (launcher)
+  const float* bias_l = (const float*)(smem + BIAS_OFF);
+  const float* ls_l = (const float*)(smem + LS_OFF);
+  for (int i = tid; i < NN; i += 256) {
+    ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
+    ((float*)(smem + LS_OFF))[i] = p.ls ? p.ls[i] : 1.f;
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)2 * NN * p.K * 2), 0x00020000);
+  const size_t mpad = (size_t)(p.M + 31) / 32 * 32;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((p.a_plane + mpad * p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
+  const unsigned wv0 = (unsigned)(wave * FW * 1024 + lane * 16);   // + u * 1024: piece wave * 6 + u of the k-step's 24
+  const unsigned rdw = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4);  // + plane * W_PLANE + t * 1024
+  const unsigned a_lo_off = (unsigned)(p.a_plane * 2);
+
+  long long t_wait = 0, t_steps = 0, t_epi = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  const int nrb = (p.M + BM - 1) / BM;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int m0w = rb * BM + wave * 32;
+    const unsigned a_base = __builtin_amdgcn_readfirstlane((unsigned)((size_t)(m0w >> 5) * nk * 1024));   // fragment (R, 0) of the hi plane
+    auto piece_w = [&](int i, int u) {
+      unsigned char* st = smem + (i % FNS) * FSTAGE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(st + (wave * FW + u) * 1024), 16, wv0 + u * 1024,
+                                               __builtin_amdgcn_readfirstlane((unsigned)i * FSTAGE), 0, 0);
+    };
+    u32x4_t afh[PD], afl[PD];
+    auto load_a = [&](int i, int slot) {
+      const unsigned so = __builtin_amdgcn_readfirstlane(a_base + (unsigned)i * 1024);
+      afh[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, so, 0);
+      afl[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, so + a_lo_off, 0);
+    };
+    __syncthreads();  // the previous row block's staging reads are done (and the bias table is visible) before DMA reuses the LDS
+    // VM queue order: the A fragments of k-steps 0 .. PD - 1 first, then the W slices 0 .. FNS - 2
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int j = 0; j < PD; ++j) load_a(j, j);
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+    for (int i0 = 0; i0 < FNS - 1; ++i0)
+      if (i0 < nk) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x16_t& a = acc[4 * c + tt];
-          const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-          *(f32x4_t*)(stg + l31 * STG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
+        for (int u = 0; u < FW; ++u) piece_w(i0, u);
+      }
+
+    f32x16_t acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int ib = 0; ib < nk; ib += PD) {
+#pragma unroll
+      for (int jj = 0; jj < PD; ++jj) {
+        const int i = ib + jj;
+        long long c0 = 0, c1 = 0;
+        if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
+        // W slice i landed.  Younger than its last piece, in steady state: the A pair of its period and (6 + 2) of each of the FNS - 2 =
+        // 3 periods since -- 26; in the first periods fewer ((FNS - 2) * 6 = 18 at i = 0): the constant 18 is safe everywhere but the tail
+        // (W requests continue past the last slice, unconditionally: the source offset then lies outside the buffer -- zeros -- and the
+        //  stage is never read; drained before the epilogue)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FNS - 2) * FW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* st = smem + (i % FNS) * FSTAGE;
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, afh[jj]), al = __builtin_bit_cast(bf16x8_t, afl[jj]);
+        bf16x8_t wh[2][2], wl[2][2];   // [pair parity][tile of the pair]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          wh[0][t] = *(const bf16x8_t*)(st + rdw + t * 1024);
+          wl[0][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + t * 1024);
         }
-      const f32x4_t b4 = *(const f32x4_t*)(bias_l + 128 * c + (lane & 31) * 4);
-      const f32x4_t l4 = *(const f32x4_t*)(ls_l + 128 * c + (lane & 31) * 4);
-      // a wave alone on its SIMD: the sixteen row fetches of the column group are requested together (64 registers), then added and
-      // stored -- four at a time they cost sixteen exposed round trips per row block (measured: 56 K cycles per epilogue)
-      u32x4_t r[16];
 #pragma unroll
-      for (int it = 0; it < 16; ++it)
-        r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff, __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldc + 128 * c) * 4), 0);
+        for (int pr = 0; pr < NTILE / 2; ++pr) {
+          const int cur = pr & 1, nx = cur ^ 1;
+          piece_w(i + FNS - 1, pr);   // slice i + 4 into the stage every wave has just left
+          if (pr + 1 < NTILE / 2) {
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * p.ldc + 128 * c) * 4);
-        const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
-        u32x4_t o;
+            for (int t = 0; t < 2; ++t) {
+              wh[nx][t] = *(const bf16x8_t*)(st + rdw + (2 * pr + 2 + t) * 1024);
+              wl[nx][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + (2 * pr + 2 + t) * 1024);
+            }
+          }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[it][e]));
-        __builtin_amdgcn_raw_buffer_store_b128(o, rs_c, cvoff, so, 0);  // rows >= M fall outside num_records: dropped
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const bf16x8_t w = term == 1 ? wl[cur][t] : wh[cur][t];
+              const bf16x8_t a = term == 0 ? al : ah;          // hi*lo, lo*hi, hi*hi
+              acc[2 * pr + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc[2 * pr + t], 0, 0, 0);
+            }
+#pragma unroll
+          for (int n = 0; n < 6; ++n) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i + PD < nk) load_a(i + PD, jj);   // (after the last MFMA that reads the slot)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TIMING) { t_wait += c1 - c0; t_steps += (long long)__builtin_amdgcn_s_memtime() - c1; }
       }
     }
+    long long e0 = 0;
+    if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
+    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l);
     if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
   }
   if constexpr (TIMING) {
@@ -247,6 +388,28 @@ int wvn_gemm_n384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   const int grid = nrb < ncu ? nrb : ncu;
   if (p.dbg) hipLaunchKernelGGL(gemm_n384_x3_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
   else hipLaunchKernelGGL(gemm_n384_x3_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+// A: fragment-major planes ([2][ceil(M / 32)][K / 16][64 lanes][8], lo plane a_plane elements behind the hi plane); W: the packed weight of
+// wvn_pack_n384_x3_weight (2 * 384 * K elements).  K % 96 == 0 (six k-steps of A in flight, unrolled).
+int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
+  if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
+  if (g.N != NN || g.K <= 0 || (g.K % (BKS * PD)) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.W || !g.C || (g.ldc % 4)) return WVN_ERR_ARG;
+  if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.W | (uintptr_t)g.C) & 15) return WVN_ERR_ARG;
+  if (g.A_lo <= g.A) return WVN_ERR_ARG;
+  const size_t a_plane = (size_t)(g.A_lo - g.A), mpad = (size_t)(g.M + 31) / 32 * 32;
+  if ((a_plane + mpad * g.K) * 2 >= (1ull << 32) || (size_t)g.M * g.ldc * 4 >= (1ull << 32) || (size_t)2 * NN * g.K * 2 >= (1ull << 31)) return WVN_ERR_ARG;
+  N384X3Params p{};
+  p.A = g.A; p.a_plane = a_plane; p.lda = g.K; p.W = g.W; p.w_plane = 0; p.ldw = g.K; p.bias = g.bias; p.ls = g.ls;
+  p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg;
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(LDS_BYTES, (const void*)gemm_n384_x3_frag_kernel<false>, (const void*)gemm_n384_x3_frag_kernel<true>)) return rc;
+  const int ncu = n384x3_num_cus(), nrb = ceil_div(g.M, BM);
+  const int grid = nrb < ncu ? nrb : ncu;
+  if (p.dbg) hipLaunchKernelGGL(gemm_n384_x3_frag_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  else hipLaunchKernelGGL(gemm_n384_x3_frag_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

@@ -13,6 +13,7 @@ enum GemmEpilogue {
   EPI_ACCUM_F32 = 5,  // C(f32)  += acc + bias                  (same arithmetic; second GEMM of a sum)
   EPI_PATCH = 6,      // patch-embed: row remap (b,p) -> b*ntok+1+p, + pos[1+p]
   EPI_QKV = 7,        // scatter to q/k [b,h,npad,64] and v^T [b,h,64,npad]
+  EPI_GELU_FRAG = 8,  // gemm_a384_x3 only: gelu(acc + bias) as fragment-major hi / lo planes (the A operand of gemm_n384_x3's AFRAG form)
 };
 
 struct GemmBf16Params {
@@ -77,6 +78,9 @@ int wvn_gemm_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 int wvn_gemm_a384_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 // the row-panel form for N == 384 residual updates (gemm_n384_x3.hip: fc2, attention projection); WVN_ERR_ARG when not eligible
 int wvn_gemm_n384_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
+// the same with A as the fragment-major planes EPI_GELU_FRAG writes and W packed by wvn_pack_n384_x3_weight's layout (k-step-major,
+// both planes, the column permutation of the fragments, swizzled 32-byte rows: every DMA piece one contiguous kilobyte)
+int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 
 // ---- fp8 (e4m3) MFMA GEMM with per-row scales of both operands (gemm_fp8.hip) + the row quantisers (fp8.hip) -----------
 struct GemmFp8Params {
