@@ -106,7 +106,7 @@ def product(a, w, mode, fmt, kdim_last_w=True):
     raise ValueError(mode)
 
 
-def vit_tokens_emulated(sd, img, patch, heads, modes, fmt):
+def vit_tokens_emulated(sd, img, patch, heads, modes, fmt, center_k=False):
     """oracle.vit.vit_tokens with per-family operand modes (dict family -> mode)."""
     B, _, S, _ = img.shape
     G = S // patch
@@ -124,6 +124,8 @@ def vit_tokens_emulated(sd, img, patch, heads, modes, fmt):
         qkv = product(y, sd[p + "attn.qkv.weight"], modes["qkv"], fmt) + sd[p + "attn.qkv.bias"]
         qkv = qkv.reshape(B, -1, 3, heads, dh).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0] * qscale, qkv[1], qkv[2]
+        if center_k:   # softmax is invariant to a per-query shift of the scores: q . (k - mean_j k) differs from q . k by a row constant
+            k = k - k.mean(dim=2, keepdim=True)
         outs = []
         for b in range(B):  # per frame: the [h, N, N] score block is 236 MB at 448^2
             s = product(q[b], k[b], modes["qk"], fmt)  # log2 domain

@@ -279,7 +279,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       RET_IF(wvn_pad_zero_launch(w.xn, d.B, (long long)d.ntok_s * d.D * 2, (long long)d.ntok * d.D * 2, (long long)(d.ntok_s - d.ntok) * d.D * 2, st));
     const long long nbh = (long long)d.B * d.H;
     const long long tokb = f32 ? 256 : 128, npl = (x3 && !mix) ? 2 : 1;  // bytes per token row of q / k; planes per tensor
-    RET_IF(wvn_pad_zero_launch(w.q, nbh * npl, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
+    RET_IF(wvn_pad_zero_launch(w.q, nbh * (x3 ? 2 : 1), d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));   // (mix: q has two fp16 planes)
     RET_IF(wvn_pad_zero_launch(w.k, nbh * npl, d.npad * tokb, d.ntok_s * tokb, (d.npad - d.ntok_s) * tokb, st));
     if (!f32)  // V^T [B*h*64][npad] (bf16, or hi / lo planes)
       RET_IF(wvn_pad_zero_launch(w.v, nbh * 64 * npl, (long long)d.npad * 2, (long long)d.ntok_s * 2, (long long)(d.npad - d.ntok_s) * 2, st));
@@ -354,15 +354,16 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       // bf16: the softmax scale is folded into q by the QKV epilogue (q leaves it as an exp2 argument) and attention takes
       // the running max as an MFMA operand (attention_bf16.hip, PRE)
       if (bf) e.q_scale = scale * 1.44269504088896340736f;
-      if (mix) { e.qkv_f16 = 1; e.q_scale = scale * 1.44269504088896340736f; }   // one fp16 plane each, q pre-scaled: the fp16 attention kernel's operands
+      // one fp16 plane each for k and v^T, q pre-scaled and in TWO fp16 planes (its rounding residue behind it): the fp16 attention kernel's operands
+      if (mix) { e.qkv_f16 = 1; e.q_scale = scale * 1.44269504088896340736f; e.q_lo = lo(w.q, pl_qkv); }
       else if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
       RET_IF(linear(w.xn, pl_xn, d.D, L.qkv_w, L.qkv_b, nullptr, 0, 0, M, 3 * d.D, d.D, EPI_QKV, nullptr, &e));
     }
     }
     {
       Span s(4, st);
-      if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr));
-      else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn)));
+      if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr, nullptr));
+      else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn), lo(w.q, pl_qkv)));
       else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }

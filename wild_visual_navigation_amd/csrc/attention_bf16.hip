@@ -67,13 +67,14 @@ __device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a,
 // rounding) and the running max enters the S^T MFMA chain as its C operand (a 16-register block holding -M, rewritten
 // only when the max moves): the accumulators come out as exp2 arguments and the 16 v_pk_fma per tile disappear.
 // SUM: how the row sums are formed.  0: v_dot2c_f32_bf16 on the packed P (16 per tile); 1: plain adds on the fp32 P.
-template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false, int SUM = 0, bool LAZY = false>
+template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false, int SUM = 0, bool LAZY = false, bool QSPLIT = false>
 __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* __restrict__ q,
                                                                   const op16_t* __restrict__ k,
                                                                   const op16_t* __restrict__ vt,
                                                                   op16_t* __restrict__ out, int heads, int nbh,
                                                                   int nqb, int ntok, int ntok_s, int npad,
-                                                                  float c_exp, long long* dbg, op16_t* __restrict__ out_lo) {
+                                                                  float c_exp, long long* dbg, op16_t* __restrict__ out_lo,
+                                                                  const op16_t* __restrict__ q_lo) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE_BYTES];  // [stage][K | Vt][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,6 +128,19 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
   // tile loop, where it would also drain the K/V DMA queue on every trip.
 #pragma unroll
   for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+  // QSPLIT (WVN_PREC_MIX): q as TWO planes, q = qf + ql (ql = the rounding residue of qf in the same format): S^T = K qf^T + K ql^T, eight
+  // more MFMAs per tile on the K fragments already read.  Why q and not k: a key's rounding error is independent from key to key and
+  // averages out over the thousands of keys of a row; the query's error is the SAME direction against every key of its row -- on the
+  // reference's real 448^2 frame q alone accounts for the 1.0e-3 token error of single-plane attention (split: 7.6e-5; k split: no
+  // change; profiles/r04d_error_budget_real_frame.md)
+  opx8_t ql[4];
+  if constexpr (QSPLIT) {
+    const op16_t* qlg = q_lo + ((size_t)bh * npad + q0 + l31) * DH + hi * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ql[s] = *(const opx8_t*)(qlg + s * 16);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(ql[s]));
+  }
 
   f32x16_t ot[2];
 #pragma unroll
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
         for (int s = 0; s < 4; ++s) {
           const opx8_t kf = *(const opx8_t*)(lds + fa[s] + t * 4096);
           st[t] = wvn_mfma_32x32x16(kf, qf[s], s == 0 ? cneg : st[t], 0, 0, 0);
+          if constexpr (QSPLIT) st[t] = wvn_mfma_32x32x16(kf, ql[s], st[t], 0, 0, 0);
         }
       if (MAYBE_TAIL && kv0 + KVB > ntok) {
 #pragma unroll
@@ -483,7 +498,16 @@ constexpr int ATTN_DEFAULT = 1;
 int g_attn_variant = ATTN_DEFAULT;   // 0: exact per-tile row max, 1: lazy (alarm on the row sums; what ships: -4 % attention time)
 
 void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out,
-                int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, op16_t* out_lo) {
+                int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, op16_t* out_lo, const op16_t* q_lo) {
+  if (q_lo) {   // two-plane q: the lazy form with 16 more registers -- three workgroups per CU
+    if (xcd)
+      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 3, false, true, 0, true, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo);
+    else
+      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 3, false, true, 0, true, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo);
+    return;
+  }
   // 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for 3 stages /
   // 3 workgroups and 13.2 for 4 stages / 2); row sums by v_dot2c_f32_bf16 on the packed P (plain fp32 adds, which hipcc packs
   // into v_pk_add_f32, measured 12.0 ms per step against 11.7).  The same arithmetic with and without the XCD block order:
@@ -491,27 +515,27 @@ void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16
   if (g_attn_variant == 2) {   // lazy max, row sums by scalar fp32 adds
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
     else
       hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
     return;
   }
   if (g_attn_variant == 1) {
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
     else
       hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
     return;
   }
   if (xcd)
     hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo);
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
 }
 
 template <int NST, int OCC>
@@ -519,15 +543,15 @@ void launch_v(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t
               int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, float c_exp, op16_t* out_lo) {
   if (g_attn_dbg) {
     hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb,
-                       ntok, ntok_s, npad, c_exp, g_attn_dbg, out_lo);
+                       ntok, ntok_s, npad, c_exp, g_attn_dbg, out_lo, nullptr);
     return;
   }
   if (xcd)
     hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
-                       ntok_s, npad, c_exp, nullptr, out_lo);
+                       ntok_s, npad, c_exp, nullptr, out_lo, nullptr);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<NST, false, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
-                       ntok_s, npad, c_exp, nullptr, out_lo);
+                       ntok_s, npad, c_exp, nullptr, out_lo, nullptr);
 }
 
 }  // namespace
@@ -538,7 +562,7 @@ void WVN_OPSYM(wvn_attention_bf16_set_variant)(int v) { g_attn_variant = v < 0 ?
 // scale > 0: q holds the raw projections.  scale == 0: q is pre-multiplied by softmax_scale * log2(e) (EPI_QKV with
 // q_scale set), the kernel with the running max folded into the S^T MFMA chain runs.
 int WVN_OPSYM(wvn_attention_bf16_launch)(const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out, int B, int heads,
-                              int ntok, int ntok_s, int npad, float scale, hipStream_t st, op16_t* out_lo) {
+                              int ntok, int ntok_s, int npad, float scale, hipStream_t st, op16_t* out_lo, const op16_t* q_lo) {
   // out_lo (WVN_PREC_MIX): the normalised output leaves as two bf16 planes, hi = bf16(o) -> out, lo = bf16(o - hi) -> out_lo (the
   // operand representation of the exact-mode projection GEMM), straight from the fp32 accumulators -- whatever this build's own
   // operand format is
@@ -549,11 +573,11 @@ int WVN_OPSYM(wvn_attention_bf16_launch)(const op16_t* q, const op16_t* k, const
   dim3 grid(nqb * nbh);
   const bool xcd = (nbh % 8) == 0;  // the XCD decode needs whole groups of 8 (frame, head) pairs
   if (scale == 0.f && !g_attn_dbg) {
-    launch_pre(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, out_lo);
+    launch_pre(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, out_lo, q_lo);
     WVN_LAUNCH_CHECK();
     return WVN_OK;
   }
-  if (scale == 0.f) return WVN_ERR_ARG;
+  if (scale == 0.f || q_lo) return WVN_ERR_ARG;
   launch_v<3, 3>(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, c_exp, out_lo);  // raw-q form: 3-stage ring, 3 workgroups / CU
   WVN_LAUNCH_CHECK();
   return WVN_OK;

@@ -168,5 +168,15 @@ __device__ inline void wvn_store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t 
 }
 #endif
 
+#if defined(__HIPCC__)
+// (a, b) -> packed fp16 pair and the packed fp16 pair of what the rounding left behind
+__device__ inline void wvn_split2_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  hi = pack_f16x2(a, b);
+  const h2_t hh = __builtin_bit_cast(h2_t, hi);
+  lo = pack_f16x2(a - (float)hh[0], b - (float)hh[1]);
+}
+#endif
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -59,6 +59,7 @@ struct X384Params {
   int heads, npad, ntok_s;
   float q_scale;
   int f16_out;                          // X_QK / X_V: 1 = ONE fp16 plane per tensor, 0 = hi / lo bf16 planes
+  int q_lo_f16;                         // with f16_out: q leaves as TWO fp16 planes (the second at qkv_base_lo + q_off)
   bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;   // one buffer descriptor over q / k / v^T (hi planes or the fp16 planes)
   bf16_t* qkv_base_lo;                  // the same span of the lo planes (f16_out == 0)
   const float* ls;                      // X_RESID: optional LayerScale
@@ -245,8 +246,13 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
           const wvn_f32x2_t o = {v0, v1};
           *(wvn_f32x2_t*)(stg + l31 * 272 + c * 4) = o;
         } else if constexpr (IS_QK && F16OUT) {
+          // fp16 planes; the rounding residue goes to a second image whatever the tile is -- only q tiles store it (part 2), and a branch
+          // here would end the scheduling region
           const float qs = n0 < p.heads * 64 ? p.q_scale : 1.f;
-          *(uint32_t*)(stg + l31 * 144 + c * 2) = pack_f16x2(v0 * qs, v1 * qs);
+          uint32_t h, l;
+          wvn_split2_f16(v0 * qs, v1 * qs, h, l);
+          *(uint32_t*)(stg + l31 * 144 + c * 2) = h;
+          *(uint32_t*)(stg + IMG_BF16 + l31 * 144 + c * 2) = l;
         } else {
           uint32_t h, l;
           split2(v0, v1, h, l);
@@ -285,13 +291,17 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       wvn_store_b128_guarded(o, rs_c, voff[0], so);
     } else if constexpr (IS_QK) {
       const int it = s & 3, pl = s >> 2;
-      if (pl == 1 && F16OUT) return;
       const int D = p.heads * 64;
       const int which = n0 / D, head = (n0 - which * D) >> 6;
       const unsigned so = __builtin_amdgcn_readfirstlane((which == 0 ? p.q_off : p.k_off) + head * p.npad * 64 * 2);
       const u32x4_t val = *(const u32x4_t*)(stg + pl * IMG_BF16 + ((lane >> 3) + it * 8) * 144 + (lane & 7) * 16);
       if (pl == 0) wvn_store_b128_guarded(val, rs_c, voff[it >> 1], so + (it & 1) * 1024);
-      else wvn_store_b128_guarded(val, rs_c2, voff[it >> 1], so + (it & 1) * 1024);
+      else {
+        // the second plane: lo planes of q and k (hi / lo bf16 form), or -- fp16 form -- q's rounding residue where the caller asked for
+        // a two-plane q (attention_bf16.hip QSPLIT); k tiles and a single-plane q drop the store through an out-of-range offset
+        const bool keep = !F16OUT || (which == 0 && p.q_lo_f16);
+        wvn_store_b128_guarded(val, rs_c2, keep ? voff[it >> 1] : OOB, so + (it & 1) * 1024);
+      }
     } else if constexpr (IS_V) {
       const int it = s & 3, pl = s >> 2;
       if (pl == 1 && F16OUT) return;
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   // VM operations an epilogue period issues per lane, exactly, or a LOWER bound where it depends on a run-time flag (allowing more
   // operations to stay outstanding than were issued would let DMA(i) itself slip through the wait).  ST2: the stores (and row fetches)
   // of part 2, in a ks == 2 period; ST01: the fragment stores of X_GELU_FRAG in the ks == 0 / 1 periods.
-  constexpr int ST2 = EPI == X_RESID ? 14 : (EPI == X_GELU || EPI == X_PLANES ? 8 : (EPI == X_GELU_FRAG ? 0 : (F16OUT ? 4 : 8)));
+  constexpr int ST2 = EPI == X_RESID ? 14 : (EPI == X_GELU || EPI == X_PLANES ? 8 : (EPI == X_GELU_FRAG ? 0 : (F16OUT ? 4 : 8)));   // (QK fp16: 4 stores are the lower bound, a two-plane q issues 8)
   constexpr int ST01 = EPI == X_GELU_FRAG ? 4 : 0;
   long long t_wait = 0, t_iss = 0, t_mfma = 0;
   const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -492,6 +502,11 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
       if (hi - lo + one >= (1ull << 31)) return WVN_ERR_ARG;
       p.qkv_base = (bf16_t*)lo; p.q_off = (unsigned)((uintptr_t)g.q - lo); p.k_off = (unsigned)((uintptr_t)g.k - lo);
       p.v_off = (unsigned)((uintptr_t)g.vt - lo); p.qkv_bytes = (unsigned)(hi - lo + one);
+      if (g.qkv_f16 && g.q_lo) {   // two-plane fp16 q: only q's second plane exists
+        if ((uintptr_t)g.q_lo < p.q_off) return WVN_ERR_ARG;
+        p.qkv_base_lo = (bf16_t*)((uintptr_t)g.q_lo - p.q_off);
+        p.q_lo_f16 = 1;
+      }
       if (!g.qkv_f16) {   // the lo planes must sit at the same distances from their base
         const uintptr_t lo2 = std::min({(uintptr_t)g.q_lo, (uintptr_t)g.k_lo, (uintptr_t)g.vt_lo});
         if ((uintptr_t)g.q_lo - lo2 != p.q_off || (uintptr_t)g.k_lo - lo2 != p.k_off || (uintptr_t)g.vt_lo - lo2 != p.v_off) return WVN_ERR_ARG;

@@ -188,6 +188,15 @@ __device__ inline void gemm_x3_tile(const GemmBf16Params& p, int tm, int tn, uns
         if constexpr (EPI == EPI_QKV) {
           if (p.qkv_f16) {   // (uniform) WVN_PREC_MIX: ONE fp16 plane for the fp16 attention kernel; q carries scale * log2(e)
             const float qs = (n0 < p.N / 3 && p.q_scale != 0.f) ? p.q_scale : 1.f;
+            if (p.q_lo && n0 < p.N / 3) {   // q as two fp16 planes (attention_bf16.hip, QSPLIT)
+              uint32_t h0, l0, h1, l1;
+              wvn_split2_f16(v[0] * qs, v[1] * qs, h0, l0);
+              wvn_split2_f16(v[2] * qs, v[3] * qs, h1, l1);
+              const u32x2_t oh = {h0, h1}, ol = {l0, l1};
+              *(u32x2_t*)((bf16_t*)smem + lane_dim * CT_BF16_STRIDE + c) = oh;
+              *(u32x2_t*)((bf16_t*)smem + CT_PLANE + lane_dim * CT_BF16_STRIDE + c) = ol;
+              continue;
+            }
             const u32x2_t oh = {pack_f16x2(v[0] * qs, v[1] * qs), pack_f16x2(v[2] * qs, v[3] * qs)};
             *(u32x2_t*)((bf16_t*)smem + lane_dim * CT_BF16_STRIDE + c) = oh;
             continue;
@@ -215,7 +224,7 @@ __device__ inline void gemm_x3_tile(const GemmBf16Params& p, int tm, int tn, uns
     const int cbase = n0 - which * D;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
-      if (pl == 1 && p.qkv_f16) break;   // (uniform) single fp16 plane
+      if (pl == 1 && p.qkv_f16 && !(p.q_lo && which == 0)) break;   // (uniform) single fp16 plane, except a two-plane q
       const bf16_t* img = (const bf16_t*)smem + pl * CT_PLANE;
       if constexpr (TR) {  // q / k : image [m][n]; dst[(b*h + head)*npad + t][d]
         bf16_t* dst = which == 0 ? (pl ? p.q_lo : p.q) : (pl ? p.k_lo : p.k);

@@ -28,7 +28,8 @@ struct GemmBf16Params {
   // EPI_QKV
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad;
   float q_scale;  // EPI_QKV: the q third is multiplied by this before it is rounded to bf16 (0 = leave as is)
-  int qkv_f16;    // gemm_x3 EPI_QKV only: q / k / vt leave as ONE fp16 plane each (the operands of the fp16 attention kernel, WVN_PREC_MIX)
+  int qkv_f16;    // x3 kernels, EPI_QKV: q / k / vt leave as ONE fp16 plane each (the operands of the fp16 attention kernel, WVN_PREC_MIX);
+                  // with q_lo set, q leaves as TWO fp16 planes (q_lo = the rounding residue of q: attention_bf16.hip QSPLIT)
   const float* ls;  // EPI_RESID_F32: optional LayerScale vector [N] (DINOv2): C += ls * (acc + bias); nullptr = plain residual
   // exact mode (gemm_x3.hip): the lo planes of the operands and of plane-typed outputs (hi planes are A / W / C / q / k / vt)
   const bf16_t* A_lo; const bf16_t* W_lo; void* C_lo; bf16_t* q_lo; bf16_t* k_lo; bf16_t* vt_lo;
@@ -64,7 +65,8 @@ struct GemmBf16Params {
   int wvn_gemm_n384_launch##SFX(const GemmBf16Params& p, int epi, hipStream_t st, int* rows_done, int force = 0);                   \
   /* attention_bf16.hip */                                                                                                          \
   int wvn_attention_bf16_launch##SFX(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads, int ntok,   \
-                                     int ntok_s, int npad, float scale, hipStream_t st, bf16_t* out_lo = nullptr);                  \
+                                     int ntok_s, int npad, float scale, hipStream_t st, bf16_t* out_lo = nullptr,                   \
+                                     const bf16_t* q_lo = nullptr);                                                                 \
   void wvn_attention_bf16_set_debug##SFX(long long* dbg); /* per-wave phase timings (TIMING build), nullptr = off */                \
   void wvn_attention_bf16_set_variant##SFX(int v);                                                                                  \
   extern long long* g_mlp_fused_dbg##SFX;                                                                                           \
