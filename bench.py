@@ -317,7 +317,9 @@ def cpu_oracle_sample(args, fe):
     what = {"full": f"ViT-S/8 12 blocks fp32 + {segwhat} + pooling + 1 MLP step",
             "backbone": "ViT-S/8 12 blocks fp32", "dinov2": "DINOv2 ViT-B/14 12 blocks fp32 + STEGO head"}[args.mode]
     base = {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} frames {args.size}x{args.size} through the CPU oracle ({what}), {dt:.1f} s wall"}
+            "sample": (f"{n} frames {args.size}x{args.size} through the CPU oracle ({what}), {dt:.1f} s wall; ViT / head / pooling / MLP = PyTorch fp32 "
+                       f"on {torch.get_num_threads()} threads, k-means = the C restatement (fmaf chains in the definition's order, OpenMP) when "
+                       "oracle/_build holds it, else numpy with a software fp32 fma (25 s per 448^2 frame instead of 0.7 s)")}
     orc = {"img": img, "toks": toks, "sd": sd, "head": head, "G": G, "P": P, "heads": heads,
            "codes": {args.stego_reading: codes}, "segs": {args.stego_reading: segs}}
     if upstream:   # (outside the timed sample) the same frames under the fast form, for the parity of the stego_fast leg
@@ -349,7 +351,8 @@ def gpu_parity(args, fe, dev, orc, precision, reading=None):
         gi = orc["img"].to(dev).repeat(reps, 1, 1, 1)
         gtok = bb.forward_tokens(gi)[:n].cpu()
         otok = torch.cat(orc["toks"])
-        par = {"mode": precision, "frames": n, "against": "oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned)",
+        par = {"mode": precision, "frames": n, "against": ("oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned; k-means = the deterministic kernel-order definition of "
+                           "oracle/interfaces.py, which states the summation order of csrc/stego.hip)"),
                "gpu_batch": int(gi.shape[0]),
                "max_abs_tokens": float((gtok - otok).abs().max()), "rel_l2_tokens": float((gtok - otok).norm() / otok.norm())}
         ocodes = orc["codes"].get(reading) if stego else None
@@ -382,6 +385,19 @@ def gpu_parity(args, fe, dev, orc, precision, reading=None):
                         want = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, G, G).int(), args.size)[0, 0].long()
                     given += int(torch.equal(seg[b], want))
                 par["seg_equal_given_gpu_code"] = f"{given}/{m}"
+                if reading == "upstream" and OI._oracle_lib() is not None:
+                    # what "bit-exact segment maps" means behind a float backbone (oracle/segmap_agreement.py): every pixel where the maps
+                    # differ lies within the MEASURED float tolerance of an oracle decision boundary: margin <= 2 (eps_x + eps_c)
+                    from oracle import segmap_agreement as SA
+                    nf = min(n, 4)
+                    rs = [SA.analyse(ocodes[b][0].numpy(), gcode[b].numpy(), G, args.size, 20) for b in range(nf)]
+                    hist = [sum(r["margin_over_eps_hist"][i] for r in rs) for i in range(7)]
+                    par["seg_tolerance"] = {
+                        "frames": nf, "all_mismatches_within_float_tolerance": all(r["within_float_tolerance"] for r in rs),
+                        "mismatching_pixels": sum(r["mismatching"] for r in rs), "max_margin": max(r["max_margin"] for r in rs),
+                        "min_bound_2eps": min(r["bound_2eps"] for r in rs), "max_eps_x": max(r["eps_x"] for r in rs),
+                        "max_eps_c": max(r["eps_c"] for r in rs),
+                        "margin_over_eps_histogram": {"edges": [0, 0.01, 0.03, 0.1, 0.3, 1.0, 2.0, "inf"], "counts": hist}}
             # pooled features: the oracle's dense features pooled over the GPU's own segment map (so that the figure measures
             # the features, not a label permutation, when the maps differ)
             worst = 0.0
@@ -478,6 +494,12 @@ def timed_leg(args, dev, world, rank, steps, warmup, precision, stego_reading, p
         comm_ms["per_step_total"] = D.max_over_ranks(comm_ms["per_step_total"], dev)
     if torch.is_tensor(rows):
         rows = int(rows.item())       # (after the timed region: the count lived on the device)
+    # deterministic replicas (trainer.py): after the timed steps every rank must hold the same parameters, Adam moments and losses, bit
+    # for bit -- checked with MIN / MAX all-reduces of their images
+    replicas_ok = None
+    if world > 1 and not backbone_only:
+        replicas_ok = D.replicas_identical(model.flat_params(), trainer.m, trainer.v, losses)
+        assert replicas_ok, "the ranks' MLP replicas differ after the timed steps"
     loss_val = float(losses[0].item()) if not backbone_only else None
 
     total_frames = (args.batch if args.scaling == "strong" else world * B) * steps
@@ -502,7 +524,7 @@ def timed_leg(args, dev, world, rank, steps, warmup, precision, stego_reading, p
             "ms_per_step": round(dt / steps * 1e3, 3), "step_ms": percentiles(step_ms),
             "backbone_tflops": round(total_flops * passes * total_frames / dt / 1e12 / world, 1), "final_loss": loss_val,
             "roofline": roof, "kernel_ms": {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
-            "allreduce_ms": comm_ms, "steps": steps, "warmup": warmup}
+            "allreduce_ms": comm_ms, "replicas_identical": replicas_ok, "steps": steps, "warmup": warmup}
 
 
 def main():
@@ -603,6 +625,7 @@ def main():
         }
         if head["allreduce_ms"] is not None:
             out["allreduce_ms"] = head["allreduce_ms"]
+            out["replicas_identical_after_timed_steps"] = head["replicas_identical"]
         orc = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], orc = cpu_oracle_sample(args, head["fe"])

@@ -47,6 +47,9 @@ def _worker(rank, world, port, q):
         traj.append([o["loss_total"], o["loss_trav"], o["loss_reco"], o["mean"], o["std"]])
     D.barrier()
     assert D.max_over_ranks(float(rank)) == float(world - 1)
+    # the collective replica check bench.py --gpus N asserts after its timed steps: identical tensors pass, a rank-dependent one fails
+    assert D.replicas_identical(*st.sd.values())
+    assert not D.replicas_identical(torch.full((3,), float(rank)))
     # numpy payloads are pickled inline (torch tensors travel as shared-memory fds that die with the worker)
     q.put((rank, traj, {k: v.detach().cpu().numpy().copy() for k, v in st.sd.items()}))
     torch.distributed.destroy_process_group()

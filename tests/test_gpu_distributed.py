@@ -165,5 +165,6 @@ def test_bench_two_ranks_through_its_own_launcher(tmp_path):
     assert abs(out["value"] - 2 * 8 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 0.02      # whole-job frames / max-over-ranks time
     ar = out["allreduce_ms"]
     assert ar["per_step_total"] > 0 and ar["stats_allreduce"]["median"] > 0 and ar["grad_allreduce"]["median"] > 0
+    assert out["replicas_identical_after_timed_steps"] is True      # parameters, Adam moments and losses bit-identical across the ranks
     assert "parity_mode" not in out and "stego_fast" not in out     # the extra legs are an N = 1 matter
     assert out["roofline"]["achieved"] > 0 and out["final_loss"] == out["final_loss"]

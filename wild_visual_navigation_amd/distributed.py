@@ -62,6 +62,25 @@ def barrier():
         dist.barrier()
 
 
+def replicas_identical(*tensors) -> bool:
+    """Whether the bytes of ``tensors`` (parameters, optimiser moments, losses) are the same on every rank: MIN and MAX over the ranks
+    of their int32 image agree everywhere.  The design's claim (trainer.py: every rank applies the same update to the same
+    parameters) as a check -- bench.py --gpus N asserts it after the timed steps.  True for a single process."""
+    if not is_parallel():
+        return True
+    ok = True
+    for t in tensors:
+        t = t.detach().contiguous().reshape(-1)
+        img = t.view(torch.int32) if t.element_size() == 4 else t.view(torch.uint8).to(torch.int32)
+        if dist.get_backend() != "nccl":
+            img = img.cpu()
+        lo, hi = img.clone(), img.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ok = ok and bool(torch.equal(lo, hi))
+    return ok
+
+
 def max_over_ranks(value: float, device=None) -> float:
     if not is_parallel():
         return value
