@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the pixel-resolution k-means on its own (GPU box): 64 frames of 56 x 56 x 90 code -> 448 x 448 labels, K = 20, 10 iterations,
-with both assignment kernels (fp32 MFMA / VALU, `wvn_debug_kmeans_assign_form`), and check that they agree bit for bit.
+with the assignment kernels (screened bf16 MFMA / VALU / the screened kernel's exact path, `wvn_debug_kmeans_assign_form`), and check that they agree bit for bit.
     python scripts/bench_pixel_kmeans.py [frames]"""
 import sys
 
@@ -17,7 +17,7 @@ code = torch.randn(B, 90, 14, 14, generator=g)
 code = torch.nn.functional.interpolate(code, (56, 56), mode="bicubic").permute(0, 2, 3, 1).reshape(B, 56 * 56, 90).contiguous()
 code = (code * 2 + 0.3).to(dev)
 res = {}
-for form, name in ((1, "mfma"), (0, "valu")):
+for form, name in ((1, "mfma"), (0, "valu"), (2, "mfma kernel, every row exact")):
     _lib.lib().wvn_debug_kmeans_assign_form(form)
     for _ in range(2):
         out = ops.kmeans_cosine_pixels(code, 56, 448, 20, return_centroids=True)
@@ -29,8 +29,18 @@ for form, name in ((1, "mfma"), (0, "valu")):
     b.record()
     torch.cuda.synchronize()
     res[name] = out
+    if form == 1:
+        import ctypes
+        st = (ctypes.c_ulonglong * 2)()
+        _lib.lib().wvn_debug_kmeans_screen_stats(st, 1)
+        _lib.lib().wvn_debug_kmeans_assign_form(3)
+        ops.kmeans_cosine_pixels(code, 56, 448, 20)
+        torch.cuda.synchronize()
+        _lib.lib().wvn_debug_kmeans_assign_form(form)
+        _lib.lib().wvn_debug_kmeans_screen_stats(st, 1)
+        print(f"screened kernel: {st[0]} of {st[1]} 64-pixel row groups re-done exactly ({100.0 * st[0] / max(st[1], 1):.3f} %)", flush=True)
     print(f"pixel k-means [{name} assign], {B} frames 448^2, K = 20, 10 iterations: {a.elapsed_time(b) / 5:.2f} ms per call", flush=True)
 _lib.lib().wvn_debug_kmeans_assign_form(-1)
-same = torch.equal(res["mfma"][0], res["valu"][0]) and torch.equal(res["mfma"][2], res["valu"][2])
+same = all(torch.equal(res[k][0], res["valu"][0]) and torch.equal(res[k][2], res["valu"][2]) for k in res)
 print("labels and centroids identical between the two forms:", same)
 sys.exit(0 if same else 1)

@@ -31,14 +31,16 @@ def test_upsample_kernel_matches_fixed_order_oracle(dev):
 
 @pytest.fixture
 def assign_form(request):
-    """Both assignment kernels of the pixel k-means: the VALU form (default) and the opt-in fp32-MFMA form (K <= 20)."""
+    """The assignment kernels of the pixel k-means: the screened bf16-MFMA form (default where K <= 20: the label is taken from the
+    split-operand similarities where their margin proves it, from the exact fmaf chains elsewhere), the same kernel with EVERY row
+    sent down its exact path, and the VALU form."""
     from wild_visual_navigation_amd import _lib
     _lib.lib().wvn_debug_kmeans_assign_form(request.param)
     yield request.param
     _lib.lib().wvn_debug_kmeans_assign_form(-1)
 
 
-@pytest.mark.parametrize("assign_form", [1, 0], indirect=True, ids=["mfma", "valu"])
+@pytest.mark.parametrize("assign_form", [1, 2, 0], indirect=True, ids=["screened", "screened-all-exact", "valu"])
 @pytest.mark.parametrize("G,H,C,K,B", [(8, 64, 90, 5, 2), (7, 50, 16, 4, 3), (28, 224, 90, 20, 1), (5, 33, 90, 6, 2), (28, 224, 90, 20, 16),
                                        (9, 70, 90, 17, 9)])
 def test_pixel_kmeans_bit_exact(dev, assign_form, G, H, C, K, B):
@@ -60,7 +62,7 @@ def test_pixel_kmeans_bit_exact(dev, assign_form, G, H, C, K, B):
         assert int(nseg[b]) == len(np.unique(want)) == int(nseg2[b])
 
 
-@pytest.mark.parametrize("assign_form", [1, 0], indirect=True, ids=["mfma", "valu"])
+@pytest.mark.parametrize("assign_form", [1, 2, 0], indirect=True, ids=["screened", "screened-all-exact", "valu"])
 def test_pixel_kmeans_at_448_against_oracle(dev, assign_form):
     """BASELINE size: one 448^2 frame, 56 x 56 x 90 code, K = 20: 200 704 points x 11 assignment passes, labels bit-exact."""
     G, H, C, K = 56, 448, 90, 20

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "wvn_gemm_bf16": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_debug_attention_variant": ([_i], _i),
     "wvn_debug_kmeans_assign_form": ([_i], _i),
+    "wvn_debug_kmeans_screen_stats": ([_p, _i], _i),
     "wvn_debug_mlp_x3_frag": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p], _i),
     "wvn_debug_gemm_n384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p], _i),
     "wvn_debug_gemm_a384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p], _i),

@@ -467,160 +467,232 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 }
 
 
-// ---- the assignment pass on the matrix pipe (round 4) ----------------------------------------------------------------------
-// The K x C similarity products of a pixel are an fp32 GEMM, and gfx950 has an fp32-input MFMA whose result is, bit for bit, the
-// k-ordered fmaf chain of the definition (MI355X guide: "exact f32 == an fmaf chain, bitwise").  The form used is
-// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products per instruction, K = 1, 8 cycles --
-//     D[blk][i][j] += A[blk][i] * B[blk][j]       A: lane 4 blk + i, B: lane 4 blk + j, D: lane 4 blk + j, register i
-// With B = the lane's OWN pixel value of one channel (lane = pixel, exactly the layout the interpolation produces) and
-// A = centroid (4 m + (lane & 3)) of that channel, one instruction advances centroids 4 m .. 4 m + 3 of all 64 pixels by one
-// channel: accumulator (m, i) of a lane IS acc_{4 m + i} of the definition, one fma per channel in ascending channel order.
-// K = 20 is five such instructions per channel and 64 pixels = 40 matrix-pipe cycles with no padded rows (the 32 x 32 x 2 and
-// 16 x 16 x 4 forms would run 32 centroid slots for 20), against 20 v_fma_f32 = 80 cycles on the VALU.
-//
-// What the first version of this kernel taught (scripts/ablate_pixel_kmeans.py, 64 frames): MFMAs, VALU and LDS reads of a wave do
-// NOT hide behind each other here -- an 8-cycle MFMA leaves no issue slot to fill -- so the kernel costs their sum, and the LDS
-// reads (13 ds_read_b128 per channel quad and image-row pair) were the largest term: 350 of 814 us.  Hence the work split:
-//   * a workgroup owns one RUN of image rows: the rows whose two source code rows (i0, i0 + 1) are the same (8 or 9 rows at
-//     448 / 56).  Only those two code rows are staged (2 x G x CP floats).
-//   * a wave item is FOUR image rows x 64 pixels of the run with the same x: all four rows read the SAME four taps, so a quad of
-//     channels costs 4 tap reads + 5 centroid-fragment reads for 256 pixels (2.25 per row instead of 6.5), and the horizontal half
-//     of the interpolation -- t0 = fma(wx1, v01, wx0 v00), t1 likewise: the values do not depend on the image row -- is computed
-//     once for the four rows (4 + 4 x 3 VALU instructions per channel instead of 4 x 7; the same operations on the same values,
-//     so the same bits).
-//   * the twenty MFMAs of a channel go to twenty different accumulators (hipcc's own order is accumulator-major, which makes every
-//     other MFMA wait out its predecessor); sched_barrier keeps the channel groups apart, each group carries the next channel's
-//     interpolation and a share of the next quad's LDS reads.
-// Labels and therefore centroids are bit-identical to the VALU form (tests/test_gpu_stego_pixels.py runs both).
-//
-// MEASURED (64 frames at 448^2, one pass): 805 us against 779 us for the VALU form -- NOT faster, so the VALU form stays the default
-// and this kernel is opt-in (wvn_debug_kmeans_assign_form(1)).  Why: the 4x4x1 instruction issues once per 16 cycles, not 8 (the
-// kernel with its interpolation removed runs at 16.0 cycles per MFMA; SQ_VALU_MFMA_BUSY_CYCLES still counts 8 per instruction),
-// i.e. 32 flop / clk / SIMD -- exactly the rate of v_fma_f32 -- and nothing else issues in its shadow.  The large fp32 forms
-// (16x16x4, 32x32x2) do reach 64 flop / clk, but with K = 20 centroids on 32 slots that is 1.25 x the VALU rate before the
-// cross-lane argmax they need: not worth a third kernel.  profiles/r04b_kmeans_assign_forms.md holds the numbers.
-constexpr int PIXM_G = 4;          // image rows per wave item
-constexpr int PIXM_MB = 5;         // centroid blocks of 4 (K <= 20)
-__host__ __device__ constexpr int pixm_cp(int C) { return (C + 3) / 4 * 4; }
-__host__ inline size_t pixm_lds_bytes(int G, int C) { return ((size_t)2 * G * pixm_cp(C) + (size_t)(pixm_cp(C) / 4) * 4 * PIXM_MB * 4) * sizeof(float); }
+// ---- the assignment pass on the matrix pipe (round 4): SCREENED argmax -------------------------------------------------------
+// Labels are an integer function of fp32 similarities that the definition fixes bit for bit (fmaf chains in channel order).  The fp32
+// MFMA forms reproduce such a chain exactly but do not outrun the VALU here (profiles/r04b_kmeans_assign_forms.md: the 4x4x1 form issues
+// at the v_fma_f32 rate, the 32-slot forms waste 37 % on K = 20).  What the 16x faster bf16 MFMA can do is DECIDE almost every pixel:
+//   a_k = sum_ch (x_hi c_hi + x_hi c_lo + x_lo c_hi)      x, c_k unit vectors as hi + lo bf16 planes, fp32 accumulation
+// differs from the real dot product by at most (2^-17 + 2^-17 + 2^-18) sum|x c| + 98 * 2^-24 <= 2.6e-5, the definition's chain e_k
+// by at most 90 * 2^-24 <= 5.4e-6 (sum|x c| <= 1): |a_k - e_k| <= 3.2e-5 for every k.  So where the screened best beats the screened
+// runner-up by more than 2 * 3.2e-5, argmax_k e_k = argmax_k a_k (and no tie is involved): the label is PROVEN without evaluating e.
+// The kernel takes tau = 1.5e-4; the pixels inside the band (about 1 in 10^4: the margin density near zero is ~0.5 per unit) are
+// re-done by the definition itself -- a wave re-runs an image row of 64 pixels with the exact fmaf chains when any of its lanes asks.
+// Net: 3 MFMAs per 16 channels and 32 pixels instead of 20 x 16 v_fma_f32 per pixel; what remains is the interpolation (shared between
+// the two image rows of an item: the horizontal half is row-independent) and the plane split.  Labels and centroids stay bit-identical
+// to the VALU form by construction AND by test (tests/test_gpu_stego_pixels.py runs both forms on every shape; a forced-fallback
+// switch, wvn_debug_kmeans_assign_form(2), runs the exact path for every row).
+constexpr float SCR_TAU = 1.5e-4f;   // > 2 * (3.2e-5 + 2e-6: the index tag in the five low significand bits of the screened values)
+__device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ unsigned long long g_scr_exact_rows[2];   // [0] 64-pixel row groups sent down the exact path, [1] row groups seen (statistics)
+__host__ __device__ constexpr int scr_cp(int C) { return (C + 15) / 16 * 16; }
+__host__ inline size_t scr_lds_bytes(int G, int C) { return (size_t)2 * G * scr_cp(C) * sizeof(float); }
 
-template <int C, bool EXACTK>
-__global__ __launch_bounds__(256) void km_pix_assign_mfma_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
-                                                                 const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
-                                                                 int K, int B) {
-  constexpr int CP = pixm_cp(C), NQ = CP / 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* rows = lds;                         // [2][G][CP]: source rows i0 and min(i0 + 1, G - 1)
-  float* tabA = lds + 2 * G * CP;            // [NQ][4][PIXM_MB][4]
+// the definition for one pixel: K fmaf chains in channel order over the interpolated, normalised row (rows: [2][G][CP] staged code rows)
+template <int C, int KMAX>
+__device__ inline int km_pix_exact_label(const float* rows, int G, int CP, const LerpTap& tx, const LerpTap& ty, float ri, const float* __restrict__ cb, int K) {
+  const float* a0 = rows + tx.i0 * CP;
+  const float* a1 = rows + tx.i1 * CP;
+  const float* b0 = rows + (G + tx.i0) * CP;
+  const float* b1 = rows + (G + tx.i1) * CP;
+  float acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+  constexpr int DB = 10;
+  for (int d0 = 0; d0 < C; d0 += DB) {   // (a run-time loop: this path runs for about one wave in three hundred)
+    float v[DB];
+#pragma unroll
+    for (int j = 0; j < DB; ++j) {
+      const int d = min(d0 + j, C - 1);
+      v[j] = __fmul_rn(bilerp_fixed(a0[d], a1[d], b0[d], b1[d], tx.w0, tx.w1, ty.w0, ty.w1), ri);
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float* ck = cb + (size_t)min(k, K - 1) * C + d0;
+#pragma unroll
+      for (int j = 0; j < DB; ++j)
+        if (d0 + j < C) acc[k] = __fmaf_rn(v[j], ck[j], acc[k]);
+    }
+  }
+  int best = 0;
+  float bv = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K && acc[k] > bv) { bv = acc[k]; best = k; }
+  return best;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void km_pix_assign_screen_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+                                                                   const float* __restrict__ cent, int* __restrict__ labels, int G, int H,
+                                                                   int K, int B, int force_exact) {
+  constexpr int CP = scr_cp(C), NS = CP / 16;
+  static_assert(C % 10 == 0 || C == 16, "km_pix_exact_label walks the channels in blocks of 10");
+  extern __shared__ __attribute__((aligned(16))) float rows[];   // [2][G][CP]: source rows i0 and min(i0 + 1, G - 1), zero-padded channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
   int i0, b;
   km_frame_map(blockIdx.x, G, B, i0, b);
   const float scale = lerp_scale(G, H);
-  // the run of image rows whose upper source row is i0: [yb, ye)
-  int yb = scale > 0.f ? max(0, (int)((float)i0 / scale) - 2) : 0;
+  int yb = scale > 0.f ? max(0, (int)((float)i0 / scale) - 2) : 0;   // the run of image rows whose upper source row is i0: [yb, ye)
   while (yb < H && lerp_tap(yb, G, scale).i0 < i0) ++yb;
   int ye = yb;
   while (ye < H && lerp_tap(ye, G, scale).i0 == i0) ++ye;
-  if (ye == yb) return;                      // (uniform: no image row maps to this source row)
+  if (ye == yb) return;
+  const float* cb = cent + (size_t)b * K * C;
   {
-    const float* cb = code + (size_t)b * G * G * C;
-    for (int rg = wave; rg < 2 * G; rg += 4) {          // one wave per (source row, patch column): a 4 C-byte run of global memory
+    const float* src0 = code + (size_t)b * G * G * C;
+    for (int rg = wave; rg < 2 * G; rg += 4) {
       const int r = rg / G, g = rg - r * G;
-      const float* src = cb + ((size_t)min(i0 + r, G - 1) * G + g) * C;
+      const float* src = src0 + ((size_t)min(i0 + r, G - 1) * G + g) * C;
       float* dst = rows + (size_t)rg * CP;
 #pragma unroll
       for (int d = lane; d < CP; d += 64) dst[d] = d < C ? src[d] : 0.f;
     }
-    const float* ck = cent + (size_t)b * K * C;
-    for (int i = tid; i < NQ * 4 * PIXM_MB * 4; i += 256) {
-      const int cq = i & 3, m = (i >> 2) % PIXM_MB, r = (i / (4 * PIXM_MB)) & 3, q = i / (16 * PIXM_MB);
-      const int k = 4 * m + r, ch = 4 * q + cq;
-      tabA[i] = (k < K && ch < C) ? ck[(size_t)k * C + ch] : 0.f;
+  }
+  // centroid fragments (MFMA A operand): lane (c = l31, hi) holds channels 16 s + 8 hi + j of centroid c as hi / lo bf16 planes
+  bf16x8_t ch_[NS], cl_[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u32x4_t uh, ul;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int d = 16 * s + 8 * hi + 2 * e;
+      const float v0 = (l31 < K && d < C) ? cb[(size_t)l31 * C + d] : 0.f, v1 = (l31 < K && d + 1 < C) ? cb[(size_t)l31 * C + d + 1] : 0.f;
+      const uint32_t h = pack_bf16x2(v0, v1);
+      uh[e] = h;
+      ul[e] = pack_bf16x2(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
     }
+    ch_[s] = __builtin_bit_cast(bf16x8_t, uh);
+    cl_[s] = __builtin_bit_cast(bf16x8_t, ul);
   }
   __syncthreads();
-  const int ngx = ceil_div_dev(H, 64), nchunk = ceil_div_dev(ye - yb, PIXM_G);
-  const f32x4_t* tA = (const f32x4_t*)tabA + (lane & 3) * PIXM_MB;
-  for (int item = wave; item < nchunk * ngx; item += 4) {
-    const int ck = item / ngx, gx = item - ck * ngx;
-    const int x = gx * 64 + lane, xc = min(x, H - 1);
-    const LerpTap tx = lerp_tap(xc, G, scale);
-    int yy[PIXM_G];
-    float wy0[PIXM_G], wy1[PIXM_G], ri[PIXM_G];
-    size_t pp[PIXM_G];
+  const int ngx = ceil_div_dev(H, 64), npair = (ye - yb + 1) / 2;
+  for (int item = wave; item < npair * ngx; item += 4) {
+    const int rp = item / ngx, gx = item - rp * ngx;
+    const int y0 = yb + 2 * rp, y1 = min(y0 + 1, ye - 1);
+    const LerpTap t0 = lerp_tap(y0, G, scale), t1 = lerp_tap(y1, G, scale);
+    unsigned need_exact = force_exact > 0 ? 3u : 0u;          // bit r: image row r of the item needs the definition
+    int lab[2][2];
+    if (force_exact <= 0) {
+      f32x16_t acc[2][2];   // [half][row]
+      LerpTap tx[2];
+      float ri[2][2];
+      const float* pt[2];
 #pragma unroll
-    for (int j = 0; j < PIXM_G; ++j) {
-      yy[j] = min(yb + ck * PIXM_G + j, ye - 1);         // (rows past the run repeat its last row; their labels are not stored)
-      const LerpTap ty = lerp_tap(yy[j], G, scale);
-      wy0[j] = ty.w0; wy1[j] = ty.w1;
-      pp[j] = (size_t)b * H * H + (size_t)yy[j] * H + xc;
-      ri[j] = rinv[pp[j]];
-    }
-    const float* p00 = rows + tx.i0 * CP;
-    const float* p01 = rows + tx.i1 * CP;
-    const float* p10 = rows + (G + tx.i0) * CP;
-    const float* p11 = rows + (G + tx.i1) * CP;
-    f32x4_t acc[PIXM_G][PIXM_MB];
+      for (int h = 0; h < 2; ++h) {
+        const int xc = min(gx * 64 + 32 * h + l31, H - 1);
+        tx[h] = lerp_tap(xc, G, scale);
+        ri[h][0] = rinv[(size_t)b * H * H + (size_t)y0 * H + xc];
+        ri[h][1] = rinv[(size_t)b * H * H + (size_t)y1 * H + xc];
+        pt[h] = rows + 8 * hi;
 #pragma unroll
-    for (int j = 0; j < PIXM_G; ++j)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int m = 0; m < PIXM_MB; ++m) acc[j][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    struct Quad { f32x4_t t00, t01, t10, t11, w[PIXM_MB]; };
-    auto fetch = [&](int q, Quad& t, int part) {   // part 0: the four taps, 1: the centroid fragments; < 0: both
-      if (part <= 0) {
-        t.t00 = *(const f32x4_t*)(p00 + 4 * q); t.t01 = *(const f32x4_t*)(p01 + 4 * q);
-        t.t10 = *(const f32x4_t*)(p10 + 4 * q); t.t11 = *(const f32x4_t*)(p11 + 4 * q);
+          for (int e = 0; e < 16; ++e) acc[h][r][e] = 0.f;
       }
-      if (part < 0 || part == 1) {
+      // (half, k-step) steps, software-pipelined by hand: the eight tap reads of step n + 1 are requested before step n's arithmetic --
+      // two waves per SIMD do not cover an LDS round trip per step on their own (measured: 646 us per pass without the prefetch)
+      struct Taps { f32x4_t a00[2], a01[2], a10[2], a11[2]; };
+      auto fetch = [&](int n, Taps& t) {
+        const int s = n >> 1, h = n & 1;
+        const float* q00 = pt[h] + tx[h].i0 * CP + 16 * s;
+        const float* q01 = pt[h] + tx[h].i1 * CP + 16 * s;
+        const float* q10 = pt[h] + (G + tx[h].i0) * CP + 16 * s;
+        const float* q11 = pt[h] + (G + tx[h].i1) * CP + 16 * s;
 #pragma unroll
-        for (int m = 0; m < PIXM_MB; ++m) t.w[m] = tA[q * 4 * PIXM_MB + m];
+        for (int q4 = 0; q4 < 2; ++q4) {
+          t.a00[q4] = *(const f32x4_t*)(q00 + 4 * q4); t.a01[q4] = *(const f32x4_t*)(q01 + 4 * q4);
+          t.a10[q4] = *(const f32x4_t*)(q10 + 4 * q4); t.a11[q4] = *(const f32x4_t*)(q11 + 4 * q4);
+        }
+      };
+      Taps cur, nxt;
+      fetch(0, cur);
+#pragma unroll
+      for (int n = 0; n < 2 * NS; ++n) {
+        const int s = n >> 1, h = n & 1;
+        if (n + 1 < 2 * NS) fetch(n + 1, nxt);
+        float v0[8], v1[8];
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {   // bilerp_fixed with the row-independent half hoisted (the same operations: the same bits)
+            const float h0 = __fmaf_rn(tx[h].w1, cur.a01[q4][e], __fmul_rn(tx[h].w0, cur.a00[q4][e]));
+            const float h1 = __fmaf_rn(tx[h].w1, cur.a11[q4][e], __fmul_rn(tx[h].w0, cur.a10[q4][e]));
+            v0[4 * q4 + e] = __fmul_rn(__fmaf_rn(t0.w1, h1, __fmul_rn(t0.w0, h0)), ri[h][0]);
+            v1[4 * q4 + e] = __fmul_rn(__fmaf_rn(t1.w1, h1, __fmul_rn(t1.w0, h0)), ri[h][1]);
+          }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const float* v = r ? v1 : v0;
+          u32x4_t uh, ul;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t hh = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            uh[e] = hh;
+            ul[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hh << 16), v[2 * e + 1] - __uint_as_float(hh & 0xffff0000u));
+          }
+          const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, uh), xl = __builtin_bit_cast(bf16x8_t, ul);
+          acc[h][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch_[s], xl, acc[h][r], 0, 0, 0);
+          acc[h][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl_[s], xh, acc[h][r], 0, 0, 0);
+          acc[h][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch_[s], xh, acc[h][r], 0, 0, 0);
+        }
+        if (n + 1 < 2 * NS) cur = nxt;
       }
-    };
-    // v[j] of channel (quad t, position cq): bilerp_fixed's operations with the row-independent half hoisted
-    auto interp = [&](const Quad& t, int cq, float (&v)[PIXM_G]) {
-      const float h0 = __fmaf_rn(tx.w1, t.t01[cq], __fmul_rn(tx.w0, t.t00[cq]));
-      const float h1 = __fmaf_rn(tx.w1, t.t11[cq], __fmul_rn(tx.w0, t.t10[cq]));
+      // screened best / runner-up per pixel: the lane's own 16 centroid slots (slot = (e & 3) + 8 (e >> 2) + 4 hi), then the partner's
 #pragma unroll
-      for (int j = 0; j < PIXM_G; ++j) v[j] = __fmul_rn(__fmaf_rn(wy1[j], h1, __fmul_rn(wy0[j], h0)), ri[j]);
-    };
-    Quad cur, nxt;
-    fetch(0, cur, -1);
-    float v[PIXM_G], vn[PIXM_G];
-    interp(cur, 0, v);
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      constexpr int dummy = 0; (void)dummy;
-      const int nch = C - 4 * q < 4 ? C - 4 * q : 4;   // (compile-time after unrolling)
+        for (int r = 0; r < 2; ++r) {
+          // the centroid index rides in the five low significand bits (2^-19 of a value <= 1: far inside the band's safety factor), so
+          // best and runner-up are plain maxima: max3 chains, the best masked out for the second pass
+          float key[16];
 #pragma unroll
-      for (int cq = 0; cq < 4; ++cq)
-        if (cq < nch) {
-          if (q + 1 < NQ && cq < 2) fetch(q + 1, nxt, cq);
+          for (int e = 0; e < 16; ++e) {
+            const int k = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            key[e] = k < K ? __uint_as_float((__float_as_uint(acc[h][r][e]) & ~31u) | (unsigned)k) : -INFINITY;
+          }
+          auto max16 = [&](const float (&a)[16]) {
+            float m0 = max3f(a[0], a[1], a[2]), m1 = max3f(a[3], a[4], a[5]);
+            m0 = max3f(m0, a[6], a[7]); m1 = max3f(m1, a[8], a[9]);
+            m0 = max3f(m0, a[10], a[11]); m1 = max3f(m1, a[12], a[13]);
+            return max3f(max3f(m0, a[14], a[15]), m1, m1);
+          };
+          const float bv = max16(key);
+          float rest[16];
 #pragma unroll
-          for (int j = 0; j < PIXM_G; ++j) vn[j] = 0.f;
-          if (cq + 1 < nch) interp(cur, cq + 1, vn);
-          else if (q + 1 < NQ) interp(nxt, 0, vn);
-#pragma unroll
-          for (int m = 0; m < PIXM_MB; ++m)
-#pragma unroll
-            for (int j = 0; j < PIXM_G; ++j) acc[j][m] = __builtin_amdgcn_mfma_f32_4x4x1f32(cur.w[m][cq], v[j], acc[j][m], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < PIXM_G; ++j) v[j] = vn[j];
+          for (int e = 0; e < 16; ++e) rest[e] = key[e] == bv ? -INFINITY : key[e];   // (keys are distinct: the index is part of them)
+          const float sv = max16(rest);
+          const float obv = __shfl_xor(bv, 32, 64), osv = __shfl_xor(sv, 32, 64);
+          const float best = fmaxf(bv, obv), second = fmaxf(fminf(bv, obv), fmaxf(sv, osv));
+          lab[h][r] = (int)(__float_as_uint(best) & 31u);    // (negative similarities order the tagged keys the other way round below
+                                                             //  2^-19: inside the band, where the exact path decides)
+          if (!(best - second > SCR_TAU)) need_exact |= 1u << r;   // (NaN-safe: anything not provably clear asks)
         }
-      if (q + 1 < NQ) cur = nxt;
+      need_exact = (__any(need_exact & 1u) ? 1u : 0u) | (__any(need_exact & 2u) ? 2u : 0u);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int x = gx * 64 + 32 * h + l31;
+        if (hi == 0 && x < H) {
+          if (!(need_exact & 1u)) labels[(size_t)b * H * H + (size_t)y0 * H + x] = lab[h][0];
+          if (!(need_exact & 2u) && y1 != y0) labels[(size_t)b * H * H + (size_t)y1 * H + x] = lab[h][1];
+        }
+      }
     }
+    if (force_exact < 0 && lane == 0) {   // (statistics run only: wvn_debug_kmeans_assign_form(3))
+      atomicAdd(&g_scr_exact_rows[1], (unsigned long long)(y1 != y0 ? 2 : 1));
+      if (need_exact) atomicAdd(&g_scr_exact_rows[0], (unsigned long long)(((need_exact & 1u) ? 1 : 0) + (((need_exact & 2u) && y1 != y0) ? 1 : 0)));
+    }
+    if (need_exact) {   // (wave-uniform) the definition, lane = pixel of the 64-pixel group
+      const int x = gx * 64 + lane, xc = min(x, H - 1);
+      const LerpTap txe = lerp_tap(xc, G, scale);
 #pragma unroll
-    for (int j = 0; j < PIXM_G; ++j) {
-      int best = 0;
-      float bv = -INFINITY;
-#pragma unroll
-      for (int m = 0; m < PIXM_MB; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 4 * m + r;
-          if ((EXACTK || k < K) && acc[j][m][r] > bv) { bv = acc[j][m][r]; best = k; }
-        }
-      if (x < H && yb + ck * PIXM_G + j < ye) labels[pp[j]] = best;
+      for (int r = 0; r < 2; ++r) {
+        const int y = r ? y1 : y0;
+        if (!(need_exact & (1u << r)) || (r == 1 && y1 == y0)) continue;
+        const size_t p = (size_t)b * H * H + (size_t)y * H + xc;
+        const int best = km_pix_exact_label<C, 20>(rows, G, CP, txe, r ? t1 : t0, rinv[p], cb, K);
+        if (x < H) labels[p] = best;
+      }
     }
   }
 }
@@ -812,9 +884,10 @@ PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
   return s;
 }
 
-// the MFMA assign kernel is eligible when K <= 20 and the two staged code rows + the fragment table fit the LDS
-static bool pixm_ok(int G, int H, int C, int K) { return K <= 4 * PIXM_MB && H >= 2 && pixm_lds_bytes(G, C) <= 150 * 1024; }
-int g_km_assign_form = -1;   // -1 / 0: the VALU form (default), 1: the fp32-MFMA form where eligible (K <= 20; tests, A/B)
+// the screened assign kernel is eligible when K <= 20 and the two staged code rows fit the LDS
+static bool pixm_ok(int G, int H, int C, int K) { return K <= 20 && H >= 2 && scr_lds_bytes(G, C) <= 150 * 1024; }
+int g_km_assign_form = -1;   // -1 / 1: the screened MFMA form where eligible (K <= 20; default), 0: the VALU form always, 2: the screened
+                             // kernel with every row sent down its exact path (tests), 3: the screened kernel counting its exact rows
 
 template <int C>
 int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int K, int iters, int relabel,
@@ -828,8 +901,8 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C, 20, true>,
                                 (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>)) return rc;
   static LdsOptIn lds_opt_in_m;
-  if (const int rc = lds_opt_in_m(150 * 1024, (const void*)km_pix_assign_mfma_kernel<C, true>, (const void*)km_pix_assign_mfma_kernel<C, false>)) return rc;
-  const bool mfma = g_km_assign_form == 1 && pixm_ok(G, H, C, K);
+  if (const int rc = lds_opt_in_m(150 * 1024, (const void*)km_pix_assign_screen_kernel<C>)) return rc;
+  const bool mfma = g_km_assign_form != 0 && pixm_ok(G, H, C, K);
   const int nrb = ceil_div(H, PIX_RPB);
   hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(nrb * B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
                      s.rinv, G, H, B);
@@ -837,8 +910,7 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   WVN_LAUNCH_CHECK();
   for (int it = 0; it <= iters; ++it) {
     const dim3 ga(nrb * B);
-    if (mfma && K == 20) hipLaunchKernelGGL((km_pix_assign_mfma_kernel<C, true>), dim3(G * B), dim3(256), pixm_lds_bytes(G, C), st, code, s.rinv, s.cent, labels, G, H, K, B);
-    else if (mfma) hipLaunchKernelGGL((km_pix_assign_mfma_kernel<C, false>), dim3(G * B), dim3(256), pixm_lds_bytes(G, C), st, code, s.rinv, s.cent, labels, G, H, K, B);
+    if (mfma) hipLaunchKernelGGL((km_pix_assign_screen_kernel<C>), dim3(G * B), dim3(256), scr_lds_bytes(G, C), st, code, s.rinv, s.cent, labels, G, H, K, B, g_km_assign_form == 2 ? 1 : (g_km_assign_form == 3 ? -1 : 0));
     else if (K == 20) hipLaunchKernelGGL((km_pix_assign_kernel<C, 20, true>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K, B);
     else if (K <= 32) hipLaunchKernelGGL((km_pix_assign_kernel<C, 32, false>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K, B);
     else hipLaunchKernelGGL((km_pix_assign_wide_kernel<C>), ga, dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K, B);
@@ -935,6 +1007,13 @@ int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* s
 }
 
 void wvn_kmeans_pixels_set_assign_form(int form) { g_km_assign_form = form; }
+// statistics of the screened kernel since the last call with reset != 0: out[0] = 64-pixel row groups re-done exactly, out[1] = all
+int wvn_kmeans_pixels_screen_stats(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scr_exact_rows), 16);
+  if (e != hipSuccess) return (int)e;
+  if (reset) { const unsigned long long z[2] = {0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_scr_exact_rows), z, 16); }
+  return e == hipSuccess ? WVN_OK : (int)e;
+}
 
 int wvn_flip_average_launch(const float* a, const float* mirrored, float* out, int B, int G, int C, hipStream_t st) {
   if (!a || !mirrored || !out || B <= 0 || G <= 0 || C <= 0) return WVN_ERR_ARG;
