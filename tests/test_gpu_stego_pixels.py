@@ -31,9 +31,9 @@ def test_upsample_kernel_matches_fixed_order_oracle(dev):
 
 @pytest.fixture
 def assign_form(request):
-    """The assignment kernels of the pixel k-means: the screened bf16-MFMA form (default where K <= 20: the label is taken from the
+    """The assignment kernels of the pixel k-means: the VALU form (default), the opt-in screened bf16-MFMA form (K <= 20: the label is taken from the
     split-operand similarities where their margin proves it, from the exact fmaf chains elsewhere), the same kernel with EVERY row
-    sent down its exact path, and the VALU form."""
+    sent down its exact path."""
     from wild_visual_navigation_amd import _lib
     _lib.lib().wvn_debug_kmeans_assign_form(request.param)
     yield request.param

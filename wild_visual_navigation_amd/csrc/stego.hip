@@ -481,6 +481,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 // the two image rows of an item: the horizontal half is row-independent) and the plane split.  Labels and centroids stay bit-identical
 // to the VALU form by construction AND by test (tests/test_gpu_stego_pixels.py runs both forms on every shape; a forced-fallback
 // switch, wvn_debug_kmeans_assign_form(2), runs the exact path for every row).
+// OPT-IN (wvn_debug_kmeans_assign_form(1)), not the default: what it buys depends on how many 64-pixel row groups hold a pixel inside
+// the band.  On code maps with cluster structure (scripts/bench_pixel_kmeans.py: 4.4 % of the row groups) a k-means call takes 14.2 ms
+// against 15.8; on the bench's SYNTHETIC-weight code, which has none -- twenty near-parallel centroids -- 85 % of the row groups
+// ask for the exact path and the headline drops from 1007 to 846 frames/s (profiles/r04b_kmeans_assign_forms.md).  A released STEGO
+// checkpoint is the first case; it cannot be measured here (no network), so the VALU form stays the default.
 constexpr float SCR_TAU = 1.5e-4f;   // > 2 * (3.2e-5 + 2e-6: the index tag in the five low significand bits of the screened values)
 __device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ unsigned long long g_scr_exact_rows[2];   // [0] 64-pixel row groups sent down the exact path, [1] row groups seen (statistics)
@@ -886,7 +891,7 @@ PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
 
 // the screened assign kernel is eligible when K <= 20 and the two staged code rows fit the LDS
 static bool pixm_ok(int G, int H, int C, int K) { return K <= 20 && H >= 2 && scr_lds_bytes(G, C) <= 150 * 1024; }
-int g_km_assign_form = -1;   // -1 / 1: the screened MFMA form where eligible (K <= 20; default), 0: the VALU form always, 2: the screened
+int g_km_assign_form = -1;   // -1 / 0: the VALU form (default), 1: the screened MFMA form where eligible (K <= 20), 2: the screened
                              // kernel with every row sent down its exact path (tests), 3: the screened kernel counting its exact rows
 
 template <int C>
@@ -902,7 +907,7 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
                                 (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>)) return rc;
   static LdsOptIn lds_opt_in_m;
   if (const int rc = lds_opt_in_m(150 * 1024, (const void*)km_pix_assign_screen_kernel<C>)) return rc;
-  const bool mfma = g_km_assign_form != 0 && pixm_ok(G, H, C, K);
+  const bool mfma = g_km_assign_form > 0 && pixm_ok(G, H, C, K);
   const int nrb = ceil_div(H, PIX_RPB);
   hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(nrb * B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
                      s.rinv, G, H, B);
