@@ -93,6 +93,9 @@ typedef struct wvn_vit_layer {
                             * stream per block instead of two and two (wvn_proj_mlp_resident).  NULL: the form without it */
   const void* qkv_w_fused; /* optional with WVN_VIT_QKV_FUSED: qkv.weight with its column index permuted the same way: the QKV kernel
                             * of this block can then start from the fragments the previous block's kernel left (wvn_qkv_prenorm) */
+  const void* proj_w_frag; /* WVN_PREC_X3 / WVN_PREC_MIX (optional, D = 384): attn.proj.weight in the packed layout of fc2_w_fused's
+                            * split-operand form.  With it, WVN_PREC_MIX's attention kernel writes its output as MFMA operand fragments
+                            * and the projection runs on the fragment form of csrc/gemm_n384_x3.hip.  NULL: the row-major projection */
 } wvn_vit_layer;
 
 typedef struct wvn_vit_model {

@@ -31,8 +31,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.VitLayer) == 21 * 8
-    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 21 * 8
+    assert C.sizeof(_lib.VitLayer) == 22 * 8
+    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 22 * 8
     assert C.sizeof(_lib.MlpDesc) == 16
 
 
@@ -53,8 +53,9 @@ def test_host_only_queries():
     m.precision = _lib.PREC_X3
     x3 = h.wvn_vit_workspace_bytes(C.byref(m), 1)
     m.precision = _lib.PREC_F32
-    # (+ the hidden activation rounded up to whole 32-row groups: the fragment-major hand-over of the split-operand MLP)
-    assert x3 == h.wvn_vit_workspace_bytes(C.byref(m), 1) + (3168 - 3152) * 1536 * 4
+    # (+ the hidden activation and the normalised / attention rows rounded up to whole 32-row groups: the fragment-major hand-overs of the
+    #  split-operand block)
+    assert x3 == h.wvn_vit_workspace_bytes(C.byref(m), 1) + (3168 - 3152) * (1536 + 384) * 4
     # DINOv2 ViT-B/14 at 518^2 (BASELINE configs[4]): 1370 tokens, patch rows 588 -> 640 for the MFMA precisions
     m.img_size, m.patch, m.dim, m.heads, m.mlp_dim, m.precision = 518, 14, 768, 12, 3072, _lib.PREC_BF16
     v2 = h.wvn_vit_workspace_bytes(C.byref(m), 1)

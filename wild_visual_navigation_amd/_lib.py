@@ -39,7 +39,7 @@ class WvnError(RuntimeError):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s", "fc2_w_fused", "fc1_w_fused", "qkv_w_fused")]
+        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s", "fc2_w_fused", "fc1_w_fused", "qkv_w_fused", "proj_w_frag")]
 
 
 class VitModel(C.Structure):

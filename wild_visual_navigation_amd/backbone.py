@@ -210,6 +210,10 @@ class VitBackbone:
                     t = pack_fc2_fragment_major(w2.to(self.device))
                     self._keep.append(t)
                     L.fc2_w_fused = t.data_ptr()
+                    if self.precision == _lib.PREC_MIX and heads * 64 == self.dim:   # the attention kernel hands its output over as fragments
+                        t = pack_fc2_fragment_major(sd[p + "attn.proj.weight"].to(self.device))
+                        self._keep.append(t)
+                        L.proj_w_frag = t.data_ptr()
                 if self.fuse_mlp:
                     # proj.weight, fc1.weight and the fused kernel's own copy of fc2.weight (hidden index in the order the fc1
                     # accumulators hand it over, wvn_hip.h), one allocation per layer

@@ -83,7 +83,7 @@ VitWs vit_carve(const VitDims& d, void* base) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return (void*)((char*)base + o); };
   w.x = (float*)take((size_t)d.M * d.D * 4);
-  w.xn = take((size_t)d.M * d.D * d.esz);
+  w.xn = take((size_t)(d.planes ? (d.M + 31) / 32 * 32 : d.M) * d.D * d.esz);
   size_t qkv = (size_t)d.B * d.H * d.npad * 64 * d.esz;
   w.q = take(qkv); w.k = take(qkv); w.v = take(qkv);
   w.hid = take((size_t)(d.planes ? (d.M + 31) / 32 * 32 : d.M) * d.F * d.esz);   // (planes: whole 32-row groups for the fragment-major MLP)
@@ -205,7 +205,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   const float scale = 1.0f / sqrtf(64.f);
   const int M = (int)d.M, Mp = (int)d.Mp;
   // exact mode: an activation / weight "matrix" is two stacked bf16 planes, hi then lo
-  const size_t pl_xn = (size_t)d.M * d.D, pl_hid = (size_t)d.M * d.F, pl_qkv = (size_t)d.B * d.H * d.npad * 64,
+  const size_t pl_xn = (size_t)(d.planes ? (d.M + 31) / 32 * 32 : d.M) * d.D, pl_hid = (size_t)d.M * d.F, pl_qkv = (size_t)d.B * d.H * d.npad * 64,
                pl_pat = (size_t)d.Mp * d.KPs;
   auto lo = [](const void* base, size_t plane_elems) { return (bf16_t*)base + plane_elems; };
 
@@ -333,6 +333,9 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       }
       continue;
     }
+    // WVN_PREC_MIX with a packed projection weight: the attention kernel writes fragments, the projection reads them (both planes of w.xn
+    // then hold ceil(M / 32) * 32 rows; pl_xn below is the plane distance of BOTH layouts)
+    const bool attn_frag = mix && x3_fast && L.proj_w_frag != nullptr;
     bool qkv_done = false;
     if (qkv_fused) {  // LayerNorm 1 + QKV projection: one launch, no xn round trip
       Span s(3, st);
@@ -362,8 +365,8 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     }
     {
       Span s(4, st);
-      if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr, nullptr));
-      else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn), lo(w.q, pl_qkv)));
+      if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr, nullptr, 0));
+      else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn), lo(w.q, pl_qkv), attn_frag ? 1 : 0));
       else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
@@ -389,6 +392,13 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       if (rc == WVN_OK) continue;
       if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
+    if (attn_frag) {   // the attention output arrived as operand fragments: the projection on the fragment form of the row-panel kernel
+      GemmBf16Params pp{};
+      pp.A = (const bf16_t*)w.xn; pp.A_lo = lo(w.xn, pl_xn); pp.lda = d.D; pp.W = (const bf16_t*)L.proj_w_frag; pp.ldw = d.D; pp.bias = L.proj_b; pp.ls = L.ls1;
+      pp.C = w.x; pp.ldc = d.D; pp.M = M; pp.N = d.D; pp.K = d.D;
+      Span s(5, st);
+      RET_IF(wvn_gemm_n384_x3_frag_launch(pp, EPI_RESID_F32, st));
+    } else
     { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
     bool ln2_done = false;
     if (mlp_fused) {  // LayerNorm 2 + fc1 + GELU + fc2 + residual: one launch, no xn / hid round trip

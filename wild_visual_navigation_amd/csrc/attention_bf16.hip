@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
                                                                   op16_t* __restrict__ out, int heads, int nbh,
                                                                   int nqb, int ntok, int ntok_s, int npad,
                                                                   float c_exp, long long* dbg, op16_t* __restrict__ out_lo,
-                                                                  const op16_t* __restrict__ q_lo) {
+                                                                  const op16_t* __restrict__ q_lo, int out_frag) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE_BYTES];  // [stage][K | Vt][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -462,7 +462,31 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
   if (qi < ntok) {
     const size_t oo = ((size_t)b * ntok_s + qi) * (heads * DH) + head * DH;
     op16_t* og = out + oo;
-    if (out_lo) {   // (uniform) hi / lo bf16 planes
+    if (out_lo && out_frag) {
+      // (uniform) hi / lo bf16 planes, FRAGMENT-MAJOR: for the 32-row group R = m >> 5 of the flat token row m and k-step s = 4 head + 2 dt + u
+      // of the projection, one 1 KB block per plane at ((R * 24 + s) * 1024), lane-major (16 bytes at ((hi * 32 + (m & 31)) * 16): the
+      // eight values whose column indices are 16 s + swap23(8 hi + j) -- exactly what this lane's accumulators hold (the layout of
+      // gemm_a384_x3.hip's EPI_GELU_FRAG; the projection's weight carries the same column permutation)
+      const size_t m = (size_t)b * ntok_s + qi;
+      const int nks = heads * 4;
+      op16_t* fb = out + (((m >> 5) * nks + head * 4) * 64 + hi * 32 + (m & 31)) * 8;
+      op16_t* fl = out_lo + (((m >> 5) * nks + head * 4) * 64 + hi * 32 + (m & 31)) * 8;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          u32x4_t oh, olo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * (2 * u + (e >> 1)) + 2 * (e & 1);      // g = 2 u + (e >> 1), elements 2 (e & 1), + 1
+            const float a = ot[dt][r] * inv, c = ot[dt][r + 1] * inv;
+            oh[e] = pack_bf16x2(a, c);
+            olo[e] = pack_bf16x2(a - __uint_as_float(oh[e] << 16), c - __uint_as_float(oh[e] & 0xffff0000u));
+          }
+          *(u32x4_t*)(fb + (2 * dt + u) * 512) = oh;
+          *(u32x4_t*)(fl + (2 * dt + u) * 512) = olo;
+        }
+    } else if (out_lo) {   // (uniform) hi / lo bf16 planes, row-major
       op16_t* ol = out_lo + oo;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -498,14 +522,14 @@ constexpr int ATTN_DEFAULT = 1;
 int g_attn_variant = ATTN_DEFAULT;   // 0: exact per-tile row max, 1: lazy (alarm on the row sums; what ships: -4 % attention time)
 
 void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out,
-                int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, op16_t* out_lo, const op16_t* q_lo) {
+                int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, op16_t* out_lo, const op16_t* q_lo, int out_frag) {
   if (q_lo) {   // two-plane q: the lazy form with 16 more registers -- three workgroups per CU
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 3, false, true, 0, true, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo, out_frag);
     else
       hipLaunchKernelGGL((attention_bf16_kernel<2, false, 3, false, true, 0, true, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo, out_frag);
     return;
   }
   // 2-stage ring, 4 workgroups per CU (the pre-scaled kernel needs 128 VGPRs: 11.96 ms per step against 12.28 for 3 stages /
@@ -515,27 +539,27 @@ void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16
   if (g_attn_variant == 2) {   // lazy max, row sums by scalar fp32 adds
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr, out_frag);
     else
       hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 1, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr, out_frag);
     return;
   }
   if (g_attn_variant == 1) {
     if (xcd)
       hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr, out_frag);
     else
       hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true, 0, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr, out_frag);
     return;
   }
   if (xcd)
     hipLaunchKernelGGL((attention_bf16_kernel<2, true, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr, out_frag);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<2, false, 4, false, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
-                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr);
+                       nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, nullptr, out_frag);
 }
 
 template <int NST, int OCC>
@@ -543,15 +567,15 @@ void launch_v(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t
               int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, float c_exp, op16_t* out_lo) {
   if (g_attn_dbg) {
     hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb,
-                       ntok, ntok_s, npad, c_exp, g_attn_dbg, out_lo, nullptr);
+                       ntok, ntok_s, npad, c_exp, g_attn_dbg, out_lo, nullptr, 0);
     return;
   }
   if (xcd)
     hipLaunchKernelGGL((attention_bf16_kernel<NST, true, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
-                       ntok_s, npad, c_exp, nullptr, out_lo, nullptr);
+                       ntok_s, npad, c_exp, nullptr, out_lo, nullptr, 0);
   else
     hipLaunchKernelGGL((attention_bf16_kernel<NST, false, OCC>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh, nqb, ntok,
-                       ntok_s, npad, c_exp, nullptr, out_lo, nullptr);
+                       ntok_s, npad, c_exp, nullptr, out_lo, nullptr, 0);
 }
 
 }  // namespace
@@ -562,7 +586,7 @@ void WVN_OPSYM(wvn_attention_bf16_set_variant)(int v) { g_attn_variant = v < 0 ?
 // scale > 0: q holds the raw projections.  scale == 0: q is pre-multiplied by softmax_scale * log2(e) (EPI_QKV with
 // q_scale set), the kernel with the running max folded into the S^T MFMA chain runs.
 int WVN_OPSYM(wvn_attention_bf16_launch)(const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out, int B, int heads,
-                              int ntok, int ntok_s, int npad, float scale, hipStream_t st, op16_t* out_lo, const op16_t* q_lo) {
+                              int ntok, int ntok_s, int npad, float scale, hipStream_t st, op16_t* out_lo, const op16_t* q_lo, int out_frag) {
   // out_lo (WVN_PREC_MIX): the normalised output leaves as two bf16 planes, hi = bf16(o) -> out, lo = bf16(o - hi) -> out_lo (the
   // operand representation of the exact-mode projection GEMM), straight from the fp32 accumulators -- whatever this build's own
   // operand format is
@@ -573,7 +597,7 @@ int WVN_OPSYM(wvn_attention_bf16_launch)(const op16_t* q, const op16_t* k, const
   dim3 grid(nqb * nbh);
   const bool xcd = (nbh % 8) == 0;  // the XCD decode needs whole groups of 8 (frame, head) pairs
   if (scale == 0.f && !g_attn_dbg) {
-    launch_pre(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, out_lo, q_lo);
+    launch_pre(xcd, grid, st, q, k, vt, out, heads, nbh, nqb, ntok, ntok_s, npad, out_lo, q_lo, out_frag);
     WVN_LAUNCH_CHECK();
     return WVN_OK;
   }

@@ -66,7 +66,7 @@ struct GemmBf16Params {
   /* attention_bf16.hip */                                                                                                          \
   int wvn_attention_bf16_launch##SFX(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int heads, int ntok,   \
                                      int ntok_s, int npad, float scale, hipStream_t st, bf16_t* out_lo = nullptr,                   \
-                                     const bf16_t* q_lo = nullptr);                                                                 \
+                                     const bf16_t* q_lo = nullptr, int out_frag = 0);                                               \
   void wvn_attention_bf16_set_debug##SFX(long long* dbg); /* per-wave phase timings (TIMING build), nullptr = off */                \
   void wvn_attention_bf16_set_variant##SFX(int v);                                                                                  \
   extern long long* g_mlp_fused_dbg##SFX;                                                                                           \
