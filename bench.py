@@ -160,7 +160,7 @@ def make_pipeline(args, dev, precision=None, stego_reading=None):
     if args.attn_variant is not None:
         from wild_visual_navigation_amd import _lib
         _lib.lib().wvn_debug_attention_variant(args.attn_variant)
-    if os.environ.get("WVN_KMEANS_ASSIGN_FORM"):   # A/B of the pixel k-means assignment kernels (0 VALU, 1 screened MFMA)
+    if os.environ.get("WVN_KMEANS_ASSIGN_FORM"):   # A/B of the pixel k-means assignment kernels (5 packed VALU = default, 0 plain VALU, 1 screened MFMA)
         from wild_visual_navigation_amd import _lib
         _lib.lib().wvn_debug_kmeans_assign_form(int(os.environ["WVN_KMEANS_ASSIGN_FORM"]))
     torch.manual_seed(42)

@@ -535,12 +535,14 @@ int wvn_debug_attention_timing(long long* dbg);
  * per-tile max; the row sums raise the alarm and the tile is redone exactly -- the default), < 0 = back to the default.  Same
  * results within the kernel's tolerance; tests/test_gpu_attention_lazy.py runs both, bench.py --attn-variant A/Bs them. */
 int wvn_debug_attention_variant(int variant);
-/* which assignment kernel subsequent wvn_kmeans_cosine_pixels calls use: -1 / 0 = the VALU form (default); 1 = the SCREENED form where
- * it is eligible (K <= 20): similarities from split-operand bf16 MFMAs decide every pixel whose best beats the runner-up by more than
- * the proven error bound, the exact fmaf chains of the definition decide the rest -- faster where the code has cluster structure,
- * slower on structure-less code (csrc/stego.hip); 2 = the screened kernel with every row sent down its exact path (tests); 3 = the
- * screened kernel counting its exact rows (wvn_debug_kmeans_screen_stats).  Bit-identical labels and centroids in all three; tests/test_gpu_stego_pixels.py runs them,
- * scripts/bench_pixel_kmeans.py A/Bs them. */
+/* which assignment kernel subsequent wvn_kmeans_cosine_pixels calls use: -1 / 5 = the PACKED VALU form where it is eligible (K <= 20;
+ * default): the fmaf chains of two clusters ride in the two halves of v_pk_fma_f32, the interpolation runs on channel pairs; 4 = packed
+ * dot products, plain interpolation; 0 = the plain VALU form (one v_fma_f32 per cluster and channel); 1 = the SCREENED form where it is
+ * eligible (K <= 20): similarities from split-operand bf16 MFMAs decide every pixel whose best beats the runner-up by more than the
+ * proven error bound, the exact fmaf chains of the definition decide the rest -- faster where the code has cluster structure, slower
+ * on structure-less code (csrc/stego.hip); 2 = the screened kernel with every row sent down its exact path (tests); 3 = the screened
+ * kernel counting its exact rows (wvn_debug_kmeans_screen_stats).  Bit-identical labels and centroids in all of them;
+ * tests/test_gpu_stego_pixels.py runs them, scripts/bench_pixel_kmeans.py A/Bs them. */
 int wvn_debug_kmeans_assign_form(int form);
 /* statistics of the screened kernel (synchronises the device): out[0] = 64-pixel row groups it re-did with the exact chains, out[1] = row
  * groups it saw, since the last call with reset != 0 */

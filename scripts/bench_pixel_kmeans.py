@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the pixel-resolution k-means on its own (GPU box): 64 frames of 56 x 56 x 90 code -> 448 x 448 labels, K = 20, 10 iterations,
-with the assignment kernels (screened bf16 MFMA / VALU / the screened kernel's exact path, `wvn_debug_kmeans_assign_form`), and check that they agree bit for bit.
+with the assignment kernels (plain / packed VALU, screened bf16 MFMA, the screened kernel's exact path: `wvn_debug_kmeans_assign_form`), and check that they agree bit for bit.
     python scripts/bench_pixel_kmeans.py [frames]"""
 import sys
 
@@ -17,7 +17,7 @@ code = torch.randn(B, 90, 14, 14, generator=g)
 code = torch.nn.functional.interpolate(code, (56, 56), mode="bicubic").permute(0, 2, 3, 1).reshape(B, 56 * 56, 90).contiguous()
 code = (code * 2 + 0.3).to(dev)
 res = {}
-for form, name in ((1, "mfma"), (0, "valu"), (2, "mfma kernel, every row exact")):
+for form, name in ((0, "valu"), (4, "valu, packed dot products"), (5, "valu, packed dot products and interpolation (default)"), (1, "mfma"), (2, "mfma kernel, every row exact")):
     _lib.lib().wvn_debug_kmeans_assign_form(form)
     for _ in range(2):
         out = ops.kmeans_cosine_pixels(code, 56, 448, 20, return_centroids=True)

@@ -6,6 +6,8 @@ its data VGPRs, stores corrupted data for some lanes (the store has not finished
 recognizer inserts the wait states for MUBUF stores with an immediate soffset and for FLAT/global stores, but treats the
 SGPR-soffset form as hazard-free, so nothing protects a raw_buffer_store_b128 whose result registers are recycled at once.
 
+Second screen: reads of scalar-load destinations before the wait (scan_smem below).
+
 Usage: check_store_hazard.py [file.s ...]   (no arguments: compiles every csrc/*.hip with -save-temps and scans the ISA)
 Exit code 1 if any unprotected pair is found."""
 import re
@@ -54,6 +56,64 @@ def scan(path):
     return hits
 
 
+SLOAD = re.compile(r"^\s*s_(?:buffer_)?load_dword(?:x(\d+))?\s+(s\[(\d+):(\d+)\]|s(\d+)),")
+SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None:
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def scan_smem(path):
+    """Second screen (round 4, csrc/stego.hip): the k-means assign kernels issue their scalar loads by hand (inline asm) and wait for them
+    later; the compiler sees the destination registers as defined from the load on, and under scalar-register pressure its allocator
+    has satisfied the tied operand of the wait with COPIES of the still in-flight registers in front of the wait.  No instruction
+    between an s_load and the next `s_waitcnt ... lgkmcnt(0)` may touch the load's destination registers (scalar loads return out of
+    order: only a zero count is a guarantee).  Tracks the loads inside inline-asm brackets, linearly over each function."""
+    hits = []
+    pending = {}   # first register of a pending destination range -> (set of registers, line number, text)
+    in_asm = False
+    for i, ln in enumerate(Path(path).read_text().splitlines()):
+        if "#ASMSTART" in ln or "#ASMEND" in ln:   # only HAND-issued loads are tracked: hipcc waits for its own before every use
+            in_asm = "#ASMSTART" in ln
+            continue
+        if SKIP.search(ln) and not re.match(r"^\s*(;|\.|$)", ln):   # a label: function entry labels reset the state
+            if not ln.lstrip().startswith(".L"):
+                pending = {}
+            continue
+        if SKIP.search(ln):
+            continue
+        code = ln.split(";")[0]
+        if re.match(r"^\s*s_endpgm", code):
+            pending = {}
+            continue
+        if re.match(r"^\s*s_waitcnt\b", code):
+            if "lgkmcnt(0)" in code or re.match(r"^\s*s_waitcnt\s+0\s*$", code):
+                pending = {}
+            continue
+        m = SLOAD.match(code)
+        touched = sregs(code)
+        if m:
+            dst = set(range(int(m.group(3)), int(m.group(4)) + 1)) if m.group(3) is not None else {int(m.group(5))}
+            rest = sregs(code[m.end():])          # the address operands (may overlap the load's own destination: read at issue)
+            for regs, l0, t0 in list(pending.values()):
+                if (rest | dst) & regs:
+                    hits.append((l0, t0, ln.strip()))
+            if in_asm:
+                pending[min(dst)] = (dst, i + 1, ln.strip())
+            continue
+        for regs, l0, t0 in list(pending.values()):
+            if touched & regs:
+                hits.append((l0, t0, ln.strip()))
+    return hits
+
+
 def main():
     files = sys.argv[1:]
     tmp = None
@@ -73,7 +133,14 @@ def main():
             bad += 1
             print(f"{Path(f).name}:{ln}: {st}\n    overwritten by: {nx}")
     print(f"{len(files)} files scanned, {bad} unprotected store/overwrite pairs")
-    return 1 if bad else 0
+    bad2 = 0
+    for f in files:
+        for ln, ld, nx in scan_smem(f):
+            bad2 += 1
+            if bad2 <= 40:
+                print(f"{Path(f).name}:{ln}: {ld}\n    destination touched before the wait by: {nx}")
+    print(f"{len(files)} files scanned, {bad2} uses of in-flight scalar-load destinations")
+    return 1 if bad or bad2 else 0
 
 
 if __name__ == "__main__":

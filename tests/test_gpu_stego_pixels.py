@@ -31,22 +31,24 @@ def test_upsample_kernel_matches_fixed_order_oracle(dev):
 
 @pytest.fixture
 def assign_form(request):
-    """The assignment kernels of the pixel k-means: the VALU form (default), the opt-in screened bf16-MFMA form (K <= 20: the label is taken from the
+    """The assignment kernels of the pixel k-means: the opt-in screened bf16-MFMA form (K <= 20: the label is taken from the
     split-operand similarities where their margin proves it, from the exact fmaf chains elsewhere), the same kernel with EVERY row
-    sent down its exact path."""
+    sent down its exact path, the plain VALU form (one v_fma_f32 per cluster and channel), and the packed forms (default: 5) -- two
+    clusters' chains in the halves of v_pk_fma_f32, with (5) or without (4) the interpolation on channel pairs."""
     from wild_visual_navigation_amd import _lib
     _lib.lib().wvn_debug_kmeans_assign_form(request.param)
     yield request.param
     _lib.lib().wvn_debug_kmeans_assign_form(-1)
 
 
-@pytest.mark.parametrize("assign_form", [1, 2, 0], indirect=True, ids=["screened", "screened-all-exact", "valu"])
+@pytest.mark.parametrize("assign_form", [1, 2, 0, 4, 5], indirect=True, ids=["screened", "screened-all-exact", "valu-plain", "valu-packed-dots", "valu-packed"])
 @pytest.mark.parametrize("G,H,C,K,B", [(8, 64, 90, 5, 2), (7, 50, 16, 4, 3), (28, 224, 90, 20, 1), (5, 33, 90, 6, 2), (28, 224, 90, 20, 16),
-                                       (9, 70, 90, 17, 9)])
+                                       (9, 70, 90, 17, 9), (9, 70, 90, 19, 3), (8, 64, 90, 16, 2)])
 def test_pixel_kmeans_bit_exact(dev, assign_form, G, H, C, K, B):
     """(7, 50) and (5, 33): chunks straddle image rows, the last group is ragged; (28, 224): the live node's default size; B = 16: the
     frame -> XCD mapping of whole multiples of 8 frames; (9, 70, K = 17): two 64-pixel groups per row with a ragged second one, a
-    partial last centroid block."""
+    partial last centroid block; K = 17 / 19 / 16: a half-used, a half-used last and two unused cluster PAIRS of the packed form (the
+    first packed kernel mislabelled 0.5 % of the pixels exactly there -- in-flight scalar registers copied under register pressure)."""
     code = torch.randn(B, G * G, C, generator=g(G * H)) * (1.0 + torch.rand(B, G * G, 1, generator=g(1)))
     lab, nseg, cent = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=False, return_centroids=True)
     lab2, nseg2 = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=True)
@@ -62,7 +64,7 @@ def test_pixel_kmeans_bit_exact(dev, assign_form, G, H, C, K, B):
         assert int(nseg[b]) == len(np.unique(want)) == int(nseg2[b])
 
 
-@pytest.mark.parametrize("assign_form", [1, 2, 0], indirect=True, ids=["screened", "screened-all-exact", "valu"])
+@pytest.mark.parametrize("assign_form", [1, 2, 0, 4, 5], indirect=True, ids=["screened", "screened-all-exact", "valu-plain", "valu-packed-dots", "valu-packed"])
 def test_pixel_kmeans_at_448_against_oracle(dev, assign_form):
     """BASELINE size: one 448^2 frame, 56 x 56 x 90 code, K = 20: 200 704 points x 11 assignment passes, labels bit-exact."""
     G, H, C, K = 56, 448, 90, 20

@@ -164,30 +164,58 @@ __global__ void km_partial_kernel(const float* __restrict__ xn, const int* __res
   for (int i = threadIdx.x; i < K; i += blockDim.x) pcnt[((size_t)b * nchunk + chunk) * K + i] = cn[i];
 }
 
+// The pair-interleaved copy of a frame's centroids that km_pix_assign_kernel's PACKED form reads (K <= 20): for a block of 16 channels
+// and a PAIR of clusters (2 kp, 2 kp + 1) the 32 floats {c_2kp[d], c_2kp+1[d]}, d ascending -- two s_load_dwordx16, every aligned
+// scalar register pair of which is the second operand of one v_pk_fma_f32.  cpk[blk][kp (KM_PK_PAIRS)][j (16)][2]
+constexpr int KM_PK_PAIRS = 10;
+__host__ __device__ inline size_t km_pk_floats(int C) { return (size_t)((C + 15) / 16) * KM_PK_PAIRS * 32; }
+__host__ __device__ inline size_t km_pk_index(int k, int d) { return ((size_t)((d >> 4) * KM_PK_PAIRS + (k >> 1)) * 16 + (d & 15)) * 2 + (k & 1); }
+
 // cent[b][k][:] = normalise(sum over chunks, ascending) if the cluster is non-empty.
 // One workgroup per (cluster, frame): thread d adds the chunk partials of (k, d) in ascending chunk order (the loads are
 // independent, only the adds are chained), thread 0 forms the squared norm over d in index order -- the same arithmetic,
 // in the same order, as a single workgroup per frame would do, on K times as many CUs.
 __global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict__ part, const int* __restrict__ pcnt,
-                                                        float* __restrict__ cent, int C, int K, int nchunk, int group) {
+                                                        float* __restrict__ cent, int C, int K, int nchunk, int group,
+                                                        float* __restrict__ cpk = nullptr) {
   __shared__ float sums[128];
   __shared__ float nrm_s;
   __shared__ int cnt_s;
   const int k = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   if (d < C) {
     float s = 0.f;
-    for (int c0 = 0; c0 < nchunk; c0 += group) {   // group = km_super(P) for chunk partials, 1 when `part` holds group partials
-      float gsum = 0.f;
-      const int c1 = min(nchunk, c0 + group);
-      for (int c = c0; c < c1; ++c) gsum = __fadd_rn(gsum, part[(((size_t)b * nchunk + c) * K + k) * C + d]);
-      s = __fadd_rn(s, gsum);
+    if (group == 1) {
+      // `part` holds group partials (the pixel-resolution form: 196 of them per centroid value at 448^2): the same chain s = s + part[c],
+      // c ascending, with the loads issued SIXTEEN at a time -- left as a load-add loop the kernel took 112 us per pass (one memory
+      // round trip per addition) for 90 MB that stream in 25.  (0 + x in the general form below is x: the chains are identical.)
+      constexpr int UB = 16;
+      const float* src = part + ((size_t)b * nchunk * K + k) * C + d;
+      const size_t step = (size_t)K * C;
+      for (int c0 = 0; c0 < nchunk; c0 += UB) {
+        float v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) v[u] = src[(size_t)min(c0 + u, nchunk - 1) * step];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const float t = __fadd_rn(s, __fadd_rn(0.f, v[u]));
+          s = c0 + u < nchunk ? t : s;
+        }
+      }
+    } else {
+      for (int c0 = 0; c0 < nchunk; c0 += group) {   // group = km_super(P) for chunk partials
+        float gsum = 0.f;
+        const int c1 = min(nchunk, c0 + group);
+        for (int c = c0; c < c1; ++c) gsum = __fadd_rn(gsum, part[(((size_t)b * nchunk + c) * K + k) * C + d]);
+        s = __fadd_rn(s, gsum);
+      }
     }
     sums[d] = s;
   }
-  if (d == 127) {
+  if (d >= 96) {   // (the last wave of the workgroup is idle above: its 32 lanes count the members)
     int n = 0;
-    for (int c = 0; c < nchunk; ++c) n += pcnt[((size_t)b * nchunk + c) * K + k];
-    cnt_s = n;
+    for (int c = d - 96; c < nchunk; c += 32) n += pcnt[((size_t)b * nchunk + c) * K + k];
+    for (int o = 16; o > 0; o >>= 1) n += __shfl_xor(n, o, 32);
+    if (d == 127) cnt_s = n;
   }
   __syncthreads();
   if (d == 0) {
@@ -196,7 +224,15 @@ __global__ __launch_bounds__(128) void km_update_kernel(const float* __restrict_
     nrm_s = rinv_norm(n2);
   }
   __syncthreads();
-  if (d < C && cnt_s > 0) cent[((size_t)b * K + k) * C + d] = __fmul_rn(sums[d], nrm_s);
+  if (d < C && cnt_s > 0) {
+    const float v = __fmul_rn(sums[d], nrm_s);
+    cent[((size_t)b * K + k) * C + d] = v;
+    if (cpk) {   // the pair-interleaved copy the packed assign kernel reads; its unused slots mirror centroid 0
+      cpk[(size_t)b * km_pk_floats(C) + km_pk_index(k, d)] = v;
+      if (k == 0)
+        for (int kk = K; kk < 2 * KM_PK_PAIRS; ++kk) cpk[(size_t)b * km_pk_floats(C) + km_pk_index(kk, d)] = v;
+    }
+  }
 }
 
 // compaction of the used ids to 0..K'-1 in ascending order (feature_extractor.py:245-246) + distinct count
@@ -339,7 +375,7 @@ __global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restric
 
 // cent[b][k][:] = x at pixel floor((2k+1) P / 2K), P = H*H
 __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* __restrict__ rinv, float* __restrict__ cent, int G,
-                                   int H, int C, int K) {
+                                   int H, int C, int K, float* __restrict__ cpk) {
   const int b = blockIdx.x;
   const long long P = (long long)H * H;
   const float scale = lerp_scale(G, H);
@@ -352,7 +388,13 @@ __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* 
     const float v = bilerp_fixed(cb[((size_t)ty.i0 * G + tx.i0) * C + d], cb[((size_t)ty.i0 * G + tx.i1) * C + d],
                                  cb[((size_t)ty.i1 * G + tx.i0) * C + d], cb[((size_t)ty.i1 * G + tx.i1) * C + d], tx.w0, tx.w1,
                                  ty.w0, ty.w1);
-    cent[(size_t)b * K * C + i] = __fmul_rn(v, rinv[(size_t)b * P + p0]);
+    const float c = __fmul_rn(v, rinv[(size_t)b * P + p0]);
+    cent[(size_t)b * K * C + i] = c;
+    if (cpk) {
+      cpk[(size_t)b * km_pk_floats(C) + km_pk_index(k, d)] = c;
+      if (k == 0)   // the unused slots mirror centroid 0 (km_pix_assign_pk_kernel)
+        for (int kk = K; kk < 2 * KM_PK_PAIRS; ++kk) cpk[(size_t)b * km_pk_floats(C) + km_pk_index(kk, d)] = c;
+    }
   }
 }
 
@@ -461,6 +503,115 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if ((EXACTK || k < K) && acc[k] > bv) { bv = acc[k]; best = k; }
+      labels[p] = best;
+    }
+  }
+}
+
+
+// ---- the same kernel with PACKED dot products (round 4) ---------------------------------------------------------------------------
+// The kernel above runs at the issue rate of plain v_fma_f32: 2440 VALU instructions per 64 pixels x 4 cycles = 0.80 ms per 64-frame
+// pass, measured 0.78 -- the "147 TFLOP/s" it was sized against in round 3 is the rate of v_pk_fma_f32 (scripts/ubench/valu_rate.hip's
+// plain loop had been packed by hipcc's SLP vectoriser).  A packed fma is two independent, correctly rounded fmas in one issue slot:
+// here the two halves are the chains of TWO CLUSTERS over the same channel,
+//     (acc_2kp, acc_2kp+1) = fma((x_d, x_d), (c_2kp[d], c_2kp+1[d]), (acc_2kp, acc_2kp+1))
+// x_d broadcast by op_sel, the centroid pair an aligned scalar register pair of the pair-interleaved copy (km_pk_index) -- every chain
+// still runs strictly in channel order from +0: the bits of the kernel above, half its dot-product instructions.  PKI: the
+// interpolation on channel pairs as well (v_pk_mul / v_pk_fma on ds_read_b64 taps).  K < 20: the unused slots of the packed copy hold
+// copies of centroid 0 (km_pix_init_kernel / km_update_kernel keep them current), so the kernel has no K at all -- twenty runtime
+// masks cost twenty scalar register pairs, and under that pressure hipcc's allocator satisfied the "+s" tie of a scalar-load wait with
+// COPIES of the still in-flight registers in front of the wait (first version: 203 of 44,100 labels wrong at K = 17;
+// tests/test_isa_hazards.py now screens the library for reads of in-flight scalar-load destinations).
+template <int C, bool PKI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void km_pix_assign_pk_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
+                                                            const float* __restrict__ cpk, int* __restrict__ labels, int G, int H,
+                                                            int K, int B) {
+  constexpr int CP = C;
+  constexpr int DB = 16;             // channels per block
+  constexpr int KP = KM_PK_PAIRS;    // cluster pairs
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [2][G][CP]
+  int bx, b;
+  km_frame_map(blockIdx.x, ceil_div_dev(H, PIX_RPB), B, bx, b);
+  const float scale = lerp_scale(G, H);
+  const float* __restrict__ cb = cpk + (size_t)b * km_pk_floats(C);   // uniform addresses: served by the scalar cache
+  int s0 = -1, s1 = -1;            // the code rows staged in LDS
+  for (int y = bx * PIX_RPB; y < min(H, (bx + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
+    const LerpTap ty = lerp_tap(y, G, scale);
+    if (ty.i0 != s0 || ty.i1 != s1) {
+      __syncthreads();
+      const float* r0 = code + ((size_t)b * G * G + (size_t)ty.i0 * G) * C;
+      const float* r1 = code + ((size_t)b * G * G + (size_t)ty.i1 * G) * C;
+      for (int i = threadIdx.x; i < G * C; i += blockDim.x) {
+        const int g = i / C, d = i - g * C;
+        rows[g * CP + d] = r0[i];
+        rows[(G + g) * CP + d] = r1[i];
+      }
+      __syncthreads();
+      s0 = ty.i0; s1 = ty.i1;
+    }
+    for (int x = threadIdx.x; x < H; x += blockDim.x) {
+      const LerpTap tx = lerp_tap(x, G, scale);
+      const size_t p = (size_t)b * H * H + (size_t)y * H + x;
+      const float ri = rinv[p];
+      const float* a0 = rows + tx.i0 * CP;
+      const float* a1 = rows + tx.i1 * CP;
+      const float* b0 = rows + (G + tx.i0) * CP;
+      const float* b1 = rows + (G + tx.i1) * CP;
+      f32x2v_t acc[KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) acc[k] = f32x2v_t{0.f, 0.f};
+      const float* pk = cb;          // ONE running address through the frame's packed centroids: [block][pair][2 x 16 floats]
+      f32x16_t cq[2][2];
+#pragma unroll
+      for (int d0 = 0; d0 < C; d0 += DB) {
+        const int n = C - d0 < DB ? C - d0 : DB;   // (compile-time after unrolling)
+        f32x2v_t v[DB / 2];                          // the block's interpolated, normalised values, channel pairs
+        if constexpr (PKI) {
+          const f32x2v_t X0 = {tx.w0, tx.w0}, X1 = {tx.w1, tx.w1}, Y0 = {ty.w0, ty.w0}, Y1 = {ty.w1, ty.w1}, R = {ri, ri};
+#pragma unroll
+          for (int j = 0; j < DB / 2; ++j)
+            if (2 * j < n) {   // (C even: pairs never straddle the end)
+              const f32x2v_t q00 = *(const f32x2v_t*)(a0 + d0 + 2 * j), q01 = *(const f32x2v_t*)(a1 + d0 + 2 * j);
+              const f32x2v_t q10 = *(const f32x2v_t*)(b0 + d0 + 2 * j), q11 = *(const f32x2v_t*)(b1 + d0 + 2 * j);
+              const f32x2v_t t0 = __builtin_elementwise_fma(X1, q01, X0 * q00);
+              const f32x2v_t t1 = __builtin_elementwise_fma(X1, q11, X0 * q10);
+              v[j] = __builtin_elementwise_fma(Y1, t1, Y0 * t0) * R;      // (the bits of bilerp_fixed * ri, two channels at once)
+            }
+        } else {
+#pragma unroll
+          for (int j = 0; j < DB; ++j)
+            if (j < n)
+              v[j >> 1][j & 1] = __fmul_rn(bilerp_fixed(a0[d0 + j], a1[d0 + j], b0[d0 + j], b1[d0 + j], tx.w0, tx.w1, ty.w0, ty.w1), ri);
+        }
+        // a pair's 32 floats arrive by TWO scalar loads, requested while the previous pair's sixteen packed fmas run (one wait per pair:
+        // scalar loads return out of order, so a wait is for all of them)
+        if (d0 == 0) { cq[0][0] = km_sload16(pk); cq[0][1] = km_sload16(pk + 16); }
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+          const int cur = (d0 / DB * KP + kp) & 1;
+          km_swait(cq[cur][0]); km_swait(cq[cur][1]);
+          if (d0 + DB < C || kp + 1 < KP) {          // the next pair (of this block or the first of the next)
+            pk += 32;
+            asm volatile("" : "+s"(pk));
+            cq[cur ^ 1][0] = km_sload16_before(pk, cq[cur][0]);
+            cq[cur ^ 1][1] = km_sload16_before(pk + 16, cq[cur][1]);
+          }
+#pragma unroll
+          for (int j = 0; j < DB; ++j)
+            if (j < n) {
+              const float xv = v[j >> 1][j & 1];
+              const f32x2v_t xb = {xv, xv};
+              const f32x2v_t cc = {cq[cur][j >> 3][2 * (j & 7)], cq[cur][j >> 3][2 * (j & 7) + 1]};
+              acc[kp] = __builtin_elementwise_fma(xb, cc, acc[kp]);
+            }
+          asm volatile("" : "+v"(acc[kp]));   // (the chains are finished here: their scalars are dead before the next request)
+        }
+      }
+      int best = 0;
+      float bv = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 2 * KP; ++k)   // (no k < K: the slots K .. 2 KP - 1 hold COPIES of centroid 0 -- their similarity equals cluster 0's
+        if (acc[k >> 1][k & 1] > bv) { bv = acc[k >> 1][k & 1]; best = k; }   //  bit for bit and a strict > never prefers them)
       labels[p] = best;
     }
   }
@@ -875,7 +1026,7 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
   if (lane < K) pcnt[((size_t)b * ngroup + g) * K + lane] = mycnt;
 }
 
-struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; size_t floats; };
+struct PixScratch { float* cent; float* part; int* pcnt; float* rinv; float* cpk; size_t floats; };
 PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
   const size_t P = (size_t)H * H, ngroup = (P + (size_t)km_super(P) * KM_CHUNK - 1) / ((size_t)km_super(P) * KM_CHUNK);
   PixScratch s;
@@ -885,14 +1036,16 @@ PixScratch pix_carve(float* base, int B, int G, int H, int C, int K) {
   s.part = take((size_t)B * ngroup * K * C);
   s.pcnt = (int*)take((size_t)B * ngroup * K);
   s.rinv = take((size_t)B * P);
+  s.cpk = take(K <= 2 * KM_PK_PAIRS ? (size_t)B * km_pk_floats(C) : 0);   // (the packed assign kernel's copy of the centroids)
   s.floats = off;
   return s;
 }
 
 // the screened assign kernel is eligible when K <= 20 and the two staged code rows fit the LDS
 static bool pixm_ok(int G, int H, int C, int K) { return K <= 20 && H >= 2 && scr_lds_bytes(G, C) <= 150 * 1024; }
-int g_km_assign_form = -1;   // -1 / 0: the VALU form (default), 1: the screened MFMA form where eligible (K <= 20), 2: the screened
-                             // kernel with every row sent down its exact path (tests), 3: the screened kernel counting its exact rows
+int g_km_assign_form = -1;   // -1 / 5: the PACKED VALU form where eligible (K <= 20; default), 4: packed dot products only, 0: the plain
+                             // VALU form, 1: the screened MFMA form where eligible (K <= 20), 2: the screened kernel with every row sent
+                             // down its exact path (tests), 3: the screened kernel counting its exact rows
 
 template <int C>
 int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int K, int iters, int relabel,
@@ -904,18 +1057,22 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   const int assign_threads = H >= 512 ? 512 : (H + 63) / 64 * 64;   // one wave per 64 pixels of an image row
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C, 20, true>,
-                                (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>)) return rc;
+                                (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>,
+                                (const void*)km_pix_assign_pk_kernel<C, false>, (const void*)km_pix_assign_pk_kernel<C, true>)) return rc;
   static LdsOptIn lds_opt_in_m;
   if (const int rc = lds_opt_in_m(150 * 1024, (const void*)km_pix_assign_screen_kernel<C>)) return rc;
-  const bool mfma = g_km_assign_form > 0 && pixm_ok(G, H, C, K);
+  const bool mfma = g_km_assign_form >= 1 && g_km_assign_form <= 3 && pixm_ok(G, H, C, K);
   const int nrb = ceil_div(H, PIX_RPB);
   hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(nrb * B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
                      s.rinv, G, H, B);
-  hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K);
+  const int pkform = K > 2 * KM_PK_PAIRS ? 0 : (g_km_assign_form < 0 || g_km_assign_form == 5) ? 5 : (g_km_assign_form == 4 ? 4 : 0);
+  hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K, pkform ? s.cpk : (float*)nullptr);
   WVN_LAUNCH_CHECK();
   for (int it = 0; it <= iters; ++it) {
     const dim3 ga(nrb * B);
     if (mfma) hipLaunchKernelGGL((km_pix_assign_screen_kernel<C>), dim3(G * B), dim3(256), scr_lds_bytes(G, C), st, code, s.rinv, s.cent, labels, G, H, K, B, g_km_assign_form == 2 ? 1 : (g_km_assign_form == 3 ? -1 : 0));
+    else if (pkform == 4) hipLaunchKernelGGL((km_pix_assign_pk_kernel<C, false>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cpk, labels, G, H, K, B);
+    else if (pkform == 5) hipLaunchKernelGGL((km_pix_assign_pk_kernel<C, true>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cpk, labels, G, H, K, B);
     else if (K == 20) hipLaunchKernelGGL((km_pix_assign_kernel<C, 20, true>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K, B);
     else if (K <= 32) hipLaunchKernelGGL((km_pix_assign_kernel<C, 32, false>), ga, dim3(assign_threads), shm_rows_pad, st, code, s.rinv, s.cent, labels, G, H, K, B);
     else hipLaunchKernelGGL((km_pix_assign_wide_kernel<C>), ga, dim3(256), shm_rows, st, code, s.rinv, s.cent, labels, G, H, K, B);
@@ -931,7 +1088,7 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
       hipLaunchKernelGGL(km_pix_partial_kernel<KM_MAXK>, dim3(ngroup * B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv,
                          labels, s.part, s.pcnt, G, H, C, K, ngroup, nsup, B);
     WVN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1);
+    hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1, pkform ? s.cpk : (float*)nullptr);
     WVN_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(km_relabel_kernel, dim3(B), dim3(1024), 0, st, labels, nseg, (int)P, K, relabel);
