@@ -924,11 +924,25 @@ __global__ __launch_bounds__(256) void km_pix_assign_wide_kernel(const float* __
 // while consecutive pixels carry the same label (the usual case: a dependent chain of one v_add per pixel) and is parked in the
 // LDS table tab[k][c] when the label changes -- the addition order per (cluster, channel) is exactly the pixel order.  The group
 // partial lives in registers (KMAX x 2 per lane); member counts come from ballots.
+//
+// Round 4, after an ablation of the kernel (profiles/r04e_kmeans_packed_assign.md: of 110 shader cycles per pixel and SIMD, 52 were the
+// eleven per-pixel VALU instructions -- a wave64 VALU instruction costs 4 cycles whatever it is --, 33 the per-chunk / per-cell skeleton,
+// 17 the label runs, 11 the tap loads):
+//   * the per-pixel weights {wx0, wx1} and 1 / norm come from LDS records the chunk's lanes wrote once (wave-uniform ds_read: an LDS
+//     instruction, not three v_readlane on the VALU), four pixels of a run at a time (one address move per four pixels);
+//   * member counts loop over the labels PRESENT in the chunk (1 - 4 with coherent labels) instead of all K;
+//   * the chunk -> group fold touches only the clusters the chunk touched (a scalar bit mask; the others would add +0, exactly nothing);
+//   * the taps are buffer loads with a SCALAR offset (the cell's, from v_readlane) and a lane-constant one: no 64-bit VALU address.
+// Same additions, same order, same bits (tests/test_gpu_stego_pixels.py: against the materialised route and the CPU oracle).
+#ifndef WVN_KM_PARTIAL_V2
+#define WVN_KM_PARTIAL_V2 1   // 0: the round-3 kernel body (scripts/build_variant.sh A/B)
+#endif
+__host__ inline size_t km_pix_partial_lds(int K, int C) { return (size_t)K * C * sizeof(float) + (WVN_KM_PARTIAL_V2 ? KM_CHUNK * 12 : 0); }
 template <int KMAX>
 __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const int* __restrict__ labels, float* __restrict__ part,
                                                             int* __restrict__ pcnt, int G, int H, int C, int K, int ngroup, int nsup, int B) {
-  extern __shared__ __attribute__((aligned(8))) float tab[];   // [K][C]: the current chunk's parked sums
+  extern __shared__ __attribute__((aligned(8))) float tab[];   // [K][C]: the current chunk's parked sums (+ V2: the chunk's pixel records)
   int g, b;
   km_frame_map(blockIdx.x, ngroup, B, g, b);
   const int lane = threadIdx.x;
@@ -945,7 +959,17 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
   const long long g0 = (long long)g * nsup * KM_CHUNK;
   const float scale = lerp_scale(G, H);
   int mycnt = 0;                       // lane k: members of cluster k in this group
+#if WVN_KM_PARTIAL_V2
+  f32x2v_t* rec_w = (f32x2v_t*)(tab + K * C);            // [KM_CHUNK] {wx0, wx1}   (K * C even: 8-byte aligned)
+  float* rec_r = (float*)(rec_w + KM_CHUNK);             // [KM_CHUNK] 1 / norm
+  const __amdgpu_buffer_rsrc_t rs_code = __builtin_amdgcn_make_buffer_rsrc((void*)cb, 0, (int)((size_t)G * G * C * sizeof(float)), 0x00020000);
+  auto tap = [&](int off) -> f32x2v_t {                  // off: wave-uniform element offset of the tap's channel 0
+    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rs_code, c2 * 4, __builtin_amdgcn_readfirstlane(off) * 4, 0);
+    return f32x2v_t{__uint_as_float(r[0]), __uint_as_float(r[1])};
+  };
+#else
   auto tap = [&](int off) -> f32x2v_t { return *(const f32x2v_t*)(cb + off + c2); };
+#endif
   for (int c = 0; c < nsup; ++c) {
     const long long p0 = g0 + (long long)c * KM_CHUNK;
     if (p0 >= P) break;                                  // (uniform)
@@ -958,10 +982,23 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
     const int o00 = (ty.i0 * G + tx.i0) * C, o01 = (ty.i0 * G + tx.i1) * C, o10 = (ty.i1 * G + tx.i0) * C, o11 = (ty.i1 * G + tx.i1) * C;
     const float rj = rv[pj];
     const int kj = lab[pj];
+    unsigned touched = 0;                                // (uniform) bit k: cluster k has members in this chunk
+#if WVN_KM_PARTIAL_V2
+    rec_w[lane] = f32x2v_t{tx.w0, tx.w1};
+    rec_r[lane] = rj;
+    for (unsigned long long todo = valid; todo;) {       // (uniform loop over the labels PRESENT in the chunk) member counts by ballot
+      const int k = __builtin_amdgcn_readlane(kj, (int)__builtin_ctzll(todo));
+      const unsigned long long m = __ballot(kj == k) & valid;
+      if (lane == k) mycnt += __builtin_popcountll(m);
+      touched |= 1u << (k & 31);
+      todo &= ~m;
+    }
+#else
     for (int k = 0; k < K; ++k) {                        // (uniform loop) member counts by ballot
       const int m = __builtin_popcountll(__ballot(kj == k) & valid);
       if (lane == k) mycnt += m;
     }
+#endif
     // ---- cells ----
     int j = 0;
     f32x2v_t n00 = tap(__builtin_amdgcn_readlane(o00, 0)), n01 = tap(__builtin_amdgcn_readlane(o01, 0));
@@ -983,6 +1020,12 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
       const float wy0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w0), j));
       const float wy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ty.w1), j));
       const f32x2v_t Y0 = {wy0, wy0}, Y1 = {wy1, wy1};
+      auto pixel = [&](f32x2v_t w, float ri) -> f32x2v_t {   // the interpolated, normalised value of one pixel of the cell (2 channels)
+        const f32x2v_t X0 = {w[0], w[0]}, X1 = {w[1], w[1]}, R = {ri, ri};
+        const f32x2v_t t0 = __builtin_elementwise_fma(X1, v01, X0 * v00);
+        const f32x2v_t t1 = __builtin_elementwise_fma(X1, v11, X0 * v10);
+        return __builtin_elementwise_fma(Y1, t1, Y0 * t0) * R;
+      };
       int jj = j;
       while (jj < jend) {                                // runs of one label inside the cell (labels are spatially coherent: usually one)
         const int k = __builtin_amdgcn_readlane(kj, jj);
@@ -993,15 +1036,23 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
           acc = *(const f32x2v_t*)(tab + k * C + c2);
           kcur = k;
         }
+#if WVN_KM_PARTIAL_V2
+        int q = jj;
+        for (; q + 4 <= jr; q += 4) {                    // four pixels: independent interpolations, then the additions in pixel order
+          const f32x2v_t w0 = rec_w[q], w1 = rec_w[q + 1], w2 = rec_w[q + 2], w3 = rec_w[q + 3];
+          const float r0 = rec_r[q], r1 = rec_r[q + 1], r2 = rec_r[q + 2], r3 = rec_r[q + 3];
+          const f32x2v_t p0v = pixel(w0, r0), p1v = pixel(w1, r1), p2v = pixel(w2, r2), p3v = pixel(w3, r3);
+          acc = acc + p0v; acc = acc + p1v; acc = acc + p2v; acc = acc + p3v;
+        }
+        for (; q < jr; ++q) acc = acc + pixel(rec_w[q], rec_r[q]);
+#else
         for (int q = jj; q < jr; ++q) {                  // the additions, in pixel order
           const float wx0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w0), q));
           const float wx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tx.w1), q));
           const float ri = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rj), q));
-          const f32x2v_t X0 = {wx0, wx0}, X1 = {wx1, wx1}, R = {ri, ri};
-          const f32x2v_t t0 = __builtin_elementwise_fma(X1, v01, X0 * v00);
-          const f32x2v_t t1 = __builtin_elementwise_fma(X1, v11, X0 * v10);
-          acc = acc + __builtin_elementwise_fma(Y1, t1, Y0 * t0) * R;
+          acc = acc + pixel(f32x2v_t{wx0, wx1}, ri);
         }
+#endif
         jj = jr;
       }
       j = jend;
@@ -1010,7 +1061,7 @@ __global__ __launch_bounds__(64) void km_pix_partial_kernel(const float* __restr
     // fold the chunk into the group partial (ascending chunk order) and clear the chunk table: a lane owns its two columns
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-      if (k < K) {
+      if (k < K && (!WVN_KM_PARTIAL_V2 || KMAX > 32 || ((touched >> k) & 1u))) {   // (an untouched cluster's chunk sum is +0: x + 0 = x)
         const f32x2v_t t = *(const f32x2v_t*)(tab + k * C + c2);
         grp[k][0] = __fadd_rn(grp[k][0], t[0]);
         grp[k][1] = __fadd_rn(grp[k][1], t[1]);
@@ -1079,13 +1130,13 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
     WVN_LAUNCH_CHECK();
     if (it == iters) break;
     if (K <= 20)   // (fewer group-partial registers: 5 waves per SIMD instead of 4)
-      hipLaunchKernelGGL(km_pix_partial_kernel<20>, dim3(ngroup * B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
+      hipLaunchKernelGGL(km_pix_partial_kernel<20>, dim3(ngroup * B), dim3(64), km_pix_partial_lds(K, C), st, code, s.rinv, labels,
                          s.part, s.pcnt, G, H, C, K, ngroup, nsup, B);
     else if (K <= 32)
-      hipLaunchKernelGGL(km_pix_partial_kernel<32>, dim3(ngroup * B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv, labels,
+      hipLaunchKernelGGL(km_pix_partial_kernel<32>, dim3(ngroup * B), dim3(64), km_pix_partial_lds(K, C), st, code, s.rinv, labels,
                          s.part, s.pcnt, G, H, C, K, ngroup, nsup, B);
     else
-      hipLaunchKernelGGL(km_pix_partial_kernel<KM_MAXK>, dim3(ngroup * B), dim3(64), (size_t)K * C * sizeof(float), st, code, s.rinv,
+      hipLaunchKernelGGL(km_pix_partial_kernel<KM_MAXK>, dim3(ngroup * B), dim3(64), km_pix_partial_lds(K, C), st, code, s.rinv,
                          labels, s.part, s.pcnt, G, H, C, K, ngroup, nsup, B);
     WVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_update_kernel, dim3(K, B), dim3(128), 0, st, s.part, s.pcnt, s.cent, C, K, ngroup, 1, pkform ? s.cpk : (float*)nullptr);
