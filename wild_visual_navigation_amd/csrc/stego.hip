@@ -522,6 +522,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 // masks cost twenty scalar register pairs, and under that pressure hipcc's allocator satisfied the "+s" tie of a scalar-load wait with
 // COPIES of the still in-flight registers in front of the wait (first version: 203 of 44,100 labels wrong at K = 17;
 // tests/test_isa_hazards.py now screens the library for reads of in-flight scalar-load destinations).
+// Timing experiments (scripts/build_variant.sh ... -DWVN_KM_ASSIGN_ABL=<bits>; results are WRONG with any bit set): 2 no scalar loads after a
+// pixel's first pair, 4 no LDS taps / interpolation (lane constants).  Measured (whole k-means call, 64 frames, 12.41 ms): 12.18 / 9.82 /
+// both 9.65 -- the scalar loads are free, the taps + interpolation cost 235 us of a 618-us pass (their VALU share is ~105: the rest is the
+// LDS pipe, 1440 bytes per pixel and pass), the dot products run at 80 % of the packed issue rate.
+#ifndef WVN_KM_ASSIGN_ABL
+#define WVN_KM_ASSIGN_ABL 0
+#endif
 template <int C, bool PKI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) void km_pix_assign_pk_kernel(const float* __restrict__ code, const float* __restrict__ rinv,
                                                             const float* __restrict__ cpk, int* __restrict__ labels, int G, int H,
@@ -566,7 +573,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       for (int d0 = 0; d0 < C; d0 += DB) {
         const int n = C - d0 < DB ? C - d0 : DB;   // (compile-time after unrolling)
         f32x2v_t v[DB / 2];                          // the block's interpolated, normalised values, channel pairs
-        if constexpr (PKI) {
+        if constexpr ((WVN_KM_ASSIGN_ABL & 4) != 0) {
+#pragma unroll
+          for (int j = 0; j < DB / 2; ++j) v[j] = f32x2v_t{ri + (float)(d0 + j), tx.w0};
+        } else if constexpr (PKI) {
           const f32x2v_t X0 = {tx.w0, tx.w0}, X1 = {tx.w1, tx.w1}, Y0 = {ty.w0, ty.w0}, Y1 = {ty.w1, ty.w1}, R = {ri, ri};
 #pragma unroll
           for (int j = 0; j < DB / 2; ++j)
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         for (int kp = 0; kp < KP; ++kp) {
           const int cur = (d0 / DB * KP + kp) & 1;
           km_swait(cq[cur][0]); km_swait(cq[cur][1]);
-          if (d0 + DB < C || kp + 1 < KP) {          // the next pair (of this block or the first of the next)
+          if ((d0 + DB < C || kp + 1 < KP) && !((WVN_KM_ASSIGN_ABL & 2) && (d0 > 0 || kp > 0))) {          // the next pair (of this block or the first of the next)
             pk += 32;
             asm volatile("" : "+s"(pk));
             cq[cur ^ 1][0] = km_sload16_before(pk, cq[cur][0]);
