@@ -9,7 +9,7 @@ rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extra-legs "$@" > $O/kt.log 2>&1
-tail -1 $O/kt.log | cut -c1-400 > $O/bench_line_profiled.json
+grep "^{\"metric\"" $O/kt.log | tail -1 | cut -c1-400 > $O/bench_line_profiled.json
 DB=$(find $O/kt -name "*.db" | head -1)
 python $R/scripts/summarize_profile.py db $DB > $O/kernel_stats.md 2>$O/sum.err
 if [ "$PMC" = "1" ]; then
