@@ -48,7 +48,9 @@ constexpr int BM = 128;
 constexpr int PIECES = SLICE_BYTES / 1024 / 4;  // 1 KB DMA pieces per wave and slice (8)
 static_assert(PIECES == 8, "one DMA piece per k-step of a slice");
 
-enum { X_GELU = 0, X_RESID = 1, X_QK = 2, X_V = 3, X_PLANES = 4, X_GELU_FRAG = 5, X_QK_F16 = 6, X_V_F16 = 7 };   // _F16: one fp16 plane per tensor
+enum { X_GELU = 0, X_RESID = 1, X_QK = 2, X_V = 3, X_PLANES = 4, X_GELU_FRAG = 5, X_QK_F16 = 6, X_V_F16 = 7, X_QKV = 8, X_QKV_F16 = 9 };   // _F16: one fp16 plane per tensor
+// X_QKV / X_QKV_F16: q | k | v^T in ONE launch -- the column tiles of q and k run in the TR orientation, those of v^T in the other; a row
+// block's two planes (192 registers) are loaded once instead of twice (617 MB per launch at 128 frames) and there is one prologue / tail
 
 struct X384Params {
   const bf16_t* A; const bf16_t* A_lo; int lda;
@@ -111,13 +113,13 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   }
   int iss_j = u_begin % NT, iss_ks = 0;
   unsigned iss_soff = 0;
-  auto issue_begin = [&]() { iss_soff = __builtin_amdgcn_readfirstlane((iss_j * BNT * KD + iss_ks * SLK) * 2); };
-  auto issue_piece = [&](int i, int u) {   // piece u of this wave's PIECES of slice i (u is a compile-time constant at every call site)
+  auto issue_begin = [&]() __attribute__((always_inline)) { iss_soff = __builtin_amdgcn_readfirstlane((iss_j * BNT * KD + iss_ks * SLK) * 2); };
+  auto issue_piece = [&](int i, int u) __attribute__((always_inline)) {   // piece u of this wave's PIECES of slice i (u is a compile-time constant at every call site)
     unsigned char* dst = smem + (i % NS) * SLICE_BYTES + wave * PIECES * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, wvoff[u], iss_soff, 0, 0);
   };
-  auto issue_end = [&]() { if (++iss_ks == NSL) { iss_ks = 0; if (++iss_j == NT) iss_j = 0; } };
-  auto issue = [&](int i) {
+  auto issue_end = [&]() __attribute__((always_inline)) { if (++iss_ks == NSL) { iss_ks = 0; if (++iss_j == NT) iss_j = 0; } };
+  auto issue = [&](int i) __attribute__((always_inline)) {
     issue_begin();
 #pragma unroll
     for (int u = 0; u < PIECES; ++u) issue_piece(i, u);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
 
   for (int i = tid; i < p.N; i += 256) ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
   bf16x8_t xh[KD / 16], xl[KD / 16];
-  auto load_a = [&]() {
+  auto load_a = [&]() __attribute__((always_inline)) {
     const size_t ro = (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
 #pragma unroll
     for (int s = 0; s < KD / 16; ++s) {
@@ -149,9 +151,12 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
 
   // ---- epilogue addressing ----
   constexpr unsigned OOB = 0x80000000u;
-  constexpr bool IS_QK = EPI == X_QK || EPI == X_QK_F16, IS_V = EPI == X_V || EPI == X_V_F16, IS_QKV = IS_QK || IS_V;
-  constexpr bool F16OUT = EPI == X_QK_F16 || EPI == X_V_F16;   // (compile-time: a run-time flag leaves branches in the slice loop)
-  using TRK = std::integral_constant<bool, !IS_V>;
+  constexpr bool MERGED = EPI == X_QKV || EPI == X_QKV_F16;   // q | k tiles (TR) and v^T tiles (!TR) in one launch: the orientation is the TILE's tag
+  constexpr bool IS_QKV = EPI == X_QK || EPI == X_QK_F16 || EPI == X_V || EPI == X_V_F16 || MERGED;
+  constexpr bool IS_V_ONLY = EPI == X_V || EPI == X_V_F16;
+  constexpr bool F16OUT = EPI == X_QK_F16 || EPI == X_V_F16 || EPI == X_QKV_F16;   // (compile-time: a run-time flag leaves branches in the slice loop)
+  using TRK = std::integral_constant<bool, !IS_V_ONLY>;
+  const int nqk = MERGED ? 2 * p.heads : (1 << 30);      // MERGED: column tiles below nqk are q | k (one head each), the rest v^T
   unsigned voff[2] = {0, 0};
   unsigned vt_off = 0, stg_rd = 0;
   const unsigned c_bytes = IS_QKV ? 0u : (unsigned)((size_t)(EPI == X_GELU_FRAG ? (p.M + 31) / 32 * 32 : p.M) * p.ldc * (EPI == X_RESID ? 4 : 2));
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
                                              : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c2 = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base_lo ? p.qkv_base_lo : p.qkv_base, 0, p.qkv_bytes, 0x00020000)
                                               : __builtin_amdgcn_make_buffer_rsrc(p.C_lo ? p.C_lo : p.C, 0, c_bytes, 0x00020000);
-  auto qkv_offsets = [&]() {
+  auto qkv_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int hblk = 0; hblk < 2; ++hblk) {
       const int m = m0w + hblk * 16 + (lane >> 3);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   bf16x8_t wh[2][2], wl[2][2];   // [k-step parity][column half]
   u32x4_t resid_q[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   u32x4_t fragh = {0, 0, 0, 0}, fragl = {0, 0, 0, 0};   // X_GELU_FRAG: the fragment being assembled
-  auto frag_read = [&](int slot, int s, int par) {
+  auto frag_read = [&](int slot, int s, int par) __attribute__((always_inline)) {
     const unsigned char* base = smem + slot * SLICE_BYTES + rd_base;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       wl[par][t] = *(const bf16x8_t*)(base + PLANE_BYTES + o);
     }
   };
-  auto mfma_step = [&](int slot, int ks, int s, auto tr_tag) {
+  auto mfma_step = [&](int slot, int ks, int s, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
     const int cur = s & 1;
     if (s + 1 < 8) frag_read(slot, s + 1, cur ^ 1);
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   // chunk.  A chunk rides between the six MFMAs of one k-step.
   // TR tiles : images [32 rows m][64 cols n] (bf16 rows of 144 B: hi image at 0, lo image at IMG_BF16; fp32 rows of 272 B)
   // !TR tiles: images [64 rows n][32 cols m] (rows of 80 B; hi at 0, lo at 64 * 80)       -- V^T
-  auto epi_chunk = [&](int part, int jp, int s, auto tr_tag) {
+  auto epi_chunk = [&](int part, int jp, int s, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
     const int n0 = jp * BNT;
     if constexpr (EPI == X_RESID) {
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
           if (p.ls) { v0 *= p.ls[n0 + c]; v1 *= p.ls[n0 + c + 1]; }
           const wvn_f32x2_t o = {v0, v1};
           *(wvn_f32x2_t*)(stg + l31 * 272 + c * 4) = o;
-        } else if constexpr (IS_QK && F16OUT) {
+        } else if constexpr (IS_QKV && F16OUT) {   // (TR: a q | k tile)
           // fp16 planes; the rounding residue goes to a second image whatever the tile is -- only q tiles store it (part 2), and a branch
           // here would end the scheduling region
           const float qs = n0 < p.heads * 64 ? p.q_scale : 1.f;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
       wvn_store_b128_guarded(o, rs_c, voff[0], so);
-    } else if constexpr (IS_QK) {
+    } else if constexpr (IS_QKV && TR) {
       const int it = s & 3, pl = s >> 2;
       const int D = p.heads * 64;
       const int which = n0 / D, head = (n0 - which * D) >> 6;
@@ -302,10 +307,10 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
         const bool keep = !F16OUT || (which == 0 && p.q_lo_f16);
         wvn_store_b128_guarded(val, rs_c2, keep ? voff[it >> 1] : OOB, so + (it & 1) * 1024);
       }
-    } else if constexpr (IS_V) {
+    } else if constexpr (IS_QKV && !TR) {
       const int it = s & 3, pl = s >> 2;
       if (pl == 1 && F16OUT) return;
-      const int head = n0 >> 6;
+      const int head = (MERGED ? n0 - 2 * p.heads * 64 : n0) >> 6;
       const u32x4_t val = *(const u32x4_t*)(stg + pl * 64 * 80 + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
       const unsigned so = __builtin_amdgcn_readfirstlane(p.v_off + (head * 64 + it * 16) * p.npad * 2);
       if (pl == 0) wvn_store_b128_guarded(val, rs_c, vt_off, so);
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     }
   };
 
-  auto init_acc = [&](int j, auto tr_tag) {
+  auto init_acc = [&](int j, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
     const int n0 = j * BNT;
     if constexpr (TR) {
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   constexpr int ST01 = EPI == X_GELU_FRAG ? 4 : 0;
   long long t_wait = 0, t_iss = 0, t_mfma = 0;
   const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, auto epi_tag) {
+  auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, auto epi_tag) __attribute__((always_inline)) {
     constexpr bool do_epi = decltype(epi_tag)::value;   // (compile-time: a branch around the epilogue would end the scheduling region)
     long long c0 = 0, c1 = 0, c2 = 0;
     if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     if constexpr (TIMING) { t_wait += c1 - c0; t_iss += c2 - c1; t_mfma += (long long)__builtin_amdgcn_s_memtime() - c2; }
   };
   int si = 0;
-  auto tile = [&](int j, int jj, int j_end, auto mtr, auto etr, auto next_tr) {
+  auto tile = [&](int j, int jj, int j_end, auto mtr, auto etr, auto next_tr) __attribute__((always_inline)) {
     if (jj >= 1) {
 #pragma unroll
       for (int ks = 0; ks < NSL; ++ks) period(si + ks, ks, j, jj >= 2, mtr, etr, std::true_type{});
@@ -422,12 +427,34 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     m0w = rb * BM + wave * 32;
     load_a();
     if constexpr (IS_QKV) qkv_offsets();
-    init_acc(j0, TRK{});
-    for (int j = j0; j < j1; ++j) tile(j, j - j0, j1, TRK{}, TRK{}, TRK{});
+    if constexpr (MERGED) {
+      using T = std::true_type; using F = std::false_type;
+      if (j0 < nqk) init_acc(j0, T{}); else init_acc(j0, F{});
+      for (int j = j0; j < j1; ++j) {   // (tile's own orientation, the previous tile's for the epilogue riding in it, the next one's for the bias)
+        if (j + 1 < nqk) tile(j, j - j0, j1, T{}, T{}, T{});
+        else if (j < nqk) tile(j, j - j0, j1, T{}, T{}, F{});
+        else if (j == nqk) tile(j, j - j0, j1, F{}, T{}, F{});
+        else tile(j, j - j0, j1, F{}, F{}, F{});
+      }
+      if (j1 - 1 < nqk) {
 #pragma unroll
-    for (int part = 0; part < 3; ++part)
+        for (int part = 0; part < 3; ++part)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) epi_chunk(part, j1 - 1, c, TRK{});
+          for (int c = 0; c < 8; ++c) epi_chunk(part, j1 - 1, c, T{});
+      } else {
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) epi_chunk(part, j1 - 1, c, F{});
+      }
+    } else {
+      init_acc(j0, TRK{});
+      for (int j = j0; j < j1; ++j) tile(j, j - j0, j1, TRK{}, TRK{}, TRK{});
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) epi_chunk(part, j1 - 1, c, TRK{});
+    }
     u += j1 - j0;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last two periods' surplus DMA requests land before the wave ends)
@@ -440,6 +467,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
 }
 
 constexpr int X384_LDS_MAX = 160 * 1024;
+bool g_x384_split_qkv = getenv("WVN_X384_SPLIT_QKV") != nullptr;   // A/B: q | k and v^T as two launches (the form before the merged kernel)
 
 int x384_num_cus() {
   static int n = 0;
@@ -513,6 +541,7 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
         p.qkv_base_lo = (bf16_t*)lo2;
       }
       const int D = g.heads * 64;
+      if (!g_x384_split_qkv) return g.qkv_f16 ? launch<X_QKV_F16>(p, st) : launch<X_QKV>(p, st);   // (p.N == 3 D: q | k | v^T in one launch)
       p.N = 2 * D;
       const int rc = g.qkv_f16 ? launch<X_QK_F16>(p, st) : launch<X_QK>(p, st);
       if (rc != WVN_OK) return rc;
