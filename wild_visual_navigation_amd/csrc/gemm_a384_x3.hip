@@ -73,16 +73,32 @@ __device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
   lo = pack_bf16x2(a - ah, b - bh);
 }
-// exact erf GELU, erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), as gemm_x3.hip
-__device__ inline float gelu_as(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // (1 ulp: far inside the formula's own 1.5e-7)
-  float p = fmaf(t, 1.061405429f, -1.453152027f);
-  p = fmaf(t, p, 1.421413741f);
-  p = fmaf(t, p, -0.284496736f);
-  p = fmaf(t, p, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(e, x));
+// erf GELU to fp32 rounding with ONE transcendental: for a = |x|
+//     gelu(x) = max(x, 0) - a * erfc(a / sqrt 2) / 2 = max(x, 0) - a * 2^R(a),     R(a) = log2 erfc(a / sqrt 2) - 1
+// R is smooth and nearly quadratic; a degree-6 polynomial fitted with the weight a * erfc(a / sqrt 2) (the derivative of the result with
+// respect to R) reproduces gelu within 2.8e-7 absolute on the whole line (float64 erfc reference, fp32 Horner; /tmp-free recipe:
+// weighted least squares reweighted towards minimax on [0, 7]) -- the same as Abramowitz-Stegun 7.1.26 (1.5e-7 on erf), which this
+// replaces: that form costs 15 VALU operations and TWO transcendentals (v_rcp, v_exp: four issue slots each) per value, and the fc1
+// epilogue rides in the shadow of the MFMAs of a wave that is alone on its SIMD (slice period 2500 cycles against 1536 of MFMAs).
+// Beyond a = 7 the subtracted term is below 1e-11: a is clamped there (the polynomial is only trusted on the fitted interval).
+// Two values at a time: the polynomial and the final fma on v_pk_fma_f32 (written on vectors: left to hipcc the scalar form becomes
+// v_fmaak_f32 with literal constants, one issue slot per value and step).
+__device__ inline void gelu_pair(float& x0, float& x1) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  const f2 a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x0), 0.f, 7.0f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x1), 0.f, 7.0f)};
+  const f2 c6 = {3.309327076e-05f, 3.309327076e-05f}, c5 = {-7.692237268e-04f, -7.692237268e-04f}, c4 = {8.080729283e-03f, 8.080729283e-03f},
+           c3 = {-5.341212451e-02f, -5.341212451e-02f}, c2 = {-4.587709606e-01f, -4.587709606e-01f}, c1 = {-1.151201725e+00f, -1.151201725e+00f},
+           c0 = {-9.999930859e-01f, -9.999930859e-01f};
+  f2 r = __builtin_elementwise_fma(a, c6, c5);
+  r = __builtin_elementwise_fma(a, r, c4);
+  r = __builtin_elementwise_fma(a, r, c3);
+  r = __builtin_elementwise_fma(a, r, c2);
+  r = __builtin_elementwise_fma(a, r, c1);
+  r = __builtin_elementwise_fma(a, r, c0);
+  const f2 e = {__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
+  const f2 m = {__builtin_amdgcn_fmed3f(x0, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x1, 0.f, 3.0e38f)};   // max(x, 0) in ONE v_med3 (fmaxf: canonicalise + v_max)
+  const f2 g = __builtin_elementwise_fma(-a, e, m);
+  x0 = g[0]; x1 = g[1];
 }
 
 template <int EPI, bool TIMING = false>
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       float v0 = prev[t][4 * g + h2], v1 = prev[t][4 * g + h2 + 1];
       if constexpr (TR) {
         const int c = 32 * t + 8 * g + 4 * hi + h2;
-        if constexpr (EPI == X_GELU || EPI == X_GELU_FRAG) { v0 = gelu_as(v0); v1 = gelu_as(v1); }
+        if constexpr (EPI == X_GELU || EPI == X_GELU_FRAG) gelu_pair(v0, v1);
         if constexpr (EPI == X_GELU_FRAG) {
           uint32_t h, l;
           split2(v0, v1, h, l);
