@@ -76,10 +76,12 @@ __device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
 // erf GELU to fp32 rounding with ONE transcendental: for a = |x|
 //     gelu(x) = max(x, 0) - a * erfc(a / sqrt 2) / 2 = max(x, 0) - a * 2^R(a),     R(a) = log2 erfc(a / sqrt 2) - 1
 // R is smooth and nearly quadratic; a degree-6 polynomial fitted with the weight a * erfc(a / sqrt 2) (the derivative of the result with
-// respect to R) reproduces gelu within 2.8e-7 absolute on the whole line (float64 erfc reference, fp32 Horner; /tmp-free recipe:
-// weighted least squares reweighted towards minimax on [0, 7]) -- the same as Abramowitz-Stegun 7.1.26 (1.5e-7 on erf), which this
+// respect to R) reproduces gelu within 2.8e-7 absolute on the whole line (float64 erfc reference, fp32 Horner; weighted least squares
+// reweighted towards minimax on [0, 7]; tests/test_host_logic.py pins the bound) -- the same as Abramowitz-Stegun 7.1.26 (1.5e-7 on erf), which this
 // replaces: that form costs 15 VALU operations and TWO transcendentals (v_rcp, v_exp: four issue slots each) per value, and the fc1
-// epilogue rides in the shadow of the MFMAs of a wave that is alone on its SIMD (slice period 2500 cycles against 1536 of MFMAs).
+// epilogue rides in the shadow of the MFMAs of a wave that is alone on its SIMD (fc1 18.6 -> 17.6 ms per 64-frame step of the mixed mode).
+// (The same idea with a cubic R in the fp16 path's mlp_fused kernel: 22.8 -> 22.55 ms per step, headline within the noise, and it gives
+//  up that path's RELATIVE accuracy on the negative tail -- not adopted.)
 // Beyond a = 7 the subtracted term is below 1e-11: a is clamped there (the polynomial is only trusted on the fitted interval).
 // Two values at a time: the polynomial and the final fma on v_pk_fma_f32 (written on vectors: left to hipcc the scalar form becomes
 // v_fmaak_f32 with literal constants, one issue slot per value and step).
