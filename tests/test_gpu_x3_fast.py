@@ -97,3 +97,24 @@ def test_fast_block_kernels_inside_the_vit(dev, precision):
         os.environ.pop("WVN_NO_A384_X3", None)
     assert (a - b).abs().max().item() < 2e-4
     assert (a - want).abs().max().item() < (5e-4 if precision == "mixed" else 1e-4)
+
+
+@pytest.mark.parametrize("precision", ["mixed", "exact"])
+def test_layernorm_across_kernel_boundaries(dev, precision):
+    """The split-operand block kernels hand the LayerNorm across their boundaries: the row-panel kernels (projection, fc2) leave {mean, rstd}
+    of the rows they update, the A-stationary kernels (fc1, the next block's QKV) normalise as they load.  4 frames at 448^2 (a partial
+    last row block) through 3 blocks with the hand-over on and off (debug bit 512: the LayerNorm kernel and the plane round trip): the
+    one-pass statistics and the different association of the affine step must stay inside fp32 noise of the two-pass kernel."""
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=3)
+    img = torch.rand(4, 3, 448, 448, generator=g(2))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    os.environ.pop("WVN_X3_DEBUG_BITS", None)
+    a = VitBackbone(sd, 448, 8, 6, device=dev, precision=precision, max_chunk=4).forward_tokens(img.to(dev)).cpu()
+    os.environ["WVN_X3_DEBUG_BITS"] = "512"
+    try:
+        b = VitBackbone(sd, 448, 8, 6, device=dev, precision=precision, max_chunk=4).forward_tokens(img.to(dev)).cpu()
+    finally:
+        os.environ.pop("WVN_X3_DEBUG_BITS", None)
+    assert not torch.equal(a, b)                      # (the two routes really are different code)
+    assert (a - b).abs().max().item() < 5e-5
+    assert (a - want).abs().max().item() < (5e-4 if precision == "mixed" else 1e-4)

@@ -77,7 +77,7 @@ VitDims vit_dims(const wvn_vit_model* m, int batch) {
   d.M = (long long)batch * d.ntok_s; d.Mp = (long long)batch * d.npatch;
   return d;
 }
-struct VitWs { float* x; void* xn; void* q; void* k; void* v; void* hid; void* patches; unsigned char* xq; unsigned char* hq; float* sa; size_t total; };
+struct VitWs { float* x; void* xn; void* q; void* k; void* v; void* hid; void* patches; unsigned char* xq; unsigned char* hq; float* sa; float* ln_stats; size_t total; };
 VitWs vit_carve(const VitDims& d, void* base) {
   VitWs w;
   size_t off = 0;
@@ -94,6 +94,7 @@ VitWs vit_carve(const VitDims& d, void* base) {
     w.hq = (unsigned char*)take((size_t)d.M * d.F);
     w.sa = (float*)take((size_t)d.M * 4);
   }
+  w.ln_stats = d.planes ? (float*)take((size_t)d.M * 8) : nullptr;   // {mean, rstd} per row: LayerNorm across kernel boundaries (split-operand block kernels)
   w.total = off;
   return w;
 }
@@ -208,6 +209,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   const size_t pl_xn = (size_t)(d.planes ? (d.M + 31) / 32 * 32 : d.M) * d.D, pl_hid = (size_t)d.M * d.F, pl_qkv = (size_t)d.B * d.H * d.npad * 64,
                pl_pat = (size_t)d.Mp * d.KPs;
   auto lo = [](const void* base, size_t plane_elems) { return (bf16_t*)base + plane_elems; };
+  bool stats_written = false;   // set by linear(): the row-panel kernel ran and left the statistics it was asked for
 
   // One linear of the chain in the model's precision.  A: activation matrix (bf16 | hi+lo planes | fp32), W: weight in the
   // same representation ([N][K], planes stacked), epilogue codes of GemmEpilogue.
@@ -237,6 +239,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       p.A_lo = lo(A, a_plane); p.W_lo = lo(W, (size_t)N * K); p.C_lo = C ? lo(C, c_plane) : nullptr;
       if (N == 384 && (epi == EPI_RESID_F32) && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 128))) {   // row panel: fc2, projection
         const int rc = wvn_gemm_n384_x3_launch(p, epi, st);
+        if (rc == WVN_OK && p.ln_stats_out) stats_written = true;   // (the tiled kernel below leaves no LayerNorm statistics)
         if (rc != WVN_ERR_ARG) return rc;
       }
       if (K == 384 && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 64))) {   // the A-stationary form from about a quarter chip of row blocks on
@@ -305,6 +308,11 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   // the split-operand block kernels (A-stationary K = 384 with the LayerNorm in its prologue, fragment-major MLP): from 8192 rows on
   const bool x3_fast = x3 && d.D == 384 && M >= 64 * 128 && !(m->flags & WVN_VIT_NO_A384_X3);
   bool pre_qkv = false;   // this block's norm1 has been applied by the previous block's projection + MLP kernel (fragments in w.hid)
+  // split-operand block kernels: LayerNorm ACROSS kernel boundaries -- the row-panel kernel that updates the residual rows (projection,
+  // fc2) leaves their {mean, rstd}, the A-stationary kernel that consumes them (fc1, next block's QKV) normalises as it loads: no LayerNorm
+  // kernel, no xn planes, between them.  ln1_stats: w.ln_stats holds the statistics of w.x for THIS block's norm1.
+  const bool ln_fuse = x3_fast && w.ln_stats && !(m->flags & 512);
+  bool ln1_stats = false;
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
     if (l == 0) pre_qkv = false;
@@ -349,9 +357,9 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       qkv_done = rc == WVN_OK;                            // descriptor spans) -- the separate kernels below, as proj_mlp does
     }
     if (!qkv_done) {
-    { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, f32 ? 0 : opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+    if (l == 0) ln1_stats = false;
+    bool qkv_lna = false;
     {
-      Span s(3, st);
       GemmBf16Params e{};
       e.q = (bf16_t*)w.q; e.k = (bf16_t*)w.k; e.vt = (bf16_t*)w.v; e.heads = d.H; e.npad = d.npad; e.ntok = d.ntok; e.ntok_s = d.ntok_s;
       // bf16: the softmax scale is folded into q by the QKV epilogue (q leaves it as an exp2 argument) and attention takes
@@ -360,8 +368,22 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       // one fp16 plane each for k and v^T, q pre-scaled and in TWO fp16 planes (its rounding residue behind it): the fp16 attention kernel's operands
       if (mix) { e.qkv_f16 = 1; e.q_scale = scale * 1.44269504088896340736f; e.q_lo = lo(w.q, pl_qkv); }
       else if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
-      RET_IF(linear(w.xn, pl_xn, d.D, L.qkv_w, L.qkv_b, nullptr, 0, 0, M, 3 * d.D, d.D, EPI_QKV, nullptr, &e));
+      if (ln_fuse && ln1_stats) {   // norm1 on load, from the statistics the previous block's fc2 kernel left
+        GemmBf16Params q = e;
+        q.W = (const bf16_t*)L.qkv_w; q.W_lo = lo(L.qkv_w, (size_t)3 * d.D * d.D); q.ldw = d.D; q.bias = L.qkv_b; q.M = M; q.N = 3 * d.D; q.K = d.D;
+        q.ln_x = w.x; q.ln_ldx = d.D; q.ln_stats = w.ln_stats; q.ln_g = L.ln1_g; q.ln_b = L.ln1_b;
+        Span s(3, st);
+        const int rc = wvn_gemm_a384_x3_launch(q, EPI_QKV, st);
+        if (rc != WVN_OK && rc != WVN_ERR_ARG) return rc;
+        qkv_lna = rc == WVN_OK;
+      }
+      if (!qkv_lna) {
+        { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln1_g, L.ln1_b, w.xn, f32 ? 0 : opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, x3 ? lo(w.xn, pl_xn) : nullptr)); }
+        Span s(3, st);
+        RET_IF(linear(w.xn, pl_xn, d.D, L.qkv_w, L.qkv_b, nullptr, 0, 0, M, 3 * d.D, d.D, EPI_QKV, nullptr, &e));
+      }
     }
+    ln1_stats = false;
     }
     {
       Span s(4, st);
@@ -392,14 +414,23 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       if (rc == WVN_OK) continue;
       if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
+    bool ln2_stats = false;   // w.ln_stats holds the statistics of w.x for this block's norm2
     if (attn_frag) {   // the attention output arrived as operand fragments: the projection on the fragment form of the row-panel kernel
       GemmBf16Params pp{};
       pp.A = (const bf16_t*)w.xn; pp.A_lo = lo(w.xn, pl_xn); pp.lda = d.D; pp.W = (const bf16_t*)L.proj_w_frag; pp.ldw = d.D; pp.bias = L.proj_b; pp.ls = L.ls1;
       pp.C = w.x; pp.ldc = d.D; pp.M = M; pp.N = d.D; pp.K = d.D;
+      if (ln_fuse) { pp.ln_stats_out = w.ln_stats; pp.ln_eps = 1e-6f; }
       Span s(5, st);
       RET_IF(wvn_gemm_n384_x3_frag_launch(pp, EPI_RESID_F32, st));
-    } else
-    { Span s(5, st); RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr)); }
+      ln2_stats = ln_fuse;
+    } else {
+      GemmBf16Params e{};
+      if (ln_fuse) { e.ln_stats_out = w.ln_stats; e.ln_eps = 1e-6f; }
+      stats_written = false;
+      Span s(5, st);
+      RET_IF(linear(w.xn, pl_xn, d.D, L.proj_w, L.proj_b, w.x, 0, d.D, M, d.D, d.D, EPI_RESID_F32, L.ls1, ln_fuse ? &e : nullptr));
+      ln2_stats = ln_fuse && stats_written;
+    }
     bool ln2_done = false;
     if (mlp_fused) {  // LayerNorm 2 + fc1 + GELU + fc2 + residual: one launch, no xn / hid round trip
       Span s(6, st);
@@ -414,19 +445,32 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       // per lane and plane -- no LDS transpose on either side, every access a contiguous kilobyte
       const size_t pl_frag = (size_t)((d.M + 31) / 32 * 32) * d.F;
       GemmBf16Params p1{};
-      { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, lo(w.xn, pl_xn))); }
-      ln2_done = true;
-      p1.A = (const bf16_t*)w.xn; p1.A_lo = lo(w.xn, pl_xn); p1.lda = d.D;
       p1.W = (const bf16_t*)L.fc1_w; p1.W_lo = lo(L.fc1_w, (size_t)d.F * d.D);
       p1.ldw = d.D; p1.bias = L.fc1_b; p1.C = w.hid; p1.C_lo = lo(w.hid, pl_frag); p1.ldc = d.F; p1.M = M; p1.N = d.F; p1.K = d.D;
-      int rc;
-      { Span s(6, st); rc = wvn_gemm_a384_x3_launch(p1, EPI_GELU_FRAG, st); }
+      int rc = WVN_ERR_ARG;
+      if (ln2_stats) {   // norm2 on load, from the statistics the projection kernel left
+        GemmBf16Params pf = p1;
+        pf.ln_x = w.x; pf.ln_ldx = d.D; pf.ln_stats = w.ln_stats; pf.ln_g = L.ln2_g; pf.ln_b = L.ln2_b;
+        Span s(6, st);
+        rc = wvn_gemm_a384_x3_launch(pf, EPI_GELU_FRAG, st);
+        if (rc != WVN_OK && rc != WVN_ERR_ARG) return rc;
+      }
+      if (rc != WVN_OK) {
+        { Span s(2, st); RET_IF(wvn_layernorm_launch(w.x, L.ln2_g, L.ln2_b, w.xn, opk.fmt, d.D, nullptr, 0, M, d.D, 1e-6f, 0, d.ntok, d.ntok_s, st, lo(w.xn, pl_xn))); }
+        ln2_done = true;
+        p1.A = (const bf16_t*)w.xn; p1.A_lo = lo(w.xn, pl_xn); p1.lda = d.D;
+        Span s(6, st);
+        rc = wvn_gemm_a384_x3_launch(p1, EPI_GELU_FRAG, st);
+      }
       if (rc == WVN_OK) {
         GemmBf16Params p2{};
         p2.A = (const bf16_t*)w.hid; p2.A_lo = lo(w.hid, pl_frag); p2.lda = d.F; p2.W = (const bf16_t*)L.fc2_w_fused; p2.ldw = d.F; p2.bias = L.fc2_b;
         p2.ls = L.ls2; p2.C = w.x; p2.ldc = d.D; p2.M = M; p2.N = d.D; p2.K = d.F;
+        const bool want = ln_fuse && l + 1 < m->depth;   // the next block's norm1
+        if (want) { p2.ln_stats_out = w.ln_stats; p2.ln_eps = 1e-6f; }
         Span s(7, st);
         RET_IF(wvn_gemm_n384_x3_frag_launch(p2, EPI_RESID_F32, st));
+        ln1_stats = want;
         continue;
       }
       if (rc != WVN_ERR_ARG) return rc;

@@ -66,6 +66,9 @@ struct X384Params {
   bf16_t* qkv_base_lo;                  // the same span of the lo planes (f16_out == 0)
   const float* ls;                      // X_RESID: optional LayerScale
   long long* dbg;                       // TIMING builds: per wave {wait + barrier, DMA issue, MFMA steps (+ epilogue chunks), total} shader cycles
+  // LNA: A = LayerNorm(ln_x) formed while the row block is loaded: ln_x fp32 [M][ln_ldx], ln_stats[m] = {mean, rstd} (left by the kernel
+  // that wrote the rows: gemm_n384_x3.hip), gamma / beta [384]
+  const float* ln_x; int ln_ldx; const float* ln_stats; const float* ln_g; const float* ln_b;
 };
 
 __device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -103,7 +106,7 @@ __device__ inline void gelu_pair(float& x0, float& x1) {
   x0 = g[0]; x1 = g[1];
 }
 
-template <int EPI, bool TIMING = false>
+template <int EPI, bool TIMING = false, bool LNA = false>
 __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -148,13 +151,60 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     if (i < total) issue(i);
 
   for (int i = tid; i < p.N; i += 256) ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
+  const float* gam_l = (const float*)(smem + BIAS_OFF + p.N * 4);   // LNA: gamma [384], beta [384] behind the bias table
+  if constexpr (LNA)
+    for (int i = tid; i < 2 * KD; i += 256) ((float*)(smem + BIAS_OFF + p.N * 4))[i] = i < KD ? p.ln_g[i] : p.ln_b[i - KD];
   bf16x8_t xh[KD / 16], xl[KD / 16];
   auto load_a = [&]() __attribute__((always_inline)) {
-    const size_t ro = (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
+    if constexpr (LNA) {
+      // the rows arrive as fp32 (the residual stream itself: the same bytes as two bf16 planes) and are normalised with the statistics
+      // their producer left, scaled, shifted and split on the way into the operand registers: ~5 VALU per value once per row block
+      // (18 - 24 column tiles of three slice periods each), instead of a kernel that reads the rows and writes the planes
+      const int row = min(m0w + l31, p.M - 1);
+      const wvn_f32x2_t st = *(const wvn_f32x2_t*)(p.ln_stats + 2 * (size_t)row);
+      const float a1 = st[1], a0 = -st[0] * st[1];
+      const float* xr = p.ln_x + (size_t)row * p.ln_ldx + hi * 8;
+      // twelve k-steps = 24 row pieces = 96 registers at a time: two memory round trips per row block, for a wave that has nothing to hide
+      // them behind (four k-steps at a time: six round trips, +4.7 ms per step; all 48 pieces at once: ~180 spilled registers).  The
+      // scheduling barriers keep each group's requests in front of its arithmetic, the empty asm keeps the arithmetic of a k-step in
+      // front of the next group's requests.
 #pragma unroll
-    for (int s = 0; s < KD / 16; ++s) {
-      xh[s] = *(const bf16x8_t*)(p.A + ro + s * 16);
-      xl[s] = *(const bf16x8_t*)(p.A_lo + ro + s * 16);
+      for (int s0 = 0; s0 < KD / 16; s0 += 12) {
+        f32x4_t u[24];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          u[2 * i] = *(const f32x4_t*)(xr + (s0 + i) * 16);
+          u[2 * i + 1] = *(const f32x4_t*)(xr + (s0 + i) * 16 + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int s = s0 + i;
+          const f32x4_t g0 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8), g1 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8 + 4);
+          const f32x4_t b0 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8), b1 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8 + 4);
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            y[e] = fmaf(fmaf(u[2 * i][e], a1, a0), g0[e], b0[e]);
+            y[4 + e] = fmaf(fmaf(u[2 * i + 1][e], a1, a0), g1[e], b1[e]);
+          }
+          uint32_t h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2(y[2 * e], y[2 * e + 1], h[e], l[e]);
+          u32x4_t hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+          asm volatile("" : "+v"(hv), "+v"(lv));
+          xh[s] = __builtin_bit_cast(bf16x8_t, hv);
+          xl[s] = __builtin_bit_cast(bf16x8_t, lv);
+        }
+      }
+    } else {
+      const size_t ro = (size_t)min(m0w + l31, p.M - 1) * p.lda + hi * 8;
+#pragma unroll
+      for (int s = 0; s < KD / 16; ++s) {
+        xh[s] = *(const bf16x8_t*)(p.A + ro + s * 16);
+        xl[s] = *(const bf16x8_t*)(p.A_lo + ro + s * 16);
+      }
     }
   };
 
@@ -500,12 +550,24 @@ int x384_num_cus() {
 
 template <int EPI>
 int launch(const X384Params& p, hipStream_t st) {
-  const int lds = BIAS_OFF + p.N * 4;
+  constexpr bool CAN_LNA = EPI == X_QKV || EPI == X_QKV_F16 || EPI == X_GELU_FRAG;   // (the LayerNorm-on-load form exists where the block kernels use it)
+  const bool lna = p.ln_x != nullptr;
+  if (lna && (!CAN_LNA || !p.ln_stats || !p.ln_g || !p.ln_b || (p.ln_ldx % 4) || ((uintptr_t)p.ln_x & 15) || ((uintptr_t)p.ln_stats & 7))) return WVN_ERR_ARG;
+  const int lds = BIAS_OFF + p.N * 4 + (lna ? 2 * KD * 4 : 0);
   if (lds > X384_LDS_MAX) return WVN_ERR_ARG;
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(X384_LDS_MAX, (const void*)gemm_a384_x3_kernel<EPI>, (const void*)gemm_a384_x3_kernel<EPI, true>)) return rc;
   const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
   const int grid = (int)(units < x384_num_cus() ? units : x384_num_cus());
+  if constexpr (CAN_LNA) {
+    if (lna) {
+      static LdsOptIn lds_opt_in_lna;
+      if (const int rc = lds_opt_in_lna(X384_LDS_MAX, (const void*)gemm_a384_x3_kernel<EPI, false, true>)) return rc;
+      hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, false, true>), dim3(grid), dim3(256), lds, st, p);
+      WVN_LAUNCH_CHECK();
+      return WVN_OK;
+    }
+  }
   if (p.dbg) hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, true>), dim3(grid), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI>), dim3(grid), dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
@@ -517,14 +579,17 @@ int launch(const X384Params& p, hipStream_t st) {
 // Eligibility: K == 384, N % 64 == 0, stacked weight planes, 16-byte aligned operands, epilogues GELU planes / residual / QKV;
 // WVN_ERR_ARG otherwise (the caller uses the tiled gemm_x3 kernel).  Worth it from about a chip of 128-row blocks on.
 int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
-  if (g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.W || !g.W_lo || (g.lda % 8) != 0) return WVN_ERR_ARG;
-  if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.W | (uintptr_t)g.W_lo) & 15) return WVN_ERR_ARG;
+  const bool lna = g.ln_x != nullptr;   // A = LayerNorm(ln_x) on load: the A planes are not read
+  if (g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.W || !g.W_lo) return WVN_ERR_ARG;
+  if (!lna && (!g.A || !g.A_lo || (g.lda % 8) != 0 || (((uintptr_t)g.A | (uintptr_t)g.A_lo) & 15))) return WVN_ERR_ARG;
+  if (((uintptr_t)g.W | (uintptr_t)g.W_lo) & 15) return WVN_ERR_ARG;
   if (g.W_lo <= g.W || (size_t)(g.W_lo - g.W) + (size_t)g.N * KD >= (1ull << 30)) return WVN_ERR_ARG;   // one descriptor over both planes
   X384Params p{};
   p.A = g.A; p.A_lo = g.A_lo; p.lda = g.lda; p.W = g.W; p.w_plane = (size_t)(g.W_lo - g.W); p.bias = g.bias;
   p.C = g.C; p.C_lo = g.C_lo; p.ldc = g.ldc; p.M = g.M; p.N = g.N;
   p.heads = g.heads; p.npad = g.npad; p.ntok_s = g.ntok_s; p.q_scale = g.q_scale != 0.f ? g.q_scale : 1.f; p.f16_out = g.qkv_f16;
   p.ls = g.ls; p.dbg = g.dbg;
+  p.ln_x = g.ln_x; p.ln_ldx = g.ln_ldx; p.ln_stats = g.ln_stats; p.ln_g = g.ln_g; p.ln_b = g.ln_b;
   switch (epi) {
     case EPI_GELU_BF16:
       if (!g.C || !g.C_lo || (g.ldc % 8) != 0 || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return WVN_ERR_ARG;
@@ -559,7 +624,7 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
         p.qkv_base_lo = (bf16_t*)lo2;
       }
       const int D = g.heads * 64;
-      if (!g_x384_split_qkv) return g.qkv_f16 ? launch<X_QKV_F16>(p, st) : launch<X_QKV>(p, st);   // (p.N == 3 D: q | k | v^T in one launch)
+      if (!g_x384_split_qkv || lna) return g.qkv_f16 ? launch<X_QKV_F16>(p, st) : launch<X_QKV>(p, st);   // (p.N == 3 D: q | k | v^T in one launch)
       p.N = 2 * D;
       const int rc = g.qkv_f16 ? launch<X_QK_F16>(p, st) : launch<X_QK>(p, st);
       if (rc != WVN_OK) return rc;

@@ -45,15 +45,23 @@ struct N384X3Params {
   float* C; int ldc;
   int M, K;
   long long* dbg;                                // TIMING builds: per wave {wait + barrier, k-steps, epilogue, total} shader cycles
+  float* stats; float eps;                       // optional: stats[m] = {mean, 1 / sqrt(var + eps)} of the updated row m (the next LayerNorm's)
 };
 
 // ---- epilogue: C[rows of this wave][384] += (acc + bias) * ls, 128 columns at a time through the wave's LDS image ----
+// stats != nullptr: the epilogue has every finished row in its hands (a row pair per store group, 32 lanes x 4 columns x 3 column groups), so
+// it also leaves the LayerNorm statistics of the rows -- sum and sum of squares per lane, folded over the row's 32 lanes at the end --
+// and the consumer (gemm_a384_x3.hip, LNA) normalises as it loads: the LayerNorm kernel between the two (1.2 GB per launch at 128 frames)
+// disappears.  (One-pass variance in fp32: 384 values, relative error ~2e-5 (1 + mean^2 / var).)
 __device__ inline void n384_epilogue(const f32x16_t (&acc)[NTILE], unsigned char* smem, int wave, int lane, int m0w, __amdgpu_buffer_rsrc_t rs_c,
-                                     int ldc, const float* bias_l, const float* ls_l) {
+                                     int ldc, const float* bias_l, const float* ls_l, float* stats = nullptr, float eps = 0.f, int M = 0) {
   const int l31 = lane & 31, hi = lane >> 5;
   __syncthreads();  // every wave is done reading the ring: the staging images overlap it
   float* stg = (float*)(smem + wave * STG_BYTES);
   const unsigned cvoff = (unsigned)(((lane >> 5) * ldc + (lane & 31) * 4) * 4);
+  float s1[16], s2[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) { s1[it] = 0.f; s2[it] = 0.f; }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
@@ -78,8 +86,37 @@ __device__ inline void n384_epilogue(const f32x16_t (&acc)[NTILE], unsigned char
       const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
       u32x4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = __float_as_uint((v[e] + b4[e]) * l4[e] + __uint_as_float(r[it][e]));
+      for (int e = 0; e < 4; ++e) {
+        const float y = (v[e] + b4[e]) * l4[e] + __uint_as_float(r[it][e]);
+        o[e] = __float_as_uint(y);
+        s1[it] += y;
+        s2[it] = fmaf(y, y, s2[it]);
+      }
       wvn_store_b128_guarded(o, rs_c, cvoff, so);  // rows >= M fall outside num_records: dropped
+    }
+  }
+  if (stats) {   // (uniform) row 2 it + (lane >> 5): its 32 lanes hold the partial sums
+    // fold over the 32 lanes on the VALU's data-parallel primitives: butterflies inside a row of 16 (quad_perm, row_half_mirror,
+    // row_mirror: every lane then holds its row's sum), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15): lanes 16 - 31 and
+    // 48 - 63 hold the totals.  (Five ds_bpermute per value through __shfl_xor: 6200 cycles per row block, 0.75 ms per step and kernel.)
+    auto dpp_add = [](float v, auto ctrl, auto rmask) {
+      constexpr int C = decltype(ctrl)::value, R = decltype(rmask)::value;
+      return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), C, R, 0xf, false));
+    };
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      float a = s1[it], b = s2[it];
+      a = dpp_add(a, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{}); b = dpp_add(b, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});
+      a = dpp_add(a, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{}); b = dpp_add(b, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});
+      a = dpp_add(a, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}); b = dpp_add(b, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});
+      a = dpp_add(a, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}); b = dpp_add(b, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});
+      a = dpp_add(a, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); b = dpp_add(b, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+      const int m = m0w + 2 * it + (lane >> 5);
+      if ((lane & 31) == 31 && m < M) {
+        const float mean = a * (1.0f / NN);
+        const float var = fmaxf(b * (1.0f / NN) - mean * mean, 0.f);
+        *(wvn_f32x2_t*)(stats + 2 * (size_t)m) = wvn_f32x2_t{mean, 1.0f / sqrtf(var + eps)};
+      }
     }
   }
 }
@@ -208,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
     long long e0 = 0;
     if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
-    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l);
+    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M);
     if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
   }
   if constexpr (TIMING) {
@@ -344,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_frag_kernel(N384X3Params 
     long long e0 = 0;
     if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
-    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l);
+    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M);
     if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
   }
   if constexpr (TIMING) {
@@ -381,7 +418,7 @@ int wvn_gemm_n384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
     return WVN_ERR_ARG;
   N384X3Params p{};
   p.A = g.A; p.a_plane = a_plane; p.lda = g.lda; p.W = g.W; p.w_plane = w_plane; p.ldw = g.ldw; p.bias = g.bias; p.ls = g.ls;
-  p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg;
+  p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg; p.stats = g.ln_stats_out; p.eps = g.ln_eps;
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(LDS_BYTES, (const void*)gemm_n384_x3_kernel<false>, (const void*)gemm_n384_x3_kernel<true>)) return rc;
   const int ncu = n384x3_num_cus(), nrb = ceil_div(g.M, BM);
@@ -403,7 +440,7 @@ int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& g, int epi, hipStream_t s
   if ((a_plane + mpad * g.K) * 2 >= (1ull << 32) || (size_t)g.M * g.ldc * 4 >= (1ull << 32) || (size_t)2 * NN * g.K * 2 >= (1ull << 31)) return WVN_ERR_ARG;
   N384X3Params p{};
   p.A = g.A; p.a_plane = a_plane; p.lda = g.K; p.W = g.W; p.w_plane = 0; p.ldw = g.K; p.bias = g.bias; p.ls = g.ls;
-  p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg;
+  p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg; p.stats = g.ln_stats_out; p.eps = g.ln_eps;
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(LDS_BYTES, (const void*)gemm_n384_x3_frag_kernel<false>, (const void*)gemm_n384_x3_frag_kernel<true>)) return rc;
   const int ncu = n384x3_num_cus(), nrb = ceil_div(g.M, BM);

@@ -34,6 +34,12 @@ struct GemmBf16Params {
   // exact mode (gemm_x3.hip): the lo planes of the operands and of plane-typed outputs (hi planes are A / W / C / q / k / vt)
   const bf16_t* A_lo; const bf16_t* W_lo; void* C_lo; bf16_t* q_lo; bf16_t* k_lo; bf16_t* vt_lo;
   long long* dbg;  // optional: per-wave phase timings of the A-stationary kernel (scripts/ab_kernels.py --timing)
+  // LayerNorm across kernel boundaries (round 4, split-operand kernels): the row-panel kernels (gemm_n384_x3.hip) can leave the statistics
+  // of the rows they have just updated, ln_stats_out[m] = {mean, 1 / sqrt(var + ln_eps)} over the N = 384 columns; the A-stationary
+  // kernel (gemm_a384_x3.hip) can take its A operand as LayerNorm(ln_x) on the fly -- ln_x fp32 [M][ln_ldx], the statistics of its rows,
+  // gamma / beta [384] -- normalising and splitting each row into its two planes as it loads it (A / A_lo are then ignored)
+  float* ln_stats_out; float ln_eps;
+  const float* ln_x; int ln_ldx; const float* ln_stats; const float* ln_g; const float* ln_b;
 };
 // The launchers of the 16-bit-operand speed path exist twice, once per operand format (operand.h): the plain names take bf16
 // operands, the *_f16 names fp16 operands (same kernels, compiled with -DWVN_OPERAND_F16=1).  "bf16_t" in these signatures
