@@ -237,7 +237,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     p.M = rows; p.N = N; p.K = K; p.ls = ls;
     if (x3) {
       p.A_lo = lo(A, a_plane); p.W_lo = lo(W, (size_t)N * K); p.C_lo = C ? lo(C, c_plane) : nullptr;
-      if (N == 384 && (epi == EPI_RESID_F32) && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 128))) {   // row panel: fc2, projection
+      if (N == 384 && (epi == EPI_RESID_F32 || epi == EPI_PATCH) && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 128))) {   // row panel: fc2, projection, patch embedding
         const int rc = wvn_gemm_n384_x3_launch(p, epi, st);
         if (rc == WVN_OK && p.ln_stats_out) stats_written = true;   // (the tiled kernel below leaves no LayerNorm statistics)
         if (rc != WVN_ERR_ARG) return rc;

@@ -46,6 +46,9 @@ struct N384X3Params {
   int M, K;
   long long* dbg;                                // TIMING builds: per wave {wait + barrier, k-steps, epilogue, total} shader cycles
   float* stats; float eps;                       // optional: stats[m] = {mean, 1 / sqrt(var + eps)} of the updated row m (the next LayerNorm's)
+  // patch embedding (EPI_PATCH): row m = (frame b, patch pp) of A lands in C row b * ntok_s + 1 + pp, and what is added to the product is
+  // the position row pos[1 + pp] (+ bias) instead of the C row itself: C = A W^T + bias + pos, the cls / padding rows untouched
+  const float* pos; int npatch, ntok_s, c_rows;
 };
 
 // ---- epilogue: C[rows of this wave][384] += (acc + bias) * ls, 128 columns at a time through the wave's LDS image ----
@@ -54,7 +57,8 @@ struct N384X3Params {
 // and the consumer (gemm_a384_x3.hip, LNA) normalises as it loads: the LayerNorm kernel between the two (1.2 GB per launch at 128 frames)
 // disappears.  (One-pass variance in fp32: 384 values, relative error ~2e-5 (1 + mean^2 / var).)
 __device__ inline void n384_epilogue(const f32x16_t (&acc)[NTILE], unsigned char* smem, int wave, int lane, int m0w, __amdgpu_buffer_rsrc_t rs_c,
-                                     int ldc, const float* bias_l, const float* ls_l, float* stats = nullptr, float eps = 0.f, int M = 0) {
+                                     int ldc, const float* bias_l, const float* ls_l, float* stats = nullptr, float eps = 0.f, int M = 0,
+                                     const float* pos = nullptr, int npatch = 0, int ntok_s = 0) {
   const int l31 = lane & 31, hi = lane >> 5;
   __syncthreads();  // every wave is done reading the ring: the staging images overlap it
   float* stg = (float*)(smem + wave * STG_BYTES);
@@ -77,12 +81,23 @@ __device__ inline void n384_epilogue(const f32x16_t (&acc)[NTILE], unsigned char
     // a wave alone on its SIMD: the sixteen row fetches of the column group are requested together (64 registers), then added and
     // stored -- four at a time they cost sixteen exposed round trips per row block (measured: 56 K cycles per epilogue)
     u32x4_t r[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it)
-      r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff, __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * ldc + 128 * c) * 4), 0);
+    unsigned so_dst[16];
+    const __amdgpu_buffer_rsrc_t rs_pos = __builtin_amdgcn_make_buffer_rsrc((void*)(pos ? pos : bias_l), 0, pos ? (unsigned)((size_t)(npatch + 1) * ldc * 4) : 0u, 0x00020000);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-      const unsigned so = __builtin_amdgcn_readfirstlane(((m0w + 2 * it) * ldc + 128 * c) * 4);
+      const int m = m0w + 2 * it;   // (npatch is even, like m: a row pair never straddles two frames)
+      if (pos) {   // (uniform) patch embedding: the addend is the position row, the destination the token row of (frame, patch)
+        const int b = m / npatch, pp = m - b * npatch;
+        so_dst[it] = __builtin_amdgcn_readfirstlane(((b * ntok_s + 1 + pp) * ldc + 128 * c) * 4);
+        r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_pos, cvoff, __builtin_amdgcn_readfirstlane(((1 + pp) * ldc + 128 * c) * 4), 0);
+      } else {
+        so_dst[it] = __builtin_amdgcn_readfirstlane((m * ldc + 128 * c) * 4);
+        r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff, so_dst[it], 0);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const unsigned so = so_dst[it];
       const f32x4_t v = *(const f32x4_t*)(stg + (2 * it + (lane >> 5)) * STG_PITCH + (lane & 31) * 4);
       u32x4_t o;
 #pragma unroll
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
 
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((p.w_plane + (size_t)NN * p.ldw) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((p.a_plane + (size_t)p.M * p.lda) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)(p.pos ? p.c_rows : p.M) * p.ldc * 4), 0x00020000);
   // W: 24 wave-instructions per slice (12 per plane: 32 rows x 32 B each), 6 per wave; LDS rows are 32 B = two 16-byte chunks, chunk c
   // of row r at position c ^ ((r >> 3) & 1): a ds_read_b128 is served 16 lanes at a time ({0-3, 12-15, 20-27}, ...), rows 8 apart
   // share their banks, and without the swizzle half of every group collides (measured: 2235 instead of ~1400 cycles per k-step)
@@ -245,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
     long long e0 = 0;
     if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
-    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M);
+    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M, p.pos, p.npatch, p.ntok_s);
     if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
   }
   if constexpr (TIMING) {
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_frag_kernel(N384X3Params 
     long long e0 = 0;
     if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
-    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M);
+    n384_epilogue(acc, smem, wave, lane, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M, p.pos, p.npatch, p.ntok_s);
     if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
   }
   if constexpr (TIMING) {
@@ -408,17 +423,21 @@ int n384x3_num_cus() {
 // Eligibility: N == 384, K % 32 == 0, residual epilogue (optional LayerScale), stacked planes, 16-byte aligned operands, 31-bit byte
 // offsets; WVN_ERR_ARG otherwise (the caller uses the tiled gemm_x3 kernel).
 int wvn_gemm_n384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
-  if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
+  const bool patch = epi == EPI_PATCH;   // C = A W^T + bias + pos into the token rows (see N384X3Params)
+  if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32 && !patch) return WVN_ERR_ARG;
+  if (patch && (!g.pos || g.npatch <= 0 || (g.npatch & 1) || g.ntok_s < g.npatch + 1 || g.ldc != NN || g.ls || (g.M % g.npatch) != 0)) return WVN_ERR_ARG;
   if (g.N != NN || g.K <= 0 || (g.K % BKS) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.W || !g.W_lo || !g.C) return WVN_ERR_ARG;
   if ((g.lda % 8) || (g.ldw % 8) || (g.ldc % 4) || g.ldw != g.K) return WVN_ERR_ARG;
   if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.W | (uintptr_t)g.W_lo | (uintptr_t)g.C) & 15) return WVN_ERR_ARG;
   if (g.A_lo <= g.A || g.W_lo <= g.W) return WVN_ERR_ARG;
   const size_t a_plane = (size_t)(g.A_lo - g.A), w_plane = (size_t)(g.W_lo - g.W);
-  if ((a_plane + (size_t)g.M * g.lda) * 2 >= (1ull << 32) || (size_t)g.M * g.ldc * 4 >= (1ull << 32) || (w_plane + (size_t)NN * g.ldw) * 2 >= (1ull << 32))
+  const size_t c_rows = patch ? (size_t)(g.M / g.npatch) * g.ntok_s : (size_t)g.M;
+  if ((a_plane + (size_t)g.M * g.lda) * 2 >= (1ull << 32) || c_rows * g.ldc * 4 >= (1ull << 32) || (w_plane + (size_t)NN * g.ldw) * 2 >= (1ull << 32))
     return WVN_ERR_ARG;
   N384X3Params p{};
   p.A = g.A; p.a_plane = a_plane; p.lda = g.lda; p.W = g.W; p.w_plane = w_plane; p.ldw = g.ldw; p.bias = g.bias; p.ls = g.ls;
   p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg; p.stats = g.ln_stats_out; p.eps = g.ln_eps;
+  if (patch) { p.pos = g.pos; p.npatch = g.npatch; p.ntok_s = g.ntok_s; p.c_rows = (int)c_rows; p.stats = nullptr; }
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(LDS_BYTES, (const void*)gemm_n384_x3_kernel<false>, (const void*)gemm_n384_x3_kernel<true>)) return rc;
   const int ncu = n384x3_num_cus(), nrb = ceil_div(g.M, BM);
