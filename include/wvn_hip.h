@@ -73,6 +73,15 @@ int wvn_version(void);
  * kernel starts from those -- no second pass over the fp32 residual stream, no statistics, half the bytes) */
 #define WVN_VIT_NO_LN_HANDOVER 16
 #define WVN_VIT_NO_A384_X3 32     /* A/B and tests: the K = 384 linears of WVN_PREC_X3 / WVN_PREC_MIX on the tiled gemm_x3 kernel instead of the A-stationary one */
+/* A/B and tests of the split-operand block kernels, one piece at a time (python: WVN_X3_DEBUG_BITS): 64 no A-stationary kernel, 128 no
+ * row-panel kernel, 256 no fragment-major MLP hand-over */
+#define WVN_VIT_X3_NO_A384 64
+#define WVN_VIT_X3_NO_N384 128
+#define WVN_VIT_X3_NO_FRAG_MLP 256
+/* ... and: no LayerNorm across kernel boundaries (default for WVN_PREC_MIX / WVN_PREC_X3 from 8192 rows on: the row-panel kernels leave
+ * {mean, rstd} of the rows they update, the A-stationary kernels normalise as they load; with this flag every LayerNorm is its own
+ * kernel writing hi / lo planes again) */
+#define WVN_VIT_X3_NO_LN_STATS 512
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */

@@ -237,12 +237,12 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     p.M = rows; p.N = N; p.K = K; p.ls = ls;
     if (x3) {
       p.A_lo = lo(A, a_plane); p.W_lo = lo(W, (size_t)N * K); p.C_lo = C ? lo(C, c_plane) : nullptr;
-      if (N == 384 && (epi == EPI_RESID_F32 || epi == EPI_PATCH) && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 128))) {   // row panel: fc2, projection, patch embedding
+      if (N == 384 && (epi == EPI_RESID_F32 || epi == EPI_PATCH) && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | WVN_VIT_X3_NO_N384))) {   // row panel: fc2, projection, patch embedding
         const int rc = wvn_gemm_n384_x3_launch(p, epi, st);
         if (rc == WVN_OK && p.ln_stats_out) stats_written = true;   // (the tiled kernel below leaves no LayerNorm statistics)
         if (rc != WVN_ERR_ARG) return rc;
       }
-      if (K == 384 && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | 64))) {   // the A-stationary form from about a quarter chip of row blocks on
+      if (K == 384 && rows >= 64 * 128 && !(m->flags & (WVN_VIT_NO_A384_X3 | WVN_VIT_X3_NO_A384))) {   // the A-stationary form from about a quarter chip of row blocks on
         const int rc = wvn_gemm_a384_x3_launch(p, epi, st);
         if (rc != WVN_ERR_ARG) return rc;
       }
@@ -311,7 +311,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
   // split-operand block kernels: LayerNorm ACROSS kernel boundaries -- the row-panel kernel that updates the residual rows (projection,
   // fc2) leaves their {mean, rstd}, the A-stationary kernel that consumes them (fc1, next block's QKV) normalises as it loads: no LayerNorm
   // kernel, no xn planes, between them.  ln1_stats: w.ln_stats holds the statistics of w.x for THIS block's norm1.
-  const bool ln_fuse = x3_fast && w.ln_stats && !(m->flags & 512);
+  const bool ln_fuse = x3_fast && w.ln_stats && !(m->flags & WVN_VIT_X3_NO_LN_STATS);
   bool ln1_stats = false;
   for (int l = 0; l < m->depth; ++l) {
     const wvn_vit_layer& L = m->layers[l];
@@ -439,7 +439,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
                                   L.ls2, w.x, d.D, M, d.F, st));
       continue;
     }
-    if (x3_fast && L.fc2_w_fused && !(m->flags & 256)) {
+    if (x3_fast && L.fc2_w_fused && !(m->flags & WVN_VIT_X3_NO_FRAG_MLP)) {
       // the split-operand MLP with the hidden activation handed over FRAGMENT-MAJOR: fc1 (gemm_a384_x3, EPI_GELU_FRAG) writes the
       // MFMA operand fragments of fc2 straight from its accumulators, fc2 (gemm_n384_x3, AFRAG) fetches them with one coalesced load
       // per lane and plane -- no LDS transpose on either side, every access a contiguous kilobyte
