@@ -41,7 +41,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from oracle import vit as ovit  # noqa: E402
 
 FAMILIES = ["patch", "qkv", "qk", "pv", "proj", "fc1", "fc2"]
-MFMA_COST = {"f32": None, "h": 1.0, "a": 2.0, "w": 2.0, "x3": 3.0, "c8": 2.0, "c6": 1.5, "c4": 1.5}
+MFMA_COST = {"f32": None, "h": 1.0, "a": 2.0, "w": 2.0, "x3": 3.0, "c8": 2.0, "c6": 1.5, "c4": 1.5, "q8r": 0.5, "q8m": 0.5, "q8x3": 1.5, "q8a": 1.0, "q8w": 1.0}
 # share of the backbone's multiply-adds per family at 448^2 (315.1 GFLOP per frame)
 FLOP_SHARE = {"patch": 0.0015, "qkv": 0.1057, "qk": 0.2878, "pv": 0.2878, "proj": 0.0352, "fc1": 0.141, "fc2": 0.141}
 
@@ -83,6 +83,13 @@ def mx_quant(x, ebits, mbits, block=32):
 MX = {"c8": (4, 3), "c6": (2, 3), "c4": (2, 1)}
 
 
+def mx_quant_elem(y):
+    """e4m3 element rounding of values already scaled into [-448, 448] (no block scale)."""
+    e = torch.floor(torch.log2(y.abs().clamp_min(1e-38))).clamp_min(-6.0)
+    q = torch.exp2(e - 3)
+    return (torch.round(y / q) * q).clamp(-448.0, 448.0)
+
+
 def product(a, w, mode, fmt, kdim_last_w=True):
     """a [..., K] x w [N, K]^T with the operand handling of `mode`; fp32 accumulation (torch's, order differs from the MFMA's:
     ~1e-7 relative, far below what is measured here)."""
@@ -98,6 +105,24 @@ def product(a, w, mode, fmt, kdim_last_w=True):
         return ah @ wh.transpose(-1, -2) + ah @ wl.transpose(-1, -2)
     if mode == "x3":
         return ah @ wh.transpose(-1, -2) + (al @ wh.transpose(-1, -2) + ah @ wl.transpose(-1, -2))
+    if mode in ("q8r", "q8m", "q8x3", "q8a", "q8w"):
+        # fp8 e4m3 operands (the --fp8 legs, BASELINE configs[4]).  q8r: per-ROW scales (activation: per token, weight: per output channel:
+        # what csrc/fp8.hip does); q8m: one power-of-two scale per 32 elements along K (OCP MX, v_mfma_scale_f32_32x32x64_f8f6f4);
+        # q8x3 / q8a: hi + lo e4m3 planes of both operands (three fp8 MFMAs) / of the activation only (two)
+        def q_row(x):
+            sc = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30) / 448.0
+            return mx_quant_elem(x / sc) * sc
+        qa, qw = (q_row, q_row) if mode != "q8m" else ((lambda x: mx_quant(x, 4, 3)),) * 2
+        a8, w8 = qa(a), qw(w)
+        if mode in ("q8r", "q8m"):
+            return a8 @ w8.transpose(-1, -2)
+        a8l = qa(a - a8) if mode != "q8w" else None
+        if mode == "q8a":
+            return (a8 + a8l) @ w8.transpose(-1, -2)
+        w8l = qw(w - w8)
+        if mode == "q8w":
+            return a8 @ (w8 + w8l).transpose(-1, -2)
+        return a8 @ w8.transpose(-1, -2) + (a8l @ w8.transpose(-1, -2) + a8 @ w8l.transpose(-1, -2))
     if mode in MX:
         eb, mb = MX[mode]
         a_lo, w_lo = a - ah, w - wh  # the fp32 residues the kernel has in registers / the weight prep has offline
@@ -210,6 +235,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--configs", default="")
     ap.add_argument("--gain", type=float, default=1.4)
+    ap.add_argument("--fp8", action="store_true", help="the fp8 table: e4m3 linears under per-row / MX block scales / hi + lo planes")
     ap.add_argument("--real-frame", action="store_true", help="the reference's one real 448^2 frame (tests/golden/graph_img_448.pt) and the "
                     "attention-operand variants of the mixed mode instead of the synthetic frames and the family table")
     args = ap.parse_args()
@@ -251,6 +277,14 @@ def main():
             m = dict(m)
             m["qk"] = mode
             configs.append((f"linears + qk {mode}, pv single", m))
+        if args.fp8:   # the fp8 legs (configs[4]): linears in e4m3, attention products in the 16-bit format
+            configs = [("all single " + args.fmt, dict(allh))]
+            for mode, what in (("q8r", "e4m3, per-row scales (shipped)"), ("q8m", "e4m3, MX block-32 scales"), ("q8a", "e4m3, activation hi + lo (2 MFMAs)"), ("q8w", "e4m3, weight hi + lo (2 MFMAs)"),
+                               ("q8x3", "e4m3, both operands hi + lo (3 MFMAs)")):
+                m = {f: mode for f in FAMILIES}
+                m["qk"] = "h"
+                m["pv"] = "h"
+                configs.append((f"linears {what}, attention {args.fmt}", m))
         if args.configs:
             keep = set(args.configs.split(";"))
             configs = [c for c in configs if c[0] in keep]
@@ -265,8 +299,10 @@ def main():
             print(f"{name:44s} max {mx:.2e}  rms {rms:.2e}  rel-L2 {rel:.2e}  mfma cost {cost(modes):.2f}  ({time.time() - t0:.0f} s)", flush=True)
     if args.out:
         with open(args.out, "w") as f:
-            f.write(f"# Error budget of the 16-bit path by kernel family ({args.weights} weights, {args.frames} frames at {args.size}^2, "
-                    f"{args.depth} blocks, operand format {args.fmt})\n\n")
+            f.write((f"# fp8 linears: what the scales can and cannot buy ({args.weights} weights, ViT-S/8, {args.frames} frame(s) at {args.size}^2, "
+                     f"{args.depth} blocks; attention products in {args.fmt})\n\n" if args.fp8 else
+                     f"# Error budget of the 16-bit path by kernel family ({args.weights} weights, {args.frames} frames at {args.size}^2, "
+                     f"{args.depth} blocks, operand format {args.fmt})\n\n"))
             f.write("CPU emulation (`scripts/error_budget.py`): operands of the named products rounded as the kernels round them, fp32 "
                     "accumulation; error of the final-LayerNorm'ed tokens against the fp32 oracle.  `mfma cost` = matrix-pipe work "
                     "relative to the all-single-16-bit path (FLOP shares of DESIGN section 4).\n\n")
