@@ -262,7 +262,7 @@ def cpu_oracle_sample(args, fe):
     timed on this box's host cores.  Returns (cpu_baseline dict, the oracle's intermediate results for the parity legs)."""
     import torch
 
-    from oracle import interfaces as OI, mlp as OM, segments as OS, vit as OV
+    from oracle import interfaces as OI, kmeans_linear as OKL, mlp as OM, segments as OS, vit as OV
 
     n = args.cpu_frames
     # PyTorch's intra-op pool does not scale to the GPU box's 256 hardware threads for these matrix
@@ -294,7 +294,7 @@ def cpu_oracle_sample(args, fe):
                 if args.mode == "dinov2":
                     continue
                 if upstream:
-                    lab = OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(code[0].numpy(), G, args.size, 20))
+                    lab = OI.relabel_ascending(OKL.kmeans_cosine_labels_pixels_linear(code[0].numpy(), G, args.size, 20))
                     seg = torch.from_numpy(lab).reshape(args.size, args.size).long()
                 else:
                     lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), 20))
@@ -341,7 +341,7 @@ def gpu_parity(args, fe, dev, orc, precision, reading=None):
     points) and `seg_equal_given_gpu_code` (the integer stage alone: the oracle's k-means run on the GPU's code)."""
     import torch
 
-    from oracle import interfaces as OI, segments as OS
+    from oracle import interfaces as OI, kmeans_linear as OKL, segments as OS
 
     reading = reading or args.stego_reading
     n, G = args.cpu_frames, orc["G"]
@@ -354,8 +354,8 @@ def gpu_parity(args, fe, dev, orc, precision, reading=None):
         gi = orc["img"].to(dev).repeat(reps, 1, 1, 1)
         gtok = bb.forward_tokens(gi)[:n].cpu()
         otok = torch.cat(orc["toks"])
-        par = {"mode": precision, "frames": n, "against": ("oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned; k-means = the deterministic kernel-order definition of "
-                           "oracle/interfaces.py, which states the summation order of csrc/stego.hip)"),
+        par = {"mode": precision, "frames": n, "against": ("oracle/ (CPU fp32 restatement; backbone / STEGO head parity unpinned; pixel k-means = the deterministic fixed-order definition of "
+                           "oracle/kmeans_linear.py (the clustering through its linearity), which csrc/stego_linear.hip follows operation for operation)"),
                "gpu_batch": int(gi.shape[0]),
                "max_abs_tokens": float((gtok - otok).abs().max()), "rel_l2_tokens": float((gtok - otok).norm() / otok.norm())}
         ocodes = orc["codes"].get(reading) if stego else None
@@ -381,7 +381,7 @@ def gpu_parity(args, fe, dev, orc, precision, reading=None):
                 given = 0
                 for b in range(m):
                     if reading == "upstream":
-                        want = torch.from_numpy(OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(gcode[b].numpy(), G, args.size, 20))
+                        want = torch.from_numpy(OI.relabel_ascending(OKL.kmeans_cosine_labels_pixels_linear(gcode[b].numpy(), G, args.size, 20))
                                                 ).reshape(args.size, args.size).long()
                     else:
                         lab = OI.relabel_ascending(OI.kmeans_cosine_labels(gcode[b].numpy(), 20))

@@ -386,6 +386,25 @@ size_t wvn_kmeans_scratch_bytes(int B, int P, int C, int K);
 size_t wvn_kmeans_pixels_scratch_bytes(int B, int G, int H, int C, int K);
 int wvn_kmeans_cosine_pixels(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K, int iters,
                              int relabel, void* stream);
+/* The pixel-resolution k-means through its LINEARITY (round 5; the form StegoInterface uses, stego_interface.py:94-109): the same
+ * clustering -- same points, same initial centroids, same iteration count, same tie rule -- with the assignment taken from a per-pass
+ * similarity table S = code . c^T interpolated per pixel (rinv_p > 0 moves no argmax, <., c_k> is linear in the four taps) and the
+ * centroid sums from per-(cluster, patch) summed tap weights times the patch codes (SURVEY.md 8(a7)'s pooling identity): ~1/20 of the
+ * arithmetic of wvn_kmeans_cosine_pixels.  Every summation order is fixed (csrc/stego_linear.hip; oracle/kmeans_linear.py states them), so
+ * labels and centroids are reproducible bit for bit; against wvn_kmeans_cosine_pixels they differ only at pixels whose two best
+ * similarities are closer than fp32 rounding.  C in {16, 90}, K <= 32 (wvn_kmeans_pixels_linear_supported_shape); scratch as above: its
+ * first B*K*C floats hold the final centroids on return. */
+int wvn_kmeans_pixels_linear_supported_shape(int G, int H, int C, int K);
+size_t wvn_kmeans_pixels_linear_scratch_bytes(int B, int G, int H, int C, int K);
+int wvn_kmeans_cosine_pixels_linear(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K,
+                                    int iters, int relabel, void* stream);
+/* labels[b][y][x] (int32, [B, H, H]) = argmax over k < K (lowest k wins ties) of the bilinear interpolation (align_corners=True, the
+ * fixed operation order of wvn_upsample_bilinear) of table[b][.][k] to H x H: the STEGO cluster probe / linear probe applied at PIXEL
+ * resolution (stego_interface.py:94-100, 107-109: postprocess acts on the up-sampled code; a probe is linear in the code and the
+ * interpolation weights sum to one, so interpolating its K outputs per patch equals evaluating it on the interpolated code).
+ * table: [B, G*G, wvn_table_argmax_slots(K)] fp32, 16-byte aligned, slots >= K ignored; K <= 32. */
+int wvn_table_argmax_slots(int K);
+int wvn_table_bilerp_argmax(const float* table, int* labels, int B, int G, int H, int K, void* stream);
 /* out = 0.5 * (a + flip_x(mirrored)) on [B, G, G, C] fp32 patch maps: the code of a frame averaged with the flipped-back code of
  * its mirror image (the second pass of the upstream Stego.get_code; the mirror pass itself is wvn_vit_forward_frames with a
  * reversed column table).  out may alias a. */
@@ -553,6 +572,9 @@ int wvn_debug_attention_variant(int variant);
  * kernel counting its exact rows (wvn_debug_kmeans_screen_stats).  Bit-identical labels and centroids in all of them;
  * tests/test_gpu_stego_pixels.py runs them, scripts/bench_pixel_kmeans.py A/Bs them. */
 int wvn_debug_kmeans_assign_form(int form);
+/* image rows of a band the linear form's assign kernel works on at a time (LDS per workgroup against barriers per band; default 5) */
+int wvn_debug_kmeans_linear_rows(int rows);
+
 /* statistics of the screened kernel (synchronises the device): out[0] = 64-pixel row groups it re-did with the exact chains, out[1] = row
  * groups it saw, since the last call with reset != 0 */
 int wvn_debug_kmeans_screen_stats(unsigned long long* out, int reset);

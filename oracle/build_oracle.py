@@ -1,4 +1,4 @@
-"""Build the C part of the oracle (oracle/kmeans_ref.c) into oracle/_build/libwvn_oracle.so with gcc.
+"""Build the C part of the oracle (oracle/kmeans_ref.c, oracle/kmeans_linear_ref.c) into oracle/_build/libwvn_oracle.so with gcc.
 
     python -m oracle.build_oracle
 
@@ -12,13 +12,13 @@ OUT = os.path.join(HERE, "_build", "libwvn_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(HERE, "kmeans_ref.c")
-    if force or not os.path.exists(OUT) or os.path.getmtime(OUT) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, "kmeans_ref.c"), os.path.join(HERE, "kmeans_linear_ref.c")]
+    if force or not os.path.exists(OUT) or any(os.path.getmtime(OUT) < os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", src, "-o", OUT, "-lm"]
+        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC"] + srcs + ["-o", OUT, "-lm"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("gcc failed on oracle/kmeans_ref.c:\n" + r.stdout + r.stderr)
+            raise RuntimeError("gcc failed on the oracle's C restatements:\n" + r.stdout + r.stderr)
     return OUT
 
 

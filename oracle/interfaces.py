@@ -163,6 +163,10 @@ def _oracle_lib():
             h.wvn_oracle_kmeans_cosine_ex.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                       ctypes.c_void_p, ctypes.c_void_p]
             h.wvn_oracle_kmeans_cosine_ex.restype = ctypes.c_int
+            if hasattr(h, "wvn_oracle_kmeans_pixels_linear"):   # (oracle/kmeans_linear_ref.c; absent from a library built before round 5)
+                h.wvn_oracle_kmeans_pixels_linear.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                h.wvn_oracle_kmeans_pixels_linear.restype = ctypes.c_int
             _ORACLE_LIB = h
     return _ORACLE_LIB or None
 
@@ -281,12 +285,14 @@ def upsample_nearest(lab: torch.Tensor, out: int) -> torch.Tensor:
 
 def stego_inference(
     sd, head, img: torch.Tensor, input_size: int, patch: int, heads: int, n_image_clusters: int,
-    flip_tta: bool = True, cluster_resolution: str = "pixel",
+    flip_tta: bool = True, cluster_resolution: str = "pixel", kmeans_form: str = "linear",
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """StegoInterface.inference as used by FeatureExtractor (run_clustering=True, run_crf=False).
     Returns (code [B,C,H,H] fp32, cluster_pred [1,B,H,H] int32).  Defaults = the upstream behaviour as this build reads it (the code
     averaged with the flipped-back code of the mirrored frame, k-means over the H x H up-sampled code pixels); flip_tta=False /
-    cluster_resolution="patch" are the cheap forms (single pass, k-means over the patch codes, labels nearest-upsampled)."""
+    cluster_resolution="patch" are the cheap forms (single pass, k-means over the patch codes, labels nearest-upsampled).
+    kmeans_form: which statement of the pixel-resolution k-means assigns the labels -- "linear" (oracle/kmeans_linear.py, the
+    product default) or "direct" (kmeans_cosine_labels_pixels above); the same clustering, equal maps except at fp32 rounding ties."""
     x = dino_transform(img, input_size)
     tok = vit.vit_tokens(sd, x, patch, heads)[:, 1:]
     B, P, D = tok.shape
@@ -299,7 +305,13 @@ def stego_inference(
     code_map = code.reshape(B, G, G, -1).permute(0, 3, 1, 2)
     H = img.shape[2]
     if cluster_resolution == "pixel":
-        labels = np.stack([kmeans_cosine_labels_pixels(code[b].numpy(), G, input_size, n_image_clusters) for b in range(B)])
+        if kmeans_form == "linear":
+            from . import kmeans_linear
+
+            km = kmeans_linear.kmeans_cosine_labels_pixels_linear
+        else:
+            km = kmeans_cosine_labels_pixels
+        labels = np.stack([km(code[b].numpy(), G, input_size, n_image_clusters) for b in range(B)])
         labels = torch.from_numpy(labels).reshape(B, input_size, input_size)
     else:
         labels = np.stack([kmeans_cosine_labels(code[b].numpy(), n_image_clusters) for b in range(B)])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import interfaces as OI, segments as OS, vit as OV
+from oracle import interfaces as OI, kmeans_linear as KL, segments as OS, vit as OV
 from wild_visual_navigation_amd import ops
 from wild_visual_navigation_amd.backbone import VitBackbone
 from wild_visual_navigation_amd.feature_extractor import DinoInterface, FeatureExtractor, StegoInterface
@@ -239,7 +239,7 @@ def test_feature_extractor_stego_pipeline(dev, reading):
         assert (code - code_ref).abs().max().item() < tol, prec
         # integer outputs: oracle clustering of the SAME fp32 code must agree bit-for-bit
         if reading == "upstream":
-            lab = OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(code[0].numpy(), G, S, K))
+            lab = OI.relabel_ascending(KL.kmeans_cosine_labels_pixels_linear(code[0].numpy(), G, S, K))
             want_seg = torch.from_numpy(lab).reshape(S, S).long()
         else:
             lab = OI.relabel_ascending(OI.kmeans_cosine_labels(code[0].numpy(), K))
@@ -321,10 +321,19 @@ def test_stego_checkpoint_probes_flip_tta_and_pixel_clustering(dev, tmp_path, la
         pix = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=True,
                              precision=prec, cluster_resolution="pixel")
         _, clu_p = pix.inference(img.to(dev))
-        dense = pix.features                                                     # [2, 90, S, S] on the GPU
+        gcode = pix.feature_tokens.cpu().numpy()                                 # [2, G*G, 90] from the GPU
         for b in range(2):
-            want = OI.relabel_ascending(OI.kmeans_cosine_labels(dense[b].permute(1, 2, 0).reshape(S * S, 90).cpu().numpy(), 5))
+            want = OI.relabel_ascending(KL.kmeans_cosine_labels_pixels_linear(gcode[b], G, S, 5))
             assert np.array_equal(clu_p[0, b].cpu().numpy().reshape(-1), want)   # bit-exact on identical fp32 input
+        # the probes under the same reading (cluster_resolution="pixel"): per-patch scores interpolated, argmax per pixel
+        pp = StegoInterface(dev, input_size=S, model_path=path, n_image_clusters=5, run_crf=False, run_clustering=False, precision=prec,
+                            flip_tta=False, cluster_resolution="pixel")
+        lin_p, clu_pp = pp.inference(img.to(dev))
+        gc = torch.from_numpy(pp.feature_tokens.cpu().numpy())
+        up = lambda t: torch.from_numpy(np.stack([OI.upsample_bilinear_fixed(t[b].reshape(G, G, -1).numpy(), S) for b in range(2)]))
+        want_lin_p = up(gc @ lin_w.T + lin_b).argmax(-1)
+        want_clu_p = up(gc @ torch.nn.functional.normalize(clusters, dim=1).T).argmax(-1)
+        assert (lin_p[0].cpu() == want_lin_p).float().mean().item() >= 0.999 and (clu_pp[0].cpu() == want_clu_p).float().mean().item() >= 0.999
         fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=S, model_path=path,
                               n_image_clusters=5, precision=prec, cluster_resolution="pixel")
         edges, feat, seg, center, _ = fe.extract(img[:1].to(dev))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import interfaces as OI, segmap_agreement as SA, vit as OV
+from oracle import interfaces as OI, kmeans_linear as KL, segmap_agreement as SA, vit as OV
 from wild_visual_navigation_amd.feature_extractor import FeatureExtractor, StegoInterface
 
 pytestmark = pytest.mark.gpu
@@ -74,7 +74,7 @@ def test_camera_height_differs_from_input_size(dev):
     assert clu.shape == (1, 2, 448, 448)
     code = si.feature_tokens.cpu()
     for b in range(2):
-        lab = OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(code[b].numpy(), 28, 224, 6))
+        lab = OI.relabel_ascending(KL.kmeans_cosine_labels_pixels_linear(code[b].numpy(), 28, 224, 6))
         want = OI.upsample_nearest(torch.from_numpy(lab).reshape(1, 224, 224).int(), 448)[0, 0]
         assert torch.equal(clu[0, b].cpu(), want.int())
     # and end to end against the oracle's own inference on the same frames (exact mode: the code agrees to 1e-3; labels may differ on

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import interfaces as OI, vit as OV
+from oracle import interfaces as OI, kmeans_linear as KL, vit as OV
 from wild_visual_navigation_amd import ops
 from wild_visual_navigation_amd.feature_extractor import FeatureExtractor, StegoInterface
 
@@ -50,8 +50,8 @@ def test_pixel_kmeans_bit_exact(dev, assign_form, G, H, C, K, B):
     partial last centroid block; K = 17 / 19 / 16: a half-used, a half-used last and two unused cluster PAIRS of the packed form (the
     first packed kernel mislabelled 0.5 % of the pixels exactly there -- in-flight scalar registers copied under register pressure)."""
     code = torch.randn(B, G * G, C, generator=g(G * H)) * (1.0 + torch.rand(B, G * G, 1, generator=g(1)))
-    lab, nseg, cent = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=False, return_centroids=True)
-    lab2, nseg2 = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=True)
+    lab, nseg, cent = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=False, return_centroids=True, form="direct")
+    lab2, nseg2 = ops.kmeans_cosine_pixels(code.to(dev), G, H, K, iters=10, relabel=True, form="direct")
     # the materialised route on the GPU: up-sample, normalise, cluster the H*H rows -- must give the same bits, labels AND
     # centroids (labels alone are robust to last-place differences of the sums: a 1-ulp square root went unnoticed that way)
     dense = ops.upsample_bilinear(code.to(dev), G, H).permute(0, 2, 3, 1).reshape(B, H * H, C).contiguous()
@@ -72,7 +72,7 @@ def test_pixel_kmeans_at_448_against_oracle(dev, assign_form):
     head = OI.make_stego_head_state_dict(384, 90, seed=2)
     img = torch.rand(1, 3, H, H, generator=g(3))
     si = StegoInterface(dev, input_size=H, n_image_clusters=K, run_crf=False, run_clustering=True, backbone_weights=sd, head_weights=head,
-                        precision="fp16", flip_tta=True, cluster_resolution="pixel", allow_synthetic=True)
+                        precision="fp16", flip_tta=True, cluster_resolution="pixel", kmeans_form="direct", allow_synthetic=True)
     _, clu = si.inference(img.to(dev))
     code = si.feature_tokens.cpu()                                                      # the GPU's own code: identical input
     want = OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(code[0].numpy(), G, H, K))
@@ -99,7 +99,7 @@ def test_upstream_reading_end_to_end(dev):
     assert (code - code_ref).abs().max().item() < 1e-3
     dense = fe._extractor.features.cpu()                                                # [2, 90, S, S]
     for b in range(2):
-        want = OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(code[b].numpy(), G, S, K))
+        want = OI.relabel_ascending(KL.kmeans_cosine_labels_pixels_linear(code[b].numpy(), G, S, K))   # (the class default: the linear form)
         assert np.array_equal(seg[b].cpu().numpy().reshape(-1), want)
         for s_ in range(int(nseg[b])):
             m = torch.from_numpy(want.reshape(S, S) == s_)

@@ -107,3 +107,46 @@ def test_stego_inference_defaults_are_the_upstream_reading_and_flip_equivariant(
     assert torch.equal(seg_1[0, 0], seg_1[0, 0].reshape(G, P, G, P)[:, :1, :, :1].expand(G, P, G, P).reshape(S, S))   # patch-aligned labels
     tok = OV.vit_tokens(sd, OI.dino_transform(img, S), P, 6)[:, 1:]
     assert torch.equal(OI.upsample_bilinear_ac(OI.stego_code_tokens(head, tok).reshape(1, G, G, 90).permute(0, 3, 1, 2), S), code_1)
+
+
+def test_linear_form_c_restatement_equals_its_numpy_statement():
+    """oracle/kmeans_linear_ref.c against oracle/kmeans_linear.py (exact fp32 fma emulation): labels AND centroids bit for bit, incl.
+    fewer pixels than patches per side (bands without rows), many rows per band, K = 27, an empty cluster."""
+    from oracle import build_oracle, kmeans_linear as KL
+
+    build_oracle.build()
+    rng = np.random.default_rng(7)
+    for G, H, C, K in [(8, 64, 90, 5), (7, 50, 16, 4), (5, 33, 90, 6), (12, 9, 16, 3), (6, 100, 16, 27), (9, 70, 90, 17)]:
+        code = (rng.standard_normal((G * G, C)) * (1 + rng.random((G * G, 1)))).astype(np.float32)
+        if K == 6:
+            code[:] = code[:1] + 1e-3 * code            # near-parallel rows: several clusters end up empty and keep their centroid
+        lab_c, cent_c = KL.kmeans_pixels_linear(code, G, H, K, iters=4)
+        lab_n, cent_n = KL.kmeans_pixels_linear(code, G, H, K, iters=4, force_numpy=True)
+        assert KL.kmeans_pixels_linear_c(code, G, H, K, iters=4) is not None
+        assert np.array_equal(lab_c, lab_n) and np.array_equal(cent_c, cent_n), (G, H, C, K)
+
+
+def test_linear_and_direct_statements_of_the_pixel_kmeans_agree_within_float_tolerance():
+    """The two definitions are the same function in exact arithmetic.  In fp32 every pixel where their maps differ must lie within
+    the float tolerance of a decision boundary of the direct statement: its margin there <= 2 (eps_x + eps_c) with eps_x = 0 (the
+    points are identical) and eps_c the distance between the two runs' final centroids -- oracle/segmap_agreement.py's criterion."""
+    from oracle import build_oracle, kmeans_linear as KL, segmap_agreement as SA
+
+    build_oracle.build()
+    gen = torch.Generator().manual_seed(3)
+    for G, H, C, K, smooth in [(28, 224, 90, 20, True), (28, 224, 90, 20, False), (9, 70, 16, 7, False)]:
+        if smooth:      # code with cluster structure, as a real segmentation's
+            code = torch.nn.functional.interpolate(torch.randn(1, C, 7, 7, generator=gen), (G, G), mode="bicubic")[0].permute(1, 2, 0).reshape(G * G, C) * 2 + 0.3
+        else:
+            code = torch.randn(G * G, C, generator=gen)
+        code = code.numpy().astype(np.float32)
+        ld, cd, x = SA.kmeans_pixels_full(code, G, H, K, form="direct")
+        ll, cl, x2 = SA.kmeans_pixels_full(code, G, H, K, form="linear")
+        assert np.array_equal(x, x2)                                       # the same points, bit for bit
+        eps_c = float(np.sqrt(((cd.astype(np.float64) - cl) ** 2).sum(1)).max())
+        mism = np.nonzero(ld != ll)[0]
+        assert mism.size <= 0.002 * ld.size, (G, H, K, mism.size)
+        if mism.size:
+            sims = x[mism].astype(np.float64) @ cd.astype(np.float64).T
+            margin = sims[np.arange(mism.size), ld[mism]] - sims[np.arange(mism.size), ll[mism]]
+            assert margin.max() <= 2 * eps_c + 2e-6, (margin.max(), eps_c)

@@ -791,6 +791,19 @@ int wvn_kmeans_cosine_pixels(const float* code, int* labels, int* nseg, void* sc
                              int relabel, void* stream) {
   return wvn_kmeans_pixels_launch(code, labels, nseg, (float*)scratch, B, G, H, C, K, iters, relabel, (hipStream_t)stream);
 }
+int wvn_kmeans_pixels_linear_supported_shape(int G, int H, int C, int K) { return wvn_kmeans_pixels_linear_supported(G, H, C, K); }
+size_t wvn_kmeans_pixels_linear_scratch_bytes(int B, int G, int H, int C, int K) {
+  return (B > 0 && wvn_kmeans_pixels_linear_supported(G, H, C, K)) ? wvn_kmeans_pixels_linear_scratch_floats(B, G, H, C, K) * sizeof(float) : 0;
+}
+int wvn_kmeans_cosine_pixels_linear(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K,
+                                    int iters, int relabel, void* stream) {
+  return wvn_kmeans_pixels_linear_launch(code, labels, nseg, (float*)scratch, B, G, H, C, K, iters, relabel, (hipStream_t)stream);
+}
+int wvn_table_argmax_slots(int K) { return wvn_table_slots(K); }
+int wvn_table_bilerp_argmax(const float* table, int* labels, int B, int G, int H, int K, void* stream) {
+  return wvn_table_bilerp_argmax_launch(table, labels, B, G, H, K, (hipStream_t)stream);
+}
+int wvn_debug_kmeans_linear_rows(int rc) { wvn_kmeans_pixels_linear_set_rows(rc); return WVN_OK; }
 int wvn_flip_average(const float* a, const float* mirrored, float* out, int B, int G, int C, void* stream) {
   return wvn_flip_average_launch(a, mirrored, out, B, G, C, (hipStream_t)stream);
 }

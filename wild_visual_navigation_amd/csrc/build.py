@@ -20,7 +20,7 @@ LIB = os.path.join(PKG, "lib", "libwvn_hip.so")
 SOURCES = [
     "api.hip", "gemm_bf16.hip", "gemm_a384.hip", "gemm_n384.hip", "mlp_fused.hip", "qkv_fused.hip", "gemm_proj.hip", "gemm_x3.hip", "gemm_a384_x3.hip", "gemm_n384_x3.hip", "gemm_fp8.hip", "fp8.hip", "gemm_f32.hip", "elementwise.hip", "attention_bf16.hip",
     "attention_x3.hip", "attention_f32.hip",
-    "segments.hip", "stego.hip", "mlp.hip", "mlp_train.hip", "pixel_mlp.hip", "supervision.hip", "slic.hip", "wire.hip",
+    "segments.hip", "stego.hip", "stego_linear.hip", "mlp.hip", "mlp_train.hip", "pixel_mlp.hip", "supervision.hip", "slic.hip", "wire.hip",
 ]
 # the kernels of the 16-bit-operand speed path are compiled twice (operand.h): bf16 operands, and fp16 operands (-> <name>_f16.o)
 DUAL_OPERAND = ["gemm_bf16.hip", "gemm_a384.hip", "gemm_n384.hip", "mlp_fused.hip", "qkv_fused.hip", "gemm_proj.hip", "attention_bf16.hip"]
@@ -28,7 +28,7 @@ HEADERS = ["common.h", "operand.h", "mlp_device.h", "wvn_internal.h", os.path.jo
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5", "-Wall",
          "-Wno-unused-function"]
 # bit-exact integer outputs need un-fused multiply/add in the k-means kernels (see stego.hip)
-EXTRA = {"stego.hip": ["-ffp-contract=off"], "supervision.hip": ["-ffp-contract=off"],
+EXTRA = {"stego.hip": ["-ffp-contract=off"], "stego_linear.hip": ["-ffp-contract=off"], "supervision.hip": ["-ffp-contract=off"],
          "attention_bf16.hip": ["-fno-honor-nans"] + os.environ.get("WVN_ATTN_FLAGS", "").split(),
          "attention_x3.hip": ["-fno-honor-nans"], "mlp_fused.hip": os.environ.get("WVN_MLP_FLAGS", "").split()}
 

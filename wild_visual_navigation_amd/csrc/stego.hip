@@ -1120,9 +1120,11 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   if (const int rc = lds_opt_in(96 * 1024, (const void*)km_pix_rinv_kernel<C>, (const void*)km_pix_assign_kernel<C, 20, true>,
                                 (const void*)km_pix_assign_kernel<C, 32, false>, (const void*)km_pix_assign_wide_kernel<C>,
                                 (const void*)km_pix_assign_pk_kernel<C, false>, (const void*)km_pix_assign_pk_kernel<C, true>)) return rc;
-  static LdsOptIn lds_opt_in_m;
-  if (const int rc = lds_opt_in_m(150 * 1024, (const void*)km_pix_assign_screen_kernel<C>)) return rc;
   const bool mfma = g_km_assign_form >= 1 && g_km_assign_form <= 3 && pixm_ok(G, H, C, K);
+  if (mfma) {   // (the opt-in screened kernel's 150 KB attribute must not be able to fail the default path)
+    static LdsOptIn lds_opt_in_m;
+    if (const int rc = lds_opt_in_m(150 * 1024, (const void*)km_pix_assign_screen_kernel<C>)) return rc;
+  }
   const int nrb = ceil_div(H, PIX_RPB);
   hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(nrb * B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
                      s.rinv, G, H, B);
@@ -1227,6 +1229,28 @@ int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* s
   if (C == 90) return run_kmeans_pixels<90>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st);
   if (C == 16) return run_kmeans_pixels<16>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st);
   return WVN_ERR_ARG;
+}
+
+// the two steps the linear form of the pixel k-means (csrc/stego_linear.hip) shares with the direct one: rinv[b][p] of every code pixel
+// and the initial centroids c_k = x at pixel floor((2k+1) P / 2K); and the ascending compaction of the used ids
+int wvn_km_pix_prepare_launch(const float* code, float* rinv, float* cent, int B, int G, int H, int C, int K, hipStream_t st) {
+  if ((size_t)2 * G * C * sizeof(float) > 96 * 1024) return WVN_ERR_ARG;
+  const int nrb = ceil_div(H, PIX_RPB), threads = H >= 512 ? 512 : (H + 63) / 64 * 64;
+  const size_t shm_rows = (size_t)2 * G * C * sizeof(float);
+  static LdsOptIn opt;
+  if (const int rc = opt(96 * 1024, (const void*)km_pix_rinv_kernel<90>, (const void*)km_pix_rinv_kernel<16>)) return rc;
+  if (C == 90) hipLaunchKernelGGL((km_pix_rinv_kernel<90>), dim3(nrb * B), dim3(threads), shm_rows, st, code, rinv, G, H, B);
+  else if (C == 16) hipLaunchKernelGGL((km_pix_rinv_kernel<16>), dim3(nrb * B), dim3(threads), shm_rows, st, code, rinv, G, H, B);
+  else return WVN_ERR_ARG;
+  WVN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, rinv, cent, G, H, C, K, (float*)nullptr);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+int wvn_km_relabel_launch(int* labels, int* nseg, int B, long long P, int K, int relabel, hipStream_t st) {
+  hipLaunchKernelGGL(km_relabel_kernel, dim3(B), dim3(1024), 0, st, labels, nseg, (int)P, K, relabel);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
 }
 
 void wvn_kmeans_pixels_set_assign_form(int form) { g_km_assign_form = form; }

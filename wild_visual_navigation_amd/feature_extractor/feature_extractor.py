@@ -40,7 +40,7 @@ class FeatureExtractor:
                 backbone_weights=kwargs.get("pretrained_weights"), head_weights=kwargs.get("head_weights"),
                 probe_weights=kwargs.get("probe_weights"), model_path=kwargs.get("model_path"),
                 max_chunk=kwargs.get("max_chunk", 16), flip_tta=kwargs.get("flip_tta", True),
-                cluster_resolution=kwargs.get("cluster_resolution", "pixel"),
+                cluster_resolution=kwargs.get("cluster_resolution", "pixel"), kmeans_form=kwargs.get("kmeans_form", "linear"),
                 allow_synthetic=kwargs.get("allow_synthetic", False), fuse_mlp=kwargs.get("fuse_mlp"), fuse_qkv=kwargs.get("fuse_qkv"), fuse_proj=kwargs.get("fuse_proj", True),
             )
         elif "dino" in self._feature_type:

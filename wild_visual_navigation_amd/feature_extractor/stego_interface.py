@@ -16,9 +16,14 @@ averages the code with the flipped-back code of the mirrored frame; postprocess 
 the cheap forms are opt-in, and bench.py names which one each of its legs ran:
   flip_tta            True | False : average the code with the code of the horizontally flipped frame (a second backbone pass; the
                                      mirror is a reversed column table of the fused ingest, no flipped frame exists)
-  cluster_resolution  "pixel" | "patch": k-means over the H x H bilinearly up-sampled code pixels (interpolated on the fly, the
-                                     dense code never exists) or over the G x G patch codes (labels then nearest-upsampled:
-                                     segments are patch-aligned; 2.8x the frames/s of the default pair)
+  cluster_resolution  "pixel" | "patch": k-means over the H x H bilinearly up-sampled code pixels (the dense code never exists) or
+                                     over the G x G patch codes (labels then nearest-upsampled: segments are patch-aligned).  The
+                                     probes of a checkpoint (run_clustering=False, linear_pred) follow the same reading: at
+                                     "pixel" their per-patch scores are interpolated and the argmax is taken per pixel
+  kmeans_form         "linear" | "direct": how the pixel-resolution k-means is evaluated -- through its linearity (a similarity
+                                     table per pass interpolated per pixel, centroid sums from summed tap weights; ~1/20 of the
+                                     arithmetic, oracle/kmeans_linear.py) or row by row (oracle/interfaces.py); same clustering,
+                                     maps equal except at fp32 rounding ties
 """
 import re
 import warnings
@@ -111,6 +116,7 @@ class StegoInterface:
         max_chunk: int = 16,
         flip_tta: bool = True,
         cluster_resolution: str = "pixel",
+        kmeans_form: str = "linear",   # "linear" | "direct": the two statements of the pixel-resolution k-means (ops.kmeans_cosine_pixels)
         allow_synthetic: bool = False,
         fuse_mlp: Optional[bool] = None,
         fuse_qkv: Optional[bool] = None,
@@ -163,6 +169,9 @@ class StegoInterface:
         self._precision = precision
         self._flip_tta = flip_tta
         self._cluster_resolution = cluster_resolution
+        if kmeans_form not in ("linear", "direct"):
+            raise _lib.WvnError("kmeans_form must be 'linear' or 'direct'")
+        self._kmeans_form = kmeans_form
         head = head_weights if head_weights is not None else synthetic_stego_head(D)
         head = {k: v.reshape(v.shape[0], -1) if v.dim() > 2 else v for k, v in head.items()}  # conv1x1 -> linear
         self._head_sd = head
@@ -297,12 +306,24 @@ class StegoInterface:
         self._labels_patch = None
         if self._cluster_resolution == "pixel":      # cluster the S x S up-sampled code pixels
             K = self._cfg.n_image_clusters
-            if self._cfg.run_clustering and ops.kmeans_cosine_pixels_supported(G, S, self._C, K):
-                # rows interpolated on the fly from the patch codes: the dense code is never built
-                labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, S, K, KMEANS_ITERS, relabel=True)
-            elif self._cfg.run_clustering:   # code dimension / cluster count outside the fused kernel's instantiations: dense rows
-                pix = ops.upsample_bilinear(code, G, S).permute(0, 2, 3, 1).reshape(B, S * S, self._C).contiguous()
-                labels, self._n_segments = ops.kmeans_cosine(pix, K, KMEANS_ITERS, relabel=True)
+            if self._cfg.run_clustering:
+                # the dense code is never built: per pass a similarity table interpolated per pixel and summed tap weights times the
+                # patch codes (kmeans_form="linear", csrc/stego_linear.hip), or every row re-created from the patch codes and
+                # multiplied out ("direct", csrc/stego.hip) -- the same clustering, fixed summation orders in both
+                form = self._kmeans_form
+                if form == "linear" and not ops.kmeans_pixels_linear_supported(G, S, self._C, K):
+                    form = "direct"
+                if form == "direct" and not ops.kmeans_cosine_pixels_supported(G, S, self._C, K):
+                    raise _lib.WvnError(f"StegoInterface: the pixel-resolution k-means has kernels for code dimension 90 or 16 and up to "
+                                        f"32 (linear form) / 64 (direct form) clusters, not C={self._C}, K={K}; use cluster_resolution='patch' "
+                                        "with C in {16, 64, 90}")
+                labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, S, K, KMEANS_ITERS, relabel=True, form=form)
+            elif self._clusters.shape[0] <= 32:
+                # the cluster probe at pixel resolution: cosine similarity is linear in the (un-normalised) code up to the pixel's
+                # positive norm, so the argmax over the interpolated patch similarities IS the argmax on the interpolated code
+                sim = ops.gemm_f32(code.reshape(B * G * G, self._C), self._clusters, None)
+                labels = ops.table_bilerp_argmax(sim.reshape(B, G * G, -1), G, S)
+                self._n_segments = None
             else:
                 pix = ops.upsample_bilinear(code, G, S).permute(0, 2, 3, 1).reshape(B * S * S, self._C)   # [B, C, S, S] -> pixel rows
                 labels = self._probe_labels(pix, self._clusters, None, cosine=True)
@@ -318,8 +339,18 @@ class StegoInterface:
             self._labels_patch = labels.reshape(B, G, G)  # patch-resolution ids (before the nearest up-sampling)
             self._cluster_pred = ops.upsample_nearest_labels(self._labels_patch, H)[None]
         if self._w_probe is not None:
-            lin = self._probe_labels(code.reshape(B * G * G, self._C), self._w_probe, self._b_probe, cosine=False)
-            self._linear_pred = ops.upsample_nearest_labels(lin.reshape(B, G, G), H)[None]
+            # ONE reading for both probes: with cluster_resolution="pixel" the linear probe too acts on the up-sampled
+            # code (stego_interface.py:94-100: postprocess works on the interpolated code) -- its logits are linear in the code and
+            # the interpolation weights sum to one, so the patch logits are interpolated and the argmax taken per pixel; with
+            # "patch" both probes label patches and the maps are nearest-upsampled
+            rows = code.reshape(B * G * G, self._C)
+            if self._cluster_resolution == "pixel" and self._w_probe.shape[0] <= 32:
+                logits = ops.gemm_f32(rows if rows.is_contiguous() else rows.contiguous(), self._w_probe, self._b_probe)
+                lin = ops.table_bilerp_argmax(logits.reshape(B, G * G, -1), G, S)
+                self._linear_pred = (lin if H == S else ops.upsample_nearest_labels(lin, H))[None]
+            else:
+                lin = self._probe_labels(rows, self._w_probe, self._b_probe, cosine=False)
+                self._linear_pred = ops.upsample_nearest_labels(lin.reshape(B, G, G), H)[None]
         else:
             self._linear_pred = None
         return self._linear_pred, self._cluster_pred

@@ -277,24 +277,61 @@ def kmeans_cosine_pixels_supported(G: int, H: int, C: int, K: int) -> bool:
     return C in (90, 16) and 0 < K <= 64 and 2 * G * C * 4 <= 96 * 1024 and G > 0 and H > 0
 
 
+def kmeans_pixels_linear_supported(G: int, H: int, C: int, K: int) -> bool:
+    """Whether the linear form of the pixel k-means (``wvn_kmeans_cosine_pixels_linear``, csrc/stego_linear.hip) has an instantiation
+    for this shape (code dimension 90 or 16, up to 32 clusters, its per-band tables within the LDS)."""
+    return bool(lib().wvn_kmeans_pixels_linear_supported_shape(G, H, C, K))
+
+
 def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int = 10, relabel: bool = True,
-                         return_centroids: bool = False):
+                         return_centroids: bool = False, form: str = "linear"):
     """code [B, G*G, C] fp32 patch codes -> (labels [B, H*H] int32, n_segments [B] int32): the k-means of ``kmeans_cosine`` over
-    the H x H bilinearly up-sampled, normalised code pixels, interpolated on the fly (the [B, H*H, C] array is never built)."""
+    the H x H bilinearly up-sampled, normalised code pixels (the [B, H*H, C] array is never built).
+    form="linear" (default, oracle/kmeans_linear.py): assignment from a per-pass similarity table interpolated per pixel, centroid
+    sums from summed tap weights times the patch codes -- the same clustering at ~1/20 of the arithmetic; form="direct"
+    (oracle/interfaces.py::kmeans_cosine_labels_pixels): every row re-created and multiplied out in every pass.  Both are
+    deterministic and bit-exact against their oracle; they differ from each other only where two similarities tie within fp32 rounding."""
     require_cuda(code, "code")
     B, P, Cc = code.shape
     if P != G * G:
         raise _lib.WvnError(f"kmeans_cosine_pixels: {P} code rows for a {G} x {G} grid")
+    if form not in ("linear", "direct"):
+        raise _lib.WvnError(f"kmeans_cosine_pixels: form must be 'linear' or 'direct', not {form!r}")
     code = code.contiguous()
     dev = code.device
     labels = torch.empty(B, H * H, dtype=torch.int32, device=dev)
     nseg = torch.empty(B, dtype=torch.int32, device=dev)
-    scratch = torch.empty(lib().wvn_kmeans_pixels_scratch_bytes(B, G, H, Cc, K), dtype=torch.uint8, device=dev)
-    check(lib().wvn_kmeans_cosine_pixels(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters, int(relabel),
-                                         stream()), "wvn_kmeans_cosine_pixels")
+    if form == "linear":
+        if not kmeans_pixels_linear_supported(G, H, Cc, K):
+            raise _lib.WvnError(f"kmeans_cosine_pixels(form='linear'): no instantiation for G={G}, H={H}, C={Cc}, K={K} "
+                                "(C in {16, 90}, K <= 32); use form='direct'")
+        scratch = torch.empty(lib().wvn_kmeans_pixels_linear_scratch_bytes(B, G, H, Cc, K), dtype=torch.uint8, device=dev)
+        check(lib().wvn_kmeans_cosine_pixels_linear(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters,
+                                                    int(relabel), stream()), "wvn_kmeans_cosine_pixels_linear")
+    else:
+        scratch = torch.empty(lib().wvn_kmeans_pixels_scratch_bytes(B, G, H, Cc, K), dtype=torch.uint8, device=dev)
+        check(lib().wvn_kmeans_cosine_pixels(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters, int(relabel),
+                                             stream()), "wvn_kmeans_cosine_pixels")
     if return_centroids:
         return labels, nseg, scratch.view(torch.float32)[: B * K * Cc].reshape(B, K, Cc).clone()
     return labels, nseg
+
+
+def table_bilerp_argmax(table: torch.Tensor, G: int, H: int) -> torch.Tensor:
+    """table [B, G*G, K] fp32 (K <= 32 scores per patch) -> labels [B, H, H] int32: per pixel the first-maximum argmax of the
+    bilinearly interpolated (align_corners=True, fixed operation order) scores -- a linear probe at pixel resolution."""
+    require_cuda(table, "table")
+    B, P, K = table.shape
+    if P != G * G:
+        raise _lib.WvnError(f"table_bilerp_argmax: {P} rows for a {G} x {G} grid")
+    KP = lib().wvn_table_argmax_slots(K)
+    if KP <= 0:
+        raise _lib.WvnError(f"table_bilerp_argmax: 1..32 scores per patch are supported, not {K}")
+    t = table.float()
+    t = torch.nn.functional.pad(t, (0, KP - K)).contiguous() if KP != K else t.contiguous()
+    labels = torch.empty(B, H, H, dtype=torch.int32, device=table.device)
+    check(lib().wvn_table_bilerp_argmax(ptr(t), ptr(labels), B, G, H, K, stream()), "wvn_table_bilerp_argmax")
+    return labels
 
 
 def flip_average(code: torch.Tensor, mirrored: torch.Tensor, G: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
