@@ -28,7 +28,8 @@ Definition (all fp32, one rounding per stated operation; `chain` = acc = fma(a, 
             band b = the rows y with i0(y) == b:   P0[b, k, j] = chain_y wy0(y) U[y, k, j],   P1[b, k, j] = chain_y wy1(y) U[y, k, j]
             A[k, i, j] = plain adds from +0, bands ascending, P0 before P1, of every P_s[b] whose patch row (b for s = 0, i1 of the band for s = 1) is i
             R[i, k, d] = chain_j A[k, i, j] code[i, j, d]
-            sums[k, d] = plain adds from +0 over i ascending of R[i, k, d]
+            Q[g, k, d] = plain adds from +0 over the patch rows i of group g (ROW_GROUP = 4 consecutive rows), ascending, of R[i, k, d]
+            sums[k, d] = plain adds from +0 over g ascending of Q[g, k, d]
             c_k        = sums_k * (1 / max(sqrt(chain_d sums_k[d]^2), 1e-12)) if the cluster has members, else unchanged
   final labels = one more assignment.
 """
@@ -39,6 +40,7 @@ import numpy as np
 from . import interfaces as OI
 
 f32 = np.float32
+ROW_GROUP = 4   # patch rows whose row sums are added before the groups are (csrc/stego_linear.hip: LIN_RG)
 
 
 def taps(G: int, H: int):
@@ -96,8 +98,11 @@ def centroid_sums(code: np.ndarray, lab: np.ndarray, rinv: np.ndarray, G: int, H
         a = np.ascontiguousarray(A[:, :, j].T)[:, :, None]                              # [i, k, 1]
         R = OI._fma32(np.broadcast_to(a, R.shape), np.broadcast_to(cmap[:, j, None, :], R.shape), R)
     sums = np.zeros((K, C), dtype=np.float32)
-    for i in range(G):
-        sums = (sums + R[i]).astype(np.float32)
+    for i0_ in range(0, G, ROW_GROUP):                                                   # two levels: rows inside a group, then the groups
+        q = np.zeros((K, C), dtype=np.float32)
+        for i in range(i0_, min(G, i0_ + ROW_GROUP)):
+            q = (q + R[i]).astype(np.float32)
+        sums = (sums + q).astype(np.float32)
     return sums
 
 

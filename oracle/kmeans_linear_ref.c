@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define ROW_GROUP 4
+
 static float lin_rinv_norm(float n2) {
   float n = sqrtf(n2);
   if (n < 1e-12f) n = 1e-12f;
@@ -130,8 +132,12 @@ int wvn_oracle_kmeans_pixels_linear(const float* code, int G, int H, int C, int 
           R[((long)i * K + k) * C + d] = acc;
         }
     for (long e = 0; e < (long)K * C; ++e) sums[e] = 0.f;
-    for (int i = 0; i < G; ++i)
-      for (long e = 0; e < (long)K * C; ++e) sums[e] = sums[e] + R[(long)i * K * C + e];
+    for (int g0 = 0; g0 < G; g0 += ROW_GROUP)      /* two levels: the rows of a group of 4 patch rows ascending, then the groups ascending */
+      for (long e = 0; e < (long)K * C; ++e) {
+        float q = 0.f;
+        for (int i = g0; i < G && i < g0 + ROW_GROUP; ++i) q = q + R[(long)i * K * C + e];
+        sums[e] = sums[e] + q;
+      }
     for (int k = 0; k < K; ++k) {
       if (cnt[k] == 0) continue;
       float n2 = 0.f;

@@ -9,7 +9,7 @@ name=$1; src=$2; shift 2
 C=wild_visual_navigation_amd/csrc; B=$C/_build; V=$B/variant_$name; mkdir -p $V
 base=${src%.hip}
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mcode-object-version=5 -Wall -Wno-unused-function"
-case $src in attention_bf16.hip|attention_x3.hip) FL="$FL -fno-honor-nans";; stego.hip|supervision.hip) FL="$FL -ffp-contract=off";; esac
+case $src in attention_bf16.hip|attention_x3.hip) FL="$FL -fno-honor-nans";; stego.hip|stego_linear.hip|supervision.hip) FL="$FL -ffp-contract=off";; esac
 /opt/rocm/bin/hipcc $FL "$@" -c $C/$src -o $V/$base.o &
 if [ -f $B/${base}_f16.o ]; then /opt/rocm/bin/hipcc $FL "$@" -DWVN_OPERAND_F16=1 -c $C/$src -o $V/${base}_f16.o & fi
 wait

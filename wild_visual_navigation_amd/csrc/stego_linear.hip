@@ -15,8 +15,10 @@
 // Kernels of one pass (all frames at once, a frame pinned to one XCD's L2 as in stego.hip):
 //   km_lin_assign   one workgroup per (frame, band b = the image rows whose upper tap is patch row b): the two table rows in LDS;
 //                   lane = pixel: K bilinear interpolations + argmax; then U[y, k, j] (ascending x), P0 / P1[b, k, j] (ascending y)
-//   km_lin_rowsum   one workgroup per (frame, patch row i): A[k, i, :] = P1[i-1] + P0[i] (+ P1[i] on the last row), R[i, k, d] = chain_j A code
-//   km_lin_table    sums = sum_i R (ascending), normalise, keep the centroids of empty clusters, then S[t, :] for 128 patches per workgroup
+//   km_lin_rowsum   one workgroup per (frame, group of 4 patch rows): A[k, i, :] = P1[i-1] + P0[i] (+ P1[i] on the last row),
+//                   R[i, k, d] = chain_j A code, Q[g, k, d] = the group's R in ascending i (registers)
+//   km_lin_table    sums = sum_g Q (ascending), normalise, keep the centroids of empty clusters, then S[t, :] for 256 patches per workgroup
+//   (the last assignment leaves a bit mask of the ids in use; km_lin_relabel compacts them ascending)
 // This translation unit is compiled with -ffp-contract=off: every fused operation is an explicit __fmaf_rn.
 #include "common.h"
 #include "wvn_internal.h"
@@ -41,11 +43,15 @@ __device__ inline void lin_frame_map(int id, int nx, int B, int& ix, int& b) {
   }
 }
 
+#ifndef WVN_LIN_ABL
+#define WVN_LIN_ABL 0   // (timing experiments only, scripts/build_variant.sh: 1 = no U phase, 2 = no P phase, 4 = no rinv loads, 8 = no member counts)
+#endif
+typedef __attribute__((ext_vector_type(2))) float f32x2l_t;
 constexpr int LIN_THREADS = 320;   // km_lin_assign: five waves (at 448^2 / 56 x 56: 5 rows x 7 wave tasks, 5 x 56 = 280 (row, patch column) tasks)
-constexpr int LIN_RC = 5;          // image rows of a band worked on at a time
+constexpr int LIN_RC = 4;          // image rows of a band worked on at a time (measured 3 / 4 / 5 / 9: 3.46 / 3.31 / 3.75 / 5.05 ms per 64-frame k-means)
 
 struct LinLds {   // byte offsets into km_lin_assign's dynamic LDS
-  int S, U, P, rinv, xw0, xw1, xj, first, cnt, lab, bytes;
+  int S, U, P, rinv, xrec, first, cnt, lab, bytes;
 };
 __host__ __device__ inline LinLds lin_lds(int G, int H, int KP, int RC) {
   const int HP = (H + 63) / 64 * 64;
@@ -55,10 +61,8 @@ __host__ __device__ inline LinLds lin_lds(int G, int H, int KP, int RC) {
   l.S = take(2 * G * KP * 4);
   l.U = take(RC * KP * G * 4);
   l.P = take(2 * KP * G * 4);
-  l.rinv = take(RC * HP * 4);
-  l.xw0 = take(HP * 4);
-  l.xw1 = take(HP * 4);
-  l.xj = take(HP * 4);
+  l.rinv = take((RC * H * 4 + 1023) / 1024 * 1024);   // [RC][H], copied by whole 1 KB direct-to-LDS pieces
+  l.xrec = take(HP * 16);                               // per index o: {i0 (int bits), w0, w1, -}: the taps are the same along x and along y
   l.first = take((G + 2) * 4);
   l.cnt = take(KP * 4);
   l.lab = take(RC * HP);
@@ -70,36 +74,35 @@ __host__ __device__ inline LinLds lin_lds(int G, int H, int KP, int RC) {
 template <int KP, bool FINAL>
 __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float* __restrict__ S, const float* __restrict__ rinv,
                                                                     float* __restrict__ Pg, int* __restrict__ cntp,
-                                                                    int* __restrict__ labels, int G, int H, int K, int B, int RC) {
+                                                                    int* __restrict__ labels, unsigned* __restrict__ used, int G, int H,
+                                                                    int K, int B, int RC) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const LinLds L = lin_lds(G, H, KP, RC);
   float* Sl = (float*)(lds + L.S);        // [2][G][KP]
   float* Ul = (float*)(lds + L.U);        // [RC][KP][G]
   float* Pl = (float*)(lds + L.P);        // [2][KP][G]
-  float* rl = (float*)(lds + L.rinv);     // [RC][HP]
-  float* xw0 = (float*)(lds + L.xw0);     // [HP]   (the taps of index o are the same along x and along y: square frames)
-  float* xw1 = (float*)(lds + L.xw1);
-  int* xj = (int*)(lds + L.xj);           // [HP] i0 of the tap
+  float* rl = (float*)(lds + L.rinv);     // [RC][H]
+  f32x4_t* xrec = (f32x4_t*)(lds + L.xrec);   // [HP] {i0, w0, w1, -}
   int* first = (int*)(lds + L.first);     // [G + 1]: first[j] = the first index whose i0 >= j (H if none)
   int* cntl = (int*)(lds + L.cnt);        // [KP]
   unsigned char* labl = lds + L.lab;      // [RC][HP]
   const int HP = (H + 63) / 64 * 64;
   int band, b;
   lin_frame_map(blockIdx.x, G, B, band, b);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = blockDim.x >> 6;
   const size_t T = (size_t)G * G;
   const float scale = lerp_scale(G, H);
   for (int i = tid; i <= G; i += blockDim.x) first[i] = H;
   if (tid < KP) cntl[tid] = 0;
-  for (int o = tid; o < H; o += blockDim.x) {
-    const LerpTap t = lerp_tap(o, G, scale);
-    xw0[o] = t.w0; xw1[o] = t.w1; xj[o] = t.i0;
+  for (int o = tid; o < HP; o += blockDim.x) {
+    const LerpTap t = lerp_tap(min(o, H - 1), G, scale);
+    xrec[o] = f32x4_t{__int_as_float(t.i0), t.w0, t.w1, 0.f};
   }
   for (int i = tid; i < 2 * KP * G; i += blockDim.x) Pl[i] = 0.f;
   __syncthreads();
   for (int o = tid; o < H; o += blockDim.x) {
-    const int prev = o == 0 ? -1 : xj[o - 1];
-    for (int j = prev + 1; j <= xj[o]; ++j) first[j] = o;   // (distinct writers: i0 is monotone)
+    const int prev = o == 0 ? -1 : __float_as_int(xrec[o - 1][0]), me = __float_as_int(xrec[o][0]);
+    for (int j = prev + 1; j <= me; ++j) first[j] = o;   // (distinct writers: i0 is monotone)
   }
   __syncthreads();
   const int ylo = first[band], yhi = first[band + 1];
@@ -115,38 +118,63 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
   }
   __syncthreads();
   const int nseg = HP >> 6;
-  int mycnt = 0;   // lane k: members of cluster k seen by this wave
+  int mycnt = 0;         // lane k: members of cluster k seen by this wave
+  unsigned mymask = 0;   // (FINAL) the labels this wave has assigned
+  // the chunk's reciprocal norms travel global -> LDS directly (buffer_load ... lds, 1 KB per wave instruction), requested before the
+  // labels are computed and waited for behind them: as register loads in front of LDS stores they cost the kernel 2.6 of its 4.2 ms
+  // (a memory round trip per wave task, then -- hoisted -- 57 registers and a workgroup of occupancy)
+  const bool dma = !FINAL && (H & 3) == 0 && !(WVN_LIN_ABL & 4);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(rinv + (FINAL ? 0 : (size_t)b * H * H)), 0,
+                                                                          FINAL ? 0u : (unsigned)((size_t)H * H * sizeof(float)), 0x00020000);
   for (int c0 = ylo; c0 < yhi; c0 += RC) {
     const int rows = min(RC, yhi - c0);
+    if (dma) {
+      const int npiece = (rows * H * 4 + 1023) >> 10;
+      for (int pc = wave; pc < npiece; pc += nwave)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (__attribute__((address_space(3))) void*)((unsigned char*)rl + pc * 1024), 16, lane * 16,
+                                                 __builtin_amdgcn_readfirstlane((c0 * H) * 4 + pc * 1024), 0, 0);
+    }
     // ---- labels of the chunk's pixels: one wave per 64 pixels of a row ----
     for (int task = wave; task < rows * nseg; task += nwave) {
       const int r = task / nseg, x = (task - r * nseg) * 64 + lane, y = c0 + r;
       const bool valid = x < H;
-      const int xc = valid ? x : H - 1;
-      const int j0 = xj[xc], j1 = j0 + (j0 < G - 1 ? 1 : 0);
-      const float wx0 = xw0[xc], wx1 = xw1[xc], wy0 = xw0[y], wy1 = xw1[y];
-      if (!FINAL) rl[r * HP + x] = valid ? rinv[(size_t)b * H * H + (size_t)y * H + x] : 0.f;
+      const f32x4_t tx = xrec[x], ty = xrec[y];
+      const int j0 = __float_as_int(tx[0]), j1 = j0 + (j0 < G - 1 ? 1 : 0);
+      const float wx0 = tx[1], wx1 = tx[2], wy0 = ty[1], wy1 = ty[2];
       const float* a0 = Sl + j0 * KP;
       const float* a1 = Sl + j1 * KP;
       const float* b0 = a0 + G * KP;
       const float* b1 = a1 + G * KP;
       float best = -INFINITY;
       int bi = 0;
+      const f32x2l_t X0 = {wx0, wx0}, X1 = {wx1, wx1}, Y0 = {wy0, wy0}, Y1 = {wy1, wy1};
 #pragma unroll
       for (int k4 = 0; k4 < KP / 4; ++k4) {
         const f32x4_t v00 = *(const f32x4_t*)(a0 + 4 * k4), v01 = *(const f32x4_t*)(a1 + 4 * k4);
         const f32x4_t v10 = *(const f32x4_t*)(b0 + 4 * k4), v11 = *(const f32x4_t*)(b1 + 4 * k4);
+        // (two clusters per v_pk_mul_f32 / v_pk_fma_f32: the halves are independent correctly rounded operations -- the bits of bilerp_fixed)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float v = bilerp_fixed(v00[q], v01[q], v10[q], v11[q], wx0, wx1, wy0, wy1);
-          if (4 * k4 + q < K && v > best) { best = v; bi = 4 * k4 + q; }
+        for (int h = 0; h < 2; ++h) {
+          const f32x2l_t c00 = {v00[2 * h], v00[2 * h + 1]}, c01 = {v01[2 * h], v01[2 * h + 1]};
+          const f32x2l_t c10 = {v10[2 * h], v10[2 * h + 1]}, c11 = {v11[2 * h], v11[2 * h + 1]};
+          const f32x2l_t t0 = __builtin_elementwise_fma(X1, c01, X0 * c00);
+          const f32x2l_t t1 = __builtin_elementwise_fma(X1, c11, X0 * c10);
+          const f32x2l_t v = __builtin_elementwise_fma(Y1, t1, Y0 * t0);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (4 * k4 + 2 * h + q < K && v[q] > best) { best = v[q]; bi = 4 * k4 + 2 * h + q; }
         }
       }
       if (FINAL) {
         if (valid) labels[(size_t)b * H * H + (size_t)y * H + x] = bi;
+        for (unsigned long long todo = __ballot(valid); todo;) {
+          const int k = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(todo));
+          mymask |= 1u << k;
+          todo &= ~__ballot(bi == k);
+        }
       } else {
         labl[r * HP + x] = (unsigned char)bi;
-        for (unsigned long long todo = __ballot(valid); todo;) {   // (uniform loop over the labels present among the 64 pixels)
+        for (unsigned long long todo = (WVN_LIN_ABL & 8) ? 0ull : __ballot(valid); todo;) {   // (uniform loop over the labels present among the 64 pixels)
           const int k = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(todo));
           const unsigned long long m = __ballot(bi == k && valid);
           if (lane == k) mycnt += __builtin_popcountll(m);
@@ -155,45 +183,75 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
       }
     }
     if (FINAL) continue;
+    if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      for (int e = tid; e < rows * H; e += blockDim.x) rl[e] = rinv[(size_t)b * H * H + (size_t)c0 * H + e];
     __syncthreads();
-    // ---- U[r][k][j]: the summed column weights of row r, cluster k, patch column j, pixels in ascending x (tap 0 before tap 1) ----
-    for (int task = tid; task < rows * G; task += blockDim.x) {
+    // ---- U[r][k][j]: the summed column weights of row r, cluster k, patch column j, pixels in ascending x (tap 0 before tap 1).
+    //      Four pixels' operands are fetched per LDS round trip; the additions stay one chain in pixel order ----
+    for (int task = tid; task < ((WVN_LIN_ABL & 1) ? 0 : rows * G); task += blockDim.x) {
       const int r = task / G, j = task - r * G;
       float* Ub = Ul + (size_t)r * KP * G + j;
       for (int k = 0; k < K; ++k) Ub[k * G] = 0.f;
       const int xa = first[max(j - 1, 0)], xb = first[j + 1];
       int cur = -1;          // the cluster whose running sum is in `acc` (the others are parked in Ub)
       float acc = 0.f;
-      for (int x = xa; x < xb; ++x) {
-        const int jx = xj[x], jx1 = jx + (jx < G - 1 ? 1 : 0);
-        const int l = labl[r * HP + x];
-        const float rr = rl[r * HP + x];
-        if (jx == j || jx1 == j) {
-          if (l != cur) {
-            if (cur >= 0) Ub[cur * G] = acc;
-            acc = Ub[l * G];
-            cur = l;
+      const unsigned char* lrow = labl + r * HP;
+      const float* rrow = rl + r * H;
+      for (int x0 = xa; x0 < xb; x0 += 4) {
+        f32x4_t tx[4];
+        int l[4];
+        float rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int x = min(x0 + u, H - 1);
+          tx[u] = xrec[x]; l[u] = lrow[x]; rr[u] = rrow[x];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jx = __float_as_int(tx[u][0]), jx1 = jx + (jx < G - 1 ? 1 : 0);
+          if (x0 + u < xb && (jx == j || jx1 == j)) {
+            if (l[u] != cur) {
+              if (cur >= 0) Ub[cur * G] = acc;
+              acc = Ub[l[u] * G];
+              cur = l[u];
+            }
+            if (jx == j) acc = __fadd_rn(acc, __fmul_rn(rr[u], tx[u][1]));
+            if (jx1 == j) acc = __fadd_rn(acc, __fmul_rn(rr[u], tx[u][2]));
           }
-          if (jx == j) acc = __fadd_rn(acc, __fmul_rn(rr, xw0[x]));
-          if (jx1 == j) acc = __fadd_rn(acc, __fmul_rn(rr, xw1[x]));
         }
       }
       if (cur >= 0) Ub[cur * G] = acc;
     }
     __syncthreads();
     // ---- P0 / P1[k][j]: chains over the band's rows in ascending y ----
-    for (int t = tid; t < K * G; t += blockDim.x) {
+    for (int t = tid; t < ((WVN_LIN_ABL & 2) ? 0 : K * G); t += blockDim.x) {
       float p0 = Pl[t], p1 = Pl[KP * G + t];
-      for (int r = 0; r < rows; ++r) {
-        const float u = Ul[(size_t)r * KP * G + t];
-        p0 = __fmaf_rn(xw0[c0 + r], u, p0);
-        p1 = __fmaf_rn(xw1[c0 + r], u, p1);
+      for (int r0 = 0; r0 < rows; r0 += 4) {
+        float u[4];
+        f32x4_t ty[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = min(r0 + q, rows - 1);
+          u[q] = Ul[(size_t)r * KP * G + t]; ty[q] = xrec[c0 + r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (r0 + q < rows) {
+            p0 = __fmaf_rn(ty[q][1], u[q], p0);
+            p1 = __fmaf_rn(ty[q][2], u[q], p1);
+          }
       }
       Pl[t] = p0; Pl[KP * G + t] = p1;
     }
     __syncthreads();
   }
-  if (FINAL) return;
+  if (FINAL) {   // the ids in use, for the ascending compaction (km_lin_relabel_kernel): one OR per workgroup
+    if (lane == 0 && mymask) atomicOr((unsigned*)&cntl[0], mymask);
+    __syncthreads();
+    if (tid == 0 && cntl[0] && used) atomicOr(&used[b], (unsigned)cntl[0]);
+    return;
+  }
   if (lane < K && mycnt) atomicAdd(&cntl[lane], mycnt);
   __syncthreads();
   float* dst = Pg + ((size_t)b * G + band) * 2 * KP * G;
@@ -201,91 +259,128 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
   if (tid < KP) cntp[((size_t)b * G + band) * KP + tid] = cntl[tid];
 }
 
-// R[b][i][k][d] = chain_j A[k][i][j] * code[b][i][j][d]; A[k][i][:] from the band tables that touch patch row i, bands ascending, P0 before P1
+// Q[b][g][k][d] = sum over the patch rows i of group g (LIN_RG consecutive rows, ascending, plain adds from +0) of
+// R[i][k][d] = chain_j A[k][i][j] * code[b][i][j][d];  A[k][i][:] from the band tables that touch patch row i, bands ascending, P0 before P1.
+// One 128-thread team per patch row of the group (thread = channel d, the row's whole code column requested at once: the chains are
+// short and a memory round trip per eight values made the kernel latency-bound), the group's rows then added in order through LDS.
+constexpr int LIN_RG = 4;   // (8 rows = 1024 threads leave 128 registers per thread: the 64-value column spilled)
+constexpr int LIN_MAXG = 64;   // patch columns a thread keeps in registers
+__host__ __device__ inline size_t lin_rowsum_lds(int G, int C, int K, int KP) { return ((size_t)LIN_RG * G * KP + (size_t)LIN_RG * K * C) * sizeof(float); }
 template <int KP>
-__global__ __launch_bounds__(128) void km_lin_rowsum_kernel(const float* __restrict__ code, const float* __restrict__ Pg,
-                                                            float* __restrict__ R, int G, int C, int K, int B) {
-  extern __shared__ __attribute__((aligned(16))) float Al[];   // [G][KP]
-  int i, b;
-  lin_frame_map(blockIdx.x, G, B, i, b);
+__global__ __launch_bounds__(LIN_RG * 128) void km_lin_rowsum_kernel(const float* __restrict__ code, const float* __restrict__ Pg,
+                                                                     float* __restrict__ Q, int G, int C, int K, int B) {
+  extern __shared__ __attribute__((aligned(16))) float Al[];   // [LIN_RG][G][KP], then R [LIN_RG][K][C]
+  float* Rl = Al + (size_t)LIN_RG * G * KP;
+  const int NG = (G + LIN_RG - 1) / LIN_RG;
+  int g, b;
+  lin_frame_map(blockIdx.x, NG, B, g, b);
   const int tid = threadIdx.x;
+  const int i0 = g * LIN_RG, nr = min(LIN_RG, G - i0);
   const float* Pb = Pg + (size_t)b * G * 2 * KP * G;
-  for (int t = tid; t < KP * G; t += blockDim.x) {
-    const int k = t / G, j = t - k * G;
-    float a = 0.f;
-    if (k < K) {
-      if (i >= 1) a = __fadd_rn(a, Pb[((size_t)(i - 1) * 2 + 1) * KP * G + t]);
-      a = __fadd_rn(a, Pb[((size_t)i * 2 + 0) * KP * G + t]);
-      if (i == G - 1) a = __fadd_rn(a, Pb[((size_t)i * 2 + 1) * KP * G + t]);
-    }
-    Al[j * KP + k] = a;
+  const int r = tid >> 7, d = tid & 127;
+  const bool act = r < nr && d < C;
+  float x[LIN_MAXG];
+  if (act) {
+    const float* cr = code + (((size_t)b * G + i0 + r) * G) * C + d;
+#pragma unroll
+    for (int j = 0; j < LIN_MAXG; ++j) x[j] = cr[(size_t)min(j, G - 1) * C];
   }
-  __syncthreads();
-  const int d = tid;
-  if (d >= C) return;
-  float acc[KP];
+  for (int e0 = tid; e0 < nr * KP * G; e0 += 4 * blockDim.x) {   // (four elements' band tables requested per round trip)
+    float pa[4], pb[4], pc[4];
 #pragma unroll
-  for (int k = 0; k < KP; ++k) acc[k] = 0.f;
-  const float* cr = code + (((size_t)b * G + i) * G) * C + d;
-  constexpr int UJ = 8;
-  for (int j0 = 0; j0 < G; j0 += UJ) {
-    float x[UJ];
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + u * (int)blockDim.x, nr * KP * G - 1);
+      const int rr = e / (KP * G), t = e - rr * KP * G, i = i0 + rr;
+      pa[u] = i >= 1 ? Pb[((size_t)(i - 1) * 2 + 1) * KP * G + t] : 0.f;
+      pb[u] = Pb[((size_t)i * 2 + 0) * KP * G + t];
+      pc[u] = i == G - 1 ? Pb[((size_t)i * 2 + 1) * KP * G + t] : 0.f;
+    }
 #pragma unroll
-    for (int u = 0; u < UJ; ++u) x[u] = cr[(size_t)min(j0 + u, G - 1) * C];
-#pragma unroll
-    for (int u = 0; u < UJ; ++u) {
-      if (j0 + u < G) {
-#pragma unroll
-        for (int k4 = 0; k4 < KP / 4; ++k4) {
-          const f32x4_t a4 = *(const f32x4_t*)(Al + (j0 + u) * KP + 4 * k4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[4 * k4 + q] = __fmaf_rn(a4[q], x[u], acc[4 * k4 + q]);
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * (int)blockDim.x;
+      if (e < nr * KP * G) {
+        const int rr = e / (KP * G), t = e - rr * KP * G, k = t / G, j = t - k * G, i = i0 + rr;
+        float a = 0.f;
+        if (k < K) {
+          if (i >= 1) a = __fadd_rn(a, pa[u]);
+          a = __fadd_rn(a, pb[u]);
+          if (i == G - 1) a = __fadd_rn(a, pc[u]);
         }
+        Al[((size_t)rr * G + j) * KP + k] = a;
       }
     }
   }
-  float* dst = R + (((size_t)b * G + i) * KP) * C + d;
+  __syncthreads();
+  if (act) {
+    float acc[KP];
 #pragma unroll
-  for (int k = 0; k < KP; ++k)
-    if (k < K) dst[(size_t)k * C] = acc[k];
+    for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+    const float* Ar = Al + (size_t)r * G * KP;
+#pragma unroll
+    for (int j = 0; j < LIN_MAXG; ++j) {
+      if (j < G) {
+#pragma unroll
+        for (int k4 = 0; k4 < KP / 4; ++k4) {
+          const f32x4_t a4 = *(const f32x4_t*)(Ar + j * KP + 4 * k4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[4 * k4 + q] = __fmaf_rn(a4[q], x[j], acc[4 * k4 + q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      if (k < K) Rl[((size_t)r * K + k) * C + d] = acc[k];
+  }
+  __syncthreads();
+  float* dst = Q + ((size_t)b * NG + g) * KP * C;
+  for (int e = tid; e < K * C; e += blockDim.x) {
+    float s = 0.f;
+    for (int rr = 0; rr < nr; ++rr) s = __fadd_rn(s, Rl[(size_t)rr * K * C + e]);
+    dst[e] = s;   // [k][d] with pitch C inside a KP * C slot
+  }
 }
 
-// (unless `first`) sums[k][d] = sum_i R[b][i][k][d] in ascending i, counts, normalisation, empty clusters keep their centroid;
-// then S[b][t][k] = chain_d code[b][t][d] * c_k[d] for the workgroup's 128 patches (thread = patch, its code row from an LDS tile)
-constexpr int LIN_TT = 128;
-template <int KP>
-__global__ __launch_bounds__(LIN_TT) void km_lin_table_kernel(const float* __restrict__ code, const float* __restrict__ R,
+// (unless `first`) sums[k][d] = sum_g Q[b][g][k][d] in ascending g, counts, normalisation, empty clusters keep their centroid;
+// then S[b][t][k] = chain_d code[b][t][d] * c_k[d] for the workgroup's 256 patches (thread = patch: its code row straight from global
+// memory, every request of the row in flight at once -- the LDS-staged tile cost a memory round trip per 16 bytes of a thread's copy loop)
+constexpr int LIN_TT = 256;
+constexpr int LIN_MAXNG = 16;
+template <int KP, int C>
+__global__ __launch_bounds__(LIN_TT) void km_lin_table_kernel(const float* __restrict__ code, const float* __restrict__ Q,
                                                               const int* __restrict__ cntp, const float* __restrict__ cent_old,
-                                                              float* __restrict__ cent_new, float* __restrict__ S, int G, int C, int K,
+                                                              float* __restrict__ cent_new, float* __restrict__ S, int G, int K,
                                                               int B, int first) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int T = G * G, NT = (T + LIN_TT - 1) / LIN_TT;
-  float* cl = sm;                        // [C][KP]
-  float* tile = cl + C * KP;             // [LIN_TT][C]   (first used as sums[K][C])
-  float* nrm = tile + LIN_TT * C;        // [KP]
-  int* cn = (int*)(nrm + KP);            // [KP]
+  __shared__ __attribute__((aligned(16))) float cl[C * KP];   // [C][KP]
+  __shared__ float sums[KP * C];
+  __shared__ float nrm[KP];
+  __shared__ int cn[KP];
+  const int T = G * G, NT = (T + LIN_TT - 1) / LIN_TT, NG = (G + LIN_RG - 1) / LIN_RG;
   int part, b;
   lin_frame_map(blockIdx.x, NT, B, part, b);
   const int tid = threadIdx.x;
   if (!first) {
-    float* sums = tile;
-    for (int e = tid; e < K * C; e += blockDim.x) {
-      const int k = e / C, d = e - k * C;
-      const float* src = R + ((size_t)b * G * KP + k) * C + d;
-      const size_t step = (size_t)KP * C;
-      float s = 0.f;
-      constexpr int UB = 8;
-      for (int i0 = 0; i0 < G; i0 += UB) {
-        float v[UB];
+    constexpr int NV = (KP * C + LIN_TT - 1) / LIN_TT;
+    float v[NV][LIN_MAXNG > 8 ? 8 : LIN_MAXNG];
+    // every partial of the thread's values requested before the first addition (8 groups at a time)
+    for (int g0 = 0; g0 < NG; g0 += 8) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) v[u] = src[(size_t)min(i0 + u, G - 1) * step];
+      for (int m = 0; m < NV; ++m) {
+        const int e = tid + m * LIN_TT, k = e / C, d = e - k * C;
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const float t = __fadd_rn(s, v[u]);
-          s = i0 + u < G ? t : s;
+        for (int u = 0; u < 8; ++u)
+          v[m][u] = (e < K * C && g0 + u < NG) ? Q[(((size_t)b * NG + g0 + u) * KP + k) * C + d] : 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < NV; ++m) {
+        const int e = tid + m * LIN_TT;
+        if (e < K * C) {
+          float sacc = g0 == 0 ? 0.f : sums[e];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (g0 + u < NG) sacc = __fadd_rn(sacc, v[m][u]);
+          sums[e] = sacc;
         }
       }
-      sums[e] = s;
     }
     if (tid < KP) {
       int n = 0;
@@ -302,12 +397,12 @@ __global__ __launch_bounds__(LIN_TT) void km_lin_table_kernel(const float* __res
     __syncthreads();
     for (int e = tid; e < KP * C; e += blockDim.x) {
       const int k = e / C, d = e - k * C;
-      float v = 0.f;
+      float val = 0.f;
       if (k < K) {
-        v = cn[k] > 0 ? __fmul_rn(sums[e], nrm[k]) : cent_old[((size_t)b * K + k) * C + d];
-        if (part == 0) cent_new[((size_t)b * K + k) * C + d] = v;
+        val = cn[k] > 0 ? __fmul_rn(sums[e], nrm[k]) : cent_old[((size_t)b * K + k) * C + d];
+        if (part == 0) cent_new[((size_t)b * K + k) * C + d] = val;
       }
-      cl[d * KP + k] = v;
+      cl[d * KP + k] = val;
     }
   } else {
     for (int e = tid; e < KP * C; e += blockDim.x) {
@@ -316,21 +411,19 @@ __global__ __launch_bounds__(LIN_TT) void km_lin_table_kernel(const float* __res
     }
   }
   __syncthreads();
-  const int t0 = part * LIN_TT, nrow = min(LIN_TT, T - t0);
-  const float* src = code + ((size_t)b * T + t0) * C;
-  if (((nrow * C) & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
-    for (int i = tid; i < nrow * C / 4; i += blockDim.x) ((f32x4_t*)tile)[i] = ((const f32x4_t*)src)[i];
-  } else {
-    for (int i = tid; i < nrow * C; i += blockDim.x) tile[i] = src[i];
-  }
-  __syncthreads();
-  if (tid >= nrow) return;
-  const float* row = tile + tid * C;
+  const int t = part * LIN_TT + tid;
+  if (t >= T) return;
+  static_assert((C & 1) == 0, "code rows are read as 8-byte pairs");
+  const f32x2l_t* row = (const f32x2l_t*)(code + ((size_t)b * T + t) * C);   // (C even: every row is 8-byte aligned)
+  f32x2l_t x2[C / 2];
+#pragma unroll
+  for (int i = 0; i < C / 2; ++i) x2[i] = row[i];
   float acc[KP];
 #pragma unroll
   for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+#pragma unroll
   for (int d = 0; d < C; ++d) {
-    const float x = row[d];
+    const float x = x2[d >> 1][d & 1];
 #pragma unroll
     for (int k4 = 0; k4 < KP / 4; ++k4) {
       const f32x4_t c4 = *(const f32x4_t*)(cl + d * KP + 4 * k4);
@@ -338,12 +431,35 @@ __global__ __launch_bounds__(LIN_TT) void km_lin_table_kernel(const float* __res
       for (int q = 0; q < 4; ++q) acc[4 * k4 + q] = __fmaf_rn(x, c4[q], acc[4 * k4 + q]);
     }
   }
-  float* dst = S + ((size_t)b * T + t0 + tid) * KP;
+  float* dst = S + ((size_t)b * T + t) * KP;
 #pragma unroll
   for (int k4 = 0; k4 < KP / 4; ++k4) *(f32x4_t*)(dst + 4 * k4) = f32x4_t{acc[4 * k4], acc[4 * k4 + 1], acc[4 * k4 + 2], acc[4 * k4 + 3]};
 }
 
-struct LinScratch { float *cent0, *cent1, *rinv, *S, *Pg, *R; int* cntp; size_t floats; };
+// ascending compaction of the ids in use (feature_extractor.py:245-246) from the mask the final assignment left: nseg[b] = their
+// number; labels -> rank of the id among the used ones (relabel != 0)
+__global__ __launch_bounds__(256) void km_lin_relabel_kernel(int* __restrict__ labels, int* __restrict__ nseg, const unsigned* __restrict__ used,
+                                                             long long P, int relabel, int nblk) {
+  const int b = blockIdx.x / nblk, part = blockIdx.x - b * nblk;
+  const unsigned m = used[b];
+  if (part == 0 && threadIdx.x == 0) nseg[b] = __builtin_popcount(m);
+  if (!relabel) return;
+  int4* lab = (int4*)(labels + (size_t)b * P);
+  const long long n4 = P / 4;
+  for (long long i = (long long)part * blockDim.x + threadIdx.x; i < n4; i += (long long)nblk * blockDim.x) {
+    int4 v = lab[i];
+    v.x = __builtin_popcount(m & ((1u << v.x) - 1u)); v.y = __builtin_popcount(m & ((1u << v.y) - 1u));
+    v.z = __builtin_popcount(m & ((1u << v.z) - 1u)); v.w = __builtin_popcount(m & ((1u << v.w) - 1u));
+    lab[i] = v;
+  }
+  if (part == 0)
+    for (long long p = n4 * 4 + threadIdx.x; p < P; p += blockDim.x) {
+      int* l = labels + (size_t)b * P + p;
+      *l = __builtin_popcount(m & ((1u << *l) - 1u));
+    }
+}
+
+struct LinScratch { float *cent0, *cent1, *rinv, *S, *Pg, *Q; int* cntp; unsigned* used; size_t floats; };
 LinScratch lin_carve(float* base, int B, int G, int H, int C, int K, int KP) {
   LinScratch s;
   size_t off = 0;
@@ -353,46 +469,53 @@ LinScratch lin_carve(float* base, int B, int G, int H, int C, int K, int KP) {
   s.rinv = take((size_t)B * H * H);
   s.S = take((size_t)B * G * G * KP);
   s.Pg = take((size_t)B * G * 2 * KP * G);
-  s.R = take((size_t)B * G * KP * C);
+  s.Q = take((size_t)B * ((G + LIN_RG - 1) / LIN_RG) * KP * C);
   s.cntp = (int*)take((size_t)B * G * KP);
+  s.used = (unsigned*)take((size_t)B);
   s.floats = off;
   return s;
 }
 inline int lin_kp(int K) { return K <= 8 ? 8 : K <= 20 ? 20 : 32; }
 int g_lin_rc = LIN_RC;
 
-template <int KP>
-int run_linear(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K, int iters, int relabel,
+template <int KP, int C>
+int run_linear(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int K, int iters, int relabel,
                hipStream_t st) {
   const LinScratch s = lin_carve(scratch, B, G, H, C, K, KP);
   const int RC = g_lin_rc;
   const LinLds L = lin_lds(G, H, KP, RC);
-  const size_t table_lds = ((size_t)C * KP + (size_t)LIN_TT * C + 2 * KP) * sizeof(float);
+  const size_t rowsum_lds = lin_rowsum_lds(G, C, K, KP);
   static LdsOptIn opt;
   if (const int rc = opt(160 * 1024, (const void*)km_lin_assign_kernel<KP, false>, (const void*)km_lin_assign_kernel<KP, true>,
-                         (const void*)km_lin_table_kernel<KP>)) return rc;
+                         (const void*)km_lin_rowsum_kernel<KP>)) return rc;
   if (const int rc = wvn_km_pix_prepare_launch(code, s.rinv, s.cent0, B, G, H, C, K, st)) return rc;
-  const int T = G * G, NT = (T + LIN_TT - 1) / LIN_TT;
+  const int T = G * G, NT = (T + LIN_TT - 1) / LIN_TT, NG = (G + LIN_RG - 1) / LIN_RG;
   float* cur = s.cent0;
   float* nxt = s.cent1;
-  hipLaunchKernelGGL((km_lin_table_kernel<KP>), dim3(NT * B), dim3(LIN_TT), table_lds, st, code, s.R, s.cntp, cur, nxt, s.S, G, C, K, B, 1);
+  hipLaunchKernelGGL((km_lin_table_kernel<KP, C>), dim3(NT * B), dim3(LIN_TT), 0, st, code, s.Q, s.cntp, cur, nxt, s.S, G, K, B, 1);
   WVN_LAUNCH_CHECK();
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL((km_lin_assign_kernel<KP, false>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, G, H, K, B, RC);
+    hipLaunchKernelGGL((km_lin_assign_kernel<KP, false>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, s.used, G, H, K, B, RC);
     WVN_LAUNCH_CHECK();
-    hipLaunchKernelGGL((km_lin_rowsum_kernel<KP>), dim3(G * B), dim3(128), (size_t)G * KP * sizeof(float), st, code, s.Pg, s.R, G, C, K, B);
+    hipLaunchKernelGGL((km_lin_rowsum_kernel<KP>), dim3(NG * B), dim3(LIN_RG * 128), rowsum_lds, st, code, s.Pg, s.Q, G, C, K, B);
     WVN_LAUNCH_CHECK();
-    hipLaunchKernelGGL((km_lin_table_kernel<KP>), dim3(NT * B), dim3(LIN_TT), table_lds, st, code, s.R, s.cntp, cur, nxt, s.S, G, C, K, B, 0);
+    hipLaunchKernelGGL((km_lin_table_kernel<KP, C>), dim3(NT * B), dim3(LIN_TT), 0, st, code, s.Q, s.cntp, cur, nxt, s.S, G, K, B, 0);
     WVN_LAUNCH_CHECK();
     float* t = cur; cur = nxt; nxt = t;
   }
-  hipLaunchKernelGGL((km_lin_assign_kernel<KP, true>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, G, H, K, B, RC);
+  hipError_t e = hipMemsetAsync(s.used, 0, (size_t)B * sizeof(unsigned), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((km_lin_assign_kernel<KP, true>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, s.used, G, H, K, B, RC);
   WVN_LAUNCH_CHECK();
   if (cur != s.cent0) {
-    const hipError_t e = hipMemcpyAsync(s.cent0, cur, (size_t)B * K * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    e = hipMemcpyAsync(s.cent0, cur, (size_t)B * K * C * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
   }
-  return wvn_km_relabel_launch(labels, nseg, B, (long long)H * H, K, relabel, st);
+  const long long P = (long long)H * H;
+  const int nblk = relabel ? (int)min((long long)64, (P / 4 + 255) / 256 > 0 ? (P / 4 + 255) / 256 : 1) : 1;
+  hipLaunchKernelGGL(km_lin_relabel_kernel, dim3(nblk * B), dim3(256), 0, st, labels, nseg, s.used, P, relabel, nblk);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
 }
 
 }  // namespace
@@ -401,7 +524,7 @@ int wvn_kmeans_pixels_linear_supported(int G, int H, int C, int K) {
   if (G <= 0 || H <= 0 || K <= 0 || K > 32 || (C != 90 && C != 16)) return 0;
   const int KP = lin_kp(K);
   if (lin_lds(G, H, KP, g_lin_rc).bytes > 160 * 1024) return 0;
-  if (((size_t)C * KP + (size_t)LIN_TT * C + 2 * KP) * sizeof(float) > 160 * 1024) return 0;
+  if (lin_rowsum_lds(G, C, K, KP) > 160 * 1024 || (G + LIN_RG - 1) / LIN_RG > LIN_MAXNG || G > LIN_MAXG) return 0;
   return 1;
 }
 
@@ -422,9 +545,9 @@ int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G
   if (const int rc = opt(160 * 1024, (const void*)km_lin_assign_kernel<8, true>, (const void*)km_lin_assign_kernel<20, true>,
                          (const void*)km_lin_assign_kernel<32, true>)) return rc;
   const dim3 grid(G * B), block(LIN_THREADS);
-  if (KP == 8) hipLaunchKernelGGL((km_lin_assign_kernel<8, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, G, H, K, B, RC);
-  else if (KP == 20) hipLaunchKernelGGL((km_lin_assign_kernel<20, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, G, H, K, B, RC);
-  else hipLaunchKernelGGL((km_lin_assign_kernel<32, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, G, H, K, B, RC);
+  if (KP == 8) hipLaunchKernelGGL((km_lin_assign_kernel<8, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC);
+  else if (KP == 20) hipLaunchKernelGGL((km_lin_assign_kernel<20, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC);
+  else hipLaunchKernelGGL((km_lin_assign_kernel<32, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -432,9 +555,11 @@ int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G
 int wvn_kmeans_pixels_linear_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K,
                                     int iters, int relabel, hipStream_t st) {
   if (!code || !labels || !nseg || !scratch || B <= 0 || iters < 0 || !wvn_kmeans_pixels_linear_supported(G, H, C, K)) return WVN_ERR_ARG;
-  switch (lin_kp(K)) {
-    case 8: return run_linear<8>(code, labels, nseg, scratch, B, G, H, C, K, iters, relabel, st);
-    case 20: return run_linear<20>(code, labels, nseg, scratch, B, G, H, C, K, iters, relabel, st);
-    default: return run_linear<32>(code, labels, nseg, scratch, B, G, H, C, K, iters, relabel, st);
-  }
+  const int KP = lin_kp(K);
+#define WVN_LIN_RUN(KP_, C_) return run_linear<KP_, C_>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st)
+  if (C == 90) { if (KP == 8) WVN_LIN_RUN(8, 90); if (KP == 20) WVN_LIN_RUN(20, 90); WVN_LIN_RUN(32, 90); }
+  if (KP == 8) WVN_LIN_RUN(8, 16);
+  if (KP == 20) WVN_LIN_RUN(20, 16);
+  WVN_LIN_RUN(32, 16);
+#undef WVN_LIN_RUN
 }
