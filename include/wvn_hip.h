@@ -82,6 +82,14 @@ int wvn_version(void);
  * {mean, rstd} of the rows they update, the A-stationary kernels normalise as they load; with this flag every LayerNorm is its own
  * kernel writing hi / lo planes again) */
 #define WVN_VIT_X3_NO_LN_STATS 512
+/* WVN_PREC_MIX: in how many LEADING blocks the attention kernel takes q as two fp16 planes (8 more MFMAs per tile, three workgroups per CU
+ * instead of four: 3.08 against 2.05 ms per 128-frame launch).  The query's rounding is the one attention operand error that does not
+ * average out over a row's keys, and it is injected in the EARLY blocks: on the reference's real 448^2 frame the token error is 1.05e-3
+ * with no block split, 5.1e-4 / 4.3e-4 / 2.3e-4 with the first 2 / 4 / 6, 7.6e-5 with all twelve -- and still 1.05e-3 with only the LAST six
+ * (profiles/r05_qsplit_blocks.md).  Bits 16 - 21 of flags hold n + 1; the field left 0 selects the default (6).  WVN_VIT_QSPLIT_BLOCKS(12)
+ * is the round-4 behaviour. */
+#define WVN_VIT_QSPLIT_BLOCKS(n) ((((n) + 1) & 63) << 16)
+#define WVN_VIT_QSPLIT_DEFAULT 6
 typedef struct wvn_vit_layer {
   const void* qkv_w;  /* [3D][D]   blocks.i.attn.qkv.weight  */
   const void* proj_w; /* [D][D]    blocks.i.attn.proj.weight */
@@ -558,6 +566,8 @@ int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, con
                           const void* W2p, const float* b2, float* x, int M, int F, long long* dbg1, long long* dbg2, void* stream);
 /* subsequent wvn_attention_bf16 launches write dbg[(workgroup * 4 + wave) * 5 + {0 wait, 1 QK^T, 2 softmax, 3 PV,
  * 4 total}]; NULL switches the instrumented build off again. */
+/* (test hook) out_f16[i] = fp16(in[i]) as the kernels convert: finite values beyond the fp16 range saturate to +-65504 (MODE.FP16_OVFL) */
+int wvn_debug_f16_saturate(const float* in, void* out_f16, int n, void* stream);
 int wvn_debug_attention_timing(long long* dbg);
 /* which form of the pre-scaled (scale == 0) attention kernel subsequent launches use: 0 = exact per-tile row max, 1 = lazy (no
  * per-tile max; the row sums raise the alarm and the tile is redone exactly -- the default), < 0 = back to the default.  Same

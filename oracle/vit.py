@@ -89,6 +89,34 @@ def make_dinov2_state_dict(arch: str = "vit_base", patch: int = 14, pretrain_gri
     return sd
 
 
+def make_vit_state_dict_heavy_tailed(
+    arch: str = "vit_small", patch: int = 8, pretrain_grid: int = 28, seed: int = 0, depth: Optional[int] = None,
+    outlier_channels=(17, 203), outlier_gain: float = 150.0, dof: float = 3.0, common_offset: float = 0.0,
+) -> Dict[str, torch.Tensor]:
+    """Synthetic weights with the two features of released DINO checkpoints the Gaussian ones above lack:
+    HEAVY-TAILED linear weights (every linear weight multiplied element-wise by a Student-t(dof) / its std factor: a few entries
+    per row are 5-10 sigma) and MASSIVE ACTIVATIONS -- a handful of residual channels that an early block's fc2 drives to
+    ~outlier_gain times the typical magnitude for every token (its bias) and that stay there (the released models carry such
+    channels from the first blocks to the last; their LayerNorm gains are small, as there).  ``common_offset`` adds the same
+    constant to EVERY channel of that bias: rows with mean^2 / var in the hundreds, the case a one-pass variance (E[y^2] - mean^2,
+    ADVICE r4) loses digits on.  Same layout as make_vit_state_dict."""
+    sd = make_vit_state_dict(arch, patch, pretrain_grid, seed, depth)
+    t = torch.distributions.StudentT(dof)
+    torch.manual_seed(seed + 4243)
+    for k in list(sd):
+        if k.endswith(("qkv.weight", "proj.weight", "fc1.weight", "fc2.weight")) and "patch_embed" not in k:
+            f = t.sample(sd[k].shape).abs().clamp(max=12.0) / 1.1      # E|t_3| ~ 1.1: the typical entry keeps its size
+            sd[k] = sd[k] * f
+    blk = "blocks.1." if "blocks.1.mlp.fc2.bias" in sd else "blocks.0."
+    sd[blk + "mlp.fc2.bias"] += common_offset
+    for c in outlier_channels:
+        sd[blk + "mlp.fc2.bias"][c] = outlier_gain * (1.0 if c % 2 else -1.0)
+        sd[blk + "mlp.fc2.weight"][c] *= 8.0
+        for name in [k for k in sd if k.endswith(("norm1.weight", "norm2.weight")) or k == "norm.weight"]:
+            sd[name][c] = 0.05 * sd[name][c]          # small LayerNorm gains on the massive channels
+    return sd
+
+
 def vit_depth(sd: Dict[str, torch.Tensor]) -> int:
     return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
 

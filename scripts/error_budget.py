@@ -131,7 +131,7 @@ def product(a, w, mode, fmt, kdim_last_w=True):
     raise ValueError(mode)
 
 
-def vit_tokens_emulated(sd, img, patch, heads, modes, fmt, center_k=False):
+def vit_tokens_emulated(sd, img, patch, heads, modes, fmt, center_k=False, qk_mode_by_block=None):
     """oracle.vit.vit_tokens with per-family operand modes (dict family -> mode)."""
     B, _, S, _ = img.shape
     G = S // patch
@@ -153,7 +153,7 @@ def vit_tokens_emulated(sd, img, patch, heads, modes, fmt, center_k=False):
             k = k - k.mean(dim=2, keepdim=True)
         outs = []
         for b in range(B):  # per frame: the [h, N, N] score block is 236 MB at 448^2
-            s = product(q[b], k[b], modes["qk"], fmt)  # log2 domain
+            s = product(q[b], k[b], modes["qk"] if qk_mode_by_block is None else qk_mode_by_block[i], fmt)  # log2 domain
             pr = torch.exp2(s - s.amax(dim=-1, keepdim=True))
             m = modes["pv"]
             if m == "f32":
@@ -215,6 +215,17 @@ def real_frame(args, sd):
             e = vit_tokens_emulated(sd, img, 8, 6, m, args.fmt, **kw) - ref
             rows.append((name, e.abs().max().item(), e.pow(2).mean().sqrt().item()))
             print(f"{name:80s} max {rows[-1][1]:.2e} rms {rows[-1][2]:.2e}", flush=True)
+        if args.qsplit_blocks:   # which blocks need the two-plane q (round 5): q split in a subset of the blocks, single elsewhere
+            depth = ovit.vit_depth(sd)
+            for spec in args.qsplit_blocks.split(";"):
+                lo, hi = (int(v) for v in spec.split("-"))
+                by_block = ["a" if lo <= i < hi else "h" for i in range(depth)]
+                m = dict(base)
+                m["qk"], m["pv"] = "h", "h"
+                e = vit_tokens_emulated(sd, img, 8, 6, m, args.fmt, qk_mode_by_block=by_block) - ref
+                name = f"q split in blocks [{lo}, {hi}) only; P V single"
+                rows.append((name, e.abs().max().item(), e.pow(2).mean().sqrt().item()))
+                print(f"{name:80s} max {rows[-1][1]:.2e} rms {rows[-1][2]:.2e}", flush=True)
     if args.out:
         with open(args.out, "w") as f:
             f.write("# Attention operands on the reference's real 448^2 frame (assets/graph/img.png), 12 blocks, linears split throughout\n\n"
@@ -238,6 +249,7 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="the fp8 table: e4m3 linears under per-row / MX block scales / hi + lo planes")
     ap.add_argument("--real-frame", action="store_true", help="the reference's one real 448^2 frame (tests/golden/graph_img_448.pt) and the "
                     "attention-operand variants of the mixed mode instead of the synthetic frames and the family table")
+    ap.add_argument("--qsplit-blocks", default="", help="with --real-frame: ';'-separated block ranges lo-hi in which q is split")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())

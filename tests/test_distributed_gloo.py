@@ -78,3 +78,32 @@ def test_two_rank_training_matches_single_process_and_reference():
     assert torch.allclose(torch.tensor(t0), ref.double().float(), rtol=3e-4, atol=2e-6)
     for k in sd0:
         assert torch.allclose(sd0[k], c["sd10"][k], atol=3e-5), k
+
+
+def _forced_worker(port, q):
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from wild_visual_navigation_amd import distributed as D
+
+    assert not D.is_parallel()
+    r, w, _ = D.init_from_env(backend="gloo", force_collectives=True)
+    t = torch.arange(4, dtype=torch.float64)
+    D.allreduce_sum_(t)                                           # a real collective of one rank: the values are unchanged
+    ok = (r, w) == (0, 1) and D.is_parallel() and torch.equal(t, torch.arange(4, dtype=torch.float64)) \
+        and D.all_ranks_ready(True) and not D.all_ranks_ready(False) and D.replicas_identical(t) and D.max_over_ranks(3.0) == 3.0
+    q.put(bool(ok))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_forced_collectives_on_one_rank():
+    """bench.py --force-collectives: a ONE-rank process group whose all-reduces are issued for real, so that the
+    RCCL kernels can be timed next to the persistent backbone kernels on a one-GPU box.  Here over gloo: the switch, the protocol."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=100) is True
+    p.join(30)

@@ -1,0 +1,48 @@
+"""Weights that look like a released checkpoint instead of a Gaussian: heavy-tailed linear weights and
+"massive activations" (a few residual channels ~100x the typical magnitude from an early block on), and rows whose mean dwarfs their
+spread.  The 16-bit paths must stay FINITE (fp16 conversions saturate, csrc/common.h: wvn_fp16_saturate) and the <= 1e-3 mode must
+stay inside 1e-3 of the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import interfaces as OI, vit as OV
+from wild_visual_navigation_amd import _lib
+from wild_visual_navigation_amd.backbone import VitBackbone
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fp16_conversions_saturate(dev):
+    """v_cvt_f16_f32 under MODE.FP16_OVFL: finite inputs beyond the fp16 range become +-65504, not +-inf; inf and nan pass."""
+    x = torch.tensor([1.0, 65504.0, 65520.0, 1e6, -3e9, 3.4e38, float("inf"), float("-inf"), float("nan"), 6e-8, -70000.0, 65519.9],
+                     device=dev)
+    out = torch.empty(x.numel(), dtype=torch.float16, device=dev)
+    _lib.check(_lib.lib().wvn_debug_f16_saturate(x.data_ptr(), out.data_ptr(), x.numel(), None), "wvn_debug_f16_saturate")
+    got = out.float().cpu().numpy()
+    want = np.array([1.0, 65504.0, 65504.0, 65504.0, -65504.0, 65504.0, np.inf, -np.inf, np.nan, 5.9604645e-08, -65504.0, 65504.0], dtype=np.float32)
+    assert np.array_equal(got, want, equal_nan=True), got
+
+
+@pytest.mark.parametrize("kind", ["massive", "offset"])
+def test_heavy_tailed_weights_and_massive_activations(dev, kind):
+    S, P, heads = 224, 8, 6
+    sd = OV.make_vit_state_dict_heavy_tailed("vit_small", P, 28, seed=3, common_offset=40.0 if kind == "offset" else 0.0,
+                                             outlier_gain=150.0 if kind == "massive" else 60.0)
+    img = torch.rand(2, 3, S, S, generator=torch.Generator().manual_seed(1))
+    taps = []
+    ref = OV.vit_tokens(sd, OI.normalize(img), P, heads, taps=taps)[:, 1:]
+    last = taps[-1]
+    if kind == "massive":
+        assert last.abs().amax().item() > 100 and last.abs().median().item() < 3          # the pattern is there
+    else:
+        assert ((last.mean(-1) ** 2) / last.var(-1)).max().item() > 50                      # |mean| >> spread
+    res = {}
+    for prec in ("fp16", "bf16", "mixed", "exact"):
+        bb = VitBackbone(sd, S, P, heads, device=dev, precision=prec)
+        tok = bb.forward_tokens(img.to(dev)).cpu()
+        assert torch.isfinite(tok).all(), f"{prec}: non-finite tokens"
+        res[prec] = (tok - ref).abs().max().item()
+    print(f"[{kind}] max |tokens - oracle|: " + ", ".join(f"{k} {v:.2e}" for k, v in res.items()))
+    assert res["mixed"] <= 1e-3 and res["exact"] <= 1e-3, res
+    assert res["fp16"] <= 5e-2 and res["bf16"] <= 0.5, res                                  # (16-bit speed paths: finite and sane)

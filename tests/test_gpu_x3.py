@@ -175,10 +175,14 @@ def test_reference_448_frame_through_the_full_backbone(dev, golden):
     err = (got - want).abs().max().item()
     print(f"img.png 448^2 exact: max|err| = {err:.3e}")
     assert err < 1e-3
-    got = VitBackbone(sd, 448, 8, 6, device=dev, precision="mixed").forward_tokens(img.to(dev)).cpu()
-    err = (got - want).abs().max().item()
-    print(f"img.png 448^2 mixed: max|err| = {err:.3e}")
-    assert err < 1e-3
+    # the <= 1e-3 mode: q as two planes in the first six blocks only (the default; include/wvn_hip.h WVN_VIT_QSPLIT_BLOCKS) -- the query's
+    # rounding enters in the early blocks: the table this prints is profiles/r05_qsplit_blocks.md's GPU column
+    errs = {}
+    for n in (None, 12, 4, 2, 0):
+        got = VitBackbone(sd, 448, 8, 6, device=dev, precision="mixed", qsplit_blocks=n).forward_tokens(img.to(dev)).cpu()
+        errs[n] = (got - want).abs().max().item()
+        print(f"img.png 448^2 mixed, q split in the first {'6 (default)' if n is None else n} blocks: max|err| = {errs[n]:.3e}")
+    assert errs[None] < 5e-4 and errs[12] < 2e-4 and errs[4] < 1e-3, errs
     bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="bf16")
     got = bb.forward_tokens(img.to(dev)).cpu()
     rel = ((got - want).norm() / want.norm()).item()

@@ -26,6 +26,12 @@ VIT_FUSE_ANY_SIZE = 4
 VIT_NO_PROJ_IN_MLP = 8
 VIT_NO_LN_HANDOVER = 16
 VIT_NO_A384_X3 = 32
+
+
+def vit_qsplit_blocks(n: int) -> int:
+    """WVN_VIT_QSPLIT_BLOCKS(n) of include/wvn_hip.h: the flag bits that make the first n blocks of WVN_PREC_MIX take q as two planes."""
+    return ((int(n) + 1) & 63) << 16
+
 PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")
 
 # epilogue codes (wvn_internal.h)
@@ -156,6 +162,7 @@ _SIGNATURES = {
     "wvn_pixel_mlp_infer_exact": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _p, _sz, _p], _i),
     "wvn_pixel_mlp_infer": ([_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _p], _i),
     "wvn_debug_gemm_bf16_timed": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p], _i),
+    "wvn_debug_f16_saturate": ([_p, _p, _i, _p], _i),
     "wvn_debug_attention_timing": ([_p], _i),
     "wvn_debug_gemm_n384": ([_p, _i, _p, _i, _p, _p, _i, _i, _i, _p], _i),
 }

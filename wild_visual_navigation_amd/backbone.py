@@ -101,6 +101,22 @@ def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
     return torch.cat([pos_embed[:, :1].float(), tab], dim=1)
 
 
+def _debug_bits() -> int:
+    """WVN_X3_DEBUG_BITS: the documented A/B bits of the split-operand block kernels only (64 | 128 | 256 | 512, include/wvn_hip.h); a
+    malformed value is an error with the variable's name in it, other bits are refused (the raw value used to be OR'ed into
+    the production flags, where bits 1 / 2 / 4 silently toggled unrelated fusions)."""
+    raw = os.environ.get("WVN_X3_DEBUG_BITS", "").strip()
+    if not raw:
+        return 0
+    try:
+        v = int(raw, 0)
+    except ValueError:
+        raise _lib.WvnError(f"WVN_X3_DEBUG_BITS={raw!r} is not an integer") from None
+    if v & ~(64 | 128 | 256 | 512):
+        raise _lib.WvnError(f"WVN_X3_DEBUG_BITS={raw!r}: only the bits 64, 128, 256 and 512 are debug switches")
+    return v
+
+
 class VitBackbone:
     """Device-resident DINO / DINOv2 ViT.  ``precision``: "bf16" (MFMA fast path), "fp16" (the same kernels with fp16 operands:
     same speed, 8x less operand rounding -- csrc/operand.h), "mixed" (the <= 1e-3 parity mode sized by the error budget: the linears as
@@ -111,7 +127,9 @@ class VitBackbone:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
                  device="cuda", precision: str = "bf16", max_chunk: int = 16, fuse_mlp: Optional[bool] = None,
-                 fuse_qkv: Optional[bool] = None, fuse_proj: bool = True):
+                 fuse_qkv: Optional[bool] = None, fuse_proj: bool = True, qsplit_blocks: Optional[int] = None):
+        """qsplit_blocks (precision "mixed"): the number of LEADING blocks whose attention takes q as two fp16 planes (None: the
+        library's default, include/wvn_hip.h WVN_VIT_QSPLIT_DEFAULT; the environment variable WVN_QSPLIT_BLOCKS overrides None)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.WvnError("VitBackbone needs a GPU device: the HIP path has no CPU fallback")
@@ -177,7 +195,13 @@ class VitBackbone:
         m.flags = ((_lib.VIT_MLP_FUSED if self.fuse_mlp else 0) | (_lib.VIT_QKV_FUSED if self.fuse_qkv else 0)
                    | (_lib.VIT_FUSE_ANY_SIZE if (fuse_mlp is True or fuse_qkv is True) else 0)
                    | (0 if fuse_proj else _lib.VIT_NO_PROJ_IN_MLP) | (_lib.VIT_NO_LN_HANDOVER if os.environ.get("WVN_NO_HANDOVER") else 0)
-                   | (_lib.VIT_NO_A384_X3 if os.environ.get("WVN_NO_A384_X3") else 0) | int(os.environ.get("WVN_X3_DEBUG_BITS", "0")))
+                   | (_lib.VIT_NO_A384_X3 if os.environ.get("WVN_NO_A384_X3") else 0) | _debug_bits())
+        if qsplit_blocks is None and os.environ.get("WVN_QSPLIT_BLOCKS", "") != "":
+            qsplit_blocks = int(os.environ["WVN_QSPLIT_BLOCKS"])
+        if qsplit_blocks is not None:
+            if not 0 <= int(qsplit_blocks) <= 62:
+                raise _lib.WvnError(f"qsplit_blocks must be in 0..62, not {qsplit_blocks}")
+            m.flags |= _lib.vit_qsplit_blocks(qsplit_blocks)
         kp = 3 * patch * patch  # the MFMA GEMMs read patch rows padded to a multiple of 64 columns (588 -> 640 for patch 14)
         m.patch_w = mat(sd["patch_embed.proj.weight"].reshape(self.dim, -1),
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)

@@ -344,6 +344,9 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     // WVN_PREC_MIX with a packed projection weight: the attention kernel writes fragments, the projection reads them (both planes of w.xn
     // then hold ceil(M / 32) * 32 rows; pl_xn below is the plane distance of BOTH layouts)
     const bool attn_frag = mix && x3_fast && L.proj_w_frag != nullptr;
+    // the two-plane q in the leading blocks only (include/wvn_hip.h: WVN_VIT_QSPLIT_BLOCKS)
+    const int qs_field = (m->flags >> 16) & 63;
+    const bool qsplit = mix && l < (qs_field ? qs_field - 1 : WVN_VIT_QSPLIT_DEFAULT);
     bool qkv_done = false;
     if (qkv_fused) {  // LayerNorm 1 + QKV projection: one launch, no xn round trip
       Span s(3, st);
@@ -366,7 +369,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       // the running max as an MFMA operand (attention_bf16.hip, PRE)
       if (bf) e.q_scale = scale * 1.44269504088896340736f;
       // one fp16 plane each for k and v^T, q pre-scaled and in TWO fp16 planes (its rounding residue behind it): the fp16 attention kernel's operands
-      if (mix) { e.qkv_f16 = 1; e.q_scale = scale * 1.44269504088896340736f; e.q_lo = lo(w.q, pl_qkv); }
+      if (mix) { e.qkv_f16 = 1; e.q_scale = scale * 1.44269504088896340736f; e.q_lo = qsplit ? lo(w.q, pl_qkv) : nullptr; }
       else if (x3) { e.q_lo = lo(w.q, pl_qkv); e.k_lo = lo(w.k, pl_qkv); e.vt_lo = lo(w.v, pl_qkv); }
       if (ln_fuse && ln1_stats) {   // norm1 on load, from the statistics the previous block's fc2 kernel left
         GemmBf16Params q = e;
@@ -388,7 +391,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     {
       Span s(4, st);
       if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr, nullptr, 0));
-      else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn), lo(w.q, pl_qkv), attn_frag ? 1 : 0));
+      else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn), qsplit ? lo(w.q, pl_qkv) : nullptr, attn_frag ? 1 : 0));
       else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
     }
@@ -613,6 +616,9 @@ int wvn_attention_x3(const void* q_hi, const void* q_lo, const void* k_hi, const
                                  ntok, npad, scale, (hipStream_t)stream);
 }
 
+int wvn_debug_f16_saturate(const float* in, void* out_f16, int n, void* stream) {
+  return (in && out_f16 && n > 0) ? wvn_f16_saturate_probe_launch(in, (uint16_t*)out_f16, n, (hipStream_t)stream) : WVN_ERR_ARG;
+}
 int wvn_debug_attention_timing(long long* dbg) { wvn_attention_bf16_set_debug(dbg); return WVN_OK; }
 int wvn_debug_mlp_fused_timing(long long* dbg) { g_mlp_fused_dbg = dbg; return WVN_OK; }
 int wvn_debug_qkv_fused_timing(long long* dbg) { g_qkv_fused_dbg = dbg; return WVN_OK; }

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
                                                                   int nqb, int ntok, int ntok_s, int npad,
                                                                   float c_exp, long long* dbg, op16_t* __restrict__ out_lo,
                                                                   const op16_t* __restrict__ q_lo, int out_frag) {
+  wvn_fp16_saturate();
   __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * TILE_BYTES];  // [stage][K | Vt][64][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -66,6 +66,21 @@ def _write_cmd(obj, cmd):
         f.write(" ".join(cmd))
 
 
+def _hazard_scanner():
+    """scripts/check_store_hazard.py as a module (None when the scripts directory is absent or WVN_SKIP_HAZARD_SCREEN is set)."""
+    if os.environ.get("WVN_SKIP_HAZARD_SCREEN", "0") not in ("", "0"):
+        return None
+    path = os.path.join(os.path.dirname(PKG), "scripts", "check_store_hazard.py")
+    if not os.path.exists(path):
+        return None
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_store_hazard", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -81,12 +96,28 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if force or _stale(obj, [src] + hdrs) or _cmd_changed(obj, cmd):
             jobs.append((o, cmd))
 
+    screen = _hazard_scanner()
+
     def run(job):
         name, cmd = job
         r = subprocess.run(cmd, capture_output=True, text=True)
+        log = r.stdout + r.stderr
+        if r.returncode == 0 and screen is not None:
+            # the gfx950 hazards LLVM does not pad (common.h: wvn_store_b128_guarded; hand-issued scalar loads) are
+            # screened on the ISA of EVERY unit that is recompiled, and a hit fails the build -- not only tests/test_isa_hazards.py
+            asm = cmd[-1] + ".s"
+            ra = subprocess.run(cmd[:-4] + ["-S", "--cuda-device-only", cmd[-3], "-o", asm], capture_output=True, text=True)
+            if ra.returncode == 0:
+                hits = [f"{name}:{ln}: {st}\n    overwritten by: {nx}" for ln, st, nx in screen.scan(asm)]
+                hits += [f"{name}:{ln}: {ld}\n    destination touched before the wait by: {nx}" for ln, ld, nx in screen.scan_smem(asm)]
+                os.remove(asm)
+                if hits:
+                    return name, 1, log + "gfx950 hazard screen (scripts/check_store_hazard.py):\n" + "\n".join(hits[:20])
+            else:
+                log += "\n(hazard screen: the -S compile failed; not screened)\n" + ra.stdout + ra.stderr
         if r.returncode == 0:
             _write_cmd(cmd[-1], cmd)
-        return name, r.returncode, r.stdout + r.stderr
+        return name, r.returncode, log
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:

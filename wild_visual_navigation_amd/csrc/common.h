@@ -59,6 +59,15 @@ __device__ inline uint32_t pack_f16x2(float lo, float hi) {  // v_cvt_pk_f16_f32
   return __builtin_bit_cast(uint32_t, b);
 }
 
+// fp16 conversions SATURATE instead of overflowing to infinity (released DINO checkpoints carry outlier channels;
+// one inf in q / k / v or in the hidden activation turns a whole frame's tokens into NaN): MODE.FP16_OVFL (hwreg 1, bit 23) makes every
+// fp16 VALU result that overflows -- v_cvt_f16_f32, v_cvt_pk_f16_f32 included -- +-65504 while true infinities and NaNs pass through.
+// One s_setreg per wave at kernel entry, nothing per element; every kernel that writes fp16 operands calls it first (a no-op for the bf16
+// builds' arithmetic).  tests/test_gpu_robustness.py::test_fp16_conversions_saturate pins the behaviour on the hardware.
+#if defined(__HIPCC__)
+__device__ inline void wvn_fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+#endif
+
 template <typename T> struct ElemIO;
 template <> struct ElemIO<f16raw_t> {
   __device__ static inline float load(const f16raw_t* p) { return f16_to_f32(p->bits); }

@@ -29,6 +29,7 @@ __device__ inline float load_pixel(const TIN* p) {
 template <typename T, int P, typename TIN = float>
 __global__ void patchify_kernel(const TIN* __restrict__ img, T* __restrict__ out, T* __restrict__ out_lo, int ldp, int B, int S,
                                 Gather gt = Gather{nullptr, nullptr, 0, 0}) {
+  wvn_fp16_saturate();
   const int G = S / P;
   const long long total = (long long)B * G * G * 3 * P;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,6 +66,7 @@ template <typename TIN, bool F16 = false>  // float: pixels in [0,1]; unsigned c
                          // 4x larger fp32 upload: quick_start.py:160-161 / ros_converter.py:113-126 do the division on the host side)
                          // F16: fp16 instead of bf16 operands (WVN_PREC_F16)
 __global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const TIN* __restrict__ img, bf16_t* __restrict__ out, int S) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192]
   const int G = S / 8, gy = blockIdx.x, b = blockIdx.y;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const TIN* __r
 template <typename TIN, bool F16>
 __global__ __launch_bounds__(256) void patchify8_gather_rows_kernel(const TIN* __restrict__ img, bf16_t* __restrict__ out, int S,
                                                                     Gather gt) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192]
   const int G = S / 8, gy = blockIdx.x, b = blockIdx.y;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ y2, int ldy2, int rows_out, int D,
                                                         float eps, int drop_cls, int ntok, int ntok_s,
                                                         T* __restrict__ y_lo) {
+  wvn_fp16_saturate();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows_out) return;
@@ -187,6 +191,7 @@ template <bool PLANES, bool F16 = false>  // PLANES: exact mode, y_lo receives t
 __global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                 bf16_t* __restrict__ y_lo, int ldy, int rows, float eps) {
+  wvn_fp16_saturate();
   const int lane = threadIdx.x & 63, sub = lane & 15, rsel = lane >> 4;
   const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   f32x4_t gm[6], bt[6];
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(256) void layernorm384_bf16_kernel(const float* __r
 template <bool F16>
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd,
                                      int rows, int cols) {
+  wvn_fp16_saturate();
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)rows * cols) return;
   int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
@@ -488,6 +494,21 @@ int wvn_upsample_bilinear_launch(const float* tok, float* out, int B, int G, int
 int wvn_upsample_nearest_i32_launch(const int* lab, int* out, int B, int G, int H, hipStream_t st) {
   long long n = (long long)B * H * H;
   hipLaunchKernelGGL(upsample_nearest_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lab, out, B, G, H);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+// (test hook) out[i] = fp16(in[i]) through the path's converters under wvn_fp16_saturate
+__global__ void f16_saturate_probe_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int n) {
+  wvn_fp16_saturate();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t pk = pack_f16x2(in[i], in[i]);
+    out[i] = (i & 1) ? (uint16_t)(pk >> 16) : f32_to_f16(in[i]);
+  }
+}
+int wvn_f16_saturate_probe_launch(const float* in, uint16_t* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(f16_saturate_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

@@ -95,6 +95,7 @@ __device__ inline f32x2_t act2(f32x2_t v) {
 
 template <int EPI, bool TIMING = false>
 __global__ __launch_bounds__(512, 2) void gemm_a384_kernel(A384Params p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

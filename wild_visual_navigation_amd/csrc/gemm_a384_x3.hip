@@ -108,6 +108,7 @@ __device__ inline void gelu_pair(float& x0, float& x1) {
 
 template <int EPI, bool TIMING = false, bool LNA = false>
 __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -43,6 +43,7 @@ struct N384Params {
 };
 
 __global__ __launch_bounds__(512, 2) void gemm_n384_kernel(N384Params p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

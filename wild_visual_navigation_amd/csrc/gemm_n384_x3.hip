@@ -138,6 +138,7 @@ __device__ inline void n384_epilogue(const f32x16_t (&acc)[NTILE], unsigned char
 
 template <bool TIMING>
 __global__ __launch_bounds__(256, 1) void gemm_n384_x3_kernel(N384X3Params p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,6 +286,7 @@ static_assert(FNS * FSTAGE <= RING_BYTES, "the fragment form's ring must fit in 
 
 template <bool TIMING>
 __global__ __launch_bounds__(256, 1) void gemm_n384_x3_frag_kernel(N384X3Params p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

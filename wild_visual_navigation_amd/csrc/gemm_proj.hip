@@ -41,6 +41,7 @@ __device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, 
 }
 
 __global__ __launch_bounds__(512, 1) void proj_resid_kernel(ProjParams p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

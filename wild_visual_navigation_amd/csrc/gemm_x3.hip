@@ -302,6 +302,7 @@ __device__ inline void gemm_x3_tile(const GemmBf16Params& p, int tm, int tn, uns
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmBf16Params p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;

@@ -130,6 +130,7 @@ __device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, 
 // block's rows are fetched into the accumulator registers as the store phase frees them.
 template <bool LNF, bool TIMING = false, bool PROJ = false, bool ACC = false, bool NXT = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(MlpFusedParams p) {
+  wvn_fp16_saturate();
   static_assert(!ACC || (PROJ && LNF), "ACC is a form of the projection + LayerNorm + MLP kernel");
   static_assert(!NXT || ACC, "NXT is an extension of the resident form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

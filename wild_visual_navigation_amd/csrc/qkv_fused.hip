@@ -68,6 +68,7 @@ __device__ inline void store_b128_guarded(u32x4_t v, __amdgpu_buffer_rsrc_t rs, 
 // qkv.weight with bits 2 and 3 of its column index swapped.
 template <bool TIMING, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void qkv_fused_kernel(QkvFusedParams p) {
+  wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

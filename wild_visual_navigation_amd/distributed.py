@@ -9,12 +9,42 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+def _pg_kwargs(backend: str) -> dict:
+    """RCCL's kernels on a HIGH-priority stream: the backbone kernels are persistent (one workgroup per CU holding the whole register
+    file), so a small kernel on a normal-priority stream is dispatched behind them like any other work, while the hardware
+    queue of a high-priority stream is served first at every workgroup boundary -- the same reason the tail of a step runs on
+    a high-priority stream (bench.py: TwoStreamPipeline).  c10d's default is a normal-priority stream from its pool."""
+    if backend != "nccl":
+        return {}
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        return {"pg_options": opts}
+    except Exception:  # noqa: BLE001  (a build without the option: the default stream)
+        return {}
+
+
+_FORCE_COLLECTIVES = False   # a process group of ONE rank whose collectives still run (RCCL's kernels on one GPU): bench.py --force-collectives
+
+
+def init_from_env(backend: str = None, force_collectives: bool = False) -> Tuple[int, int, int]:
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    Returns (rank, world_size, local_rank).  No-op for a single process -- unless ``force_collectives``: then a one-rank process
+    group is created and every all-reduce of the path is issued for real (with backend "nccl" each one launches RCCL's reduction
+    kernel on this GPU: what a collective costs NEXT TO the persistent backbone kernels can be measured on a one-GPU box)."""
+    global _FORCE_COLLECTIVES
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if force_collectives and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=0, world_size=1, **_pg_kwargs(backend))
+        _FORCE_COLLECTIVES = True
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -23,12 +53,12 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **_pg_kwargs(backend))
     return rank, world, local
 
 
 def is_parallel() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -109,7 +109,7 @@ class StegoInterface:
         cfg=None,
         backbone_type: str = None,     # extension: default = what the weights say (the released ckpt is ViT-Base), else vit_small
         patch_size: int = 8,
-        precision: str = "fp16",       # "fp16" (default speed path) | "bf16" | "mixed" / "exact" (<= 1e-3 parity modes) | "fp32" | "fp8"
+        precision: str = "mixed",      # "mixed" (default: <= 1e-3 of the fp32 reference) | "exact" | "fp32" | "fp16" / "bf16" (opt-in speed paths) | "fp8"
         backbone_weights=None,
         head_weights: Optional[Dict[str, torch.Tensor]] = None,
         probe_weights: Optional[Dict[str, torch.Tensor]] = None,
