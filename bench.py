@@ -159,7 +159,8 @@ def make_pipeline(args, dev, precision=None, stego_reading=None):
         fe = FeatureExtractor(dev, segmentation_type="stego", feature_type="stego", input_size=518, n_image_clusters=20,
                               precision=precision, max_chunk=args.chunk, backbone_type="vit_base", patch_size=14,
                               pretrained_weights=synthetic_vit_state_dict("vit_base", 14, pretrain_grid=37, seed=0, dinov2=True),
-                              head_weights=synthetic_stego_head(768), allow_synthetic=True)
+                              head_weights=synthetic_stego_head(768), allow_synthetic=True,
+                              flip_tta=False)   # configs[4] names the backbone + STEGO head: ONE pass per frame (the class default would add the mirror pass)
     else:
         ftype = "stego" if (args.segmentation == "stego" and args.mode == "full") else "dino"
         seg = args.segmentation if args.mode == "full" else "grid"
@@ -672,7 +673,7 @@ def main():
                 o["workload"] = ("BASELINE configs[1]: DINO ViT-S/8 448x448 batch=32, feature extraction only (fp16 operands, fp32 accumulate)"
                                  if name == "backbone_b32" else
                                  "BASELINE configs[4], one GPU's share: DINOv2 ViT-B/14 518x518 batch=16 (1370 tokens, LayerScale) + STEGO head -> "
-                                 "90-d code; block linears in fp8-e4m3 on the generic 128 x 128 tiles (no D = 768 row-panel kernels exist)")
+                                 "90-d code, one backbone pass per frame (no flip TTA); block linears in fp8-e4m3 on the generic 128 x 128 tiles (no D = 768 row-panel kernels exist)")
                 if not args.no_cpu_baseline:   # its own bounded oracle sample (2 frames): other weights / another architecture
                     la.cpu_frames = 2
                     _, orc_l = cpu_oracle_sample(la, leg["fe"])
