@@ -131,7 +131,8 @@ def product(a, w, mode, fmt, kdim_last_w=True):
     raise ValueError(mode)
 
 
-def vit_tokens_emulated(sd, img, patch, heads, modes, fmt, center_k=False, qk_mode_by_block=None):
+def vit_tokens_emulated(sd, img, patch, heads, modes, fmt, center_k=False, qk_mode_by_block=None, tail_blocks=0, tail_modes=None):
+    """tail_blocks / tail_modes: the LAST `tail_blocks` blocks run with `tail_modes` (dict family -> mode) instead of `modes`."""
     """oracle.vit.vit_tokens with per-family operand modes (dict family -> mode)."""
     B, _, S, _ = img.shape
     G = S // patch
@@ -143,7 +144,10 @@ def vit_tokens_emulated(sd, img, patch, heads, modes, fmt, center_k=False, qk_mo
     x = x + ovit.interpolate_pos_embed(sd["pos_embed"], G)
     dh = D // heads
     qscale = dh**-0.5 * math.log2(math.e)
-    for i in range(ovit.vit_depth(sd)):
+    depth_ = ovit.vit_depth(sd)
+    modes_all = modes
+    for i in range(depth_):
+        modes = tail_modes if (tail_modes is not None and i >= depth_ - tail_blocks) else modes_all
         p = f"blocks.{i}."
         y = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
         qkv = product(y, sd[p + "attn.qkv.weight"], modes["qkv"], fmt) + sd[p + "attn.qkv.bias"]
@@ -215,6 +219,17 @@ def real_frame(args, sd):
             e = vit_tokens_emulated(sd, img, 8, 6, m, args.fmt, **kw) - ref
             rows.append((name, e.abs().max().item(), e.pow(2).mean().sqrt().item()))
             print(f"{name:80s} max {rows[-1][1]:.2e} rms {rows[-1][2]:.2e}", flush=True)
+        if args.fp16_tail:   # (round 5) the LAST n blocks entirely on the single-fp16 speed kernels, the rest = the mixed mode with q split in the first six
+            depth = ovit.vit_depth(sd)
+            allh = {f: "h" for f in FAMILIES}
+            for n in (int(v) for v in args.fp16_tail.split(";")):
+                by_block = ["a" if i < 6 else "h" for i in range(depth)]
+                m = dict(base)
+                m["qk"], m["pv"] = "h", "h"
+                e = vit_tokens_emulated(sd, img, 8, 6, m, args.fmt, qk_mode_by_block=by_block, tail_blocks=n, tail_modes=allh) - ref
+                name = f"mixed (q split in the first 6), the LAST {n} blocks all single fp16"
+                rows.append((name, e.abs().max().item(), e.pow(2).mean().sqrt().item()))
+                print(f"{name:80s} max {rows[-1][1]:.2e} rms {rows[-1][2]:.2e}", flush=True)
         if args.qsplit_blocks:   # which blocks need the two-plane q (round 5): q split in a subset of the blocks, single elsewhere
             depth = ovit.vit_depth(sd)
             for spec in args.qsplit_blocks.split(";"):
@@ -249,6 +264,7 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="the fp8 table: e4m3 linears under per-row / MX block scales / hi + lo planes")
     ap.add_argument("--real-frame", action="store_true", help="the reference's one real 448^2 frame (tests/golden/graph_img_448.pt) and the "
                     "attention-operand variants of the mixed mode instead of the synthetic frames and the family table")
+    ap.add_argument("--fp16-tail", default="", help="with --real-frame: ';'-separated counts n: the last n blocks on single fp16 operands")
     ap.add_argument("--qsplit-blocks", default="", help="with --real-frame: ';'-separated block ranges lo-hi in which q is split")
     args = ap.parse_args()
     torch.manual_seed(0)

@@ -61,8 +61,17 @@ def test_a_stationary_k384_every_row(dev, M, N, epi):
         assert torch.equal(c[M:], x0[M:])
 
 
+@pytest.fixture
+def n384_pair(request):
+    """The two forms of the fragment-major row-panel kernel: a wave pair per 32 rows (two waves per SIMD, opt-in) / one wave per SIMD (default)."""
+    _lib.lib().wvn_debug_n384_pair(request.param)
+    yield request.param
+    _lib.lib().wvn_debug_n384_pair(0)
+
+
+@pytest.mark.parametrize("n384_pair", [1, 0], indirect=True, ids=["wave-pair", "one-wave-per-simd"])
 @pytest.mark.parametrize("M", [12608, 128 * 65 + 16])
-def test_fragment_major_mlp_every_row(dev, M):
+def test_fragment_major_mlp_every_row(dev, M, n384_pair):
     """fc1 writes the hidden activation as MFMA operand fragments (EPI_GELU_FRAG), fc2 consumes them (AFRAG) with the packed weight."""
     lib = _lib.lib()
     F = 1536
@@ -79,6 +88,13 @@ def test_fragment_major_mlp_every_row(dev, M):
     want = x0[:M].double() + torch.nn.functional.gelu(a.double() @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
     assert (x[:M].double() - want).abs().max().item() < 2e-4
     assert torch.equal(x[M:], x0[M:])
+    if n384_pair:   # the same products in the same order per output element: the two forms agree bit for bit
+        lib.wvn_debug_n384_pair(0)
+        x1 = x0.clone()
+        _lib.check(lib.wvn_debug_mlp_x3_frag(ap[0].data_ptr(), ap[1].data_ptr(), w1p[0].data_ptr(), w1p[1].data_ptr(), b1.data_ptr(), hid[0].data_ptr(), hid[1].data_ptr(),
+                                             w2p.data_ptr(), b2.data_ptr(), x1.data_ptr(), M, F, 0, 0, _lib.stream()), "mlp_x3_frag")
+        assert torch.equal(x, x1)
+        lib.wvn_debug_n384_pair(1)
 
 
 @pytest.mark.parametrize("precision", ["mixed", "exact"])

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "wvn_kmeans_pixels_linear_scratch_bytes": ([_i, _i, _i, _i, _i], _sz),
     "wvn_kmeans_cosine_pixels_linear": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "wvn_debug_kmeans_linear_rows": ([_i], _i),
+    "wvn_debug_n384_pair": ([_i], _i),
     "wvn_table_argmax_slots": ([_i], _i),
     "wvn_table_bilerp_argmax": ([_p, _p, _i, _i, _i, _i, _p], _i),
     "wvn_cast_rows": ([_p, _i, _p, _i, _i, _i, _i, _p], _i),

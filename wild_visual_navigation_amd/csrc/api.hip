@@ -662,6 +662,7 @@ int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, con
   p2.M = M; p2.N = 384; p2.K = F; p2.dbg = dbg2;
   return wvn_gemm_n384_x3_frag_launch(p2, EPI_RESID_F32, (hipStream_t)stream);
 }
+int wvn_debug_n384_pair(int on) { wvn_gemm_n384_x3_set_pair(on); return WVN_OK; }
 int wvn_debug_kmeans_screen_stats(unsigned long long* out, int reset) { return out ? wvn_kmeans_pixels_screen_stats(out, reset) : WVN_ERR_ARG; }
 int wvn_debug_kmeans_assign_form(int form) { wvn_kmeans_pixels_set_assign_form(form); return WVN_OK; }
 int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); wvn_attention_bf16_set_variant_f16(v); return WVN_OK; }

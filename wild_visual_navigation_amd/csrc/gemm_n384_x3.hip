@@ -409,6 +409,222 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_frag_kernel(N384X3Params 
   }
 }
 
+// ---- the fragment form with a WAVE PAIR per 32 rows (round 5) ------------------------------------------------------------------------------
+// Eight waves per workgroup, two per SIMD: wave (rg, ch) owns rows 32 rg .. 32 rg + 31 of the 128-row block and output columns
+// 192 ch .. 192 ch + 191 -- six accumulator tiles (96 registers) instead of twelve, 18 MFMAs and THREE DMA pieces per k-step instead of 36
+// and six.  The matrix work per SIMD and k-step is unchanged (36 MFMAs = 1152 cycles); what changes is that a wave which is issuing a DMA
+// piece (~54 cycles each for a wave that is alone on its SIMD), waiting at the barrier or for a fragment no longer idles the matrix pipe:
+// its partner's MFMAs fill it (scripts/ubench/wave_pair.hip: 1675 -> 1333 cycles per k-step for the untuned instruction streams; THIS kernel:
+// 1546 -> 1481 against the tuned one-wave form, with no change in wall time -- it ships as an opt-in, wvn_debug_n384_pair(1)).  Price:
+// both waves of a pair fetch the row group's A fragments (the second fetch hits the L2), and the LayerNorm statistics of a row are the sum
+// of two waves' partials (exchanged through LDS, half 0 + half 1: a fixed order).  Same products in the same order per output element:
+// C is bit-identical to gemm_n384_x3_frag_kernel's.
+constexpr int PFW = 3;                            // W DMA pieces per wave and k-step
+constexpr int PSTG_PITCH = 68;                    // floats per staged row (64 columns + 4)
+constexpr int PSTG_BYTES = 32 * PSTG_PITCH * 4;   // per wave: 8704 (the eight images overlap the ring's first 68 KB)
+constexpr int PSTAT_OFF = LDS_BYTES;              // [2 column halves][128 rows] {sum, sum of squares}
+constexpr int PAIR_LDS_BYTES = PSTAT_OFF + 2 * BM * 8;
+static_assert(8 * PSTG_BYTES <= RING_BYTES, "staging images must fit in the ring");
+
+__device__ inline void n384_pair_epilogue(const f32x16_t (&acc)[NTILE / 2], unsigned char* smem, int wave, int lane, int rg, int ch, int m0w,
+                                          __amdgpu_buffer_rsrc_t rs_c, int ldc, const float* bias_l, const float* ls_l, float* stats, float eps, int M) {
+  const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, rq = lane >> 4;
+  __syncthreads();  // every wave is done reading the ring: the staging images overlap it
+  float* stg = (float*)(smem + wave * PSTG_BYTES);
+  const unsigned cvoff = (unsigned)((rq * ldc + l15 * 4) * 4);
+  const int col0 = 192 * ch;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) { s1[it] = 0.f; s2[it] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x16_t& a = acc[2 * c + tt];
+        const f32x4_t o = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+        *(f32x4_t*)(stg + l31 * PSTG_PITCH + 32 * tt + 8 * g + 4 * hi) = o;
+      }
+    const f32x4_t b4 = *(const f32x4_t*)(bias_l + col0 + 64 * c + l15 * 4);
+    const f32x4_t l4 = *(const f32x4_t*)(ls_l + col0 + 64 * c + l15 * 4);
+    u32x4_t r[8];
+    unsigned so_dst[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {   // the eight row-quad fetches of the column group requested together
+      so_dst[it] = __builtin_amdgcn_readfirstlane(((m0w + 4 * it) * ldc + col0 + 64 * c) * 4);
+      r[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff, so_dst[it], 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const f32x4_t v = *(const f32x4_t*)(stg + (4 * it + rq) * PSTG_PITCH + l15 * 4);
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = (v[e] + b4[e]) * l4[e] + __uint_as_float(r[it][e]);
+        o[e] = __float_as_uint(y);
+        s1[it] += y;
+        s2[it] = fmaf(y, y, s2[it]);
+      }
+      wvn_store_b128_guarded(o, rs_c, cvoff, so_dst[it]);  // rows >= M fall outside num_records: dropped
+    }
+  }
+  if (stats) {   // (uniform) row 4 it + rq of the wave: its 16 lanes hold the partial sums of this column half
+    float* sx = (float*)(smem + PSTAT_OFF);
+    auto dpp_add = [](float v, auto ctrl) {
+      constexpr int C = decltype(ctrl)::value;
+      return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), C, 0xf, 0xf, false));
+    };
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      float a = s1[it], b = s2[it];
+      a = dpp_add(a, std::integral_constant<int, 0xB1>{}); b = dpp_add(b, std::integral_constant<int, 0xB1>{});
+      a = dpp_add(a, std::integral_constant<int, 0x4E>{}); b = dpp_add(b, std::integral_constant<int, 0x4E>{});
+      a = dpp_add(a, std::integral_constant<int, 0x141>{}); b = dpp_add(b, std::integral_constant<int, 0x141>{});
+      a = dpp_add(a, std::integral_constant<int, 0x140>{}); b = dpp_add(b, std::integral_constant<int, 0x140>{});
+      if (l15 == 0) *(wvn_f32x2_t*)(sx + ((size_t)ch * BM + rg * 32 + 4 * it + rq) * 2) = wvn_f32x2_t{a, b};
+    }
+    __syncthreads();
+    if (ch == 0 && lane < 32) {
+      const int m = m0w + lane;
+      if (m < M) {
+        const wvn_f32x2_t p0 = *(const wvn_f32x2_t*)(sx + ((size_t)rg * 32 + lane) * 2), p1 = *(const wvn_f32x2_t*)(sx + ((size_t)BM + rg * 32 + lane) * 2);
+        const float a = p0[0] + p1[0], b = p0[1] + p1[1];
+        const float mean = a * (1.0f / NN);
+        const float var = fmaxf(b * (1.0f / NN) - mean * mean, 0.f);
+        *(wvn_f32x2_t*)(stats + 2 * (size_t)m) = wvn_f32x2_t{mean, 1.0f / sqrtf(var + eps)};
+      }
+    }
+  }
+}
+
+template <bool TIMING>
+__global__ __launch_bounds__(512, 1) void gemm_n384_x3_frag_pair_kernel(N384X3Params p) {
+  wvn_fp16_saturate();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave & 3, ch = wave >> 2;        // (waves w and w + 4 -- the two column halves of a row group -- share a SIMD)
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nk = p.K / BKS;                      // a multiple of PD (launcher)
+  const float* bias_l = (const float*)(smem + BIAS_OFF);
+  const float* ls_l = (const float*)(smem + LS_OFF);
+  for (int i = tid; i < NN; i += 512) {
+    ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
+    ((float*)(smem + LS_OFF))[i] = p.ls ? p.ls[i] : 1.f;
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)2 * NN * p.K * 2), 0x00020000);
+  const size_t mpad = (size_t)(p.M + 31) / 32 * 32;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)((p.a_plane + mpad * p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
+  const unsigned wv0 = (unsigned)(wave * PFW * 1024 + lane * 16);   // + u * 1024: piece wave * 3 + u of the k-step's 24
+  const unsigned rdw = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4) + ch * 6 * 1024;  // + plane * W_PLANE + t * 1024: this wave's six column tiles
+  const unsigned a_lo_off = (unsigned)(p.a_plane * 2);
+
+  long long t_wait = 0, t_steps = 0, t_epi = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  const int nrb = (p.M + BM - 1) / BM;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int m0w = rb * BM + rg * 32;
+    const unsigned a_base = __builtin_amdgcn_readfirstlane((unsigned)((size_t)(m0w >> 5) * nk * 1024));   // fragment (R, 0) of the hi plane
+    auto piece_w = [&](int i, int u) {
+      unsigned char* st = smem + (i % FNS) * FSTAGE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(st + (wave * PFW + u) * 1024), 16, wv0 + u * 1024,
+                                               __builtin_amdgcn_readfirstlane((unsigned)i * FSTAGE), 0, 0);
+    };
+    u32x4_t afh[PD], afl[PD];
+    auto load_a = [&](int i, int slot) {
+      const unsigned so = __builtin_amdgcn_readfirstlane(a_base + (unsigned)i * 1024);
+      afh[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, so, 0);
+      afl[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, so + a_lo_off, 0);
+    };
+    __syncthreads();  // the previous row block's staging / statistics reads are done (and the bias table is visible) before DMA reuses the LDS
+#pragma unroll
+    for (int j = 0; j < PD; ++j) load_a(j, j);
+#pragma unroll
+    for (int i0 = 0; i0 < FNS - 1; ++i0)
+      if (i0 < nk) {
+#pragma unroll
+        for (int u = 0; u < PFW; ++u) piece_w(i0, u);
+      }
+
+    f32x16_t acc[NTILE / 2];
+#pragma unroll
+    for (int t = 0; t < NTILE / 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int ib = 0; ib < nk; ib += PD) {
+#pragma unroll
+      for (int jj = 0; jj < PD; ++jj) {
+        const int i = ib + jj;
+        long long c0 = 0, c1 = 0;
+        if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
+        // W slice i landed: younger than its last piece are at least the (FNS - 2) * PFW pieces of the slices since (the A pairs make the
+        // wait conservative in steady state, as in the one-wave form)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FNS - 2) * PFW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* st = smem + (i % FNS) * FSTAGE;
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, afh[jj]), al = __builtin_bit_cast(bf16x8_t, afl[jj]);
+        bf16x8_t wh[2][2], wl[2][2];   // [pair parity][tile of the pair]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          wh[0][t] = *(const bf16x8_t*)(st + rdw + t * 1024);
+          wl[0][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + t * 1024);
+        }
+#pragma unroll
+        for (int pr = 0; pr < NTILE / 4; ++pr) {
+          const int cur = pr & 1, nx = cur ^ 1;
+          piece_w(i + FNS - 1, pr);   // slice i + 4 into the stage every wave has just left: one piece per tile pair
+          if (pr + 1 < NTILE / 4) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              wh[nx][t] = *(const bf16x8_t*)(st + rdw + (2 * pr + 2 + t) * 1024);
+              wl[nx][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + (2 * pr + 2 + t) * 1024);
+            }
+          }
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const bf16x8_t w = term == 1 ? wl[cur][t] : wh[cur][t];
+              const bf16x8_t a = term == 0 ? al : ah;          // hi*lo, lo*hi, hi*hi
+              acc[2 * pr + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc[2 * pr + t], 0, 0, 0);
+            }
+#pragma unroll
+          for (int n = 0; n < 6; ++n) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i + PD < nk) load_a(i + PD, jj);   // (after the last MFMA that reads the slot)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TIMING) { t_wait += c1 - c0; t_steps += (long long)__builtin_amdgcn_s_memtime() - c1; }
+      }
+    }
+    long long e0 = 0;
+    if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
+    n384_pair_epilogue(acc, smem, wave, lane, rg, ch, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M);
+    if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg && ch == 0) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + rg) * 4;
+      d[0] = t_wait; d[1] = t_steps; d[2] = t_epi; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+    }
+  }
+}
+
+int g_n384_pair = 0;   // 1: the wave-pair form of the fragment kernel, 0: one wave per SIMD (default; wvn_debug_n384_pair).  Measured (scripts/bench_n384_pair.py,
+                       // profiles/r05_wave_pair.md): 1481 against 1546 cycles per k-step and SIMD, and the SAME wall time (fc1 + fc2 2893 / 2811 us against
+                       // 2905 / 2803): the denser MFMA stream runs at a lower clock
+
 int n384x3_num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -463,11 +679,16 @@ int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& g, int epi, hipStream_t s
   p.A = g.A; p.a_plane = a_plane; p.lda = g.K; p.W = g.W; p.w_plane = 0; p.ldw = g.K; p.bias = g.bias; p.ls = g.ls;
   p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg; p.stats = g.ln_stats_out; p.eps = g.ln_eps;
   static LdsOptIn lds_opt_in;
-  if (const int rc = lds_opt_in(LDS_BYTES, (const void*)gemm_n384_x3_frag_kernel<false>, (const void*)gemm_n384_x3_frag_kernel<true>)) return rc;
+  if (const int rc = lds_opt_in(PAIR_LDS_BYTES, (const void*)gemm_n384_x3_frag_kernel<false>, (const void*)gemm_n384_x3_frag_kernel<true>,
+                                (const void*)gemm_n384_x3_frag_pair_kernel<false>, (const void*)gemm_n384_x3_frag_pair_kernel<true>)) return rc;
   const int ncu = n384x3_num_cus(), nrb = ceil_div(g.M, BM);
   const int grid = nrb < ncu ? nrb : ncu;
-  if (p.dbg) hipLaunchKernelGGL(gemm_n384_x3_frag_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  if (g_n384_pair) {
+    if (p.dbg) hipLaunchKernelGGL(gemm_n384_x3_frag_pair_kernel<true>, dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p);
+    else hipLaunchKernelGGL(gemm_n384_x3_frag_pair_kernel<false>, dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p);
+  } else if (p.dbg) hipLaunchKernelGGL(gemm_n384_x3_frag_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
   else hipLaunchKernelGGL(gemm_n384_x3_frag_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
+void wvn_gemm_n384_x3_set_pair(int on) { g_n384_pair = on ? 1 : 0; }

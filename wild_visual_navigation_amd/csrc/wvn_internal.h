@@ -198,6 +198,7 @@ void wvn_kmeans_pixels_linear_set_rows(int rc);
 int wvn_kmeans_pixels_linear_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K,
                                     int iters, int relabel, hipStream_t st);
 int wvn_f16_saturate_probe_launch(const float* in, uint16_t* out, int n, hipStream_t st);
+void wvn_gemm_n384_x3_set_pair(int on);
 int wvn_table_slots(int K);
 int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G, int H, int K, hipStream_t st);
 void wvn_kmeans_pixels_set_assign_form(int form);
