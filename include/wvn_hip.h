@@ -582,7 +582,7 @@ int wvn_debug_attention_variant(int variant);
  * kernel counting its exact rows (wvn_debug_kmeans_screen_stats).  Bit-identical labels and centroids in all of them;
  * tests/test_gpu_stego_pixels.py runs them, scripts/bench_pixel_kmeans.py A/Bs them. */
 /* the fragment form of the split-operand row-panel kernel (fc2 / projection of WVN_PREC_MIX / WVN_PREC_X3): 1 = a wave PAIR per 32 rows, two waves per
- * SIMD (round 5: 4 % fewer cycles per k-step, the same wall time), 0 = one wave per SIMD (default).  Bit-identical C; A/B and tests */
+ * SIMD (round 5, default: 12 % fewer cycles per k-step, fc2 -4 % wall time), 0 = one wave per SIMD (round 4).  Bit-identical C; A/B and tests */
 int wvn_debug_n384_pair(int on);
 int wvn_debug_kmeans_assign_form(int form);
 /* image rows of a band the linear form's assign kernel works on at a time (LDS per workgroup against barriers per band; default 5) */

@@ -48,7 +48,7 @@ for pair in (0, 1, 0, 1):
     ks2 = (F // 16) * nrb / 256.0
     print(f"fc1 + fc2, {'wave pair (2 per SIMD)' if pair else 'one wave per SIMD'}: {ms * 1e3:.0f} us per pair of launches; fc2 per k-step: wait+barrier {t2[0] / ks2:.0f}, "
           f"steps {t2[1] / ks2:.0f} (floor 1152 per SIMD), epilogue {t2[2] / ks2:.0f}, total {t2[3] / ks2:.0f} cycles", flush=True)
-lib.wvn_debug_n384_pair(0)
+lib.wvn_debug_n384_pair(1)
 print("residual update bit-identical between the two forms:", bool(torch.equal(res[0], res[1])))
 want = x0[:4096].double() + torch.nn.functional.gelu(a[:4096].double() @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
 print("max |err| vs fp64 on the first 4096 rows:", (res[1][:4096].double() - want).abs().max().item())

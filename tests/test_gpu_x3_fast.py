@@ -63,10 +63,10 @@ def test_a_stationary_k384_every_row(dev, M, N, epi):
 
 @pytest.fixture
 def n384_pair(request):
-    """The two forms of the fragment-major row-panel kernel: a wave pair per 32 rows (two waves per SIMD, opt-in) / one wave per SIMD (default)."""
+    """The two forms of the fragment-major row-panel kernel: a wave pair per 32 rows (two waves per SIMD, the default) / one wave per SIMD."""
     _lib.lib().wvn_debug_n384_pair(request.param)
     yield request.param
-    _lib.lib().wvn_debug_n384_pair(0)
+    _lib.lib().wvn_debug_n384_pair(1)
 
 
 @pytest.mark.parametrize("n384_pair", [1, 0], indirect=True, ids=["wave-pair", "one-wave-per-simd"])

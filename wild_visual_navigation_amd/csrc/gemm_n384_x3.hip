@@ -414,17 +414,23 @@ __global__ __launch_bounds__(256, 1) void gemm_n384_x3_frag_kernel(N384X3Params 
 // 192 ch .. 192 ch + 191 -- six accumulator tiles (96 registers) instead of twelve, 18 MFMAs and THREE DMA pieces per k-step instead of 36
 // and six.  The matrix work per SIMD and k-step is unchanged (36 MFMAs = 1152 cycles); what changes is that a wave which is issuing a DMA
 // piece (~54 cycles each for a wave that is alone on its SIMD), waiting at the barrier or for a fragment no longer idles the matrix pipe:
-// its partner's MFMAs fill it (scripts/ubench/wave_pair.hip: 1675 -> 1333 cycles per k-step for the untuned instruction streams; THIS kernel:
-// 1546 -> 1481 against the tuned one-wave form, with no change in wall time -- it ships as an opt-in, wvn_debug_n384_pair(1)).  Price:
+// its partner's MFMAs fill it (scripts/ubench/wave_pair.hip: 1675 -> 1333 cycles per k-step for the untuned instruction streams; THIS kernel
+// against the tuned one-wave form: 1546 -> 1481 with the barrier of k-step i covering slice i, -> 1355 with it covering slice i + 1 and the
+// first fragments of the next k-step fetched under the tail of this one; wall time of fc2 -4 %: the denser MFMA stream clocks lower).  Price:
 // both waves of a pair fetch the row group's A fragments (the second fetch hits the L2), and the LayerNorm statistics of a row are the sum
 // of two waves' partials (exchanged through LDS, half 0 + half 1: a fixed order).  Same products in the same order per output element:
 // C is bit-identical to gemm_n384_x3_frag_kernel's.
 constexpr int PFW = 3;                            // W DMA pieces per wave and k-step
+constexpr int PNS = 6;                            // ring depth: the barrier at the top of k-step i covers slice i + 1 (its first fragments are fetched under
+                                                  // the tail of k-step i), slices i + 2 .. i + 4 in flight, slice i + 5 requested during k-step i
+constexpr int PRING_BYTES = PNS * FSTAGE;         // 144 KB
 constexpr int PSTG_PITCH = 68;                    // floats per staged row (64 columns + 4)
 constexpr int PSTG_BYTES = 32 * PSTG_PITCH * 4;   // per wave: 8704 (the eight images overlap the ring's first 68 KB)
-constexpr int PSTAT_OFF = LDS_BYTES;              // [2 column halves][128 rows] {sum, sum of squares}
+constexpr int PBIAS_OFF = PRING_BYTES;
+constexpr int PLS_OFF = PBIAS_OFF + NN * 4;
+constexpr int PSTAT_OFF = PLS_OFF + NN * 4;       // [2 column halves][128 rows] {sum, sum of squares}
 constexpr int PAIR_LDS_BYTES = PSTAT_OFF + 2 * BM * 8;
-static_assert(8 * PSTG_BYTES <= RING_BYTES, "staging images must fit in the ring");
+static_assert(8 * PSTG_BYTES <= PRING_BYTES && PAIR_LDS_BYTES <= 160 * 1024, "staging images must fit in the ring, the whole in the LDS");
 
 __device__ inline void n384_pair_epilogue(const f32x16_t (&acc)[NTILE / 2], unsigned char* smem, int wave, int lane, int rg, int ch, int m0w,
                                           __amdgpu_buffer_rsrc_t rs_c, int ldc, const float* bias_l, const float* ls_l, float* stats, float eps, int M) {
@@ -507,11 +513,11 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_x3_frag_pair_kernel(N384X3Pa
   const int rg = wave & 3, ch = wave >> 2;        // (waves w and w + 4 -- the two column halves of a row group -- share a SIMD)
   const int l31 = lane & 31, hi = lane >> 5;
   const int nk = p.K / BKS;                      // a multiple of PD (launcher)
-  const float* bias_l = (const float*)(smem + BIAS_OFF);
-  const float* ls_l = (const float*)(smem + LS_OFF);
+  const float* bias_l = (const float*)(smem + PBIAS_OFF);
+  const float* ls_l = (const float*)(smem + PLS_OFF);
   for (int i = tid; i < NN; i += 512) {
-    ((float*)(smem + BIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
-    ((float*)(smem + LS_OFF))[i] = p.ls ? p.ls[i] : 1.f;
+    ((float*)(smem + PBIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
+    ((float*)(smem + PLS_OFF))[i] = p.ls ? p.ls[i] : 1.f;
   }
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)2 * NN * p.K * 2), 0x00020000);
   const size_t mpad = (size_t)(p.M + 31) / 32 * 32;
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_x3_frag_pair_kernel(N384X3Pa
     const int m0w = rb * BM + rg * 32;
     const unsigned a_base = __builtin_amdgcn_readfirstlane((unsigned)((size_t)(m0w >> 5) * nk * 1024));   // fragment (R, 0) of the hi plane
     auto piece_w = [&](int i, int u) {
-      unsigned char* st = smem + (i % FNS) * FSTAGE;
+      unsigned char* st = smem + (i % PNS) * FSTAGE;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(st + (wave * PFW + u) * 1024), 16, wv0 + u * 1024,
                                                __builtin_amdgcn_readfirstlane((unsigned)i * FSTAGE), 0, 0);
     };
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_x3_frag_pair_kernel(N384X3Pa
 #pragma unroll
     for (int j = 0; j < PD; ++j) load_a(j, j);
 #pragma unroll
-    for (int i0 = 0; i0 < FNS - 1; ++i0)
+    for (int i0 = 0; i0 < PNS - 1; ++i0)
       if (i0 < nk) {
 #pragma unroll
         for (int u = 0; u < PFW; ++u) piece_w(i0, u);
@@ -554,35 +560,46 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_x3_frag_pair_kernel(N384X3Pa
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // slice 0 landed (younger: the pieces of slices 1 .. PNS - 2), every wave's part of it: its first tile pair into slot 0
+    bf16x8_t wh[2][2], wl[2][2];   // [slot][tile of the pair]; the first pair of k-step i sits in slot i & 1 (three pairs per k-step: the slots alternate)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PNS - 2) * PFW) : "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      wh[0][t] = *(const bf16x8_t*)(smem + rdw + t * 1024);
+      wl[0][t] = *(const bf16x8_t*)(smem + rdw + W_PLANE + t * 1024);
+    }
     for (int ib = 0; ib < nk; ib += PD) {
 #pragma unroll
       for (int jj = 0; jj < PD; ++jj) {
         const int i = ib + jj;
         long long c0 = 0, c1 = 0;
         if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
-        // W slice i landed: younger than its last piece are at least the (FNS - 2) * PFW pieces of the slices since (the A pairs make the
-        // wait conservative in steady state, as in the one-wave form)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FNS - 2) * PFW) : "memory");
+        // slice i + 1 landed: younger than its last piece are at least the (PNS - 3) * PFW pieces of the three slices since.  The barrier also says
+        // that every wave has left k-step i - 1: the stage of slice i - 1 is free for slice i + 5
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PNS - 3) * PFW) : "memory");
         __builtin_amdgcn_s_barrier();
         if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* st = smem + (i % FNS) * FSTAGE;
+        const unsigned char* st = smem + (i % PNS) * FSTAGE;
+        const unsigned char* st1 = smem + ((i + 1) % PNS) * FSTAGE;
         const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, afh[jj]), al = __builtin_bit_cast(bf16x8_t, afl[jj]);
-        bf16x8_t wh[2][2], wl[2][2];   // [pair parity][tile of the pair]
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          wh[0][t] = *(const bf16x8_t*)(st + rdw + t * 1024);
-          wl[0][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + t * 1024);
-        }
+        const int s0 = jj & 1;   // (PD is even: the slot parity of a k-step is a constant of the unrolled body)
 #pragma unroll
         for (int pr = 0; pr < NTILE / 4; ++pr) {
-          const int cur = pr & 1, nx = cur ^ 1;
-          piece_w(i + FNS - 1, pr);   // slice i + 4 into the stage every wave has just left: one piece per tile pair
+          const int cur = (s0 + pr) & 1, nx = cur ^ 1;
+          piece_w(i + PNS - 1, pr);   // slice i + 5 into the stage every wave has left: one piece per tile pair
           if (pr + 1 < NTILE / 4) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               wh[nx][t] = *(const bf16x8_t*)(st + rdw + (2 * pr + 2 + t) * 1024);
               wl[nx][t] = *(const bf16x8_t*)(st + rdw + W_PLANE + (2 * pr + 2 + t) * 1024);
+            }
+          } else {   // the FIRST pair of the next k-step (its slice is visible since this k-step's barrier): no LDS round trip behind the next barrier
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              wh[nx][t] = *(const bf16x8_t*)(st1 + rdw + t * 1024);
+              wl[nx][t] = *(const bf16x8_t*)(st1 + rdw + W_PLANE + t * 1024);
             }
           }
 #pragma unroll
@@ -621,9 +638,8 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_x3_frag_pair_kernel(N384X3Pa
   }
 }
 
-int g_n384_pair = 0;   // 1: the wave-pair form of the fragment kernel, 0: one wave per SIMD (default; wvn_debug_n384_pair).  Measured (scripts/bench_n384_pair.py,
-                       // profiles/r05_wave_pair.md): 1481 against 1546 cycles per k-step and SIMD, and the SAME wall time (fc1 + fc2 2893 / 2811 us against
-                       // 2905 / 2803): the denser MFMA stream runs at a lower clock
+int g_n384_pair = 1;   // 1: the wave-pair form of the fragment kernel (default since its barrier covers the NEXT slice: 1355 against 1546 cycles per k-step and
+                       // SIMD, fc2 -4 % wall time), 0: one wave per SIMD (round 4; wvn_debug_n384_pair).  scripts/bench_n384_pair.py, profiles/r05_wave_pair.md
 
 int n384x3_num_cus() {
   static int n = 0;
