@@ -31,7 +31,7 @@ def test_tables_are_the_image_op(golden):
     assert torch.equal(OI.resize_nearest_center_crop(raw.float(), 224).to(torch.uint8), golden("demo_frames_224.pt")["frames_u8"])
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16", "exact", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "exact", "mixed", "fp32"])
 def test_demo_frames_ingest_is_bit_identical(dev, golden, prec):
     raw_cpu = golden("demo_frames_raw.pt")["frames_u8"]                                # the reference's frames, undecimated
     raw = raw_cpu.to(dev)
@@ -46,7 +46,7 @@ def test_demo_frames_ingest_is_bit_identical(dev, golden, prec):
     # up-sizing ingest (224 x 299 -> 448 network input): rows / columns repeat
     bb448 = VitBackbone(sd, 448, 8, 6, device=dev, precision=prec, max_chunk=2)
     assert torch.equal(bb448.forward_tokens(raw[:2]), bb448.forward_tokens(resize_nearest_center_crop(f01[:2], 448).contiguous().to(dev)))
-    if prec == "exact":   # and against the CPU oracle's own transform + backbone at the north_star tolerance
+    if prec in ("exact", "mixed"):   # and against the CPU oracle's own transform + backbone at the north_star tolerance
         ref = OV.vit_tokens(sd, OI.dino_transform(f01[:2], 224), 8, 6)[:, 1:]
         assert (bb.forward_tokens(raw[:2]).cpu() - ref).abs().max().item() < 1e-3
 

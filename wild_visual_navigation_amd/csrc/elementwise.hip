@@ -95,23 +95,33 @@ __global__ __launch_bounds__(256) void patchify8_bf16_rows_kernel(const TIN* __r
 
 // The same patch-row panel gathered from a larger source frame through the ingest tables (one element per thread and step:
 // a NEAREST down-sampling touches isolated pixels, there is nothing to vectorise on the read side).
-template <typename TIN, bool F16>
+// PLANES (the split-operand modes): hi = bf16(v) -> out, lo = bf16(v - hi) -> out_lo, a second LDS image (the element-order kernel above wrote the
+// two planes of the <= 1e-3 modes in 16-byte fragments 384 B apart: 628 us per 128-frame launch pair against ~200 here)
+template <typename TIN, bool F16, bool PLANES = false>
 __global__ __launch_bounds__(256) void patchify8_gather_rows_kernel(const TIN* __restrict__ img, bf16_t* __restrict__ out, int S,
-                                                                    Gather gt) {
+                                                                    Gather gt, bf16_t* __restrict__ out_lo = nullptr) {
   wvn_fp16_saturate();
-  extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192]
+  extern __shared__ __attribute__((aligned(16))) bf16_t prow[];  // [G][192] (PLANES: two of them)
   const int G = S / 8, gy = blockIdx.x, b = blockIdx.y;
+  bf16_t* plo = prow + G * 192;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float stdv[3] = {0.229f, 0.224f, 0.225f};
   for (int i = threadIdx.x; i < 3 * 8 * S; i += 256) {
     const int c = i / (8 * S), r = i - c * 8 * S, py = r / S, x = r - py * S;
     const float raw = load_pixel(img + (((size_t)b * 3 + c) * gt.Hs + gt.rows[gy * 8 + py]) * gt.Ws + gt.cols[x]);
     const float v = (raw - mean[c]) / stdv[c];
-    prow[(x >> 3) * 192 + c * 64 + py * 8 + (x & 7)] = F16 ? f32_to_f16(v) : f32_to_bf16(v);
+    const int o = (x >> 3) * 192 + c * 64 + py * 8 + (x & 7);
+    const bf16_t h = F16 ? f32_to_f16(v) : f32_to_bf16(v);
+    prow[o] = h;
+    if constexpr (PLANES) plo[o] = f32_to_bf16(v - bf16_to_f32(h));
   }
   __syncthreads();
   u32x4_t* dst = (u32x4_t*)(out + ((size_t)b * G * G + (size_t)gy * G) * 192);
   for (int i = threadIdx.x; i < G * 192 / 8; i += 256) dst[i] = ((const u32x4_t*)prow)[i];
+  if constexpr (PLANES) {
+    u32x4_t* dl = (u32x4_t*)(out_lo + ((size_t)b * G * G + (size_t)gy * G) * 192);
+    for (int i = threadIdx.x; i < G * 192 / 8; i += 256) dl[i] = ((const u32x4_t*)plo)[i];
+  }
 }
 
 // NEAREST resize + crop as an image (ImageProjector.resize_image, image_projector.py:199-200): out[b,c,y,x] = in[b,c,rows[y],cols[x]]
@@ -339,10 +349,14 @@ static int patchify_any(const TIN* img, void* patches, void* patches_lo, int out
   bf16_t* lo = out_mode == 2 ? (bf16_t*)patches_lo : nullptr;
   const bool rows_ok = P == 8 && ldp == KP && (S % 8) == 0 && (((uintptr_t)patches) & 15) == 0 && (S / 8) * 192 * 2 <= 64 * 1024;
   const size_t shm = (size_t)(S / 8) * 192 * 2;
+  if (rows_ok && out_mode == 2 && gt.rows && (((uintptr_t)patches_lo) & 15) == 0 && 2 * shm <= 64 * 1024) {   // hi / lo planes through the ingest tables
+    hipLaunchKernelGGL((patchify8_gather_rows_kernel<TIN, false, true>), dim3(S / 8, B), dim3(256), 2 * shm, st, img, (bf16_t*)patches, S, gt, lo);
+    return WVN_OK;
+  }
   if (rows_ok && (out_mode == 1 || out_mode == 3)) {
     if (gt.rows) {
-      if (out_mode == 3) hipLaunchKernelGGL((patchify8_gather_rows_kernel<TIN, true>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S, gt);
-      else hipLaunchKernelGGL((patchify8_gather_rows_kernel<TIN, false>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S, gt);
+      if (out_mode == 3) hipLaunchKernelGGL((patchify8_gather_rows_kernel<TIN, true>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S, gt, (bf16_t*)nullptr);
+      else hipLaunchKernelGGL((patchify8_gather_rows_kernel<TIN, false>), dim3(S / 8, B), dim3(256), shm, st, img, (bf16_t*)patches, S, gt, (bf16_t*)nullptr);
       return WVN_OK;
     }
     if ((((uintptr_t)img) & (sizeof(TIN) == 1 ? 3 : 15)) == 0) {
