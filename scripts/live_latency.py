@@ -29,10 +29,10 @@ def wall(fn, iters):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-def run(dev, S, ftype):
+def run(dev, S, ftype, precision="bf16"):
     sd = synthetic_vit_state_dict(depth=12, pretrain_grid=28)
     fe = FeatureExtractor(device=dev, segmentation_type="stego" if ftype == "stego" else "grid", feature_type=ftype, patch_size=8,
-                          backbone_type="vit_small", input_size=S, pretrained_weights=sd, precision="bf16")
+                          backbone_type="vit_small", input_size=S, pretrained_weights=sd, precision=precision)
     params = ExperimentParams()
     params.model.simple_mlp_cfg.input_size = fe.feature_dim
     model = get_model(params.model).to(dev)
@@ -41,13 +41,19 @@ def run(dev, S, ftype):
     cg.mean[0], cg.std[0] = 0.9, 0.25
     frame = torch.randint(0, 256, (1, 3, S, S), dtype=torch.uint8, device=dev)
     eager = wall(lambda: fe.predict_per_pixel(frame, model, cg), 50)
-    return {"frame": f"{S}x{S} uint8", "features": ftype, "ms_per_frame": round(eager, 3)}
+    # the segmentation + pooling half of the node's frame (extract): k-means / grid segments, pooled rows
+    seg_ms = wall(lambda: fe.extract(frame), 30)
+    return {"frame": f"{S}x{S} uint8", "features": ftype, "precision": precision, "predict_per_pixel_ms": round(eager, 3), "extract_ms": round(seg_ms, 3)}
 
 
 def main():
     dev = torch.device("cuda:0")
     # BASELINE's 448x448 DINO configuration, and the node's own default (default.yaml: 224x224, feature_type stego)
-    print(json.dumps([run(dev, 448, "dino"), run(dev, 224, "stego"), run(dev, 224, "dino")]))
+    # (round 5: the class default is precision="mixed", the <= 1e-3 mode; the 16-bit speed paths beside it)
+    out = []
+    for prec in ("mixed", "fp16", "bf16"):
+        out += [run(dev, 448, "dino", prec), run(dev, 224, "stego", prec), run(dev, 224, "dino", prec)]
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
