@@ -28,7 +28,7 @@ Definition (all fp32, one rounding per stated operation; `chain` = acc = fma(a, 
             band b = the rows y with i0(y) == b:   P0[b, k, j] = chain_y wy0(y) U[y, k, j],   P1[b, k, j] = chain_y wy1(y) U[y, k, j]
             A[k, i, j] = plain adds from +0, bands ascending, P0 before P1, of every P_s[b] whose patch row (b for s = 0, i1 of the band for s = 1) is i
             R[i, k, d] = chain_j A[k, i, j] code[i, j, d]
-            Q[g, k, d] = plain adds from +0 over the patch rows i of group g (ROW_GROUP = 4 consecutive rows), ascending, of R[i, k, d]
+            Q[g, k, d] = plain adds from +0 over the patch rows i of group g (ROW_GROUP = 2 consecutive rows), ascending, of R[i, k, d]
             sums[k, d] = plain adds from +0 over g ascending of Q[g, k, d]
             c_k        = sums_k * (1 / max(sqrt(chain_d sums_k[d]^2), 1e-12)) if the cluster has members, else unchanged
   final labels = one more assignment.
@@ -40,7 +40,7 @@ import numpy as np
 from . import interfaces as OI
 
 f32 = np.float32
-ROW_GROUP = 4   # patch rows whose row sums are added before the groups are (csrc/stego_linear.hip: LIN_RG)
+ROW_GROUP = 2   # patch rows whose row sums are added before the groups are (csrc/stego_linear.hip: LIN_RG)
 
 
 def taps(G: int, H: int):

@@ -8,7 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define ROW_GROUP 4
+#define ROW_GROUP 2
 
 static float lin_rinv_norm(float n2) {
   float n = sqrtf(n2);
@@ -132,7 +132,7 @@ int wvn_oracle_kmeans_pixels_linear(const float* code, int G, int H, int C, int 
           R[((long)i * K + k) * C + d] = acc;
         }
     for (long e = 0; e < (long)K * C; ++e) sums[e] = 0.f;
-    for (int g0 = 0; g0 < G; g0 += ROW_GROUP)      /* two levels: the rows of a group of 4 patch rows ascending, then the groups ascending */
+    for (int g0 = 0; g0 < G; g0 += ROW_GROUP)      /* two levels: the rows of a group of 2 patch rows ascending, then the groups ascending */
       for (long e = 0; e < (long)K * C; ++e) {
         float q = 0.f;
         for (int i = g0; i < G && i < g0 + ROW_GROUP; ++i) q = q + R[(long)i * K * C + e];

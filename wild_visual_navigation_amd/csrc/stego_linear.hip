@@ -15,7 +15,7 @@
 // Kernels of one pass (all frames at once, a frame pinned to one XCD's L2 as in stego.hip):
 //   km_lin_assign   one workgroup per (frame, band b = the image rows whose upper tap is patch row b): the two table rows in LDS;
 //                   lane = pixel: K bilinear interpolations + argmax; then U[y, k, j] (ascending x), P0 / P1[b, k, j] (ascending y)
-//   km_lin_rowsum   one workgroup per (frame, group of 4 patch rows): A[k, i, :] = P1[i-1] + P0[i] (+ P1[i] on the last row),
+//   km_lin_rowsum   one workgroup per (frame, pair of patch rows): A[k, i, :] = P1[i-1] + P0[i] (+ P1[i] on the last row),
 //                   R[i, k, d] = chain_j A code, Q[g, k, d] = the group's R in ascending i (registers)
 //   km_lin_table    sums = sum_g Q (ascending), normalise, keep the centroids of empty clusters, then S[t, :] for 256 patches per workgroup
 //   (the last assignment leaves a bit mask of the ids in use; km_lin_relabel compacts them ascending)
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
 // R[i][k][d] = chain_j A[k][i][j] * code[b][i][j][d];  A[k][i][:] from the band tables that touch patch row i, bands ascending, P0 before P1.
 // One 128-thread team per patch row of the group (thread = channel d, the row's whole code column requested at once: the chains are
 // short and a memory round trip per eight values made the kernel latency-bound), the group's rows then added in order through LDS.
-constexpr int LIN_RG = 4;   // (8 rows = 1024 threads leave 128 registers per thread: the 64-value column spilled)
+constexpr int LIN_RG = 2;   // patch rows per workgroup (measured 8 / 4 / 2: 88 / 81 / 56 us per pass -- 896 workgroups of four rows were 1.17 rounds of the chip: the tail ran alone)
 constexpr int LIN_MAXG = 64;   // patch columns a thread keeps in registers
 __host__ __device__ inline size_t lin_rowsum_lds(int G, int C, int K, int KP) { return ((size_t)LIN_RG * G * KP + (size_t)LIN_RG * K * C) * sizeof(float); }
 template <int KP>
@@ -279,11 +279,12 @@ __global__ __launch_bounds__(LIN_RG * 128) void km_lin_rowsum_kernel(const float
   const float* Pb = Pg + (size_t)b * G * 2 * KP * G;
   const int r = tid >> 7, d = tid & 127;
   const bool act = r < nr && d < C;
-  float x[LIN_MAXG];
+  constexpr int XH = LIN_MAXG / 2;   // the row's code column in two halves of 32 patch columns (64 registers of it kept the kernel at three waves per SIMD)
+  float x[XH];
+  const float* cr = code + (((size_t)b * G + i0 + (r < nr ? r : 0)) * G) * C + (d < C ? d : 0);
   if (act) {
-    const float* cr = code + (((size_t)b * G + i0 + r) * G) * C + d;
 #pragma unroll
-    for (int j = 0; j < LIN_MAXG; ++j) x[j] = cr[(size_t)min(j, G - 1) * C];
+    for (int j = 0; j < XH; ++j) x[j] = cr[(size_t)min(j, G - 1) * C];
   }
   for (int e0 = tid; e0 < nr * KP * G; e0 += 4 * blockDim.x) {   // (four elements' band tables requested per round trip)
     float pa[4], pb[4], pc[4];
@@ -317,13 +318,20 @@ __global__ __launch_bounds__(LIN_RG * 128) void km_lin_rowsum_kernel(const float
     for (int k = 0; k < KP; ++k) acc[k] = 0.f;
     const float* Ar = Al + (size_t)r * G * KP;
 #pragma unroll
-    for (int j = 0; j < LIN_MAXG; ++j) {
-      if (j < G) {
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) {   // the second half is requested once the first has been consumed (the same chain order: j ascending)
 #pragma unroll
-        for (int k4 = 0; k4 < KP / 4; ++k4) {
-          const f32x4_t a4 = *(const f32x4_t*)(Ar + j * KP + 4 * k4);
+        for (int j = 0; j < XH; ++j) x[j] = cr[(size_t)min(XH + j, G - 1) * C];
+      }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[4 * k4 + q] = __fmaf_rn(a4[q], x[j], acc[4 * k4 + q]);
+      for (int j = 0; j < XH; ++j) {
+        if (h * XH + j < G) {
+#pragma unroll
+          for (int k4 = 0; k4 < KP / 4; ++k4) {
+            const f32x4_t a4 = *(const f32x4_t*)(Ar + (h * XH + j) * KP + 4 * k4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * k4 + q] = __fmaf_rn(a4[q], x[j], acc[4 * k4 + q]);
+          }
         }
       }
     }
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(LIN_RG * 128) void km_lin_rowsum_kernel(const float
 // then S[b][t][k] = chain_d code[b][t][d] * c_k[d] for the workgroup's 256 patches (thread = patch: its code row straight from global
 // memory, every request of the row in flight at once -- the LDS-staged tile cost a memory round trip per 16 bytes of a thread's copy loop)
 constexpr int LIN_TT = 256;
-constexpr int LIN_MAXNG = 16;
+constexpr int LIN_MAXNG = 32;
 template <int KP, int C>
 __global__ __launch_bounds__(LIN_TT) void km_lin_table_kernel(const float* __restrict__ code, const float* __restrict__ Q,
                                                               const int* __restrict__ cntp, const float* __restrict__ cent_old,
