@@ -118,8 +118,7 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
   }
   __syncthreads();
   const int nseg = HP >> 6;
-  int mycnt = 0;         // lane k: members of cluster k seen by this wave
-  unsigned mymask = 0;   // (FINAL) the labels this wave has assigned
+  unsigned mymask = 0;   // the labels this lane has assigned
   // the chunk's reciprocal norms travel global -> LDS directly (buffer_load ... lds, 1 KB per wave instruction), requested before the
   // labels are computed and waited for behind them: as register loads in front of LDS stores they cost the kernel 2.6 of its 4.2 ms
   // (a memory round trip per wave task, then -- hoisted -- 57 registers and a workgroup of occupancy)
@@ -165,21 +164,13 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
             if (4 * k4 + 2 * h + q < K && v[q] > best) { best = v[q]; bi = 4 * k4 + 2 * h + q; }
         }
       }
+      // which clusters have members is all the update needs ("an empty cluster keeps its centroid"): every lane collects the ids it has
+      // assigned in a bit mask, folded once per workgroup at the end (a ballot loop over the labels present per 64 pixels cost 0.3 ms per call)
+      if (valid) mymask |= 1u << bi;
       if (FINAL) {
         if (valid) labels[(size_t)b * H * H + (size_t)y * H + x] = bi;
-        for (unsigned long long todo = __ballot(valid); todo;) {
-          const int k = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(todo));
-          mymask |= 1u << k;
-          todo &= ~__ballot(bi == k);
-        }
       } else {
         labl[r * HP + x] = (unsigned char)bi;
-        for (unsigned long long todo = (WVN_LIN_ABL & 8) ? 0ull : __ballot(valid); todo;) {   // (uniform loop over the labels present among the 64 pixels)
-          const int k = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(todo));
-          const unsigned long long m = __ballot(bi == k && valid);
-          if (lane == k) mycnt += __builtin_popcountll(m);
-          todo &= ~m;
-        }
       }
     }
     if (FINAL) continue;
@@ -246,17 +237,18 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
     }
     __syncthreads();
   }
-  if (FINAL) {   // the ids in use, for the ascending compaction (km_lin_relabel_kernel): one OR per workgroup
-    if (lane == 0 && mymask) atomicOr((unsigned*)&cntl[0], mymask);
-    __syncthreads();
+  // the ids in use: OR over the wave (butterfly), one LDS atomic per wave, one global word per workgroup
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mymask |= (unsigned)__shfl_xor((int)mymask, o, 64);
+  if (lane == 0 && mymask) atomicOr((unsigned*)&cntl[0], mymask);
+  __syncthreads();
+  if (FINAL) {   // for the ascending compaction (km_lin_relabel_kernel)
     if (tid == 0 && cntl[0] && used) atomicOr(&used[b], (unsigned)cntl[0]);
     return;
   }
-  if (lane < K && mycnt) atomicAdd(&cntl[lane], mycnt);
-  __syncthreads();
   float* dst = Pg + ((size_t)b * G + band) * 2 * KP * G;
   for (int i = tid; i < 2 * KP * G; i += blockDim.x) dst[i] = Pl[i];
-  if (tid < KP) cntp[((size_t)b * G + band) * KP + tid] = cntl[tid];
+  if (tid == 0) cntp[(size_t)b * G + band] = cntl[0];   // bit k: cluster k has members in this band
 }
 
 // Q[b][g][k][d] = sum over the patch rows i of group g (LIN_RG consecutive rows, ascending, plain adds from +0) of
@@ -391,10 +383,9 @@ __global__ __launch_bounds__(LIN_TT) void km_lin_table_kernel(const float* __res
       }
     }
     if (tid < KP) {
-      int n = 0;
-      if (tid < K)
-        for (int i = 0; i < G; ++i) n += cntp[((size_t)b * G + i) * KP + tid];
-      cn[tid] = n;
+      unsigned m = 0;
+      for (int i = 0; i < G; ++i) m |= (unsigned)cntp[(size_t)b * G + i];
+      cn[tid] = (tid < K && ((m >> tid) & 1u)) ? 1 : 0;   // cluster tid has members
     }
     __syncthreads();
     if (tid < K) {
@@ -478,7 +469,7 @@ LinScratch lin_carve(float* base, int B, int G, int H, int C, int K, int KP) {
   s.S = take((size_t)B * G * G * KP);
   s.Pg = take((size_t)B * G * 2 * KP * G);
   s.Q = take((size_t)B * ((G + LIN_RG - 1) / LIN_RG) * KP * C);
-  s.cntp = (int*)take((size_t)B * G * KP);
+  s.cntp = (int*)take((size_t)B * G);   // per (frame, band): bit k = cluster k has members
   s.used = (unsigned*)take((size_t)B);
   s.floats = off;
   return s;
