@@ -11,4 +11,4 @@ for k in ('fp16_speed', 'parity_mode', 'stego_fast', 'backbone_b32', 'dinov2_fp8
         print(k, d[k]['value'], d[k]['ms_per_step'], d[k]['roofline'].get('frac'), d[k].get('parity'))
 print('roofline', d['roofline'])
 PY
-bash scripts/profile_job.sh r05c_headline 1
+bash scripts/profile_job.sh r05d_headline 0
