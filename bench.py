@@ -338,7 +338,7 @@ def cpu_oracle_sample(args, fe):
     base = {"value": round(n / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": (f"{n} frames {args.size}x{args.size} through the CPU oracle ({what}), {dt:.1f} s wall; ViT / head / pooling / MLP = PyTorch fp32 "
                        f"on {torch.get_num_threads()} threads, k-means = the C restatement (fmaf chains in the definition's order, OpenMP) when "
-                       "oracle/_build holds it, else numpy with a software fp32 fma (25 s per 448^2 frame instead of 0.7 s)")}
+                       "oracle/_build holds it, else numpy with a software fp32 fma (about 20 s per 448^2 frame instead of 0.1 s)")}
     orc = {"img": img, "toks": toks, "sd": sd, "head": head, "G": G, "P": P, "heads": heads,
            "codes": {args.stego_reading: codes}, "segs": {args.stego_reading: segs}}
     if upstream:   # (outside the timed sample) the same frames under the fast form, for the parity of the stego_fast leg
@@ -618,7 +618,8 @@ def main():
             metric = "frames/sec (448x448 DINO-ViT-S/8 + seg + MLP train-step)"
             segdesc = ("grid segmentation (32-pixel cells)" if args.segmentation != "stego" else
                        "STEGO head with flip TTA (two backbone passes per frame: the frame and its mirror) + per-image cosine k-means "
-                       "over the 448x448 up-sampled code pixels (20 clusters; rows interpolated on the fly) -- the defaults of "
+                       "over the 448x448 up-sampled code pixels (20 clusters; evaluated through its linearity: a similarity table per pass interpolated per pixel, "
+                       "centroid sums from summed tap weights -- the dense code never exists) -- the defaults of "
                        "StegoInterface = the absent STEGO package's get_code / postprocess as published"
                        if args.stego_reading == "upstream" else
                        "STEGO head + per-image cosine k-means (20 clusters, at patch resolution, single pass: no flip TTA -- the opt-in "
