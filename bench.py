@@ -98,7 +98,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-oracle sample (about 15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", default=None, choices=["fp16", "bf16", "mixed", "exact", "fp32", "fp8"],
-                    help="default: fp16 (fp8 for --mode dinov2)")
+                    help="default: mixed for --mode full (the <= 1e-3 headline), fp16 for --mode backbone / fast, fp8 for --mode dinov2")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline leg only (no fp16_speed / stego_fast / backbone_b32 / dinov2_fp8 legs)")
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of each extra leg (after 5 warm-up steps)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],

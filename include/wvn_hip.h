@@ -564,6 +564,14 @@ int wvn_debug_gemm_n384_x3(const void* A, const void* A_lo, int lda, const void*
  * WVN_PREC_X3 / WVN_PREC_MIX layout.  dbg1 / dbg2 (optional): per-wave cycle counters of the two instrumented builds. */
 int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, const void* W1_lo, const float* b1, void* hid, void* hid_lo,
                           const void* W2p, const float* b2, float* x, int M, int F, long long* dbg1, long long* dbg2, void* stream);
+/* The MX form of the row-panel kernel (round 6; what WVN_PREC_MIX runs for fc2 and the attention projection by default): every operand as
+ * an fp16 value h, the e5m2 image l8 of its rounding residue * 2^12 and the e5m2 image h8 of the value; the product = A_h W_h on fp16 MFMAs
+ * + 2^-12 (A_h8 W_l8 + A_l8 W_h8) on scaled 8-bit MFMAs of K = 64 (csrc/gemm_n384_x3.hip: gemm_n384_mx_pair_kernel).  A_h: fragment-major
+ * fp16 [ceil(M / 32)][K / 16][64 lanes][8]; A_l8 / A_h8: [ceil(M / 32)][K / 64][2 halves][64 lanes][16 bytes] (backbone.mx_fragments states
+ * the element order), both behind A_h inside one 4 GB span; Wp: backbone.pack_n384_mx(W [384][K]); C [M][ldc] fp32 += (A W^T + bias) (* ls);
+ * K % 128 == 0.  dbg as wvn_debug_gemm_n384_x3. */
+int wvn_debug_gemm_n384_mx(const void* A_h, const void* A_l8, const void* A_h8, const void* Wp, const float* bias, const float* ls, float* C,
+                           int ldc, int M, int K, long long* dbg, void* stream);
 /* subsequent wvn_attention_bf16 launches write dbg[(workgroup * 4 + wave) * 5 + {0 wait, 1 QK^T, 2 softmax, 3 PV,
  * 4 total}]; NULL switches the instrumented build off again. */
 /* (test hook) out_f16[i] = fp16(in[i]) as the kernels convert: finite values beyond the fp16 range saturate to +-65504 (MODE.FP16_OVFL) */
@@ -585,7 +593,7 @@ int wvn_debug_attention_variant(int variant);
  * SIMD (round 5, default: 12 % fewer cycles per k-step, fc2 -4 % wall time), 0 = one wave per SIMD (round 4).  Bit-identical C; A/B and tests */
 int wvn_debug_n384_pair(int on);
 int wvn_debug_kmeans_assign_form(int form);
-/* image rows of a band the linear form's assign kernel works on at a time (LDS per workgroup against barriers per band; default 5) */
+/* image rows of a band the linear form's assign kernel works on at a time (LDS per workgroup against barriers per band; default 4) */
 int wvn_debug_kmeans_linear_rows(int rows);
 
 /* statistics of the screened kernel (synchronises the device): out[0] = 64-pixel row groups it re-did with the exact chains, out[1] = row

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "wvn_debug_kmeans_screen_stats": ([_p, _i], _i),
     "wvn_debug_mlp_x3_frag": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p], _i),
     "wvn_debug_gemm_n384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p], _i),
+    "wvn_debug_gemm_n384_mx": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p], _i),
     "wvn_debug_gemm_a384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p], _i),
     "wvn_stream_create_cu_mask": ([_p, _p, _i], _i),
     "wvn_stream_destroy": ([_p], _i),

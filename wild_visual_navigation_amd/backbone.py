@@ -83,6 +83,76 @@ def pack_fc2_fragment_major(w: torch.Tensor) -> torch.Tensor:
     return p.permute(2, 0, 1, 3, 4).contiguous()
 
 
+# ---- MX correction terms (round 6): an operand v as  h = fp16(v),  l8 = e5m2((v - h) * 2^12),  h8 = e5m2(v)  (csrc/gemm_n384_x3.hip) ----
+MX_RES_SCALE = 4096.0
+
+
+def _e5m2_bytes(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> e5m2 bytes (round to nearest even, finite overflow saturates at +-57344: what v_cvt_*_bf8_* does under MODE.FP16_OVFL)."""
+    return t.float().clamp(-57344.0, 57344.0).to(torch.float8_e5m2).view(torch.uint8)
+
+
+def mx_split(t: torch.Tensor):
+    """fp32 [...] -> (h fp16, l8 uint8, h8 uint8): the three planes of the MX operand representation."""
+    t = t.detach().float()
+    h = t.clamp(-65504.0, 65504.0).to(torch.float16)
+    return h, _e5m2_bytes((t - h.float()) * MX_RES_SCALE), _e5m2_bytes(t)
+
+
+def _swap23(n: int, device=None) -> torch.Tensor:
+    i = torch.arange(n, device=device)
+    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)
+
+
+def pack_n384_mx(w: torch.Tensor) -> torch.Tensor:
+    """W [384][K] fp32 -> the stage list of gemm_n384_mx_pair_kernel: uint8 [K / 64][4 stages][24 KB].  Per 64 k (c): stage 0 / 1 = W_h of
+    k-steps (4c + 0 | 1) / (4c + 2 | 3): [x = k-step parity][384 n][2 chunks][8 fp16], element j of chunk h = W_h[n, 16 s + swap23(8 h + j)];
+    stage 2 / 3 = W_l8 / W_h8: [x = half][384 n][2 chunks][16 bytes], byte (sp, j) of chunk h in half x = W8[n, 16 (4c + 2x + sp) + swap23(8 h + j)]
+    -- the element order in which the producers' accumulators hold a row.  The two 16-byte chunks of row n are exchanged where (n >> 3) & 1
+    (the LDS bank swizzle, baked in because the DMA copies lane-linear)."""
+    N, K = w.shape
+    assert N == 384 and K % 128 == 0
+    h, l8, h8 = mx_split(w)
+    sw = _swap23(16, w.device)
+    flip = ((torch.arange(N, device=w.device) >> 3) & 1).bool()
+    hp = h.reshape(N, K // 16, 16)[..., sw].reshape(N, K // 64, 2, 2, 2, 8).clone()      # [n][c][stage][x][h][j]
+    hp[flip] = hp[flip].flip(dims=[4])
+    hp = hp.permute(1, 2, 3, 0, 4, 5).contiguous().view(torch.uint8).reshape(K // 64, 2, 24576)
+    planes = []
+    for b8 in (l8, h8):
+        q = b8.reshape(N, K // 16, 16)[..., sw].reshape(N, K // 64, 2, 2, 2, 8)           # [n][c][x][sp][h][j]
+        q = q.permute(1, 2, 0, 4, 3, 5).reshape(K // 64, 2, N, 2, 16).clone()            # [c][x][n][h][(sp, j)]
+        q[:, :, flip] = q[:, :, flip].flip(dims=[3])
+        planes.append(q.reshape(K // 64, 1, 24576))
+    return torch.cat([hp] + planes, dim=1).contiguous()
+
+
+def mx_fragments(a: torch.Tensor):
+    """A [M][K] fp32 -> the fragment-major MX planes the row-panel kernel reads (what the producers' epilogues write):
+    (h fp16 [R][K / 16][64][8], l8 uint8 [R][K / 64][2][64][16], h8 likewise), R = ceil(M / 32); lane = 32 hw + row, element j of k-step s =
+    A[32 R + row, 16 s + swap23(8 hw + j)], byte (sp, j) of half x of 64-k step c = A8[.., 16 (4c + 2x + sp) + swap23(8 hw + j)].  Rows past M: 0."""
+    M, K = a.shape
+    R = (M + 31) // 32
+    ap = torch.zeros(R * 32, K, device=a.device)
+    ap[:M] = a.float()
+    h, l8, h8 = mx_split(ap)
+    sw = _swap23(16, a.device)
+    hf = h.reshape(R, 32, K // 16, 16)[..., sw].reshape(R, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()    # [R][s][hw][row][j]
+    outs = [hf.reshape(R, K // 16, 64, 8)]
+    for b8 in (l8, h8):
+        q = b8.reshape(R, 32, K // 16, 16)[..., sw].reshape(R, 32, K // 64, 2, 2, 2, 8)    # [R][row][c][x][sp][hw][j]
+        outs.append(q.permute(0, 2, 3, 5, 1, 4, 6).contiguous().reshape(R, K // 64, 2, 64, 16))
+    return tuple(outs)
+
+
+def mx_matmul_reference(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """float64 statement of what an MX kernel computes for a [M][K] x w [N][K]^T (the operand roundings exactly, the sums in float64)."""
+    ah, al8, ah8 = mx_split(a)
+    wh, wl8, wh8 = mx_split(w)
+    f = lambda b: b.view(torch.float8_e5m2).double()   # noqa: E731
+    return ah.double() @ wh.double().T + (f(ah8) @ f(wl8).T + f(al8) @ f(wh8).T) / MX_RES_SCALE
+
+
 def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
     """DINO's position-table resampling (bicubic, scale (grid+0.1)/g; DINOv2 keeps the same rule with its default
     interpolate_offset = 0.1, antialias off), done ONCE when the model is

@@ -662,6 +662,13 @@ int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, con
   p2.M = M; p2.N = 384; p2.K = F; p2.dbg = dbg2;
   return wvn_gemm_n384_x3_frag_launch(p2, EPI_RESID_F32, (hipStream_t)stream);
 }
+int wvn_debug_gemm_n384_mx(const void* A_h, const void* A_l8, const void* A_h8, const void* Wp, const float* bias, const float* ls, float* C,
+                           int ldc, int M, int K, long long* dbg, void* stream) {
+  GemmBf16Params p{};
+  p.A = (const bf16_t*)A_h; p.A_lo = (const bf16_t*)A_l8; p.A_h8 = A_h8; p.lda = K; p.W = (const bf16_t*)Wp; p.ldw = K; p.bias = bias; p.ls = ls;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = 384; p.K = K; p.dbg = dbg;
+  return wvn_gemm_n384_mx_launch(p, EPI_RESID_F32, (hipStream_t)stream);
+}
 int wvn_debug_n384_pair(int on) { wvn_gemm_n384_x3_set_pair(on); return WVN_OK; }
 int wvn_debug_kmeans_screen_stats(unsigned long long* out, int reset) { return out ? wvn_kmeans_pixels_screen_stats(out, reset) : WVN_ERR_ARG; }
 int wvn_debug_kmeans_assign_form(int form) { wvn_kmeans_pixels_set_assign_form(form); return WVN_OK; }

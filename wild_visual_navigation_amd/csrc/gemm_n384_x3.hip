@@ -638,6 +638,214 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_x3_frag_pair_kernel(N384X3Pa
   }
 }
 
+// ---- MX correction terms (round 6): hi * hi on fp16 MFMAs, the two correction products on v_mfma_scale_f32_32x32x64_f8f6f4 ------------------
+// The <= 1e-3 mode needs every linear's operand rounding compensated (scripts/error_budget_r6.py); the bf16 x 3 form above pays three full-rate
+// MFMAs per fragment pair for it.  Here an operand v is  h = fp16(v),  l8 = e5m2((v - h) * 2^12),  h8 = e5m2(v)  and
+//     sum a w  ~=  sum a_h w_h  +  2^-12 (sum a_h8 w_l8 + sum a_l8 w_h8):
+// per 64 k of a 32 x 32 tile four v_mfma_f32_32x32x16_f16 (128 cycles) and TWO scaled 8-bit MFMAs of K = 64 (2 x 64 cycles) instead of twelve
+// bf16 MFMAs (384): two thirds of the matrix-pipe time.  e5m2 IS the top byte of an fp16, so the 8-bit planes need no block scales: the
+// residues carry ONE constant factor 2^12 (undone by the instruction's E8M0 scale operand, 115 = 2^-12, identical in every lane and block:
+// the hardware's assignment of scale bytes to 32-k blocks -- registers 0-3 of both half-waves = block 0, scripts/ubench/mx_formats.hip --
+// never matters), and |l8| <= |v| keeps them inside the format wherever v fits fp16.  What the correction products lose is the 2-bit
+// significand of their operands: (2^-12 / sqrt 3) * ~7 % of a product -- tokens 2.9e-4 / 3.4e-4 from the fp32 oracle in the emulation
+// (synthetic / the reference's real frame; the bf16 x 3 form: 1.1e-4 / 2.3e-4, both dominated by the fp16 attention operands).
+//
+// Structure = gemm_n384_x3_frag_pair_kernel (wave pair per 32 rows, 6-deep ring of 24 KB stages, three DMA pieces per wave and stage), with
+// FOUR stage kinds per 64 k (the packed weight of backbone.pack_n384_mx lists them in this order, every stage 24 x 1 KB blocks [x][tile]):
+//   0: W_h of k-steps 0 | 1 (x = k-step)  -> 2 x 6 fp16 MFMAs per wave      2: W_l8 (x = 16-byte half of the lane's 32 bytes) -> 6 scaled MFMAs on a_h8
+//   1: W_h of k-steps 2 | 3                                                 3: W_h8                                           -> 6 scaled MFMAs on a_l8
+// -- 384 matrix-pipe cycles per wave and stage whatever its kind (576 in the bf16 x 3 form), the same LDS reads (12 per wave and stage) and
+// DMA pieces.  A: fragment-major again, per row group R and 64-k step c four 1 KB fp16 fragments (hi plane, as EPI_GELU_FRAG) and two 1 KB
+// halves in each of the two 8-bit planes: lane (row, h) holds bytes (s', j) = k-step s' of the four, element j of its eight -- the order the
+// producers' accumulators hold them; two 64-k steps in flight (64 registers).
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+constexpr int MXD = 2;                            // 64-k steps of A in flight
+constexpr int MX_SC_ONE = 0x7f7f7f7f, MX_SC_RES = 0x73737373;   // E8M0 scale bytes: 2^0, 2^-12 (all four bytes alike: op_sel never matters)
+
+struct N384MXExtra { unsigned a_l8_off, a_h8_off; };   // byte offsets of the two 8-bit planes behind the fp16 plane (one buffer descriptor)
+
+// VAR (timing experiments only, results are garbage for VAR != 0): 1 = no W DMA inside the loop, 2 = no A loads inside the loop, 3 = neither,
+// 4 = no barrier / wait at the stage boundaries
+template <bool TIMING, int VAR = 0>
+__global__ __launch_bounds__(512, 1) void gemm_n384_mx_pair_kernel(N384X3Params p, N384MXExtra ex) {
+  wvn_fp16_saturate();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave & 3, ch = wave >> 2;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nk = p.K / BKS;                      // stages: four per 64 k; a multiple of 8 (launcher)
+  const int nmac = p.K / 64;
+  const float* bias_l = (const float*)(smem + PBIAS_OFF);
+  const float* ls_l = (const float*)(smem + PLS_OFF);
+  for (int i = tid; i < NN; i += 512) {
+    ((float*)(smem + PBIAS_OFF))[i] = p.bias ? p.bias[i] : 0.f;
+    ((float*)(smem + PLS_OFF))[i] = p.ls ? p.ls[i] : 1.f;
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)4 * NN * p.K), 0x00020000);
+  const size_t mpad = (size_t)(p.M + 31) / 32 * 32;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)(ex.a_h8_off + mpad * p.K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
+  const unsigned wv0 = (unsigned)(wave * PFW * 1024 + lane * 16);
+  const unsigned rdw = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4) + ch * 6 * 1024;  // + x * W_PLANE + t * 1024: this wave's six column tiles
+
+  long long t_wait = 0, t_steps = 0, t_epi = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  const int nrb = (p.M + BM - 1) / BM;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int m0w = rb * BM + rg * 32;
+    const unsigned a_base = __builtin_amdgcn_readfirstlane((unsigned)((size_t)(m0w >> 5) * p.K * 64));    // fragment (R, 0) of the fp16 plane
+    const unsigned a8_base = __builtin_amdgcn_readfirstlane((unsigned)((size_t)(m0w >> 5) * p.K * 32));   // (R, 0) of an 8-bit plane
+    auto piece_w = [&](int i, int u) {
+      unsigned char* st = smem + (i % PNS) * FSTAGE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(st + (wave * PFW + u) * 1024), 16, wv0 + u * 1024,
+                                               __builtin_amdgcn_readfirstlane((unsigned)i * FSTAGE), 0, 0);
+    };
+    u32x4_t ah[MXD][4], a8[MXD][2][2];   // a8[slot][0 = h8 | 1 = l8][half]
+    auto load_ah = [&](int c, int slot) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        ah[slot][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, __builtin_amdgcn_readfirstlane(a_base + (unsigned)(c * 4 + s) * 1024), 0);
+    };
+    auto load_a8 = [&](int c, int slot, int which) {
+      const unsigned off = which ? ex.a_l8_off : ex.a_h8_off;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+        a8[slot][which][x] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, __builtin_amdgcn_readfirstlane(a8_base + off + (unsigned)(c * 2 + x) * 1024), 0);
+    };
+    __syncthreads();  // the previous row block's staging / statistics reads are done (and the bias table is visible) before DMA reuses the LDS
+    // (the order is pinned: hipcc counts the operations behind a register load to size the vmcnt wait in front of its first use, and takes the
+    //  minimum over the loop's two entry edges -- left to the scheduler, the operands of stage 0 were requested LAST and every trip waited for
+    //  all but the 15 youngest operations, i.e. for A fragments requested two stages earlier from HBM)
+#pragma unroll
+    for (int c = 0; c < MXD; ++c) {
+      load_ah(c, c);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a8(c, c, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a8(c, c, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < PNS - 1; ++i0)
+      if (i0 < nk) {
+#pragma unroll
+        for (int u = 0; u < PFW; ++u) piece_w(i0, u);
+      }
+
+    f32x16_t acc[NTILE / 2];
+#pragma unroll
+    for (int t = 0; t < NTILE / 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    u32x4_t wq[2][2][2];   // [slot][x][tile of the pair]; the first pair of stage i sits in slot i & 1 (three pairs per stage: the slots alternate)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PNS - 2) * PFW) : "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wq[0][x][t] = *(const u32x4_t*)(smem + rdw + x * W_PLANE + t * 1024);
+    for (int ib = 0; ib < nk; ib += 4 * MXD) {
+#pragma unroll
+      for (int jj = 0; jj < 4 * MXD; ++jj) {
+        const int i = ib + jj;
+        const int kind = jj & 3, slot = jj >> 2;   // (compile-time constants of the unrolled body)
+        long long c0 = 0, c1 = 0;
+        if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
+        // (the barrier also says that every wave has left stage i - 1: its ring slot is free)
+        // slice i + 1 landed: younger than its last piece are EXACTLY the (PNS - 3) * PFW pieces of the three stages since and the A loads those
+        // stages ended with (kind 1: four, kinds 2 / 3: two each; requested unconditionally -- past the last 64-k step the offsets fall outside the
+        // buffer and return zeros into registers nobody reads -- so that the count is a constant of the stage kind: waiting for "all but nine"
+        // also waited for A fragments requested from HBM two stages earlier, 125 cycles per stage)
+        if constexpr (VAR != 4) {
+          // A loads of the three stages before a stage of kind 0 / 1 / 2 / 3: 8 / 4 / 6 / 6 -- behind the prologue (whose A loads all precede its
+          // pieces) stages 0 / 1 / 2 see 0 / 0 / 4 (uniform branches at a stage boundary, where the barrier ends the scheduling region anyway)
+          constexpr int W3 = (PNS - 3) * PFW;
+          if (jj == 0) { if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 8) : "memory"); }
+          else if (jj == 1) { if (i == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 4) : "memory"); }
+          else if (jj == 2) { if (i == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 4) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 6) : "memory"); }
+          else if ((jj & 3) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 8) : "memory");
+          else if ((jj & 3) == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 4) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 6) : "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* st = smem + (i % PNS) * FSTAGE;
+        const unsigned char* st1 = smem + ((i + 1) % PNS) * FSTAGE;
+        const int s0 = jj & 1;
+#pragma unroll
+        for (int pr = 0; pr < NTILE / 4; ++pr) {
+          const int cur = (s0 + pr) & 1, nx = cur ^ 1;
+          if constexpr (!(VAR & 1) || VAR == 4) piece_w(i + PNS - 1, pr);   // stage i + 5 into the slot every wave has left: one piece per tile pair
+          const unsigned char* src = pr + 1 < NTILE / 4 ? st + (2 * pr + 2) * 1024 : st1;   // (the last pair's partner: the FIRST pair of the next stage)
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) wq[nx][x][t] = *(const u32x4_t*)(src + rdw + x * W_PLANE + t * 1024);
+          if (kind < 2) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                acc[2 * pr + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wq[cur][x][t]), __builtin_bit_cast(f16x8_t, ah[slot][2 * kind + x]),
+                                                                         acc[2 * pr + t], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+          } else {
+            const u32x4_t a0 = a8[slot][kind - 2][0], a1 = a8[slot][kind - 2][1];
+            const i32x8_t av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const u32x4_t w0 = wq[cur][0][t], w1 = wq[cur][1][t];
+              const i32x8_t wv = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+              // kind 2: W_l8 (carries 2^12) x a_h8;  kind 3: W_h8 x a_l8 (carries 2^12)
+              acc[2 * pr + t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc[2 * pr + t], 1, 1, 0, kind == 2 ? MX_SC_RES : MX_SC_ONE, 0,
+                                                                                kind == 2 ? MX_SC_ONE : MX_SC_RES);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the operands of 64-k step c + MXD into the registers this stage has just finished with
+        const int c2 = (i >> 2) + MXD;
+        if constexpr (!(VAR & 2) || VAR == 4) {
+          if (kind == 1) load_ah(c2, slot);
+          if (kind == 2) load_a8(c2, slot, 0);
+          if (kind == 3) load_a8(c2, slot, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TIMING) { t_wait += c1 - c0; t_steps += (long long)__builtin_amdgcn_s_memtime() - c1; }
+      }
+    }
+    long long e0 = 0;
+    if constexpr (TIMING) e0 = (long long)__builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA requests have landed before the ring becomes staging
+    n384_pair_epilogue(acc, smem, wave, lane, rg, ch, m0w, rs_c, p.ldc, bias_l, ls_l, p.stats, p.eps, p.M);
+    if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
+  }
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg && ch == 0) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + rg) * 4;
+      d[0] = t_wait; d[1] = t_steps; d[2] = t_epi; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+    }
+  }
+}
+
+int g_n384_mx_var = 0;   // timing experiments of the instrumented MX build (wvn_debug_n384_pair(16 + var))
 int g_n384_pair = 1;   // 1: the wave-pair form of the fragment kernel (default since its barrier covers the NEXT slice: 1355 against 1546 cycles per k-step and
                        // SIMD, fc2 -4 % wall time), 0: one wave per SIMD (round 4; wvn_debug_n384_pair).  scripts/bench_n384_pair.py, profiles/r05_wave_pair.md
 
@@ -707,4 +915,37 @@ int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& g, int epi, hipStream_t s
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
-void wvn_gemm_n384_x3_set_pair(int on) { g_n384_pair = on ? 1 : 0; }
+// MX form (see gemm_n384_mx_pair_kernel): A = fragment-major fp16 plane (g.A) + the two 8-bit planes (g.A_lo = l8, g.A_h8 = h8, both behind g.A
+// within 4 GB); W = backbone.pack_n384_mx's stage list (4 * 384 * K bytes).  K % 128 == 0.
+int wvn_gemm_n384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
+  if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
+  if (g.N != NN || g.K <= 0 || (g.K % 128) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.A_h8 || !g.W || !g.C || (g.ldc % 4)) return WVN_ERR_ARG;
+  if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.A_h8 | (uintptr_t)g.W | (uintptr_t)g.C) & 15) return WVN_ERR_ARG;
+  const size_t mpad = (size_t)(g.M + 31) / 32 * 32;
+  const uintptr_t a0 = (uintptr_t)g.A, al = (uintptr_t)g.A_lo, ah = (uintptr_t)g.A_h8;
+  if (al < a0 + mpad * g.K * 2 || ah < a0 + mpad * g.K * 2) return WVN_ERR_ARG;
+  const uintptr_t top = (al > ah ? al : ah) + mpad * g.K;
+  if (top - a0 >= (1ull << 32) || (size_t)g.M * g.ldc * 4 >= (1ull << 32) || (size_t)4 * NN * g.K >= (1ull << 31)) return WVN_ERR_ARG;
+  N384X3Params p{};
+  p.A = g.A; p.a_plane = 0; p.lda = g.K; p.W = g.W; p.w_plane = 0; p.ldw = g.K; p.bias = g.bias; p.ls = g.ls;
+  p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg; p.stats = g.ln_stats_out; p.eps = g.ln_eps;
+  N384MXExtra ex{(unsigned)(al - a0), (unsigned)(ah - a0)};
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(PAIR_LDS_BYTES, (const void*)gemm_n384_mx_pair_kernel<false>, (const void*)gemm_n384_mx_pair_kernel<true>,
+                                (const void*)gemm_n384_mx_pair_kernel<true, 1>, (const void*)gemm_n384_mx_pair_kernel<true, 2>,
+                                (const void*)gemm_n384_mx_pair_kernel<true, 3>, (const void*)gemm_n384_mx_pair_kernel<true, 4>)) return rc;
+  const int ncu = n384x3_num_cus(), nrb = ceil_div(g.M, BM);
+  const int grid = nrb < ncu ? nrb : ncu;
+  if (p.dbg && g_n384_mx_var == 1) hipLaunchKernelGGL((gemm_n384_mx_pair_kernel<true, 1>), dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p, ex);
+  else if (p.dbg && g_n384_mx_var == 2) hipLaunchKernelGGL((gemm_n384_mx_pair_kernel<true, 2>), dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p, ex);
+  else if (p.dbg && g_n384_mx_var == 3) hipLaunchKernelGGL((gemm_n384_mx_pair_kernel<true, 3>), dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p, ex);
+  else if (p.dbg && g_n384_mx_var == 4) hipLaunchKernelGGL((gemm_n384_mx_pair_kernel<true, 4>), dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p, ex);
+  else if (p.dbg) hipLaunchKernelGGL(gemm_n384_mx_pair_kernel<true>, dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p, ex);
+  else hipLaunchKernelGGL(gemm_n384_mx_pair_kernel<false>, dim3(grid), dim3(512), PAIR_LDS_BYTES, st, p, ex);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+void wvn_gemm_n384_x3_set_pair(int on) {
+  if (on >= 16) { g_n384_mx_var = on - 16; return; }
+  g_n384_pair = on ? 1 : 0;
+}

@@ -33,6 +33,9 @@ struct GemmBf16Params {
   const float* ls;  // EPI_RESID_F32: optional LayerScale vector [N] (DINOv2): C += ls * (acc + bias); nullptr = plain residual
   // exact mode (gemm_x3.hip): the lo planes of the operands and of plane-typed outputs (hi planes are A / W / C / q / k / vt)
   const bf16_t* A_lo; const bf16_t* W_lo; void* C_lo; bf16_t* q_lo; bf16_t* k_lo; bf16_t* vt_lo;
+  // MX correction terms (round 6; gemm_n384_x3.hip / gemm_a384_x3.hip): operands as an fp16 plane + two e5m2 planes (l8 = the rounding residue * 2^12,
+  // h8 = the value itself); A_lo / C_lo name the l8 plane, A_h8 / C_h8 the h8 plane
+  const void* A_h8; void* C_h8;
   long long* dbg;  // optional: per-wave phase timings of the A-stationary kernel (scripts/ab_kernels.py --timing)
   // LayerNorm across kernel boundaries (round 4, split-operand kernels): the row-panel kernels (gemm_n384_x3.hip) can leave the statistics
   // of the rows they have just updated, ln_stats_out[m] = {mean, 1 / sqrt(var + ln_eps)} over the N = 384 columns; the A-stationary
@@ -89,6 +92,8 @@ int wvn_gemm_n384_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 // the same with A as the fragment-major planes EPI_GELU_FRAG writes and W packed by wvn_pack_n384_x3_weight's layout (k-step-major,
 // both planes, the column permutation of the fragments, swizzled 32-byte rows: every DMA piece one contiguous kilobyte)
 int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& p, int epi, hipStream_t st);
+// the MX form of the fragment kernel (fp16 hi plane + two e5m2 planes per operand; W packed by backbone.pack_n384_mx)
+int wvn_gemm_n384_mx_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 
 // ---- fp8 (e4m3) MFMA GEMM with per-row scales of both operands (gemm_fp8.hip) + the row quantisers (fp8.hip) -----------
 struct GemmFp8Params {
