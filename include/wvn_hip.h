@@ -82,6 +82,9 @@ int wvn_version(void);
  * {mean, rstd} of the rows they update, the A-stationary kernels normalise as they load; with this flag every LayerNorm is its own
  * kernel writing hi / lo planes again) */
 #define WVN_VIT_X3_NO_LN_STATS 512
+/* WVN_PREC_MIX: do NOT use the MX form of the block linears (round 6) even where the layer carries the packed weights *_w_mx: the bf16 x 3
+ * kernels of rounds 4 / 5 (A/B runs and tests) */
+#define WVN_VIT_NO_MX 1024
 /* WVN_PREC_MIX: in how many LEADING blocks the attention kernel takes q as two fp16 planes (8 more MFMAs per tile, three workgroups per CU
  * instead of four: 3.08 against 2.05 ms per 128-frame launch).  The query's rounding is the one attention operand error that does not
  * average out over a row's keys, and it is injected in the EARLY blocks: on the reference's real 448^2 frame the token error is 1.05e-3
@@ -113,6 +116,15 @@ typedef struct wvn_vit_layer {
   const void* proj_w_frag; /* WVN_PREC_X3 / WVN_PREC_MIX (optional, D = 384): attn.proj.weight in the packed layout of fc2_w_fused's
                             * split-operand form.  With it, WVN_PREC_MIX's attention kernel writes its output as MFMA operand fragments
                             * and the projection runs on the fragment form of csrc/gemm_n384_x3.hip.  NULL: the row-major projection */
+  /* WVN_PREC_MIX, D = 384 (optional, all four or none): the weights in the MX operand representation -- per element h = fp16(w), l8 = e5m2((w - h) * 2^12),
+   * h8 = e5m2(w) -- packed for the MX kernels (round 6): qkv / fc1 by backbone.pack_a384_mx ([2 planes][N][768 bytes], csrc/gemm_a384_x3.hip), proj / fc2 by
+   * backbone.pack_n384_mx ([K / 64][4 stages][24 KB], csrc/gemm_n384_x3.hip).  With them every block linear from block 1 on (block 0's QKV has no producer
+   * of LayerNorm statistics in front of it) computes a w = a_h w_h (fp16 MFMAs) + 2^-12 (a_h8 w_l8 + a_l8 w_h8) (scaled e5m2 MFMAs of K = 64): two thirds of
+   * the matrix-pipe time of the bf16 x 3 products; the activations travel between the kernels in the same three-plane form */
+  const void* qkv_w_mx;
+  const void* proj_w_mx;
+  const void* fc1_w_mx;
+  const void* fc2_w_mx;
 } wvn_vit_layer;
 
 typedef struct wvn_vit_model {
@@ -572,6 +584,17 @@ int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, con
  * K % 128 == 0.  dbg as wvn_debug_gemm_n384_x3. */
 int wvn_debug_gemm_n384_mx(const void* A_h, const void* A_l8, const void* A_h8, const void* Wp, const float* bias, const float* ls, float* C,
                            int ldc, int M, int K, long long* dbg, void* stream);
+/* The block MLP of WVN_PREC_MIX in its MX form: hid = gelu(LayerNorm(x) W1^T + b1) by csrc/gemm_a384_x3.hip (LayerNorm formed on load from
+ * ln_stats[m] = {mean, 1 / sqrt(var + eps)}; W1p = backbone.pack_a384_mx(fc1.weight)), written as the MX operand planes hid_h / hid_l8 / hid_h8
+ * (fragment-major, ceil(M / 32) * 32 rows of F), then xout [M][384] fp32 += hid W2^T + b2 by the MX row-panel kernel (W2p =
+ * backbone.pack_n384_mx(fc2.weight)).  W2p == NULL: fc1 only.  dbg1 / dbg2: per-wave cycle counters of the instrumented builds. */
+int wvn_debug_mlp_mx(const float* x, int ldx, const float* ln_stats, const float* ln_g, const float* ln_b, const void* W1p, const float* b1,
+                     void* hid_h, void* hid_l8, void* hid_h8, const void* W2p, const float* b2, float* xout, int M, int F, long long* dbg1,
+                     long long* dbg2, void* stream);
+/* LayerNorm-on-load + QKV in the MX form: q (pre-scaled by q_scale; q_lo != NULL: its fp16 rounding residue as a second plane) | k | v^T fp16 in
+ * the layouts of wvn_attention_f16 (Wp = backbone.pack_a384_mx(qkv.weight)). */
+int wvn_debug_qkv_mx(const float* x, int ldx, const float* ln_stats, const float* ln_g, const float* ln_b, const void* Wp, const float* bias, void* q,
+                     void* q_lo, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, long long* dbg, void* stream);
 /* subsequent wvn_attention_bf16 launches write dbg[(workgroup * 4 + wave) * 5 + {0 wait, 1 QK^T, 2 softmax, 3 PV,
  * 4 total}]; NULL switches the instrumented build off again. */
 /* (test hook) out_f16[i] = fp16(in[i]) as the kernels convert: finite values beyond the fp16 range saturate to +-65504 (MODE.FP16_OVFL) */

@@ -39,3 +39,115 @@ def test_row_panel_mx_every_row(dev, M, K):
     assert (got - same).abs().max().item() < 3e-6 * scale, "the kernel does not compute the MX statement"
     assert (got - want).abs().max().item() < 4e-5 * scale      # (measured 1.7e-5: 2^-12 / sqrt 3 x the e5m2 rounding of the correction operands)
     assert torch.equal(c[M:], x0[M:])
+
+
+def _ln_stats(x, eps=1e-6):
+    mean = x.double().mean(-1)
+    var = x.double().var(-1, unbiased=False)
+    return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=-1).float().contiguous()
+
+
+def _unfrag(h, l8, h8, M, K):
+    """The inverse of backbone.mx_fragments: (h + l8 / 4096, h8) as [M][K] float64."""
+    from wild_visual_navigation_amd.backbone import MX_RES_SCALE, _swap23
+    R = h.shape[0]
+    sw = _swap23(16)
+    inv = torch.empty(16, dtype=torch.long)
+    inv[sw] = torch.arange(16)
+    hf = h.cpu().reshape(R, K // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(R, 32, K // 16, 16)[..., inv].reshape(R * 32, K)
+    outs = []
+    for b8 in (l8, h8):
+        q = b8.cpu().view(torch.float8_e5m2).double().reshape(R, K // 64, 2, 2, 32, 2, 8)        # [R][c][x][hw][row][sp][j]
+        q = q.permute(0, 4, 1, 2, 5, 3, 6).reshape(R, 32, K // 16, 16)[..., inv].reshape(R * 32, K)
+        outs.append(q)
+    return (hf.double() + outs[0] / MX_RES_SCALE)[:M], outs[1][:M]
+
+
+@pytest.mark.parametrize("M", [12608, 128 * 65 + 16])
+def test_mx_block_mlp_every_row(dev, M):
+    """LayerNorm-on-load fc1 + GELU writes the MX operand planes (fp16 fragments, l8, h8), the MX row-panel kernel consumes them."""
+    from wild_visual_navigation_amd.backbone import pack_a384_mx
+    lib = _lib.lib()
+    F = 1536
+    x = torch.randn(M, 384, generator=g(M)) * 1.7 + 0.3
+    gam, bet = 1.0 + 0.1 * torch.randn(384, generator=g(7)), 0.05 * torch.randn(384, generator=g(8))
+    w1, b1 = torch.randn(F, 384, generator=g(1)) * 0.05, torch.randn(F, generator=g(2)) * 0.1
+    w2, b2 = torch.randn(384, F, generator=g(3)) * 0.03, torch.randn(384, generator=g(4)) * 0.1
+    st = _ln_stats(x)
+    Mp = (M + 31) // 32 * 32
+    hid = torch.zeros(Mp * F * 4, dtype=torch.uint8, device=dev)
+    n_h, n_8 = Mp * F * 2, Mp * F
+    x0 = torch.randn(M + 64, 384, generator=g(5)).to(dev)
+    xo = x0.clone()
+    d = lambda t: t.to(dev).contiguous()   # noqa: E731
+    xd, sd_, gd, bd, w1p, b1d, w2p, b2d = d(x), d(st), d(gam), d(bet), pack_a384_mx(d(w1)), d(b1), pack_n384_mx(d(w2)), d(b2)
+    _lib.check(lib.wvn_debug_mlp_mx(xd.data_ptr(), 384, sd_.data_ptr(), gd.data_ptr(), bd.data_ptr(), w1p.data_ptr(), b1d.data_ptr(), hid.data_ptr(),
+                                    hid.data_ptr() + n_h, hid.data_ptr() + n_h + n_8, w2p.data_ptr(), b2d.data_ptr(), xo.data_ptr(), M, F, 0, 0, _lib.stream()), "mlp_mx")
+    y = torch.nn.functional.layer_norm(x.double(), (384,), gam.double(), bet.double(), eps=1e-6)
+    hidden = torch.nn.functional.gelu(y @ w1.double().T + b1.double())
+    R = Mp // 32
+    hv, h8v = _unfrag(hid[:n_h].view(torch.float16).reshape(R, F // 16, 64, 8), hid[n_h:n_h + n_8].reshape(R, F // 64, 2, 64, 16),
+                      hid[n_h + n_8:].reshape(R, F // 64, 2, 64, 16), M, F)
+    assert (hv - hidden).abs().max().item() < 2e-4                       # fc1 through the MX products, hidden = h + l8 / 4096
+    assert ((h8v - hidden).abs() <= 0.126 * hidden.abs() + 1e-4).all()   # the e5m2 image of the value itself
+    want = x0[:M].double().cpu() + hidden @ w2.double().T + b2.double()
+    assert (xo[:M].double().cpu() - want).abs().max().item() < 4e-4
+    assert torch.equal(xo[M:], x0[M:])
+
+
+def test_mx_qkv(dev):
+    """LayerNorm-on-load + q | k | v^T with the MX products: fp16 planes in the attention kernel's layouts (q pre-scaled, two planes)."""
+    from wild_visual_navigation_amd.backbone import pack_a384_mx
+    lib = _lib.lib()
+    B, ntok, heads = 4, 3137, 6
+    ntok_s, npad = 3152, 3200
+    M = B * ntok_s
+    x = torch.randn(M, 384, generator=g(11)) * 1.3
+    gam, bet = 1.0 + 0.1 * torch.randn(384, generator=g(7)), 0.05 * torch.randn(384, generator=g(8))
+    w, b = torch.randn(1152, 384, generator=g(1)) * 0.06, torch.randn(1152, generator=g(2)) * 0.02
+    qs = 0.125 * 1.4426950408889634
+    d = lambda t: t.to(dev).contiguous()   # noqa: E731
+    q = torch.zeros(2, B, heads, npad, 64, dtype=torch.float16, device=dev)
+    k = torch.zeros(B, heads, npad, 64, dtype=torch.float16, device=dev)
+    vt = torch.zeros(B, heads, 64, npad, dtype=torch.float16, device=dev)
+    xd, sd_, gd, bd, wp, bb = d(x), d(_ln_stats(x)), d(gam), d(bet), pack_a384_mx(d(w)), d(b)
+    _lib.check(lib.wvn_debug_qkv_mx(xd.data_ptr(), 384, sd_.data_ptr(), gd.data_ptr(), bd.data_ptr(), wp.data_ptr(), bb.data_ptr(), q[0].data_ptr(), q[1].data_ptr(),
+                                    k.data_ptr(), vt.data_ptr(), heads, npad, ntok_s, qs, M, 0, _lib.stream()), "qkv_mx")
+    y = torch.nn.functional.layer_norm(x.double(), (384,), gam.double(), bet.double(), eps=1e-6)
+    ref = (y @ w.double().T + b.double()).reshape(B, ntok_s, 3, heads, 64)
+    qg = (q[0].double() + q[1].double()).cpu()[:, :, :ntok_s]
+    assert (qg - ref[:, :, 0].permute(0, 2, 1, 3) * qs).abs().max().item() < 2e-4
+    kg = k.double().cpu()[:, :, :ntok_s]
+    kr = ref[:, :, 1].permute(0, 2, 1, 3)
+    assert ((kg - kr).abs() <= 6e-4 * kr.abs() + 2e-4).all()             # one fp16 plane: its own rounding
+    # v^T: tokens of every aligned group of 16 in the order 0-3, 8-11, 4-7, 12-15
+    t = torch.arange(ntok_s)
+    perm = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    vg = vt.double().cpu()[:, :, :, :ntok_s][..., perm]
+    vr = ref[:, :, 2].permute(0, 2, 3, 1)
+    assert ((vg - vr).abs() <= 6e-4 * vr.abs() + 2e-4).all()
+
+
+def test_mx_block_kernels_inside_the_vit(dev):
+    """4 frames at 448^2 (12608 rows) through 3 blocks in precision "mixed" with the MX kernels (default) and with the bf16 x 3 kernels
+    (WVN_NO_MX): both inside the mode's gate against the CPU oracle, and close to each other."""
+    import os
+
+    from oracle import interfaces as OI, vit as OV
+    from wild_visual_navigation_amd.backbone import VitBackbone
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=0, depth=3)
+    img = torch.rand(4, 3, 448, 448, generator=g(1))
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
+    os.environ.pop("WVN_NO_MX", None)
+    bb = VitBackbone(sd, 448, 8, 6, device=dev, precision="mixed", max_chunk=4)
+    assert bb.mx and bb.model.layers[1].fc1_w_mx
+    a = bb.forward_tokens(img.to(dev)).cpu()
+    os.environ["WVN_NO_MX"] = "1"
+    try:
+        b = VitBackbone(sd, 448, 8, 6, device=dev, precision="mixed", max_chunk=4).forward_tokens(img.to(dev)).cpu()
+    finally:
+        os.environ.pop("WVN_NO_MX", None)
+    assert not torch.equal(a, b)                         # (the two routes really are different code)
+    print(f"tokens vs oracle: MX {(a - want).abs().max().item():.2e}, bf16 x 3 {(b - want).abs().max().item():.2e}; MX vs x3 {(a - b).abs().max().item():.2e}")
+    assert (a - want).abs().max().item() < 5e-4
+    assert (a - b).abs().max().item() < 4e-4

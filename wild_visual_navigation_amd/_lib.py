@@ -26,6 +26,7 @@ VIT_FUSE_ANY_SIZE = 4
 VIT_NO_PROJ_IN_MLP = 8
 VIT_NO_LN_HANDOVER = 16
 VIT_NO_A384_X3 = 32
+VIT_NO_MX = 1024
 
 
 def vit_qsplit_blocks(n: int) -> int:
@@ -45,7 +46,8 @@ class WvnError(RuntimeError):
 
 class VitLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s", "fc2_w_fused", "fc1_w_fused", "qkv_w_fused", "proj_w_frag")]
+        "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ls1", "ls2", "qkv_s", "proj_s", "fc1_s", "fc2_s", "fc2_w_fused", "fc1_w_fused", "qkv_w_fused", "proj_w_frag",
+        "qkv_w_mx", "proj_w_mx", "fc1_w_mx", "fc2_w_mx")]
 
 
 class VitModel(C.Structure):
@@ -83,6 +85,8 @@ _SIGNATURES = {
     "wvn_debug_mlp_x3_frag": ([_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p], _i),
     "wvn_debug_gemm_n384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p], _i),
     "wvn_debug_gemm_n384_mx": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p], _i),
+    "wvn_debug_mlp_mx": ([_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p], _i),
+    "wvn_debug_qkv_mx": ([_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p], _i),
     "wvn_debug_gemm_a384_x3": ([_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p], _i),
     "wvn_stream_create_cu_mask": ([_p, _p, _i], _i),
     "wvn_stream_destroy": ([_p], _i),

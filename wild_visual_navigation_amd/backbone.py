@@ -127,6 +127,19 @@ def pack_n384_mx(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([hp] + planes, dim=1).contiguous()
 
 
+def pack_a384_mx(w: torch.Tensor) -> torch.Tensor:
+    """W [N][384] fp32 -> the operand of the A-stationary MX kernel (csrc/gemm_a384_x3.hip): uint8 [2 planes][N][768]; plane 0 = fp16(W) row-major,
+    plane 1 = per 128-k slice ks sixteen 16-byte chunks, chunk 2 s'' + h with s'' = 4 which + 2 mm + x (which: 0 = l8, 1 = h8; mm: 64-k step of the
+    slice; x: half of the lane's 32 bytes), byte (sp, j) of it = W8[n, 128 ks + 64 mm + 16 (2 x + sp) + 8 h + j] -- natural k order, the order the
+    LayerNorm-on-load prologue fills the A operands in."""
+    N, K = w.shape
+    assert K == 384
+    h, l8, h8 = mx_split(w)
+    q = torch.stack([l8, h8], dim=1).reshape(N, 2, 3, 2, 2, 2, 2, 8)            # [n][which][ks][mm][x][sp][h][j]
+    q = q.permute(0, 2, 1, 3, 4, 6, 5, 7).contiguous().reshape(N, 768)          # [n][ks][which][mm][x][h][sp][j]
+    return torch.stack([h.contiguous().view(torch.uint8).reshape(N, 768), q]).contiguous()
+
+
 def mx_fragments(a: torch.Tensor):
     """A [M][K] fp32 -> the fragment-major MX planes the row-panel kernel reads (what the producers' epilogues write):
     (h fp16 [R][K / 16][64][8], l8 uint8 [R][K / 64][2][64][16], h8 likewise), R = ceil(M / 32); lane = 32 hw + row, element j of k-step s =
@@ -226,6 +239,8 @@ class VitBackbone:
             raise _lib.WvnError("fuse_qkv needs precision 'bf16' or 'fp16', dim 384 and 6 heads")
         self.fuse_qkv = can_fuse_qkv if fuse_qkv is None else bool(fuse_qkv)
         self._fuse_args = (fuse_mlp, fuse_qkv, fuse_proj)
+        # precision "mixed": the MX form of the block linears (fp16 hi * hi + scaled e5m2 correction products); WVN_NO_MX=1: the bf16 x 3 kernels (A/B, tests)
+        self.mx = self.precision == _lib.PREC_MIX and not os.environ.get("WVN_NO_MX")
         self._sd = state_dict  # kept (host / original tensors) so that .to(device) can re-home the model
         self._keep = []  # device tensors referenced by raw pointers in the C struct
 
@@ -308,6 +323,12 @@ class VitBackbone:
                         t = pack_fc2_fragment_major(sd[p + "attn.proj.weight"].to(self.device))
                         self._keep.append(t)
                         L.proj_w_frag = t.data_ptr()
+                        if self.mlp_dim % 128 == 0 and self.mx:   # the MX operand form of the four block linears (round 6)
+                            for name, key, pack in (("qkv_w_mx", "attn.qkv.weight", pack_a384_mx), ("proj_w_mx", "attn.proj.weight", pack_n384_mx),
+                                                    ("fc1_w_mx", "mlp.fc1.weight", pack_a384_mx), ("fc2_w_mx", "mlp.fc2.weight", pack_n384_mx)):
+                                t = pack(sd[p + key].detach().float().to(self.device))
+                                self._keep.append(t)
+                                setattr(L, name, t.data_ptr())
                 if self.fuse_mlp:
                     # proj.weight, fc1.weight and the fused kernel's own copy of fc2.weight (hidden index in the order the fc1
                     # accumulators hand it over, wvn_hip.h), one allocation per layer

@@ -344,6 +344,15 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     // WVN_PREC_MIX with a packed projection weight: the attention kernel writes fragments, the projection reads them (both planes of w.xn
     // then hold ceil(M / 32) * 32 rows; pl_xn below is the plane distance of BOTH layouts)
     const bool attn_frag = mix && x3_fast && L.proj_w_frag != nullptr;
+    // MX form of the block linears (round 6): fp16 hi * hi + two scaled e5m2 correction MFMAs per 64 k; the activations travel as three planes
+    // (fp16 fragments | l8 | h8) through w.xn (attention -> projection) and w.hid (fc1 -> fc2).  Needs the LayerNorm statistics hand-over.
+    const bool mx = mix && x3_fast && ln_fuse && d.H * 64 == d.D && (d.F % 128) == 0 && L.qkv_w_mx && L.proj_w_mx && L.fc1_w_mx && L.fc2_w_mx &&
+                    !(m->flags & WVN_VIT_NO_MX);
+    const size_t mpad32 = (size_t)((d.M + 31) / 32 * 32);
+    unsigned char* xn_l8 = (unsigned char*)w.xn + mpad32 * d.D * 2;     // MX planes of the attention output: fp16 fragments | l8 | h8
+    unsigned char* xn_h8 = xn_l8 + mpad32 * d.D;
+    unsigned char* hid_l8 = (unsigned char*)w.hid + mpad32 * d.F * 2;   // ... and of the hidden activation
+    unsigned char* hid_h8 = hid_l8 + mpad32 * d.F;
     // the two-plane q in the leading blocks only (include/wvn_hip.h: WVN_VIT_QSPLIT_BLOCKS)
     const int qs_field = (m->flags >> 16) & 63;
     const bool qsplit = mix && l < (qs_field ? qs_field - 1 : WVN_VIT_QSPLIT_DEFAULT);
@@ -376,7 +385,14 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
         q.W = (const bf16_t*)L.qkv_w; q.W_lo = lo(L.qkv_w, (size_t)3 * d.D * d.D); q.ldw = d.D; q.bias = L.qkv_b; q.M = M; q.N = 3 * d.D; q.K = d.D;
         q.ln_x = w.x; q.ln_ldx = d.D; q.ln_stats = w.ln_stats; q.ln_g = L.ln1_g; q.ln_b = L.ln1_b;
         Span s(3, st);
-        const int rc = wvn_gemm_a384_x3_launch(q, EPI_QKV, st);
+        int rc = WVN_ERR_ARG;
+        if (mx) {
+          GemmBf16Params qm = q;
+          qm.W = (const bf16_t*)L.qkv_w_mx; qm.W_lo = (const bf16_t*)L.qkv_w_mx + (size_t)3 * d.D * d.D;
+          rc = wvn_gemm_a384_mx_launch(qm, EPI_QKV, st);
+          if (rc != WVN_OK && rc != WVN_ERR_ARG) return rc;
+        }
+        if (rc != WVN_OK) rc = wvn_gemm_a384_x3_launch(q, EPI_QKV, st);
         if (rc != WVN_OK && rc != WVN_ERR_ARG) return rc;
         qkv_lna = rc == WVN_OK;
       }
@@ -391,6 +407,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     {
       Span s(4, st);
       if (bf) RET_IF(opk.attention((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr, nullptr, 0));
+      else if (mix && mx) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, (bf16_t*)xn_l8, qsplit ? lo(w.q, pl_qkv) : nullptr, 2));
       else if (mix) RET_IF(wvn_attention_bf16_launch_f16((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, lo(w.xn, pl_xn), qsplit ? lo(w.q, pl_qkv) : nullptr, attn_frag ? 1 : 0));
       else if (x3) RET_IF(wvn_attention_x3_launch((const bf16_t*)w.q, lo(w.q, pl_qkv), (const bf16_t*)w.k, lo(w.k, pl_qkv), (const bf16_t*)w.v, lo(w.v, pl_qkv), (bf16_t*)w.xn, lo(w.xn, pl_xn), d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
       else RET_IF(wvn_attention_f32_launch((const float*)w.q, (const float*)w.k, (const float*)w.v, (float*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, scale, st));
@@ -418,7 +435,15 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       if (rc != WVN_ERR_ARG) return rc;   // (WVN_ERR_ARG: not eligible -- separate kernels)
     }
     bool ln2_stats = false;   // w.ln_stats holds the statistics of w.x for this block's norm2
-    if (attn_frag) {   // the attention output arrived as operand fragments: the projection on the fragment form of the row-panel kernel
+    if (mx) {   // the attention output arrived as MX operand planes: the projection on the MX row-panel kernel
+      GemmBf16Params pp{};
+      pp.A = (const bf16_t*)w.xn; pp.A_lo = (const bf16_t*)xn_l8; pp.A_h8 = xn_h8; pp.lda = d.D; pp.W = (const bf16_t*)L.proj_w_mx; pp.ldw = d.D; pp.bias = L.proj_b; pp.ls = L.ls1;
+      pp.C = w.x; pp.ldc = d.D; pp.M = M; pp.N = d.D; pp.K = d.D;
+      pp.ln_stats_out = w.ln_stats; pp.ln_eps = 1e-6f;
+      Span s(5, st);
+      RET_IF(wvn_gemm_n384_mx_launch(pp, EPI_RESID_F32, st));
+      ln2_stats = true;
+    } else if (attn_frag) {   // the attention output arrived as operand fragments: the projection on the fragment form of the row-panel kernel
       GemmBf16Params pp{};
       pp.A = (const bf16_t*)w.xn; pp.A_lo = lo(w.xn, pl_xn); pp.lda = d.D; pp.W = (const bf16_t*)L.proj_w_frag; pp.ldw = d.D; pp.bias = L.proj_b; pp.ls = L.ls1;
       pp.C = w.x; pp.ldc = d.D; pp.M = M; pp.N = d.D; pp.K = d.D;
@@ -440,6 +465,22 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
       if (!L.fc2_w_fused) return WVN_ERR_ARG;
       RET_IF(opk.mlp_fused(nullptr, 0, L.ln2_g, L.ln2_b, 1e-6f, (const bf16_t*)L.fc1_w, L.fc1_b, (const bf16_t*)L.fc2_w_fused, L.fc2_b,
                                   L.ls2, w.x, d.D, M, d.F, st));
+      continue;
+    }
+    if (mx && ln2_stats) {   // LayerNorm-on-load fc1 + GELU -> MX operand planes -> MX row-panel fc2 (+ the next block's LayerNorm statistics)
+      GemmBf16Params p1{};
+      p1.W = (const bf16_t*)L.fc1_w_mx; p1.W_lo = (const bf16_t*)L.fc1_w_mx + (size_t)d.F * d.D; p1.ldw = d.D; p1.bias = L.fc1_b;
+      p1.C = w.hid; p1.C_lo = hid_l8; p1.C_h8 = hid_h8; p1.ldc = d.F; p1.M = M; p1.N = d.F; p1.K = d.D;
+      p1.ln_x = w.x; p1.ln_ldx = d.D; p1.ln_stats = w.ln_stats; p1.ln_g = L.ln2_g; p1.ln_b = L.ln2_b;
+      { Span s(6, st); RET_IF(wvn_gemm_a384_mx_launch(p1, EPI_GELU_FRAG, st)); }
+      GemmBf16Params p2{};
+      p2.A = (const bf16_t*)w.hid; p2.A_lo = (const bf16_t*)hid_l8; p2.A_h8 = hid_h8; p2.lda = d.F; p2.W = (const bf16_t*)L.fc2_w_mx; p2.ldw = d.F; p2.bias = L.fc2_b;
+      p2.ls = L.ls2; p2.C = w.x; p2.ldc = d.D; p2.M = M; p2.N = d.D; p2.K = d.F;
+      const bool want = l + 1 < m->depth;   // the next block's norm1
+      if (want) { p2.ln_stats_out = w.ln_stats; p2.ln_eps = 1e-6f; }
+      Span s(7, st);
+      RET_IF(wvn_gemm_n384_mx_launch(p2, EPI_RESID_F32, st));
+      ln1_stats = want;
       continue;
     }
     if (x3_fast && L.fc2_w_fused && !(m->flags & WVN_VIT_X3_NO_FRAG_MLP)) {
@@ -668,6 +709,29 @@ int wvn_debug_gemm_n384_mx(const void* A_h, const void* A_l8, const void* A_h8, 
   p.A = (const bf16_t*)A_h; p.A_lo = (const bf16_t*)A_l8; p.A_h8 = A_h8; p.lda = K; p.W = (const bf16_t*)Wp; p.ldw = K; p.bias = bias; p.ls = ls;
   p.C = C; p.ldc = ldc; p.M = M; p.N = 384; p.K = K; p.dbg = dbg;
   return wvn_gemm_n384_mx_launch(p, EPI_RESID_F32, (hipStream_t)stream);
+}
+int wvn_debug_mlp_mx(const float* x, int ldx, const float* ln_stats, const float* ln_g, const float* ln_b, const void* W1p, const float* b1,
+                     void* hid_h, void* hid_l8, void* hid_h8, const void* W2p, const float* b2, float* xout, int M, int F, long long* dbg1,
+                     long long* dbg2, void* stream) {
+  GemmBf16Params p1{};
+  p1.W = (const bf16_t*)W1p; p1.W_lo = (const bf16_t*)W1p + (size_t)F * 384; p1.ldw = 384; p1.bias = b1;
+  p1.C = hid_h; p1.C_lo = hid_l8; p1.C_h8 = hid_h8; p1.ldc = F; p1.M = M; p1.N = F; p1.K = 384; p1.dbg = dbg1;
+  p1.ln_x = x; p1.ln_ldx = ldx; p1.ln_stats = ln_stats; p1.ln_g = ln_g; p1.ln_b = ln_b;
+  RET_IF(wvn_gemm_a384_mx_launch(p1, EPI_GELU_FRAG, (hipStream_t)stream));
+  if (!W2p) return WVN_OK;
+  GemmBf16Params p2{};
+  p2.A = (const bf16_t*)hid_h; p2.A_lo = (const bf16_t*)hid_l8; p2.A_h8 = hid_h8; p2.lda = F; p2.W = (const bf16_t*)W2p; p2.ldw = F; p2.bias = b2;
+  p2.C = xout; p2.ldc = 384; p2.M = M; p2.N = 384; p2.K = F; p2.dbg = dbg2;
+  return wvn_gemm_n384_mx_launch(p2, EPI_RESID_F32, (hipStream_t)stream);
+}
+int wvn_debug_qkv_mx(const float* x, int ldx, const float* ln_stats, const float* ln_g, const float* ln_b, const void* Wp, const float* bias, void* q,
+                     void* q_lo, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, int M, long long* dbg, void* stream) {
+  GemmBf16Params p{};
+  p.W = (const bf16_t*)Wp; p.W_lo = (const bf16_t*)Wp + (size_t)3 * heads * 64 * 384; p.ldw = 384; p.bias = bias; p.M = M; p.N = 3 * heads * 64; p.K = 384;
+  p.q = (bf16_t*)q; p.q_lo = (bf16_t*)q_lo; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.heads = heads; p.npad = npad; p.ntok_s = ntok_s; p.q_scale = q_scale;
+  p.qkv_f16 = 1; p.dbg = dbg;
+  p.ln_x = x; p.ln_ldx = ldx; p.ln_stats = ln_stats; p.ln_g = ln_g; p.ln_b = ln_b;
+  return wvn_gemm_a384_mx_launch(p, EPI_QKV, (hipStream_t)stream);
 }
 int wvn_debug_n384_pair(int on) { wvn_gemm_n384_x3_set_pair(on); return WVN_OK; }
 int wvn_debug_kmeans_screen_stats(unsigned long long* out, int reset) { return out ? wvn_kmeans_pixels_screen_stats(out, reset) : WVN_ERR_ARG; }

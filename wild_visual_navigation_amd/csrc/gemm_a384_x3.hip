@@ -57,6 +57,7 @@ struct X384Params {
   const bf16_t* W; size_t w_plane;      // [2][N][384]: lo plane w_plane elements behind the hi plane
   const float* bias;
   void* C; void* C_lo; int ldc;         // planes (bf16) or fp32 (X_RESID: in/out; C_lo unused)
+  void* C_h8;                           // MX, X_GELU_FRAG: C = fp16 fragments, C_lo = the l8 plane, C_h8 = the h8 plane (gemm_n384_x3.hip's MX operand)
   int M, N;
   int heads, npad, ntok_s;
   float q_scale;
@@ -106,8 +107,27 @@ __device__ inline void gelu_pair(float& x0, float& x1) {
   x0 = g[0]; x1 = g[1];
 }
 
-template <int EPI, bool TIMING = false, bool LNA = false>
+// MX (round 6; LNA only, X_GELU_FRAG / X_QKV_F16): the operand representation of gemm_n384_x3.hip's MX kernel -- h = fp16(v), l8 = e5m2((v - h) * 2^12),
+// h8 = e5m2(v) -- for both operands: per k-step region TWO fp16 MFMAs (hi * hi of the two column halves) and ONE scaled e5m2 MFMA of K = 64 (one of
+// the slice's eight correction products: 2 column halves x 2 64-k steps x {a_h8 w_l8, a_l8 w_h8}) = 128 matrix-pipe cycles instead of 192, the same
+// four ds_read_b128.  W: plane 0 = fp16 [N][384]; plane 1 = bytes [N][768] in the chunk order the kernel reads them (backbone.pack_a384_mx).
+// The row block's operands stay resident as before: 24 fp16 fragments + 6 + 6 eight-register e5m2 operands = the same 192 registers.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+constexpr int MX_SC_ONE = 0x7f7f7f7f, MX_SC_RES = 0x73737373;   // E8M0 scale bytes 2^0 / 2^-12 (every byte alike)
+constexpr float MX_RES_INV = 1.0f / 4096.0f;                    // v_cvt_scalef32_* DIVIDES by its scale operand (scripts/ubench/mx_formats.hip)
+__device__ inline uint32_t mx_pk8(uint32_t old, float a, float b, float inv_scale, bool hi_word) {
+  const s16x2_t o = __builtin_bit_cast(s16x2_t, old);
+  return __builtin_bit_cast(uint32_t, hi_word ? __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(o, a, b, inv_scale, true)
+                                              : __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(o, a, b, inv_scale, false));
+}
+
+constexpr int X384_LDS_MAX = 160 * 1024;
+
+template <int EPI, bool TIMING = false, bool LNA = false, bool MX = false>
 __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
+  static_assert(!MX || (LNA && (EPI == X_GELU_FRAG || EPI == X_QKV_F16)), "the MX form exists for the LayerNorm-on-load fc1 / QKV instantiations");
   wvn_fp16_saturate();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -156,8 +176,56 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   if constexpr (LNA)
     for (int i = tid; i < 2 * KD; i += 256) ((float*)(smem + BIAS_OFF + p.N * 4))[i] = i < KD ? p.ln_g[i] : p.ln_b[i - KD];
   bf16x8_t xh[KD / 16], xl[KD / 16];
+  u32x4_t mh[KD / 16];                    // MX: the fp16 fragments
+  u32x4_t m8[2][KD / 64][2];              // MX: [0 = h8 | 1 = l8][64-k step][half]: dword 2 (s & 1) + e of half (s >> 1) & 1 = bytes j = 4 e .. 4 e + 3 of k-step s
   auto load_a = [&]() __attribute__((always_inline)) {
-    if constexpr (LNA) {
+    if constexpr (LNA && MX) {
+      const int row = min(m0w + l31, p.M - 1);
+      const wvn_f32x2_t st = *(const wvn_f32x2_t*)(p.ln_stats + 2 * (size_t)row);
+      const float a1 = st[1], a0 = -st[0] * st[1];
+      const float* xr = p.ln_x + (size_t)row * p.ln_ldx + hi * 8;
+#pragma unroll
+      for (int s0 = 0; s0 < KD / 16; s0 += 12) {
+        f32x4_t u[24];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          u[2 * i] = *(const f32x4_t*)(xr + (s0 + i) * 16);
+          u[2 * i + 1] = *(const f32x4_t*)(xr + (s0 + i) * 16 + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int s = s0 + i;
+          const f32x4_t g0 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8), g1 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8 + 4);
+          const f32x4_t b0 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8), b1 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8 + 4);
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            y[e] = fmaf(fmaf(u[2 * i][e], a1, a0), g0[e], b0[e]);
+            y[4 + e] = fmaf(fmaf(u[2 * i + 1][e], a1, a0), g1[e], b1[e]);
+          }
+          u32x4_t hv;
+          uint32_t d8[2][2] = {{0, 0}, {0, 0}};   // [h8 | l8][dword]
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+            const uint32_t hb = pack_f16x2(y[2 * e], y[2 * e + 1]);   // (bit_cast of the SCALAR: clang reads element 0 when handed a vector element)
+            hv[e] = hb;
+            const h2_t hh = __builtin_bit_cast(h2_t, hb);
+            d8[0][e >> 1] = mx_pk8(d8[0][e >> 1], y[2 * e], y[2 * e + 1], 1.0f, e & 1);
+            d8[1][e >> 1] = mx_pk8(d8[1][e >> 1], y[2 * e] - (float)hh[0], y[2 * e + 1] - (float)hh[1], MX_RES_INV, e & 1);
+          }
+          asm volatile("" : "+v"(hv));
+          mh[s] = hv;
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            m8[w][s >> 2][(s >> 1) & 1][2 * (s & 1)] = d8[w][0];
+            m8[w][s >> 2][(s >> 1) & 1][2 * (s & 1) + 1] = d8[w][1];
+          }
+        }
+      }
+    } else if constexpr (LNA) {
       // the rows arrive as fp32 (the residual stream itself: the same bytes as two bf16 planes) and are normalised with the statistics
       // their producer left, scaled, shifted and split on the way into the operand registers: ~5 VALU per value once per row block
       // (18 - 24 column tiles of three slice periods each), instead of a kernel that reads the rows and writes the planes
@@ -232,7 +300,8 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   const __amdgpu_buffer_rsrc_t rs_c = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base, 0, p.qkv_bytes, 0x00020000)
                                              : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c2 = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base_lo ? p.qkv_base_lo : p.qkv_base, 0, p.qkv_bytes, 0x00020000)
-                                              : __builtin_amdgcn_make_buffer_rsrc(p.C_lo ? p.C_lo : p.C, 0, c_bytes, 0x00020000);
+                                              : __builtin_amdgcn_make_buffer_rsrc(p.C_lo ? p.C_lo : p.C, 0, MX ? c_bytes / 2 : c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c3 = __builtin_amdgcn_make_buffer_rsrc(MX && p.C_h8 ? p.C_h8 : (void*)p.W, 0, MX && p.C_h8 ? c_bytes / 2 : 0u, 0x00020000);   // MX fc1: the h8 plane
   auto qkv_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int hblk = 0; hblk < 2; ++hblk) {
@@ -260,8 +329,20 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   bf16x8_t wh[2][2], wl[2][2];   // [k-step parity][column half]
   u32x4_t resid_q[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   u32x4_t fragh = {0, 0, 0, 0}, fragl = {0, 0, 0, 0};   // X_GELU_FRAG: the fragment being assembled
+  u32x4_t frag8h = {0, 0, 0, 0}, frag8l = {0, 0, 0, 0};  // MX: the 16-byte half of the e5m2 operands being assembled
+  u32x4_t wq[2][2], w8[2][2];   // MX: [k-step parity][column half] fp16 fragments; [k-step parity][half] of the region's e5m2 operand
   auto frag_read = [&](int slot, int s, int par) __attribute__((always_inline)) {
     const unsigned char* base = smem + slot * SLICE_BYTES + rd_base;
+    if constexpr (MX) {
+      // region s: the fp16 fragments of k-step s (both column halves) and correction product s = (64-k step mm = s >> 2, which = (s >> 1) & 1:
+      // 0 = w_l8 (x a_h8), 1 = w_h8 (x a_l8); column half t8 = s & 1): plane-1 chunks 2 s'' + hi, s'' = 4 which + 2 mm + x
+      const int mm = s >> 2, which = (s >> 1) & 1, t8 = s & 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) wq[par][t] = *(const u32x4_t*)(base + t * 8192 + (((2 * s + hi) ^ xorc) << 4));
+#pragma unroll
+      for (int x = 0; x < 2; ++x) w8[par][x] = *(const u32x4_t*)(base + PLANE_BYTES + t8 * 8192 + (((2 * (4 * which + 2 * mm + x) + hi) ^ xorc) << 4));
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const unsigned o = t * 8192 + (((2 * s + hi) ^ xorc) << 4);
@@ -273,6 +354,26 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     constexpr bool TR = decltype(tr_tag)::value;
     const int cur = s & 1;
     if (s + 1 < 8) frag_read(slot, s + 1, cur ^ 1);
+    if constexpr (MX) {
+      const int mm = s >> 2, which = (s >> 1) & 1, t8 = s & 1;
+      const f16x8_t af = __builtin_bit_cast(f16x8_t, mh[ks * 8 + s]);
+      const u32x4_t a0 = m8[which][ks * 2 + mm][0], a1 = m8[which][ks * 2 + mm][1];
+      const i32x8_t av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+      const u32x4_t w0 = w8[cur][0], w1 = w8[cur][1];
+      const i32x8_t wv = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+      // accumulators alternate: even regions 0, 1, 0 -- odd regions 1, 0, 1 (the scaled MFMA goes to column half t8 = s & 1)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int t = n ^ t8;
+        const f16x8_t wf = __builtin_bit_cast(f16x8_t, wq[cur][t]);
+        if constexpr (TR) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, acc[t], 0, 0, 0);
+      }
+      // which 0: W_l8 (carries 2^12) x a_h8;  which 1: W_h8 x a_l8 (carries 2^12)
+      if constexpr (TR) acc[t8] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc[t8], 1, 1, 0, which ? MX_SC_ONE : MX_SC_RES, 0, which ? MX_SC_RES : MX_SC_ONE);
+      else acc[t8] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, wv, acc[t8], 1, 1, 0, which ? MX_SC_RES : MX_SC_ONE, 0, which ? MX_SC_ONE : MX_SC_RES);
+      return;
+    }
     const bf16x8_t ah = xh[ks * 8 + s], al = xl[ks * 8 + s];
 #pragma unroll
     for (int term = 0; term < 3; ++term)
@@ -303,6 +404,26 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       if constexpr (TR) {
         const int c = 32 * t + 8 * g + 4 * hi + h2;
         if constexpr (EPI == X_GELU || EPI == X_GELU_FRAG) gelu_pair(v0, v1);
+        if constexpr (EPI == X_GELU_FRAG && MX) {
+          // part t fills half t of the tile's (= the consumer's 64-k step jp) e5m2 operands, chunk s its bytes 2 s, 2 s + 1; every fourth chunk completes
+          // one fp16 fragment (consumer k-step 4 jp + 2 t + (g >> 1)), the eighth the 16-byte halves
+          typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+          const uint32_t h = pack_f16x2(v0, v1);
+          const h2_t hh = __builtin_bit_cast(h2_t, h);
+          fragh[2 * (g & 1) + (h2 >> 1)] = h;
+          frag8h[s >> 1] = mx_pk8(frag8h[s >> 1], v0, v1, 1.0f, s & 1);
+          frag8l[s >> 1] = mx_pk8(frag8l[s >> 1], v0 - (float)hh[0], v1 - (float)hh[1], MX_RES_INV, s & 1);
+          if ((s & 3) == 3) {
+            const unsigned so = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 4)) + 4 * jp + 2 * t + (g >> 1)) * 1024);
+            wvn_store_b128_guarded(fragh, rs_c, lane * 16, so);
+          }
+          if (s == 7) {
+            const unsigned so8 = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 6)) + jp) * 2048 + t * 1024);
+            wvn_store_b128_guarded(frag8l, rs_c2, lane * 16, so8);
+            wvn_store_b128_guarded(frag8h, rs_c3, lane * 16, so8);
+          }
+          return;
+        }
         if constexpr (EPI == X_GELU_FRAG) {
           uint32_t h, l;
           split2(v0, v1, h, l);
@@ -462,6 +583,21 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       issue_piece(i + NS - 1, s);
       mfma_step(i % NS, ks, s, mtr);
       if constexpr (do_epi) epi_chunk(ks, j - 1, s, etr);
+      if constexpr (MX) {   // three MFMAs per region (32 + 32 + 64 cycles): the other instructions in three groups, the largest behind the scaled MFMA
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);
+      } else {
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -469,6 +605,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
         __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -535,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   }
 }
 
-constexpr int X384_LDS_MAX = 160 * 1024;
+
 bool g_x384_split_qkv = getenv("WVN_X384_SPLIT_QKV") != nullptr;   // A/B: q | k and v^T as two launches (the form before the merged kernel)
 
 int x384_num_cus() {
@@ -547,6 +684,21 @@ int x384_num_cus() {
     if (n <= 0) n = 256;
   }
   return n;
+}
+
+template <int EPI>
+int launch_mx(const X384Params& p, hipStream_t st) {
+  if (!p.ln_x || !p.ln_stats || !p.ln_g || !p.ln_b || (p.ln_ldx % 4) || ((uintptr_t)p.ln_x & 15) || ((uintptr_t)p.ln_stats & 7)) return WVN_ERR_ARG;
+  const int lds = BIAS_OFF + p.N * 4 + 2 * KD * 4;
+  if (lds > X384_LDS_MAX) return WVN_ERR_ARG;
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(X384_LDS_MAX, (const void*)gemm_a384_x3_kernel<EPI, false, true, true>, (const void*)gemm_a384_x3_kernel<EPI, true, true, true>)) return rc;
+  const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
+  const int grid = (int)(units < x384_num_cus() ? units : x384_num_cus());
+  if (p.dbg) hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, true, true, true>), dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, false, true, true>), dim3(grid), dim3(256), lds, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
 }
 
 template <int EPI>
@@ -633,6 +785,42 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
       p.bias = g.bias ? g.bias + 2 * D : nullptr;
       p.N = D;
       return g.qkv_f16 ? launch<X_V_F16>(p, st) : launch<X_V>(p, st);
+    }
+    default: return WVN_ERR_ARG;
+  }
+}
+
+// MX form (LayerNorm on load only): W = backbone.pack_a384_mx (plane 0 fp16 [N][384] at g.W, plane 1 bytes [N][768] at g.W_lo); EPI_GELU_FRAG writes the
+// MX operand planes of gemm_n384_x3.hip's MX kernel (g.C fp16 fragments, g.C_lo = l8, g.C_h8 = h8), EPI_QKV the fp16 q (| q_lo) | k | v^T planes.
+int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
+  if (!g.ln_x || g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.W || !g.W_lo) return WVN_ERR_ARG;
+  if (((uintptr_t)g.W | (uintptr_t)g.W_lo) & 15) return WVN_ERR_ARG;
+  if (g.W_lo <= g.W || (size_t)(g.W_lo - g.W) + (size_t)g.N * KD >= (1ull << 30)) return WVN_ERR_ARG;
+  X384Params p{};
+  p.lda = KD; p.W = g.W; p.w_plane = (size_t)(g.W_lo - g.W); p.bias = g.bias;
+  p.C = g.C; p.C_lo = g.C_lo; p.C_h8 = g.C_h8; p.ldc = g.ldc; p.M = g.M; p.N = g.N;
+  p.heads = g.heads; p.npad = g.npad; p.ntok_s = g.ntok_s; p.q_scale = g.q_scale != 0.f ? g.q_scale : 1.f; p.f16_out = 1;
+  p.dbg = g.dbg;
+  p.ln_x = g.ln_x; p.ln_ldx = g.ln_ldx; p.ln_stats = g.ln_stats; p.ln_g = g.ln_g; p.ln_b = g.ln_b;
+  switch (epi) {
+    case EPI_GELU_FRAG:
+      if (!g.C || !g.C_lo || !g.C_h8 || g.ldc != g.N || (g.N % 64) || (((uintptr_t)g.C | (uintptr_t)g.C_lo | (uintptr_t)g.C_h8) & 15) || ((size_t)g.M + 32) * g.ldc * 2 >= (1ull << 31))
+        return WVN_ERR_ARG;
+      return launch_mx<X_GELU_FRAG>(p, st);
+    case EPI_QKV: {
+      if (!g.qkv_f16 || g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 16) || (g.M % 16) || (g.npad % 16)) return WVN_ERR_ARG;
+      const uintptr_t lo = std::min({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
+      const uintptr_t hi = std::max({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
+      const size_t one = (size_t)(g.M / (g.ntok_s > 0 ? g.ntok_s : 1)) * g.heads * g.npad * 64 * 2;
+      if (hi - lo + one >= (1ull << 31)) return WVN_ERR_ARG;
+      p.qkv_base = (bf16_t*)lo; p.q_off = (unsigned)((uintptr_t)g.q - lo); p.k_off = (unsigned)((uintptr_t)g.k - lo);
+      p.v_off = (unsigned)((uintptr_t)g.vt - lo); p.qkv_bytes = (unsigned)(hi - lo + one);
+      if (g.q_lo) {
+        if ((uintptr_t)g.q_lo < p.q_off) return WVN_ERR_ARG;
+        p.qkv_base_lo = (bf16_t*)((uintptr_t)g.q_lo - p.q_off);
+        p.q_lo_f16 = 1;
+      }
+      return launch_mx<X_QKV_F16>(p, st);
     }
     default: return WVN_ERR_ARG;
   }

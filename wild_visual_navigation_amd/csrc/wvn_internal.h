@@ -94,6 +94,8 @@ int wvn_gemm_n384_x3_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 // the MX form of the fragment kernel (fp16 hi plane + two e5m2 planes per operand; W packed by backbone.pack_n384_mx)
 int wvn_gemm_n384_mx_launch(const GemmBf16Params& p, int epi, hipStream_t st);
+// the MX form of the A-stationary kernel (LayerNorm on load; EPI_GELU_FRAG -> MX fragment planes, EPI_QKV -> fp16 q | k | v^T); W packed by backbone.pack_a384_mx
+int wvn_gemm_a384_mx_launch(const GemmBf16Params& p, int epi, hipStream_t st);
 
 // ---- fp8 (e4m3) MFMA GEMM with per-row scales of both operands (gemm_fp8.hip) + the row quantisers (fp8.hip) -----------
 struct GemmFp8Params {
