@@ -173,6 +173,9 @@ def make_pipeline(args, dev, precision=None, stego_reading=None):
     if args.attn_variant is not None:
         from wild_visual_navigation_amd import _lib
         _lib.lib().wvn_debug_attention_variant(args.attn_variant)
+    if os.environ.get("WVN_QSPLIT_FORM"):   # A/B of the two-plane q's second plane: 2 = one scaled e5m2 MFMA per sub-tile (default), 1 = fp16 MFMAs (round 4)
+        from wild_visual_navigation_amd import _lib
+        _lib.lib().wvn_debug_attention_variant(16 + int(os.environ["WVN_QSPLIT_FORM"]))
     if os.environ.get("WVN_N384_PAIR"):   # A/B of the two forms of the fragment-major row-panel kernel (1 wave pair = default, 0 one wave per SIMD)
         from wild_visual_navigation_amd import _lib
         _lib.lib().wvn_debug_n384_pair(int(os.environ["WVN_N384_PAIR"]))

@@ -67,7 +67,10 @@ __device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a,
 // rounding) and the running max enters the S^T MFMA chain as its C operand (a 16-register block holding -M, rewritten
 // only when the max moves): the accumulators come out as exp2 arguments and the 16 v_pk_fma per tile disappear.
 // SUM: how the row sums are formed.  0: v_dot2c_f32_bf16 on the packed P (16 per tile); 1: plain adds on the fp32 P.
-template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false, int SUM = 0, bool LAZY = false, bool QSPLIT = false>
+// QSPLIT: 0 = one q plane; 1 = q as two planes of the operand format (eight more MFMAs per tile); 2 (round 6, fp16 build) = the second plane as ONE scaled
+// e5m2 MFMA of K = 64 per 32-key sub-tile: q_lo -> e5m2(q_lo * 2^12) once per workgroup, the keys' e5m2 image = the top bytes of the fp16 K fragments already in
+// registers (two v_perm per fragment: truncation, a 9 % shortfall of a term that is itself 2^-12 of the score) -- 64 matrix-pipe cycles per sub-tile instead of 128
+template <int NST, bool XCDMAP, int OCC, bool TIMING = false, bool PRE = false, int SUM = 0, bool LAZY = false, int QSPLIT = 0>
 __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* __restrict__ q,
                                                                   const op16_t* __restrict__ k,
                                                                   const op16_t* __restrict__ vt,
@@ -135,13 +138,36 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
   // reference's real 448^2 frame q alone accounts for the 1.0e-3 token error of single-plane attention (split: 7.6e-5; k split: no
   // change; profiles/r04d_error_budget_real_frame.md)
   opx8_t ql[4];
-  if constexpr (QSPLIT) {
+  typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+  i32x8_t ql8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (QSPLIT != 0) {
     const op16_t* qlg = q_lo + ((size_t)bh * npad + q0 + l31) * DH + hi * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) ql[s] = *(const opx8_t*)(qlg + s * 16);
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(ql[s]));
   }
+#if WVN_OPERAND_F16
+  if constexpr (QSPLIT == 2) {   // byte (s, j) of the lane's 32 = e5m2(q_lo[16 s + 8 hi + j] * 2^12): the order the K fragments' top bytes are gathered in below
+    typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32x4_t raw = __builtin_bit_cast(u32x4_t, ql[s]);
+      uint32_t d[2] = {0, 0};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t pr = raw[e];   // (scalar copy: clang's bit_cast of a vector element reads element 0)
+        const s16x2_t o = __builtin_bit_cast(s16x2_t, d[e >> 1]);
+        d[e >> 1] = __builtin_bit_cast(uint32_t, (e & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f / 4096.0f, true)
+                                                         : __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f / 4096.0f, false));
+      }
+      ql8[2 * s] = (int)d[0];
+      ql8[2 * s + 1] = (int)d[1];
+    }
+    asm volatile("" : "+v"(ql8));
+  }
+#endif
 
   f32x16_t ot[2];
 #pragma unroll
@@ -332,11 +358,22 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
     auto qk = [&]() {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
+        {
+          i32x8_t k8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const opx8_t kf = *(const opx8_t*)(lds + fa[s] + t * 4096);
-          st[t] = wvn_mfma_32x32x16(kf, qf[s], s == 0 ? cneg : st[t], 0, 0, 0);
-          if constexpr (QSPLIT) st[t] = wvn_mfma_32x32x16(kf, ql[s], st[t], 0, 0, 0);
+          for (int s = 0; s < 4; ++s) {
+            const opx8_t kf = *(const opx8_t*)(lds + fa[s] + t * 4096);
+            st[t] = wvn_mfma_32x32x16(kf, qf[s], s == 0 ? cneg : st[t], 0, 0, 0);
+            if constexpr (QSPLIT == 1) st[t] = wvn_mfma_32x32x16(kf, ql[s], st[t], 0, 0, 0);
+            if constexpr (QSPLIT == 2) {   // the top bytes of the eight fp16 values = their e5m2 image, truncated
+              const u32x4_t kr = __builtin_bit_cast(u32x4_t, kf);
+              k8[2 * s] = (int)__builtin_amdgcn_perm(kr[1], kr[0], 0x07050301u);
+              k8[2 * s + 1] = (int)__builtin_amdgcn_perm(kr[3], kr[2], 0x07050301u);
+            }
+          }
+#if WVN_OPERAND_F16
+          if constexpr (QSPLIT == 2) st[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k8, ql8, st[t], 1, 1, 0, 0x7f7f7f7f, 0, 0x73737373);
+#endif
         }
       if (MAYBE_TAIL && kv0 + KVB > ntok) {
 #pragma unroll
@@ -566,16 +603,27 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
 long long* g_attn_dbg = nullptr;  // set by wvn_debug_attention_timing (scripts/attn_timing.py)
 
 constexpr int ATTN_DEFAULT = 1;
-int g_attn_variant = ATTN_DEFAULT;   // 0: exact per-tile row max, 1: lazy (alarm on the row sums; what ships: -4 % attention time)
+int g_attn_variant = ATTN_DEFAULT;
+int g_attn_qsplit_form = 2;   // two-plane q: 2 = the second plane on a scaled e5m2 MFMA (round 6, fp16 build), 1 = both planes on fp16 MFMAs (round 4)   // 0: exact per-tile row max, 1: lazy (alarm on the row sums; what ships: -4 % attention time)
 
 void launch_pre(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t* k, const op16_t* vt, op16_t* out,
                 int heads, int nbh, int nqb, int ntok, int ntok_s, int npad, op16_t* out_lo, const op16_t* q_lo, int out_frag) {
-  if (q_lo) {   // two-plane q: the lazy form with 16 more registers -- three workgroups per CU
+  if (q_lo && WVN_OPERAND_F16 && g_attn_qsplit_form == 2) {   // two-plane q, the second plane on ONE scaled e5m2 MFMA per sub-tile (round 6); 148 registers: three
+    // workgroups per CU (forced to four -- 128 registers, 68 bytes of scratch -- it runs 14 % slower: 31.0 against 27.2 ms of attention per step)
     if (xcd)
-      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 3, false, true, 0, true, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 3, false, true, 0, true, 2>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
                          nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo, out_frag);
     else
-      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 3, false, true, 0, true, true>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 3, false, true, 0, true, 2>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo, out_frag);
+    return;
+  }
+  if (q_lo) {   // two-plane q: the lazy form with 16 more registers -- three workgroups per CU
+    if (xcd)
+      hipLaunchKernelGGL((attention_bf16_kernel<2, true, 3, false, true, 0, true, 1>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
+                         nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo, out_frag);
+    else
+      hipLaunchKernelGGL((attention_bf16_kernel<2, false, 3, false, true, 0, true, 1>), grid, dim3(256), 0, st, q, k, vt, out, heads, nbh,
                          nqb, ntok, ntok_s, npad, 1.f, nullptr, out_lo, q_lo, out_frag);
     return;
   }
@@ -628,7 +676,10 @@ void launch_v(bool xcd, dim3 grid, hipStream_t st, const op16_t* q, const op16_t
 }  // namespace
 
 void WVN_OPSYM(wvn_attention_bf16_set_debug)(long long* dbg) { g_attn_dbg = dbg; }
-void WVN_OPSYM(wvn_attention_bf16_set_variant)(int v) { g_attn_variant = v < 0 ? ATTN_DEFAULT : v; }  // < 0: back to the default
+void WVN_OPSYM(wvn_attention_bf16_set_variant)(int v) {
+  if (v >= 16) { g_attn_qsplit_form = v - 16; return; }   // 17 / 18: the form of the two-plane q (wvn_debug_attention_variant)
+  g_attn_variant = v < 0 ? ATTN_DEFAULT : v;
+}  // < 0: back to the default
 
 // scale > 0: q holds the raw projections.  scale == 0: q is pre-multiplied by softmax_scale * log2(e) (EPI_QKV with
 // q_scale set), the kernel with the running max folded into the S^T MFMA chain runs.
