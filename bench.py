@@ -17,9 +17,10 @@ the 64-frame batch over the ranks):
   --mode backbone (configs[1]): --batch 32 frames through the ViT only (feature extraction).
   --mode dinov2   (configs[4]): DINOv2 ViT-B/14 at 518x518 (1370 tokens, LayerScale) + STEGO head, --batch 16 frames per GPU
                   (128 over 8 GPUs); meant for --precision fp8 (block linears on e4m3 MFMA), also runs in bf16 / exact.
-  --precision mixed: the <= 1e-3 mode and the DEFAULT of --mode full (north_star: outputs within 1e-3 of the fp32 reference): every linear
-                     with hi + lo split bf16 operands (three MFMAs per product), the attention products on the fp16-operand kernel with q
-                     as two planes in the first six blocks -- the cheapest mix the per-family error budget allows
+  --precision mixed: the <= 1e-3 mode and the DEFAULT of --mode full (north_star: outputs within 1e-3 of the fp32 reference): every block linear
+                     as fp16 hi * hi + two scaled e5m2 correction products (MX form, round 6; WVN_NO_MX=1: hi + lo split bf16 operands, three
+                     MFMAs per product), the attention products on the fp16-operand kernel with q as two planes in the first six blocks -- the
+                     cheapest mix the per-family error budget allows
   --precision exact: every product split (fp32-class results on the matrix pipe); --precision fp32: the FMA cross-check
   --precision fp16 : ONE fp16 value per MFMA operand (11 significand bits), fp32 accumulate / residual / statistics: the opt-in speed
                      path (tokens 4.5e-3 from the oracle)
@@ -35,6 +36,8 @@ line, each with its own roofline and parity:
                      less work per frame by definition, reported as an option
   `backbone_b32`   : BASELINE configs[1] (ViT-S/8 448^2, batch 32, feature extraction only, fp16 operands)
   `dinov2_fp8`     : BASELINE configs[4], one GPU's share (DINOv2 ViT-B/14 518^2 + STEGO head, batch 16, fp8 block linears)
+  `grid_mixed`     : SURVEY 8(d) C3-(i): the same 64 frames with `grid` segmentation (32-pixel cells, 196 segments per frame, ONE backbone pass,
+                     12 544 MLP rows per step: the general learner path) in --precision mixed -- NOT the metric (north_star names the STEGO segmentation)
 (--no-extra-legs skips them; A/B runs and N > 1 runs never run them).
 """
 import argparse
@@ -48,7 +51,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (scaled K = 64 / 128 forms)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "attention_traffic.json")  # PMC-derived HBM bytes of the dominant kernel
 
 
@@ -70,6 +74,16 @@ def vit_flops_per_frame(S=448, P=8, D=384, depth=12):
     N = G * G + 1
     per_block = 24 * N * D * D + 4 * N * N * D
     return depth * per_block + 2 * G * G * 3 * P * P * D, 4 * N * N * D  # (total, attention per block)
+
+
+def linear_flops_per_frame(S=448, P=8, D=384, depth=12):
+    """Algorithmic FLOPs of the four block linears (QKV, projection, fc1, fc2) of one frame pass: depth * 24 N D^2."""
+    N = (S // P) ** 2 + 1
+    return depth * 24 * N * D * D
+
+
+# matrix-pipe work the block linears ISSUE per algorithmic product, in units of one fp16 / bf16 MFMA pass over it
+LINEAR_ISSUE = {"fp16": 1.0, "bf16": 1.0, "exact": 3.0, "mixed": 2.0, "mixed_x3": 3.0, "fp8": 0.5, "fp32": None}
 
 
 def parse():
@@ -446,7 +460,8 @@ KERNEL_NAME = {"fp16": "attention_bf16_kernel (fp16-operand build)", "bf16": "at
                "mixed": "attention_bf16_kernel (fp16-operand build, hi + lo plane output)",
                "fp32": "attention_f32_kernel", "fp8": "attention_bf16_kernel"}
 DTYPE = {"fp16": "f16", "bf16": "bf16", "exact": "bf16x3 (hi+lo split operands, fp32-class)", "fp32": "f32",
-         "mixed": "bf16x3 linears (hi+lo split operands) + f16 attention products, fp32 accumulate / residual (<= 1e-3 parity mode)",
+         "mixed": ("fp16 + e5m2-MX-correction linears (a w = a_h w_h + 2^-12 (a_h8 w_l8 + a_l8 w_h8); ~16 significand bits per product) + f16 attention products "
+                   "(two-plane q in the first six blocks), fp32 accumulate / residual (<= 1e-3 parity mode)"),
          "fp8": "fp8-e4m3 linears (per-token / per-channel scales), bf16 attention, fp32 residual"}
 
 
@@ -542,6 +557,33 @@ def timed_leg(args, dev, world, rank, steps, warmup, precision, stego_reading, p
     if precision == "exact":  # three MFMAs per algorithmic product: what the matrix pipe actually issues
         roof["mfma_issued"] = round(3 * att_tflops, 1)
         roof["frac_issued"] = round(3 * att_tflops / PEAK_BF16_TFLOPS, 4)
+    # the block linears as a family (QKV + projection + fc1 + fc2; HIP-event time of their spans inside the timed region): in the <= 1e-3 mode they are
+    # the larger share of the step and sit far lower against the roof than the attention kernel -- VERDICT r5 item 4 asks to see both
+    lin_ms = sum(prof[k][0] for k in ("qkv_gemm", "proj_gemm", "fc1_gemm", "fc2_gemm") if k in prof)
+    lin_launches = sum(prof[k][1] for k in ("qkv_gemm", "proj_gemm", "fc1_gemm", "fc2_gemm") if k in prof)
+    lin_flops = (linear_flops_per_frame(518, 14, 768) if args.mode == "dinov2" else linear_flops_per_frame(args.size)) * passes * B * steps
+    mxkey = "mixed_x3" if (precision == "mixed" and os.environ.get("WVN_NO_MX")) else precision
+    lin = None
+    if lin_ms > 0:
+        lin_tf = lin_flops / (lin_ms * 1e-3) / 1e12
+        peak = PEAK_FP8_TFLOPS if precision == "fp8" else PEAK_BF16_TFLOPS
+        lin = {"kernels": "QKV + projection + fc1 + fc2 of all blocks (" + {"mixed": "gemm_a384_x3 MX / gemm_n384_mx_pair", "mixed_x3": "gemm_a384_x3 / gemm_n384_x3_frag_pair",
+                                                                              "exact": "gemm_a384_x3 / gemm_n384_x3", "fp8": "gemm_fp8 (128 x 128 tiles) + row quantisers",
+                                                                              "fp32": "gemm_f32"}.get(mxkey, "qkv_fused + mlp_fused") + ")",
+               "ms_per_step": round(lin_ms / steps, 3), "launches_per_step": round(lin_launches / steps, 1), "achieved": round(lin_tf, 1), "peak": peak, "unit": "TFLOP/s",
+               "frac": round(lin_tf / peak, 4), "algorithmic_flops_per_step": lin_flops / steps}
+        iss = LINEAR_ISSUE.get(mxkey)
+        if iss is not None and precision != "fp8":
+            lin["issued_per_product"] = iss
+            lin["frac_issued"] = round(iss * lin_tf / PEAK_BF16_TFLOPS, 4)
+        roof["linears"] = lin
+        roof["attention_ms_per_step"] = round(att_ms / steps, 3)
+    if precision == "fp8" and lin is not None:
+        # configs[4]: the leg's dominant family is the fp8 linears (6.5 of its 9.2 ms), priced against the 5 PF fp8 peak; the attention kernel's own figure stays beside it
+        att = dict(roof)
+        att.pop("linears", None)
+        roof = {"bound": "mfma", "kernel": lin["kernels"], "achieved": lin["achieved"], "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": lin["frac"],
+                "traffic": None, "ms_per_step": lin["ms_per_step"], "algorithmic_flops_per_step": lin["algorithmic_flops_per_step"], "attention": att}
     return {"fe": fe, "pipe": pipe, "rows": rows, "dt": dt, "value": round(total_frames / dt, 2),
             "ms_per_step": round(dt / steps * 1e3, 3), "step_ms": percentiles(step_ms),
             "backbone_tflops": round(total_flops * passes * total_frames / dt / 1e12 / world, 1), "final_loss": loss_val,
@@ -598,6 +640,12 @@ def main():
         legs["stego_fast"] = timed_leg(args, dev, world, rank, max(20, args.extra_steps), 5, SPEED, "patch", pool, labels, B)
         # the other two single-GPU configurations of BASELINE.json, on the kernels as they are today: configs[1]
         # (backbone only, batch 32) and configs[4]'s per-GPU share (DINOv2 ViT-B/14 518^2 fp8 + STEGO head, 16 frames per GPU)
+        # `grid` segmentation (cell 32: 196 segments per frame, one backbone pass, 12 544 MLP rows -- the general learner path) in the
+        # <= 1e-3 mode; labelled as what it is: NOT the metric (north_star: STEGO seg)
+        ag = argparse.Namespace(**vars(args)); ag.segmentation, ag.precision = "grid", "mixed"
+        labels_g = [torch.rand(B, (args.size // 32) ** 2, 2, generator=gen).to(dev) for _ in range(len(pool))]
+        legs["grid_mixed"] = timed_leg(ag, dev, world, rank, max(20, args.extra_steps), 5, "mixed", "upstream", pool, labels_g, B)
+        legs["grid_mixed"]["args"] = ag
         a1 = argparse.Namespace(**vars(args)); a1.mode, a1.batch, a1.precision = "backbone", 32, "fp16"
         legs["backbone_b32"] = timed_leg(a1, dev, world, rank, 20, 5, "fp16", "upstream", [p[:32] for p in pool], labels, 32)
         legs["backbone_b32"]["args"] = a1
@@ -646,7 +694,10 @@ def main():
             "config": {"workload": workload, "frames_per_gpu_per_step": B, "backbone_chunk": chunk, "input_pool": len(pool),
                        "parallelism": f"dp{world} (frame sharding, {'gloo' if args.backend == 'gloo' else 'RCCL'} all-reduce of MLP statistics + gradients)",
                        "ranks_seen": ranks_seen,
-                       "block_kernels": ("separate LayerNorm / GEMM kernels" if not lowp16 or args.mode == "dinov2" else
+                       "block_kernels": ("per block: LayerNorm-on-load QKV (A-stationary, MX) | attention (MX planes out) | projection (row panel, MX; leaves the LayerNorm statistics) | "
+                                         "LayerNorm-on-load fc1 + GELU (MX planes out) | fc2 (row panel, MX; leaves the next block's statistics): five launches, no LayerNorm kernel"
+                                         if (args.precision == "mixed" and args.mode == "full" and not os.environ.get("WVN_NO_MX")) else
+                                         "separate LayerNorm / GEMM kernels" if not lowp16 or args.mode == "dinov2" else
                                          "LayerNorm+QKV: %s; proj+LayerNorm+MLP: %s (kernel_ms: a fused kernel is booked under its first stage, "
                                          "qkv_gemm / fc1_gemm)" % ("separate" if args.no_fuse_qkv else "one kernel",
                                                                      "separate" if args.no_fuse_mlp else
@@ -674,6 +725,18 @@ def main():
             o = {"value": leg["value"], "unit": "frames/s", "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
                  "warmup": leg["warmup"], "step_ms": leg["step_ms"], "backbone_tflops": leg["backbone_tflops"],
                  "roofline": leg["roofline"], "kernel_ms": leg["kernel_ms"]}
+            if name == "grid_mixed":
+                la = leg["args"]
+                o["dtype"] = DTYPE["mixed"]
+                o["workload"] = (f"SURVEY 8(d) C3-(i) -- NOT the metric (north_star names the STEGO segmentation): DINO ViT-S/8 448x448 batch={B} + grid segmentation (32-pixel cells: 196 "
+                                 f"segments per frame, ONE backbone pass per frame) + fused segment pooling of the 384-d tokens + 1 traversability-MLP Adam step on {leg['rows']} rows "
+                                 "(the general learner path: split-K GEMM phases, not the <= 2048-row fused step), --precision mixed")
+                if not args.no_cpu_baseline:
+                    la.cpu_frames = 2
+                    _, orc_g = cpu_oracle_sample(la, leg["fe"])
+                    o["parity"] = gpu_parity(la, leg["fe"], dev, orc_g, "mixed")
+                out[name] = o
+                continue
             if name in ("backbone_b32", "dinov2_fp8"):
                 la = leg["args"]
                 o["dtype"] = DTYPE[la.precision]
@@ -696,9 +759,9 @@ def main():
                     o["parity"] = gpu_parity(args, leg["fe"], dev, orc, SPEED, "upstream")
             elif name == "parity_mode":
                 o["dtype"] = DTYPE[PARITY_PRECISION]
-                o["workload"] = (f"the headline workload with --precision {PARITY_PRECISION}: the <= 1e-3 parity path (every linear with hi + lo "
-                                 "split operands, three MFMAs per product; the attention products on the fp16 kernel: the mix the "
-                                 "per-family error budget of profiles/r04a_error_budget_*.md selects)")
+                o["workload"] = (f"the headline workload with --precision {PARITY_PRECISION}: the <= 1e-3 parity path (every block linear as fp16 hi * hi + two scaled "
+                                 "e5m2 correction products; the attention products on the fp16 kernel: the mix the per-family error budgets of "
+                                 "profiles/r04a_error_budget_*.md / r06_error_budget.md select)")
                 if orc is not None:
                     o["parity"] = gpu_parity(args, leg["fe"], dev, orc, PARITY_PRECISION, "upstream")
             else:

@@ -12,6 +12,14 @@ direct statement).  Two facts remove ~95 % of its arithmetic without changing wh
     -- a [K, G*G] table of summed tap weights per pass (the identity SURVEY.md 8(a7) states for segment pooling), then one small
     product, instead of re-creating and adding H*H rows of C channels.
 
+WHAT THIS DEFINITION IS ANCHORED TO: its operation ORDER -- ROW_GROUP, the band chains, P0 before P1 -- was chosen together with
+csrc/stego_linear.hip's tiling and changes when that tiling does (round 5 changed ROW_GROUP 4 -> 2 in the commit that re-tiled the kernel), so
+"the GPU is bit-exact against this file" says the kernel computes THIS order, not that the order is canonical.  What the pair is held to is the
+DIRECT statement (oracle/interfaces.py::kmeans_cosine_labels_pixels, which has no tiling to tune): identical points bit for bit, final centroids
+within fp32 summation noise, and label maps that differ only within the float tolerance of a decision boundary --
+tests/test_oracle_stego.py::test_linear_and_direct_statements_at_the_headline_shape_pinned_numbers pins the numbers at G = 56, H = 448, K = 20
+(0 of 200 704 pixels, centroid distance 2.6e-7): re-run it whenever this file is edited.
+
 The two statements are the same function of exact arithmetic; in fp32 they round differently, so their label maps can differ at
 pixels whose two best similarities are closer than the rounding error (tests/test_oracle_stego.py holds the two against each
 other with oracle/segmap_agreement.py's tolerance).  THIS file fixes every operation order of the linear form; csrc/stego_linear.hip

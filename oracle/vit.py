@@ -121,12 +121,17 @@ def vit_depth(sd: Dict[str, torch.Tensor]) -> int:
     return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
 
 
-def interpolate_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
+def interpolate_pos_embed(pos_embed: torch.Tensor, grid: int, rule: str = "dino") -> torch.Tensor:
     """Resample the [1, 1+g*g, D] position table to a grid x grid token map.
 
-    Published DINO behaviour (vision_transformer.py, interpolate_pos_encoding): identity when
-    the grid matches; otherwise bicubic on the patch part with scale factor (grid+0.1)/g, the
-    class slot is passed through.  Done once at model-build time (weights prep), not per frame.
+    ``rule="dino"`` (default): the published DINO / DINOv2 behaviour (facebookresearch/dino vision_transformer.py, interpolate_pos_encoding --
+    the code STEGO's backbone package copies): identity when the grid matches; otherwise bicubic on the patch part with
+    ``scale_factor=(grid + 0.1) / g`` (the 0.1 keeps the output size from rounding down; since torch 1.6 the given factor -- 2.0036 at
+    28 -> 56 -- is ALSO the sampling step), the class slot passed through.  ``rule="size"``: bicubic to ``size=(grid, grid)``, i.e. a sampling
+    step of exactly g / grid -- what HuggingFace's ``ViTModel(..., interpolate_pos_encoding=True)`` computes today and what the DINO code
+    computed under torch < 1.6 (``recompute_scale_factor``).  The two differ by up to 15 % of the table's magnitude on a random table
+    (tests/test_oracle_vit.py pins the number); which one a checkpoint's authors ran cannot be decided from /root/reference, so the rule is a
+    switch here and in the product (``VitBackbone(pos_embed_rule=...)``).  Done once at model-build time (weights prep), not per frame.
     """
     n_pre = pos_embed.shape[1] - 1
     g = int(round(math.sqrt(n_pre)))
@@ -135,8 +140,13 @@ def interpolate_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
         return pos_embed.clone()
     D = pos_embed.shape[-1]
     table = pos_embed[:, 1:].reshape(1, g, g, D).permute(0, 3, 1, 2)
-    sf = (grid + 0.1) / g
-    table = F.interpolate(table, scale_factor=(sf, sf), mode="bicubic")
+    if rule == "dino":
+        sf = (grid + 0.1) / g
+        table = F.interpolate(table, scale_factor=(sf, sf), mode="bicubic")
+    elif rule == "size":
+        table = F.interpolate(table, size=(grid, grid), mode="bicubic", align_corners=False)
+    else:
+        raise ValueError(f"pos-embed rule {rule!r}: 'dino' or 'size'")
     assert table.shape[-1] == grid and table.shape[-2] == grid, table.shape
     table = table.permute(0, 2, 3, 1).reshape(1, grid * grid, D)
     return torch.cat([pos_embed[:, :1], table], dim=1)
@@ -148,6 +158,7 @@ def vit_tokens(
     patch: int,
     heads: int,
     taps: Optional[List[torch.Tensor]] = None,
+    pos_embed_rule: str = "dino",
 ) -> torch.Tensor:
     """Normalised image [B,3,S,S] -> final-LayerNorm'ed tokens [B, 1+G*G, D] (fp32).
 
@@ -161,7 +172,7 @@ def vit_tokens(
     D = x.shape[1]
     x = x.flatten(2).transpose(1, 2)  # [B, G*G, D], row-major over (gy, gx)
     x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1)
-    x = x + interpolate_pos_embed(sd["pos_embed"], G)
+    x = x + interpolate_pos_embed(sd["pos_embed"], G, pos_embed_rule)
     if taps is not None:
         taps.append(x.clone())
     dh = D // heads

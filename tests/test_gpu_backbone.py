@@ -380,3 +380,18 @@ def test_full_size_properties_448(dev):
     # weights of every segment sum to one: pooling a constant map returns the constant
     ones = torch.ones(1, 3136, 8, device=dev)
     assert (ops.segpool_bilinear_mean(seg[None].int(), ones, 56, 196) - 1).abs().max().item() < 1e-5
+
+
+def test_position_table_rule_size_matches_the_oracle(dev):
+    """VitBackbone(pos_embed_rule="size"): HuggingFace's reading of the position-table resampling (oracle/vit.py rule "size", cross-checked against
+    transformers at G = 56 in tests/test_oracle_vit.py) -- a different table, the same network."""
+    from wild_visual_navigation_amd.backbone import VitBackbone
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=5, depth=2)
+    img = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(6))
+    for rule in ("dino", "size"):
+        want = OV.vit_tokens(sd, OI.normalize(img), 8, 6, pos_embed_rule=rule)[:, 1:]
+        got = VitBackbone(sd, 128, 8, 6, device=dev, precision="exact", pos_embed_rule=rule).forward_tokens(img.to(dev)).cpu()
+        assert (got - want).abs().max().item() < 1e-3, rule
+    a = OV.vit_tokens(sd, OI.normalize(img), 8, 6, pos_embed_rule="dino")
+    b = OV.vit_tokens(sd, OI.normalize(img), 8, 6, pos_embed_rule="size")
+    assert (a - b).abs().max().item() > 1e-3      # (the two readings really are different networks on a random table)

@@ -104,3 +104,19 @@ def test_upstream_reading_end_to_end(dev):
         for s_ in range(int(nseg[b])):
             m = torch.from_numpy(want.reshape(S, S) == s_)
             assert (feat[b, s_].cpu() - dense[b][:, m].mean(1)).abs().max().item() < 1e-4
+
+
+def test_dense_row_fallback_for_shapes_outside_the_fused_kernels(dev):
+    """a code dimension the fused pixel-resolution kernels have no instantiation for (a 64-d head) still clusters at pixel
+    resolution -- through the materialised up-sampled rows and the patch-resolution kernel; labels = the oracle's cosine k-means on the same rows."""
+    S, G, K = 64, 8, 5
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=11, depth=1)
+    head = OI.make_stego_head_state_dict(384, 64, seed=3)
+    img = torch.rand(1, 3, S, S, generator=g(13))
+    st = StegoInterface(dev, input_size=S, n_image_clusters=K, run_clustering=True, run_crf=False, backbone_weights=sd, head_weights=head,
+                        precision="exact", flip_tta=False, cluster_resolution="pixel", allow_synthetic=True)
+    _, cluster = st.inference(img.to(dev))
+    assert cluster.shape == (1, 1, S, S)
+    rows = ops.upsample_bilinear(st.feature_tokens, G, S).permute(0, 2, 3, 1).reshape(S * S, 64).cpu().numpy()
+    want = OI.relabel_ascending(OI.kmeans_cosine_labels(rows, K))
+    assert np.array_equal(cluster[0, 0].cpu().numpy().reshape(-1), want)

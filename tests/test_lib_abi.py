@@ -31,8 +31,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.VitLayer) == 22 * 8
-    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 22 * 8
+    assert C.sizeof(_lib.VitLayer) == 26 * 8      # (22 pointers + the four MX weights of round 6)
+    assert C.sizeof(_lib.VitModel) == 8 * 4 + 6 * 8 + _lib.WVN_MAX_DEPTH * 26 * 8
     assert C.sizeof(_lib.MlpDesc) == 16
 
 

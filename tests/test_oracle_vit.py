@@ -118,3 +118,39 @@ def test_dinov2_matches_huggingface(arch, heads, img, depth):
         hf = m(pixel_values=x).last_hidden_state
     assert ours.shape == hf.shape and (ours - hf).abs().max().item() < 2e-4
     assert sum(v.numel() for v in OV.make_dinov2_state_dict("vit_base", 14, 37).values()) == 86_580_480 - 768   # SURVEY.md 8 (minus mask_token)
+
+
+def test_position_table_resampling_against_huggingface_at_the_448_grid():
+    """the bicubic resampling of the position table at G = 56 (448^2 frames, patch 8, a 28-grid table).  oracle/vit.py
+    follows the published DINO code (scale_factor = (56 + 0.1) / 28: since torch 1.6 the sampling step too); HuggingFace's
+    interpolate_pos_encoding resamples to size = (56, 56).  Both readings exist in the oracle (`rule`) and in the product
+    (`VitBackbone(pos_embed_rule=...)`, same torch call: tests/test_gpu_backbone.py); this test pins each against its source and records how far
+    apart they are -- on a RANDOM table (no smoothness: the worst case) up to ~15 % of the table's magnitude, at a handful of positions near
+    the grid's far edge where the 0.18 % longer step has drifted a tenth of a source cell."""
+    transformers = pytest.importorskip("transformers")   # noqa: F841
+    sd = OV.make_vit_state_dict("vit_small", 8, pretrain_grid=28, seed=1, depth=1)
+    G = 56
+    hf_model = _hf_model(sd, 8, 6, 224)
+    with torch.no_grad():
+        hf = hf_model.embeddings.interpolate_pos_encoding(torch.zeros(1, 1 + G * G, 384), 448, 448)
+    size_rule = OV.interpolate_pos_embed(sd["pos_embed"], G, rule="size")
+    dino_rule = OV.interpolate_pos_embed(sd["pos_embed"], G)
+    assert (size_rule - hf).abs().max().item() < 1e-6                       # rule "size" IS HuggingFace's resampling
+    tab = sd["pos_embed"][:, 1:].reshape(1, 28, 28, 384).permute(0, 3, 1, 2)
+    sf = (G + 0.1) / 28
+    want = torch.nn.functional.interpolate(tab, scale_factor=(sf, sf), mode="bicubic").permute(0, 2, 3, 1).reshape(1, G * G, 384)
+    assert torch.equal(dino_rule[:, 1:], want) and torch.equal(dino_rule[:, :1], sd["pos_embed"][:, :1])   # rule "dino" IS the published call
+    gap = (dino_rule - size_rule).abs()
+    scale = sd["pos_embed"].abs().max().item()
+    assert 0.02 * scale < gap.max().item() < 0.25 * scale                   # the two readings are NOT the same table
+    # a smooth table (what a trained one looks like) moves far less: the drift is a tenth of a cell
+    smooth = torch.nn.functional.interpolate(torch.randn(1, 384, 4, 4, generator=torch.Generator().manual_seed(0)), (28, 28), mode="bicubic")
+    pe = torch.cat([torch.zeros(1, 1, 384), smooth.permute(0, 2, 3, 1).reshape(1, 784, 384)], 1)
+    g2 = (OV.interpolate_pos_embed(pe, G) - OV.interpolate_pos_embed(pe, G, rule="size")).abs().max().item()
+    assert g2 < 0.04 * pe.abs().max().item()
+    # ... and through the network: the tokens of the two readings at 448^2 (1 block)
+    x = OI.normalize(torch.rand(1, 3, 448, 448, generator=torch.Generator().manual_seed(2)))
+    with torch.no_grad():
+        ours = OV.vit_tokens(sd, x, 8, 6, pos_embed_rule="size")
+        ref = hf_model(pixel_values=x, interpolate_pos_encoding=True).last_hidden_state
+    assert (ours - ref).abs().max().item() < 2e-4                           # the whole forward at G = 56 against HuggingFace

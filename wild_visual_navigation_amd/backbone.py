@@ -166,9 +166,10 @@ def mx_matmul_reference(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return ah.double() @ wh.double().T + (f(ah8) @ f(wl8).T + f(al8) @ f(wh8).T) / MX_RES_SCALE
 
 
-def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
-    """DINO's position-table resampling (bicubic, scale (grid+0.1)/g; DINOv2 keeps the same rule with its default
-    interpolate_offset = 0.1, antialias off), done ONCE when the model is
+def resample_pos_embed(pos_embed: torch.Tensor, grid: int, rule: str = "dino") -> torch.Tensor:
+    """DINO's position-table resampling (rule "dino": bicubic, scale (grid+0.1)/g; DINOv2 keeps the same rule with its default
+    interpolate_offset = 0.1, antialias off; rule "size": bicubic to size=(grid, grid) -- HuggingFace's interpolate_pos_encoding and the
+    DINO code under torch < 1.6: the sampling step differs by 0.18 %), done ONCE when the model is
     built -- it depends only on the input size, so it is weight preparation, not per-frame work."""
     n_pre = pos_embed.shape[1] - 1
     g = int(round(math.sqrt(n_pre)))
@@ -176,8 +177,13 @@ def resample_pos_embed(pos_embed: torch.Tensor, grid: int) -> torch.Tensor:
         return pos_embed.clone()
     D = pos_embed.shape[-1]
     tab = pos_embed[:, 1:].reshape(1, g, g, D).permute(0, 3, 1, 2).float()
-    sf = (grid + 0.1) / g
-    tab = F.interpolate(tab, scale_factor=(sf, sf), mode="bicubic")
+    if rule == "dino":
+        sf = (grid + 0.1) / g
+        tab = F.interpolate(tab, scale_factor=(sf, sf), mode="bicubic")
+    elif rule == "size":
+        tab = F.interpolate(tab, size=(grid, grid), mode="bicubic", align_corners=False)
+    else:
+        raise _lib.WvnError(f"pos_embed_rule {rule!r}: 'dino' or 'size'")
     if tab.shape[-1] != grid or tab.shape[-2] != grid:
         raise _lib.WvnError(f"position table resampling produced {tuple(tab.shape)}, expected grid {grid}")
     tab = tab.permute(0, 2, 3, 1).reshape(1, grid * grid, D)
@@ -210,7 +216,7 @@ class VitBackbone:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], img_size: int, patch: int, heads: int,
                  device="cuda", precision: str = "bf16", max_chunk: int = 16, fuse_mlp: Optional[bool] = None,
-                 fuse_qkv: Optional[bool] = None, fuse_proj: bool = True, qsplit_blocks: Optional[int] = None):
+                 fuse_qkv: Optional[bool] = None, fuse_proj: bool = True, qsplit_blocks: Optional[int] = None, pos_embed_rule: str = "dino"):
         """qsplit_blocks (precision "mixed"): the number of LEADING blocks whose attention takes q as two fp16 planes (None: the
         library's default, include/wvn_hip.h WVN_VIT_QSPLIT_DEFAULT; the environment variable WVN_QSPLIT_BLOCKS overrides None)."""
         self.device = torch.device(device)
@@ -292,7 +298,8 @@ class VitBackbone:
                         0 if self.precision == _lib.PREC_F32 else (-kp) % 64)
         m.patch_b = vec(sd["patch_embed.proj.bias"])
         self.dinov2 = any(k.endswith("ls1.gamma") for k in sd)
-        pos = resample_pos_embed(sd["pos_embed"].float().cpu(), self.grid)[0]  # [1+G*G, D]
+        self.pos_embed_rule = pos_embed_rule   # "dino": scale_factor (grid + 0.1) / g as published | "size": HuggingFace's / torch < 1.6's reading
+        pos = resample_pos_embed(sd["pos_embed"].float().cpu(), self.grid, pos_embed_rule)[0]  # [1+G*G, D]
         m.cls_pos = vec(sd["cls_token"].reshape(-1).float().cpu() + pos[0])
         m.pos = vec(pos)
         m.norm_g, m.norm_b = vec(sd["norm.weight"]), vec(sd["norm.bias"])
@@ -365,7 +372,8 @@ class VitBackbone:
         if device == self.device:
             return self
         return VitBackbone(self._sd, self.img_size, self.patch, self.heads, device=device, precision=self.precision_name,
-                           max_chunk=self.max_chunk, fuse_mlp=self._fuse_args[0], fuse_qkv=self._fuse_args[1], fuse_proj=self._fuse_args[2])
+                           max_chunk=self.max_chunk, fuse_mlp=self._fuse_args[0], fuse_qkv=self._fuse_args[1], fuse_proj=self._fuse_args[2],
+                           pos_embed_rule=self.pos_embed_rule)
 
     # ---- workspace (needs no initialisation: wvn_vit_forward resets the padding rows it relies on at every call) ----
     def _workspace(self, batch: int) -> torch.Tensor:

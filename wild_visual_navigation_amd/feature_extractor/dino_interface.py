@@ -52,6 +52,7 @@ class DinoInterface:
         fuse_mlp: Optional[bool] = None,
         fuse_qkv: Optional[bool] = None,
         fuse_proj: bool = True,  # None: fused block MLP wherever it applies (bf16, dim 384); False: the un-fused pair
+        pos_embed_rule: str = "dino",  # position-table resampling: "dino" (scale_factor (G + 0.1) / g, as published) | "size" (HuggingFace's / torch < 1.6's reading)
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(backbone=backbone, backbone_type=backbone_type, input_size=input_size,
@@ -75,7 +76,7 @@ class DinoInterface:
         self._precision = precision
         self._device = torch.device(device)
         self._model = VitBackbone(sd, c.input_size, c.patch_size, heads, device=self._device, precision=precision,
-                                  max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv, fuse_proj=fuse_proj)
+                                  max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv, fuse_proj=fuse_proj, pos_embed_rule=pos_embed_rule)
 
     def change_device(self, device):
         """dino_interface.py:61-68: move the model to another device (another GPU: the HIP path has no CPU form)."""

@@ -122,6 +122,7 @@ class StegoInterface:
         fuse_qkv: Optional[bool] = None,
         fuse_proj: bool = True,
         skip_crf: Optional[bool] = None,  # run_crf=True without pydensecrf: None -> WVN_SKIP_CRF env, True -> warn and drop the CRF step
+        pos_embed_rule: str = "dino",   # position-table resampling of the backbone (backbone.resample_pos_embed)
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(model_path=model_path, input_size=input_size, run_crf=run_crf,
@@ -165,7 +166,7 @@ class StegoInterface:
                               "(shapes and speed are real, the segmentation is meaningless); pass model_path=... or "
                               "allow_synthetic=True to silence", stacklevel=2)
         self._bb = VitBackbone(sd, self._cfg.input_size, patch_size, heads, device=self._device, precision=precision,
-                               max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv, fuse_proj=fuse_proj)
+                               max_chunk=max_chunk, fuse_mlp=fuse_mlp, fuse_qkv=fuse_qkv, fuse_proj=fuse_proj, pos_embed_rule=pos_embed_rule)
         self._precision = precision
         self._flip_tta = flip_tta
         self._cluster_resolution = cluster_resolution
@@ -314,10 +315,21 @@ class StegoInterface:
                 if form == "linear" and not ops.kmeans_pixels_linear_supported(G, S, self._C, K):
                     form = "direct"
                 if form == "direct" and not ops.kmeans_cosine_pixels_supported(G, S, self._C, K):
-                    raise _lib.WvnError(f"StegoInterface: the pixel-resolution k-means has kernels for code dimension 90 or 16 and up to "
-                                        f"32 (linear form) / 64 (direct form) clusters, not C={self._C}, K={K}; use cluster_resolution='patch' "
-                                        "with C in {16, 64, 90}")
-                labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, S, K, KMEANS_ITERS, relabel=True, form=form)
+                    form = "dense"
+                if form == "dense":
+                    # shapes outside the fused kernels' instantiations (e.g. a 64-d head) keep working through the dense rows:
+                    # the up-sampled code is materialised (H * H * C floats per frame) and clustered by the patch-resolution kernel
+                    # (code dimension 16 / 64 / 90); only a shape that kernel has no instantiation for either is an error
+                    if self._C not in (16, 64, 90):
+                        raise _lib.WvnError(f"StegoInterface: no k-means kernel for code dimension C={self._C} (fused pixel-resolution forms: 16 or 90 with "
+                                            "up to 32 / 64 clusters; dense rows and cluster_resolution='patch': 16, 64 or 90)")
+                    pix = ops.upsample_bilinear(code, G, S).permute(0, 2, 3, 1).reshape(B, S * S, self._C).contiguous()
+                    try:
+                        labels, self._n_segments = ops.kmeans_cosine(pix, K, KMEANS_ITERS, relabel=True)
+                    except _lib.WvnError as e:
+                        raise _lib.WvnError(f"StegoInterface: the dense-row k-means has no instantiation for C={self._C}, K={K} ({e})") from None
+                else:
+                    labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, S, K, KMEANS_ITERS, relabel=True, form=form)
             elif self._clusters.shape[0] <= 32:
                 # the cluster probe at pixel resolution: cosine similarity is linear in the (un-normalised) code up to the pixel's
                 # positive norm, so the argmax over the interpolated patch similarities IS the argmax on the interpolated code
