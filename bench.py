@@ -422,6 +422,15 @@ def gpu_parity(args, fe, dev, orc, precision, reading=None):
                     given += int(torch.equal(seg[b], want))
                 par["seg_equal_given_gpu_code"] = f"{given}/{m}"
                 if reading == "upstream" and OI._oracle_lib() is not None:
+                    # the same check against the DIRECT statement (oracle/interfaces.py::kmeans_cosine_labels_pixels: every pixel's row re-created and
+                    # multiplied out -- the reading of the reference's postprocess that has no tiling co-designed with the kernel), on the GPU's own code
+                    nd = min(n, 2)
+                    agree = []
+                    for b in range(nd):
+                        wd = torch.from_numpy(OI.relabel_ascending(OI.kmeans_cosine_labels_pixels(gcode[b].numpy(), G, args.size, 20))).reshape(args.size, args.size).long()
+                        agree.append(float((seg[b] == wd).float().mean()))
+                    par["seg_pixel_agreement_with_direct_form_given_gpu_code"] = {"frames": nd, "min": min(agree), "mean": sum(agree) / nd}
+                if reading == "upstream" and OI._oracle_lib() is not None:
                     # what "bit-exact segment maps" means behind a float backbone (oracle/segmap_agreement.py): every pixel where the maps
                     # differ lies within the MEASURED float tolerance of an oracle decision boundary: margin <= 2 (eps_x + eps_c)
                     from oracle import segmap_agreement as SA

@@ -125,7 +125,7 @@ __device__ inline uint32_t mx_pk8(uint32_t old, float a, float b, float inv_scal
 
 constexpr int X384_LDS_MAX = 160 * 1024;
 
-template <int EPI, bool TIMING = false, bool LNA = false, bool MX = false>
+template <int EPI, bool TIMING = false, bool LNA = false, bool MX = false, bool BURST = false>
 __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   static_assert(!MX || (LNA && (EPI == X_GELU_FRAG || EPI == X_QKV_F16)), "the MX form exists for the LayerNorm-on-load fc1 / QKV instantiations");
   wvn_fp16_saturate();
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   auto mfma_step = [&](int slot, int ks, int s, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
     const int cur = s & 1;
-    if (s + 1 < 8) frag_read(slot, s + 1, cur ^ 1);
+    if (!MX && s + 1 < 8) frag_read(slot, s + 1, cur ^ 1);   // (MX: requested at the top of the region, in front of a scheduling barrier -- see period())
     if constexpr (MX) {
       const int mm = s >> 2, which = (s >> 1) & 1, t8 = s & 1;
       const f16x8_t af = __builtin_bit_cast(f16x8_t, mh[ks * 8 + s]);
@@ -577,26 +577,35 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     // MFMAs' shadow (<= 5 slots per 32-cycle MFMA): inside a region the issue order is pinned to MFMA, LDS read, VALU..., and the
     // regions keep the epilogue spread evenly over the slice (one region for the whole slice: the scheduler left the epilogue behind
     // the last MFMA)
+    if constexpr (BURST) {   // (MX experiment) the slice's eight DMA pieces in one burst behind the barrier instead of one per region
+#pragma unroll
+      for (int s = 0; s < 8; ++s) issue_piece(i + NS - 1, s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     frag_read(i % NS, 0, 0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      issue_piece(i + NS - 1, s);
+      if constexpr (MX) {
+        // the NEXT region's four fragments are requested first and pinned there: left inside the region the scheduler placed each read behind the MFMA
+        // that frees its (coalesced) registers, i.e. one LDS round trip in front of every MFMA (2075 cycles per slice against 1024 of MFMAs)
+        if (s + 1 < 8) frag_read(i % NS, s + 1, (s & 1) ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!BURST) issue_piece(i + NS - 1, s);
       mfma_step(i % NS, ks, s, mtr);
       if constexpr (do_epi) epi_chunk(ks, j - 1, s, etr);
       if constexpr (MX) {   // three MFMAs per region (32 + 32 + 64 cycles): the other instructions in three groups, the largest behind the scaled MFMA
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x030, 2, 0);
       } else {
 #pragma unroll
       for (int n = 0; n < 6; ++n) {
@@ -695,6 +704,15 @@ int launch_mx(const X384Params& p, hipStream_t st) {
   if (const int rc = lds_opt_in(X384_LDS_MAX, (const void*)gemm_a384_x3_kernel<EPI, false, true, true>, (const void*)gemm_a384_x3_kernel<EPI, true, true, true>)) return rc;
   const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
   const int grid = (int)(units < x384_num_cus() ? units : x384_num_cus());
+  static const bool burst = getenv("WVN_A384_MX_BURST") != nullptr;
+  if (burst) {
+    static LdsOptIn lds_opt_in_b;
+    if (const int rc = lds_opt_in_b(X384_LDS_MAX, (const void*)gemm_a384_x3_kernel<EPI, false, true, true, true>, (const void*)gemm_a384_x3_kernel<EPI, true, true, true, true>)) return rc;
+    if (p.dbg) hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, true, true, true, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, false, true, true, true>), dim3(grid), dim3(256), lds, st, p);
+    WVN_LAUNCH_CHECK();
+    return WVN_OK;
+  }
   if (p.dbg) hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, true, true, true>), dim3(grid), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gemm_a384_x3_kernel<EPI, false, true, true>), dim3(grid), dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
