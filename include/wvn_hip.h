@@ -418,6 +418,13 @@ int wvn_kmeans_pixels_linear_supported_shape(int G, int H, int C, int K);
 size_t wvn_kmeans_pixels_linear_scratch_bytes(int B, int G, int H, int C, int K);
 int wvn_kmeans_cosine_pixels_linear(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K,
                                     int iters, int relabel, void* stream);
+/* The same with the OTHER reading of how the code is interpolated before it is clustered (round 6): align_corners = 0 takes ATen's half-pixel taps
+ * (F.interpolate(code, size, mode="bilinear", align_corners=False): what the public STEGO evaluation code uses) instead of the align_corners=True
+ * taps WVN's own later up-sample uses (stego_interface.py:107).  The reference hands postprocess() to an absent package (stego_interface.py:94-100), so
+ * which one runs upstream cannot be decided here: StegoInterface(code_align_corners=...) selects it, oracle/kmeans_linear.py states both, the GPU is
+ * bit-exact against either.  align_corners != 0: identical to wvn_kmeans_cosine_pixels_linear. */
+int wvn_kmeans_cosine_pixels_linear_ac(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K,
+                                       int iters, int relabel, int align_corners, void* stream);
 /* labels[b][y][x] (int32, [B, H, H]) = argmax over k < K (lowest k wins ties) of the bilinear interpolation (align_corners=True, the
  * fixed operation order of wvn_upsample_bilinear) of table[b][.][k] to H x H: the STEGO cluster probe / linear probe applied at PIXEL
  * resolution (stego_interface.py:94-100, 107-109: postprocess acts on the up-sampled code; a probe is linear in the code and the
@@ -425,6 +432,8 @@ int wvn_kmeans_cosine_pixels_linear(const float* code, int* labels, int* nseg, v
  * table: [B, G*G, wvn_table_argmax_slots(K)] fp32, 16-byte aligned, slots >= K ignored; K <= 32. */
 int wvn_table_argmax_slots(int K);
 int wvn_table_bilerp_argmax(const float* table, int* labels, int B, int G, int H, int K, void* stream);
+/* the same with the taps of align_corners (0: half-pixel coordinates; see wvn_kmeans_cosine_pixels_linear_ac) */
+int wvn_table_bilerp_argmax_ac(const float* table, int* labels, int B, int G, int H, int K, int align_corners, void* stream);
 /* out = 0.5 * (a + flip_x(mirrored)) on [B, G, G, C] fp32 patch maps: the code of a frame averaged with the flipped-back code of
  * its mirror image (the second pass of the upstream Stego.get_code; the mirror pass itself is wvn_vit_forward_frames with a
  * reversed column table).  out may alias a. */

@@ -163,6 +163,10 @@ def _oracle_lib():
             h.wvn_oracle_kmeans_cosine_ex.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                       ctypes.c_void_p, ctypes.c_void_p]
             h.wvn_oracle_kmeans_cosine_ex.restype = ctypes.c_int
+            if hasattr(h, "wvn_oracle_kmeans_pixels_linear_ac"):   # (round 6: the tap rule as a parameter)
+                h.wvn_oracle_kmeans_pixels_linear_ac.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+                h.wvn_oracle_kmeans_pixels_linear_ac.restype = ctypes.c_int
             if hasattr(h, "wvn_oracle_kmeans_pixels_linear"):   # (oracle/kmeans_linear_ref.c; absent from a library built before round 5)
                 h.wvn_oracle_kmeans_pixels_linear.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -229,21 +233,35 @@ def kmeans_cosine_labels_numpy(code: np.ndarray, K: int, iters: int = KMEANS_ITE
     return assign(cent)
 
 
-def upsample_bilinear_fixed(code: np.ndarray, H: int) -> np.ndarray:
-    """[G, G, C] fp32 patch map -> [H, H, C] fp32: F.interpolate(.., (H, H), mode="bilinear", align_corners=True) in the ONE
+def bilinear_taps_fixed(G: int, H: int, align_corners: bool = True):
+    """(i0, i1, w0, w1) per output index o < H of the fixed-order bilinear interpolation (csrc/common.h: lerp_tap / lerp_tap_ac), every operation
+    rounded to fp32 on its own.  align_corners=True (WVN's own up-sample, dino_interface.py:87-90 / stego_interface.py:107): ATen's coordinates
+    src = o (G - 1) / (H - 1).  align_corners=False (the other reading of the absent STEGO package's code interpolation; ATen's
+    area_pixel_compute_source_index): src = max((G / H) (o + 0.5) - 0.5, 0).  Both: i0 = floor(src), i1 = min(i0 + 1, G - 1), w1 = src - i0, w0 = 1 - w1."""
+    f32 = np.float32
+    o = np.arange(H, dtype=np.float32)
+    if align_corners:
+        scale = (f32(G - 1) / f32(H - 1)) if H > 1 else f32(0)
+        sc = (scale * o).astype(np.float32)
+    else:
+        scale = f32(G) / f32(H)
+        m = (scale * (o + f32(0.5)).astype(np.float32)).astype(np.float32)
+        sc = np.maximum((m - f32(0.5)).astype(np.float32), f32(0))
+    i0 = sc.astype(np.int32)
+    i1 = i0 + (i0 < G - 1)
+    w1 = (sc - i0.astype(np.float32)).astype(np.float32)
+    w0 = (f32(1) - w1).astype(np.float32)
+    return i0, i1, w0, w1
+
+
+def upsample_bilinear_fixed(code: np.ndarray, H: int, align_corners: bool = True) -> np.ndarray:
+    """[G, G, C] fp32 patch map -> [H, H, C] fp32: F.interpolate(.., (H, H), mode="bilinear", align_corners=...) in the ONE
     fixed operation order of the HIP kernels (csrc/common.h lerp_tap / bilerp_fixed: ATen's coordinates, then
     t0 = fma(wx1, v01, wx0 * v00), t1 = fma(wx1, v11, wx0 * v10), out = fma(wy1, t1, wy0 * t0)), bit for bit -- ATen's own CPU
     kernel rounds in another order, so integer results derived from the up-sampled code are pinned through this form."""
     code = np.ascontiguousarray(code, dtype=np.float32)
     G = code.shape[0]
-    f32 = np.float32
-    scale = (f32(G - 1) / f32(H - 1)) if H > 1 else f32(0)
-    o = np.arange(H, dtype=np.float32)
-    sc = (scale * o).astype(np.float32)
-    i0 = sc.astype(np.int32)
-    i1 = i0 + (i0 < G - 1)
-    w1 = (sc - i0.astype(np.float32)).astype(np.float32)
-    w0 = (f32(1) - w1).astype(np.float32)
+    i0, i1, w0, w1 = bilinear_taps_fixed(G, H, align_corners)
     wx0, wx1 = w0[None, :, None], w1[None, :, None]
     out = np.empty((H, H, code.shape[2]), dtype=np.float32)
     for y in range(H):   # row by row: the whole [H, H, C] set of temporaries would be several GB at 448^2 x 90
@@ -263,10 +281,10 @@ def stego_code_flip_average(head: Dict[str, torch.Tensor], tok: torch.Tensor, to
     return (code + c2) * 0.5
 
 
-def kmeans_cosine_labels_pixels(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = KMEANS_ITERS) -> np.ndarray:
-    """cluster_resolution="pixel": the k-means above over the H x H up-sampled (fixed-order bilinear, align_corners=True) code
+def kmeans_cosine_labels_pixels(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = KMEANS_ITERS, align_corners: bool = True) -> np.ndarray:
+    """cluster_resolution="pixel": the k-means above over the H x H up-sampled (fixed-order bilinear, align_corners as given) code
     pixels of one frame.  code_tokens [G*G, C] -> int32 labels [H*H] (not compacted)."""
-    dense = upsample_bilinear_fixed(code_tokens.reshape(G, G, -1), H)
+    dense = upsample_bilinear_fixed(code_tokens.reshape(G, G, -1), H, align_corners)
     return kmeans_cosine_labels(dense.reshape(H * H, -1), K, iters)
 
 

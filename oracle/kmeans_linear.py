@@ -51,20 +51,14 @@ f32 = np.float32
 ROW_GROUP = 2   # patch rows whose row sums are added before the groups are (csrc/stego_linear.hip: LIN_RG)
 
 
-def taps(G: int, H: int):
-    """(i0, i1, w0, w1) per output index -- the coordinates of upsample_bilinear_fixed (csrc/common.h: lerp_tap)."""
-    scale = (f32(G - 1) / f32(H - 1)) if H > 1 else f32(0)
-    sc = (scale * np.arange(H, dtype=np.float32)).astype(np.float32)
-    i0 = sc.astype(np.int32)
-    i1 = i0 + (i0 < G - 1)
-    w1 = (sc - i0.astype(np.float32)).astype(np.float32)
-    w0 = (f32(1) - w1).astype(np.float32)
-    return i0, i1, w0, w1
+def taps(G: int, H: int, align_corners: bool = True):
+    """(i0, i1, w0, w1) per output index -- the coordinates of upsample_bilinear_fixed (csrc/common.h: lerp_tap / lerp_tap_ac)."""
+    return OI.bilinear_taps_fixed(G, H, align_corners)
 
 
-def pixel_rinv_and_init(code: np.ndarray, G: int, H: int, K: int) -> Tuple[np.ndarray, np.ndarray]:
+def pixel_rinv_and_init(code: np.ndarray, G: int, H: int, K: int, align_corners: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """rinv [H, H] and the initial centroids [K, C]: exactly the direct form's (the dense rows exist here once, never in a pass)."""
-    dense = OI.upsample_bilinear_fixed(code.reshape(G, G, -1), H)                       # [H, H, C]
+    dense = OI.upsample_bilinear_fixed(code.reshape(G, G, -1), H, align_corners)        # [H, H, C]
     n2 = OI._seq_dot_f32(dense, dense)
     n = np.maximum(np.sqrt(n2).astype(np.float32), f32(1e-12))
     rinv = (f32(1.0) / n).astype(np.float32)
@@ -75,14 +69,14 @@ def pixel_rinv_and_init(code: np.ndarray, G: int, H: int, K: int) -> Tuple[np.nd
     return rinv, cent
 
 
-def assign(code: np.ndarray, cent: np.ndarray, G: int, H: int) -> np.ndarray:
+def assign(code: np.ndarray, cent: np.ndarray, G: int, H: int, align_corners: bool = True) -> np.ndarray:
     S = OI._seq_dot_f32(code[:, None, :], cent[None, :, :])                              # [G*G, K]
-    sim = OI.upsample_bilinear_fixed(S.reshape(G, G, -1), H)                             # [H, H, K]: the same fixed-order interpolation
+    sim = OI.upsample_bilinear_fixed(S.reshape(G, G, -1), H, align_corners)              # [H, H, K]: the same fixed-order interpolation
     return np.argmax(sim, axis=2).astype(np.int32)                                       # first maximum == lowest index
 
 
-def centroid_sums(code: np.ndarray, lab: np.ndarray, rinv: np.ndarray, G: int, H: int, K: int) -> np.ndarray:
-    i0, i1, w0, w1 = taps(G, H)
+def centroid_sums(code: np.ndarray, lab: np.ndarray, rinv: np.ndarray, G: int, H: int, K: int, align_corners: bool = True) -> np.ndarray:
+    i0, i1, w0, w1 = taps(G, H, align_corners)
     C = code.shape[1]
     ys = np.arange(H)
     U = np.zeros((H, K, G), dtype=np.float32)
@@ -114,40 +108,42 @@ def centroid_sums(code: np.ndarray, lab: np.ndarray, rinv: np.ndarray, G: int, H
     return sums
 
 
-def kmeans_pixels_linear_c(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS, want_rows: bool = False):
+def kmeans_pixels_linear_c(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS, want_rows: bool = False,
+                           align_corners: bool = True):
     """The C restatement (oracle/kmeans_linear_ref.c in oracle/_build/libwvn_oracle.so): (labels, centroids[, normalised rows [H*H, C]])
     or None when the library has not been built."""
     h = OI._oracle_lib()
-    if h is None or not hasattr(h, "wvn_oracle_kmeans_pixels_linear"):
+    if h is None or not hasattr(h, "wvn_oracle_kmeans_pixels_linear_ac"):
         return None
     code = np.ascontiguousarray(code_tokens, dtype=np.float32)
     C = code.shape[1]
     labels = np.empty(H * H, dtype=np.int32)
     cent = np.empty((K, C), dtype=np.float32)
     x = np.empty((H * H, C), dtype=np.float32) if want_rows else None
-    if h.wvn_oracle_kmeans_pixels_linear(code.ctypes.data, G, H, C, K, iters, labels.ctypes.data, cent.ctypes.data,
-                                         x.ctypes.data if want_rows else None) != 0:
+    if h.wvn_oracle_kmeans_pixels_linear_ac(code.ctypes.data, G, H, C, K, iters, labels.ctypes.data, cent.ctypes.data,
+                                            x.ctypes.data if want_rows else None, 1 if align_corners else 0) != 0:
         raise MemoryError("oracle k-means (linear form)")
     return (labels, cent, x) if want_rows else (labels, cent)
 
 
-def kmeans_pixels_linear(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS, force_numpy: bool = False):
+def kmeans_pixels_linear(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS, force_numpy: bool = False,
+                         align_corners: bool = True):
     """code_tokens [G*G, C] fp32 -> (labels int32 [H*H] not compacted, final centroids [K, C] fp32).  Through the C restatement when
     it is built (tests/test_oracle_stego.py holds it against the numpy statement below), else -- and with force_numpy -- the numpy
     statement itself."""
     if not force_numpy:
-        r = kmeans_pixels_linear_c(code_tokens, G, H, K, iters)
+        r = kmeans_pixels_linear_c(code_tokens, G, H, K, iters, align_corners=align_corners)
         if r is not None:
             return r
     code = np.ascontiguousarray(code_tokens, dtype=np.float32)
-    rinv, cent = pixel_rinv_and_init(code, G, H, K)
+    rinv, cent = pixel_rinv_and_init(code, G, H, K, align_corners)
     for _ in range(iters):
-        lab = assign(code, cent, G, H)
-        sums = centroid_sums(code, lab, rinv, G, H, K)
+        lab = assign(code, cent, G, H, align_corners)
+        sums = centroid_sums(code, lab, rinv, G, H, K, align_corners)
         cnt = np.bincount(lab.reshape(-1), minlength=K)
         cent = np.where((cnt > 0)[:, None], OI._normalize_rows_f32(sums), cent).astype(np.float32)
-    return assign(code, cent, G, H).reshape(-1), cent
+    return assign(code, cent, G, H, align_corners).reshape(-1), cent
 
 
-def kmeans_cosine_labels_pixels_linear(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS) -> np.ndarray:
-    return kmeans_pixels_linear(code_tokens, G, H, K, iters)[0]
+def kmeans_cosine_labels_pixels_linear(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS, align_corners: bool = True) -> np.ndarray:
+    return kmeans_pixels_linear(code_tokens, G, H, K, iters, align_corners=align_corners)[0]

@@ -54,7 +54,7 @@ static void assign(const float* code, const float* cent, const taps_t* t, int G,
 /* code [G*G][C] fp32 patch codes -> labels [H*H] int32 (not compacted); when not NULL: the final centroids [K][C] and the normalised
  * up-sampled rows [H*H][C] (the points of the clustering; oracle/segmap_agreement.py).  Returns 0, or 1 when out of memory. */
 __attribute__((target_clones("fma", "default")))
-int wvn_oracle_kmeans_pixels_linear(const float* code, int G, int H, int C, int K, int iters, int* labels, float* cent_out, float* x_out) {
+int wvn_oracle_kmeans_pixels_linear_ac(const float* code, int G, int H, int C, int K, int iters, int* labels, float* cent_out, float* x_out, int align_corners) {
   const long P = (long)H * H, T = (long)G * G;
   int* i0 = (int*)malloc(sizeof(int) * H); int* i1 = (int*)malloc(sizeof(int) * H);
   float* w0 = (float*)malloc(sizeof(float) * H); float* w1 = (float*)malloc(sizeof(float) * H);
@@ -69,9 +69,16 @@ int wvn_oracle_kmeans_pixels_linear(const float* code, int G, int H, int C, int 
   long* cnt = (long*)malloc(sizeof(long) * K);
   float* row = (float*)malloc(sizeof(float) * C);
   if (!i0 || !i1 || !w0 || !w1 || !rinv || !cent || !S || !U || !P0 || !P1 || !A || !R || !sums || !cnt || !row) return 1;
-  const float scale = H > 1 ? (float)(G - 1) / (float)(H - 1) : 0.f;
+  /* align_corners = 0: ATen's half-pixel coordinates, src = max((G / H) (o + 0.5) - 0.5, 0), every operation rounded on its own (-ffp-contract=off) */
+  const float scale = align_corners ? (H > 1 ? (float)(G - 1) / (float)(H - 1) : 0.f) : (float)G / (float)H;
   for (int o = 0; o < H; ++o) {
-    const float s = scale * (float)o;
+    float s;
+    if (align_corners) s = scale * (float)o;
+    else {
+      volatile float m = scale * ((float)o + 0.5f);
+      s = m - 0.5f;
+      if (s < 0.f) s = 0.f;
+    }
     i0[o] = (int)s;
     i1[o] = i0[o] + (i0[o] < G - 1 ? 1 : 0);
     w1[o] = s - (float)i0[o];
@@ -150,4 +157,9 @@ int wvn_oracle_kmeans_pixels_linear(const float* code, int G, int H, int C, int 
   if (cent_out) memcpy(cent_out, cent, sizeof(float) * K * C);
   free(i0); free(i1); free(w0); free(w1); free(rinv); free(cent); free(S); free(U); free(P0); free(P1); free(A); free(R); free(sums); free(cnt); free(row);
   return 0;
+}
+
+__attribute__((target_clones("fma", "default")))
+int wvn_oracle_kmeans_pixels_linear(const float* code, int G, int H, int C, int K, int iters, int* labels, float* cent_out, float* x_out) {
+  return wvn_oracle_kmeans_pixels_linear_ac(code, G, H, C, K, iters, labels, cent_out, x_out, 1);
 }

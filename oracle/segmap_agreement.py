@@ -26,7 +26,7 @@ import numpy as np
 from . import interfaces as OI
 
 
-def kmeans_pixels_full(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS, form: str = "linear"):
+def kmeans_pixels_full(code_tokens: np.ndarray, G: int, H: int, K: int, iters: int = OI.KMEANS_ITERS, form: str = "linear", align_corners: bool = True):
     """labels [H*H] (not compacted), final centroids [K, C], normalised rows [H*H, C] of the pixel-resolution k-means of one frame in
     the statement `form` ("linear": oracle/kmeans_linear.py, the product default; "direct": oracle/interfaces.py).
     Needs the C restatements (oracle/_build/libwvn_oracle.so)."""
@@ -36,11 +36,11 @@ def kmeans_pixels_full(code_tokens: np.ndarray, G: int, H: int, K: int, iters: i
     if form == "linear":
         from . import kmeans_linear
 
-        r = kmeans_linear.kmeans_pixels_linear_c(np.asarray(code_tokens, dtype=np.float32), G, H, K, iters, want_rows=True)
+        r = kmeans_linear.kmeans_pixels_linear_c(np.asarray(code_tokens, dtype=np.float32), G, H, K, iters, want_rows=True, align_corners=align_corners)
         if r is None:
             raise RuntimeError("oracle/_build/libwvn_oracle.so predates oracle/kmeans_linear_ref.c (python -m oracle.build_oracle)")
         return r
-    dense = np.ascontiguousarray(OI.upsample_bilinear_fixed(code_tokens.reshape(G, G, -1), H).reshape(H * H, -1), dtype=np.float32)
+    dense = np.ascontiguousarray(OI.upsample_bilinear_fixed(code_tokens.reshape(G, G, -1), H, align_corners).reshape(H * H, -1), dtype=np.float32)
     P, C = dense.shape
     labels = np.empty(P, dtype=np.int32)
     cent = np.empty((K, C), dtype=np.float32)

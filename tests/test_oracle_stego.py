@@ -180,3 +180,39 @@ def test_linear_and_direct_statements_at_the_headline_shape_pinned_numbers():
     assert eps_c < 2e-6                                # the two statements' final centroids: fp32 summation-order noise (measured 2.6e-7)
     assert mism.size <= 10                             # (measured: 0 of 200 704)
     assert worst <= 2 * eps_c + 2e-6                   # every one of them within the float tolerance of a decision boundary
+
+
+def test_half_pixel_taps_are_atens_align_corners_false_and_both_statements_follow_them():
+    """the code interpolation of the absent STEGO package as a switch.  The oracle's align_corners=False taps are ATen's
+    (F.interpolate(..., align_corners=False)) up to rounding; the C restatement of the linear form equals its numpy statement bit for bit under them;
+    the linear and the direct statement agree within the float tolerance of a decision boundary, as under align_corners=True."""
+    from oracle import build_oracle, kmeans_linear as KL, segmap_agreement as SA
+
+    build_oracle.build(force=False)
+    code = torch.randn(9, 9, 12, generator=torch.Generator().manual_seed(0)) * 3
+    got = torch.from_numpy(OI.upsample_bilinear_fixed(code.numpy(), 70, align_corners=False))
+    aten = torch.nn.functional.interpolate(code.permute(2, 0, 1)[None], (70, 70), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    assert (got - aten).abs().max().item() < 1.5e-5          # (values up to ~10: fp32 operation-order noise; a wrong tap would be O(1))
+    i0, i1, w0, w1 = OI.bilinear_taps_fixed(9, 70, align_corners=False)
+    assert i0[0] == 0 and w1[0] == 0.0 and i0[-1] == 8 and i1[-1] == 8                    # clamped at both edges
+    assert not np.array_equal(OI.bilinear_taps_fixed(9, 70)[3], w1)                       # (not the align_corners=True taps)
+    rng = np.random.default_rng(9)
+    for G, H, C, K in [(8, 64, 90, 5), (7, 50, 16, 4), (12, 9, 16, 3), (9, 70, 90, 17)]:
+        c = (rng.standard_normal((G * G, C)) * (1 + rng.random((G * G, 1)))).astype(np.float32)
+        lab_c, cent_c = KL.kmeans_pixels_linear(c, G, H, K, iters=4, align_corners=False)
+        lab_n, cent_n = KL.kmeans_pixels_linear(c, G, H, K, iters=4, force_numpy=True, align_corners=False)
+        assert np.array_equal(lab_c, lab_n) and np.array_equal(cent_c, cent_n), (G, H, C, K)
+        assert not np.array_equal(lab_c, KL.kmeans_pixels_linear(c, G, H, K, iters=4)[0]) or H <= G    # the other reading is another map
+    gen = torch.Generator().manual_seed(3)
+    G, H, C, K = 28, 224, 90, 20
+    c = torch.nn.functional.interpolate(torch.randn(1, C, 7, 7, generator=gen), (G, G), mode="bicubic")[0].permute(1, 2, 0).reshape(G * G, C) * 2 + 0.3
+    c = c.numpy().astype(np.float32)
+    ld, cd, x = SA.kmeans_pixels_full(c, G, H, K, form="direct", align_corners=False)
+    ll, cl, x2 = SA.kmeans_pixels_full(c, G, H, K, form="linear", align_corners=False)
+    assert np.array_equal(x, x2)
+    eps_c = float(np.sqrt(((cd.astype(np.float64) - cl) ** 2).sum(1)).max())
+    mism = np.nonzero(ld != ll)[0]
+    assert mism.size <= 0.002 * ld.size
+    if mism.size:
+        sims = x[mism].astype(np.float64) @ cd.astype(np.float64).T
+        assert (sims[np.arange(mism.size), ld[mism]] - sims[np.arange(mism.size), ll[mism]]).max() <= 2 * eps_c + 2e-6

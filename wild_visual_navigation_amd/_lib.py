@@ -147,6 +147,8 @@ _SIGNATURES = {
     "wvn_debug_n384_pair": ([_i], _i),
     "wvn_table_argmax_slots": ([_i], _i),
     "wvn_table_bilerp_argmax": ([_p, _p, _i, _i, _i, _i, _p], _i),
+    "wvn_table_bilerp_argmax_ac": ([_p, _p, _i, _i, _i, _i, _i, _p], _i),
+    "wvn_kmeans_cosine_pixels_linear_ac": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p], _i),
     "wvn_cast_rows": ([_p, _i, _p, _i, _i, _i, _i, _p], _i),
     "wvn_kmeans_cosine": ([_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "wvn_mlp_param_count": ([_p], _sz),

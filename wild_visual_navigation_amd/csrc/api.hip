@@ -877,6 +877,13 @@ int wvn_kmeans_cosine_pixels_linear(const float* code, int* labels, int* nseg, v
                                     int iters, int relabel, void* stream) {
   return wvn_kmeans_pixels_linear_launch(code, labels, nseg, (float*)scratch, B, G, H, C, K, iters, relabel, (hipStream_t)stream);
 }
+int wvn_kmeans_cosine_pixels_linear_ac(const float* code, int* labels, int* nseg, void* scratch, int B, int G, int H, int C, int K,
+                                       int iters, int relabel, int align_corners, void* stream) {
+  return wvn_kmeans_pixels_linear_launch(code, labels, nseg, (float*)scratch, B, G, H, C, K, iters, relabel, (hipStream_t)stream, align_corners ? 1 : 0);
+}
+int wvn_table_bilerp_argmax_ac(const float* table, int* labels, int B, int G, int H, int K, int align_corners, void* stream) {
+  return wvn_table_bilerp_argmax_launch(table, labels, B, G, H, K, (hipStream_t)stream, align_corners ? 1 : 0);
+}
 int wvn_table_argmax_slots(int K) { return wvn_table_slots(K); }
 int wvn_table_bilerp_argmax(const float* table, int* labels, int B, int G, int H, int K, void* stream) {
   return wvn_table_bilerp_argmax_launch(table, labels, B, G, H, K, (hipStream_t)stream);

@@ -112,9 +112,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 hits += [f"{name}:{ln}: {ld}\n    destination touched before the wait by: {nx}" for ln, ld, nx in screen.scan_smem(asm)]
                 os.remove(asm)
                 if hits:
+                    # (the object must not survive: it is newer than its sources, and the next build would link it unscreened)
+                    for stale in (cmd[-1], cmd[-1] + ".cmd"):
+                        if os.path.exists(stale):
+                            os.remove(stale)
                     return name, 1, log + "gfx950 hazard screen (scripts/check_store_hazard.py):\n" + "\n".join(hits[:20])
             else:
-                log += "\n(hazard screen: the -S compile failed; not screened)\n" + ra.stdout + ra.stderr
+                # an unscreened unit is a build failure, not a log line (WVN_SKIP_HAZARD_SCREEN=1 switches the screen off knowingly)
+                for stale in (cmd[-1], cmd[-1] + ".cmd"):
+                    if os.path.exists(stale):
+                        os.remove(stale)
+                return name, 1, log + "\nhazard screen: the -S compile failed; unit not screened\n" + ra.stdout + ra.stderr
         if r.returncode == 0:
             _write_cmd(cmd[-1], cmd)
         return name, r.returncode, log

@@ -104,11 +104,37 @@ __device__ inline double wave_sum_d(double v) {
 // must produce the same bits whatever contraction flags their translation unit is compiled with.
 // ATen: src = dst * (G-1)/(H-1) (fp32), i0 = (int)src, i1 = i0 + (i0 < G-1), w1 = src - i0, w0 = 1 - w1.
 struct LerpTap { int i0, i1; float w0, w1; };
-__host__ __device__ inline float lerp_scale(int G, int H) { return H > 1 ? (float)(G - 1) / (float)(H - 1) : 0.f; }
+// align_corners = 0 (round 6: the OTHER reading of the absent STEGO package's code interpolation, StegoInterface(code_align_corners=False)): ATen's
+// half-pixel coordinates src = max((G / H) (o + 0.5) - 0.5, 0), every operation rounded on its own; the mode travels as the SIGN of the scale
+// (-G / H), so every kernel that derives its taps through lerp_tap serves both readings
+__host__ __device__ inline float lerp_scale(int G, int H, int align_corners = 1) {
+  if (!align_corners) return -((float)G / (float)H);
+  return H > 1 ? (float)(G - 1) / (float)(H - 1) : 0.f;
+}
 __device__ inline LerpTap lerp_tap(int o, int G, float scale) {
   // __fmul_rn / __fsub_rn are plain operators to the compiler, and under HIP's default -ffp-contract=fast the backend fuses
   // s - i0 into fma(scale, o, -i0) whatever pragma the source carries: the product is made opaque before it is used again
   float s = __fmul_rn(scale, (float)o);
+  asm volatile("" : "+v"(s));
+  LerpTap t;
+  t.i0 = (int)s;
+  t.i1 = t.i0 + (t.i0 < G - 1 ? 1 : 0);
+  t.w1 = __fsub_rn(s, (float)t.i0);
+  t.w0 = __fsub_rn(1.f, t.w1);
+  return t;
+}
+// the same for a scale of either sign (lerp_scale's align_corners = 0 form); a separate function so that the kernels that only ever see
+// align_corners=True keep their instruction streams (the packed k-means assign kernel's hand-issued scalar loads sit on a knife's edge of
+// the register allocator: the hazard screen of csrc/build.py fired when this branch was added to lerp_tap itself)
+__device__ inline LerpTap lerp_tap_ac(int o, int G, float scale) {
+  float s;
+  if (scale >= 0.f) {
+    s = __fmul_rn(scale, (float)o);
+  } else {
+    float m = __fmul_rn(-scale, (float)o + 0.5f);
+    asm volatile("" : "+v"(m));
+    s = fmaxf(__fsub_rn(m, 0.5f), 0.f);
+  }
   asm volatile("" : "+v"(s));
   LerpTap t;
   t.i0 = (int)s;

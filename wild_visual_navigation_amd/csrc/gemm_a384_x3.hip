@@ -640,7 +640,14 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   for (int u = u_begin; u < u_end;) {
     const int rb = u / NT, j0 = u - rb * NT, j1 = min(NT, j0 + (u_end - u));
     m0w = rb * BM + wave * 32;
-    load_a();
+    if constexpr (TIMING) {   // (the row block's operand load -- LayerNorm on load: two HBM round trips + the conversions -- is booked under "DMA issue")
+      const long long l0 = (long long)__builtin_amdgcn_s_memtime();
+      load_a();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      t_iss += (long long)__builtin_amdgcn_s_memtime() - l0;
+    } else {
+      load_a();
+    }
     if constexpr (IS_QKV) qkv_offsets();
     if constexpr (MERGED) {
       using T = std::true_type; using F = std::false_type;

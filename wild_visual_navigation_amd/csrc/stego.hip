@@ -337,14 +337,14 @@ __device__ inline void pix_row(const float* rows, int G, const LerpTap& tx, cons
 // channel order; the row is interpolated sixteen channels at a time (nothing but the chain's accumulator lives across the blocks:
 // ~30 registers, and with one wave per 64 pixels of an image row the kernel fills the CU like the assign kernel does).
 template <int C>
-__global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H, int B) {
+__global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restrict__ code, float* __restrict__ rinv, int G, int H, int B, int ac) {
   extern __shared__ float rows[];  // [2][G][C]
   int bx, b;
   km_frame_map(blockIdx.x, ceil_div_dev(H, PIX_RPB), B, bx, b);
-  const float scale = lerp_scale(G, H);
+  const float scale = lerp_scale(G, H, ac);
   int s0 = -1, s1 = -1;            // the code rows staged in LDS
   for (int y = bx * PIX_RPB; y < min(H, (bx + 1) * PIX_RPB); ++y) {   // consecutive image rows mostly share them
-    const LerpTap ty = lerp_tap(y, G, scale);
+    const LerpTap ty = lerp_tap_ac(y, G, scale);
     if (ty.i0 != s0 || ty.i1 != s1) {
       __syncthreads();
       pix_stage_rows(code, b, G, C, ty.i0, ty.i1, rows);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restric
       s0 = ty.i0; s1 = ty.i1;
     }
     for (int x = threadIdx.x; x < H; x += blockDim.x) {
-      const LerpTap tx = lerp_tap(x, G, scale);
+      const LerpTap tx = lerp_tap_ac(x, G, scale);
       const float* a0 = rows + tx.i0 * C;
       const float* a1 = rows + tx.i1 * C;
       const float* b0 = rows + G * C + tx.i0 * C;
@@ -375,15 +375,15 @@ __global__ __launch_bounds__(512) void km_pix_rinv_kernel(const float* __restric
 
 // cent[b][k][:] = x at pixel floor((2k+1) P / 2K), P = H*H
 __global__ void km_pix_init_kernel(const float* __restrict__ code, const float* __restrict__ rinv, float* __restrict__ cent, int G,
-                                   int H, int C, int K, float* __restrict__ cpk) {
+                                   int H, int C, int K, float* __restrict__ cpk, int ac = 1) {
   const int b = blockIdx.x;
   const long long P = (long long)H * H;
-  const float scale = lerp_scale(G, H);
+  const float scale = lerp_scale(G, H, ac);
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
     const int k = i / C, d = i - k * C;
     const long long p0 = ((long long)(2 * k + 1) * P) / (2 * K);
     const int y = (int)(p0 / H), x = (int)(p0 - (long long)y * H);
-    const LerpTap ty = lerp_tap(y, G, scale), tx = lerp_tap(x, G, scale);
+    const LerpTap ty = lerp_tap_ac(y, G, scale), tx = lerp_tap_ac(x, G, scale);
     const float* cb = code + (size_t)b * G * G * C;
     const float v = bilerp_fixed(cb[((size_t)ty.i0 * G + tx.i0) * C + d], cb[((size_t)ty.i0 * G + tx.i1) * C + d],
                                  cb[((size_t)ty.i1 * G + tx.i0) * C + d], cb[((size_t)ty.i1 * G + tx.i1) * C + d], tx.w0, tx.w1,
@@ -1127,7 +1127,7 @@ int run_kmeans_pixels(const float* code, int* labels, int* nseg, float* scratch,
   }
   const int nrb = ceil_div(H, PIX_RPB);
   hipLaunchKernelGGL((km_pix_rinv_kernel<C>), dim3(nrb * B), dim3(H >= 512 ? 512 : (H + 63) / 64 * 64), shm_rows, st, code,
-                     s.rinv, G, H, B);
+                     s.rinv, G, H, B, 1);
   const int pkform = K > 2 * KM_PK_PAIRS ? 0 : (g_km_assign_form < 0 || g_km_assign_form == 5) ? 5 : (g_km_assign_form == 4 ? 4 : 0);
   hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, s.rinv, s.cent, G, H, C, K, pkform ? s.cpk : (float*)nullptr);
   WVN_LAUNCH_CHECK();
@@ -1233,17 +1233,17 @@ int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* s
 
 // the two steps the linear form of the pixel k-means (csrc/stego_linear.hip) shares with the direct one: rinv[b][p] of every code pixel
 // and the initial centroids c_k = x at pixel floor((2k+1) P / 2K); and the ascending compaction of the used ids
-int wvn_km_pix_prepare_launch(const float* code, float* rinv, float* cent, int B, int G, int H, int C, int K, hipStream_t st) {
+int wvn_km_pix_prepare_launch(const float* code, float* rinv, float* cent, int B, int G, int H, int C, int K, hipStream_t st, int ac) {
   if ((size_t)2 * G * C * sizeof(float) > 96 * 1024) return WVN_ERR_ARG;
   const int nrb = ceil_div(H, PIX_RPB), threads = H >= 512 ? 512 : (H + 63) / 64 * 64;
   const size_t shm_rows = (size_t)2 * G * C * sizeof(float);
   static LdsOptIn opt;
   if (const int rc = opt(96 * 1024, (const void*)km_pix_rinv_kernel<90>, (const void*)km_pix_rinv_kernel<16>)) return rc;
-  if (C == 90) hipLaunchKernelGGL((km_pix_rinv_kernel<90>), dim3(nrb * B), dim3(threads), shm_rows, st, code, rinv, G, H, B);
-  else if (C == 16) hipLaunchKernelGGL((km_pix_rinv_kernel<16>), dim3(nrb * B), dim3(threads), shm_rows, st, code, rinv, G, H, B);
+  if (C == 90) hipLaunchKernelGGL((km_pix_rinv_kernel<90>), dim3(nrb * B), dim3(threads), shm_rows, st, code, rinv, G, H, B, ac);
+  else if (C == 16) hipLaunchKernelGGL((km_pix_rinv_kernel<16>), dim3(nrb * B), dim3(threads), shm_rows, st, code, rinv, G, H, B, ac);
   else return WVN_ERR_ARG;
   WVN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, rinv, cent, G, H, C, K, (float*)nullptr);
+  hipLaunchKernelGGL(km_pix_init_kernel, dim3(B), dim3(256), 0, st, code, rinv, cent, G, H, C, K, (float*)nullptr, ac);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }

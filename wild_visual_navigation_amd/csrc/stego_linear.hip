@@ -75,7 +75,7 @@ template <int KP, bool FINAL>
 __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float* __restrict__ S, const float* __restrict__ rinv,
                                                                     float* __restrict__ Pg, int* __restrict__ cntp,
                                                                     int* __restrict__ labels, unsigned* __restrict__ used, int G, int H,
-                                                                    int K, int B, int RC) {
+                                                                    int K, int B, int RC, int ac) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const LinLds L = lin_lds(G, H, KP, RC);
   float* Sl = (float*)(lds + L.S);        // [2][G][KP]
@@ -91,11 +91,11 @@ __global__ __launch_bounds__(LIN_THREADS) void km_lin_assign_kernel(const float*
   lin_frame_map(blockIdx.x, G, B, band, b);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = blockDim.x >> 6;
   const size_t T = (size_t)G * G;
-  const float scale = lerp_scale(G, H);
+  const float scale = lerp_scale(G, H, ac);   // ac = 0: half-pixel (align_corners=False) taps -- the band structure below only needs i0 monotone and i1 = min(i0 + 1, G - 1)
   for (int i = tid; i <= G; i += blockDim.x) first[i] = H;
   if (tid < KP) cntl[tid] = 0;
   for (int o = tid; o < HP; o += blockDim.x) {
-    const LerpTap t = lerp_tap(min(o, H - 1), G, scale);
+    const LerpTap t = lerp_tap_ac(min(o, H - 1), G, scale);
     xrec[o] = f32x4_t{__int_as_float(t.i0), t.w0, t.w1, 0.f};
   }
   for (int i = tid; i < 2 * KP * G; i += blockDim.x) Pl[i] = 0.f;
@@ -479,7 +479,7 @@ int g_lin_rc = LIN_RC;
 
 template <int KP, int C>
 int run_linear(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int K, int iters, int relabel,
-               hipStream_t st) {
+               hipStream_t st, int ac) {
   const LinScratch s = lin_carve(scratch, B, G, H, C, K, KP);
   const int RC = g_lin_rc;
   const LinLds L = lin_lds(G, H, KP, RC);
@@ -487,14 +487,14 @@ int run_linear(const float* code, int* labels, int* nseg, float* scratch, int B,
   static LdsOptIn opt;
   if (const int rc = opt(160 * 1024, (const void*)km_lin_assign_kernel<KP, false>, (const void*)km_lin_assign_kernel<KP, true>,
                          (const void*)km_lin_rowsum_kernel<KP>)) return rc;
-  if (const int rc = wvn_km_pix_prepare_launch(code, s.rinv, s.cent0, B, G, H, C, K, st)) return rc;
+  if (const int rc = wvn_km_pix_prepare_launch(code, s.rinv, s.cent0, B, G, H, C, K, st, ac)) return rc;
   const int T = G * G, NT = (T + LIN_TT - 1) / LIN_TT, NG = (G + LIN_RG - 1) / LIN_RG;
   float* cur = s.cent0;
   float* nxt = s.cent1;
   hipLaunchKernelGGL((km_lin_table_kernel<KP, C>), dim3(NT * B), dim3(LIN_TT), 0, st, code, s.Q, s.cntp, cur, nxt, s.S, G, K, B, 1);
   WVN_LAUNCH_CHECK();
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL((km_lin_assign_kernel<KP, false>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, s.used, G, H, K, B, RC);
+    hipLaunchKernelGGL((km_lin_assign_kernel<KP, false>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, s.used, G, H, K, B, RC, ac);
     WVN_LAUNCH_CHECK();
     hipLaunchKernelGGL((km_lin_rowsum_kernel<KP>), dim3(NG * B), dim3(LIN_RG * 128), rowsum_lds, st, code, s.Pg, s.Q, G, C, K, B);
     WVN_LAUNCH_CHECK();
@@ -504,7 +504,7 @@ int run_linear(const float* code, int* labels, int* nseg, float* scratch, int B,
   }
   hipError_t e = hipMemsetAsync(s.used, 0, (size_t)B * sizeof(unsigned), st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((km_lin_assign_kernel<KP, true>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, s.used, G, H, K, B, RC);
+  hipLaunchKernelGGL((km_lin_assign_kernel<KP, true>), dim3(G * B), dim3(LIN_THREADS), L.bytes, st, s.S, s.rinv, s.Pg, s.cntp, labels, s.used, G, H, K, B, RC, ac);
   WVN_LAUNCH_CHECK();
   if (cur != s.cent0) {
     e = hipMemcpyAsync(s.cent0, cur, (size_t)B * K * C * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -535,7 +535,7 @@ void wvn_kmeans_pixels_linear_set_rows(int rc) { g_lin_rc = rc >= 1 && rc <= 16 
 // the km_lin_assign kernel on a caller-made table -- the STEGO cluster probe and linear probe at pixel resolution (a probe is linear
 // in the code and the bilinear weights sum to one, so interpolating its K outputs equals applying it to the interpolated code)
 int wvn_table_slots(int K) { return K > 0 && K <= 32 ? lin_kp(K) : 0; }
-int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G, int H, int K, hipStream_t st) {
+int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G, int H, int K, hipStream_t st, int ac) {
   if (!table || !labels || B <= 0 || G <= 0 || H <= 0 || K <= 0 || K > 32 || (((uintptr_t)table) & 15)) return WVN_ERR_ARG;
   const int KP = lin_kp(K), RC = 1;
   const LinLds L = lin_lds(G, H, KP, RC);
@@ -544,18 +544,18 @@ int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G
   if (const int rc = opt(160 * 1024, (const void*)km_lin_assign_kernel<8, true>, (const void*)km_lin_assign_kernel<20, true>,
                          (const void*)km_lin_assign_kernel<32, true>)) return rc;
   const dim3 grid(G * B), block(LIN_THREADS);
-  if (KP == 8) hipLaunchKernelGGL((km_lin_assign_kernel<8, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC);
-  else if (KP == 20) hipLaunchKernelGGL((km_lin_assign_kernel<20, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC);
-  else hipLaunchKernelGGL((km_lin_assign_kernel<32, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC);
+  if (KP == 8) hipLaunchKernelGGL((km_lin_assign_kernel<8, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC, ac);
+  else if (KP == 20) hipLaunchKernelGGL((km_lin_assign_kernel<20, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC, ac);
+  else hipLaunchKernelGGL((km_lin_assign_kernel<32, true>), grid, block, L.bytes, st, table, (const float*)nullptr, (float*)nullptr, (int*)nullptr, labels, (unsigned*)nullptr, G, H, K, B, RC, ac);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
 
 int wvn_kmeans_pixels_linear_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K,
-                                    int iters, int relabel, hipStream_t st) {
+                                    int iters, int relabel, hipStream_t st, int ac) {
   if (!code || !labels || !nseg || !scratch || B <= 0 || iters < 0 || !wvn_kmeans_pixels_linear_supported(G, H, C, K)) return WVN_ERR_ARG;
   const int KP = lin_kp(K);
-#define WVN_LIN_RUN(KP_, C_) return run_linear<KP_, C_>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st)
+#define WVN_LIN_RUN(KP_, C_) return run_linear<KP_, C_>(code, labels, nseg, scratch, B, G, H, K, iters, relabel, st, ac)
   if (C == 90) { if (KP == 8) WVN_LIN_RUN(8, 90); if (KP == 20) WVN_LIN_RUN(20, 90); WVN_LIN_RUN(32, 90); }
   if (KP == 8) WVN_LIN_RUN(8, 16);
   if (KP == 20) WVN_LIN_RUN(20, 16);

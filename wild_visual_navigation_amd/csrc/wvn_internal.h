@@ -197,17 +197,17 @@ size_t wvn_kmeans_scratch_floats(int B, int P, int C, int K);
 size_t wvn_kmeans_pixels_scratch_floats(int B, int G, int H, int C, int K);
 int wvn_kmeans_pixels_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K, int iters,
                              int relabel, hipStream_t st);
-int wvn_km_pix_prepare_launch(const float* code, float* rinv, float* cent, int B, int G, int H, int C, int K, hipStream_t st);
+int wvn_km_pix_prepare_launch(const float* code, float* rinv, float* cent, int B, int G, int H, int C, int K, hipStream_t st, int align_corners = 1);
 int wvn_km_relabel_launch(int* labels, int* nseg, int B, long long P, int K, int relabel, hipStream_t st);
 int wvn_kmeans_pixels_linear_supported(int G, int H, int C, int K);
 size_t wvn_kmeans_pixels_linear_scratch_floats(int B, int G, int H, int C, int K);
 void wvn_kmeans_pixels_linear_set_rows(int rc);
 int wvn_kmeans_pixels_linear_launch(const float* code, int* labels, int* nseg, float* scratch, int B, int G, int H, int C, int K,
-                                    int iters, int relabel, hipStream_t st);
+                                    int iters, int relabel, hipStream_t st, int align_corners = 1);
 int wvn_f16_saturate_probe_launch(const float* in, uint16_t* out, int n, hipStream_t st);
 void wvn_gemm_n384_x3_set_pair(int on);
 int wvn_table_slots(int K);
-int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G, int H, int K, hipStream_t st);
+int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G, int H, int K, hipStream_t st, int align_corners = 1);
 void wvn_kmeans_pixels_set_assign_form(int form);
 int wvn_kmeans_pixels_screen_stats(unsigned long long* out, int reset);   // -1 default (MFMA where eligible), 0 the VALU form always
 int wvn_flip_average_launch(const float* a, const float* mirrored, float* out, int B, int G, int C, hipStream_t st);

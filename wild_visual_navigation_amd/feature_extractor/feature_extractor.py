@@ -42,7 +42,7 @@ class FeatureExtractor:
                 max_chunk=kwargs.get("max_chunk", 16), flip_tta=kwargs.get("flip_tta", True),
                 cluster_resolution=kwargs.get("cluster_resolution", "pixel"), kmeans_form=kwargs.get("kmeans_form", "linear"),
                 allow_synthetic=kwargs.get("allow_synthetic", False), fuse_mlp=kwargs.get("fuse_mlp"), fuse_qkv=kwargs.get("fuse_qkv"), fuse_proj=kwargs.get("fuse_proj", True),
-                pos_embed_rule=kwargs.get("pos_embed_rule", "dino"),
+                pos_embed_rule=kwargs.get("pos_embed_rule", "dino"), code_align_corners=kwargs.get("code_align_corners", True),
             )
         elif "dino" in self._feature_type:
             self._feature_dim = 384  # the reference hard-codes 384 for any dino type (feature_extractor.py:56)

@@ -123,6 +123,9 @@ class StegoInterface:
         fuse_proj: bool = True,
         skip_crf: Optional[bool] = None,  # run_crf=True without pydensecrf: None -> WVN_SKIP_CRF env, True -> warn and drop the CRF step
         pos_embed_rule: str = "dino",   # position-table resampling of the backbone (backbone.resample_pos_embed)
+        code_align_corners: bool = True,   # how postprocess() up-samples the code BEFORE clustering / probing (the absent package's choice, stego_interface.py:94-100):
+        #                                    True = the align_corners=True taps of WVN's own later up-sample (:107); False = the half-pixel taps of the public STEGO
+        #                                    evaluation code.  `features` (stego_interface.py:107) and the pooling are WVN's own code: always align_corners=True
     ):
         if cfg is None or len(cfg) == 0:
             self._cfg = _Cfg(model_path=model_path, input_size=input_size, run_crf=run_crf,
@@ -170,6 +173,9 @@ class StegoInterface:
         self._precision = precision
         self._flip_tta = flip_tta
         self._cluster_resolution = cluster_resolution
+        self._code_ac = bool(code_align_corners)
+        if not self._code_ac and (cluster_resolution != "pixel" or kmeans_form != "linear"):
+            raise _lib.WvnError("code_align_corners=False needs cluster_resolution='pixel' and kmeans_form='linear' (the patch-resolution forms interpolate nothing)")
         if kmeans_form not in ("linear", "direct"):
             raise _lib.WvnError("kmeans_form must be 'linear' or 'direct'")
         self._kmeans_form = kmeans_form
@@ -313,6 +319,8 @@ class StegoInterface:
                 # multiplied out ("direct", csrc/stego.hip) -- the same clustering, fixed summation orders in both
                 form = self._kmeans_form
                 if form == "linear" and not ops.kmeans_pixels_linear_supported(G, S, self._C, K):
+                    if not self._code_ac:
+                        raise _lib.WvnError(f"StegoInterface(code_align_corners=False): the linear form has no instantiation for C={self._C}, K={K}")
                     form = "direct"
                 if form == "direct" and not ops.kmeans_cosine_pixels_supported(G, S, self._C, K):
                     form = "dense"
@@ -329,12 +337,12 @@ class StegoInterface:
                     except _lib.WvnError as e:
                         raise _lib.WvnError(f"StegoInterface: the dense-row k-means has no instantiation for C={self._C}, K={K} ({e})") from None
                 else:
-                    labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, S, K, KMEANS_ITERS, relabel=True, form=form)
+                    labels, self._n_segments = ops.kmeans_cosine_pixels(code, G, S, K, KMEANS_ITERS, relabel=True, form=form, align_corners=self._code_ac)
             elif self._clusters.shape[0] <= 32:
                 # the cluster probe at pixel resolution: cosine similarity is linear in the (un-normalised) code up to the pixel's
                 # positive norm, so the argmax over the interpolated patch similarities IS the argmax on the interpolated code
                 sim = ops.gemm_f32(code.reshape(B * G * G, self._C), self._clusters, None)
-                labels = ops.table_bilerp_argmax(sim.reshape(B, G * G, -1), G, S)
+                labels = ops.table_bilerp_argmax(sim.reshape(B, G * G, -1), G, S, align_corners=self._code_ac)
                 self._n_segments = None
             else:
                 pix = ops.upsample_bilinear(code, G, S).permute(0, 2, 3, 1).reshape(B * S * S, self._C)   # [B, C, S, S] -> pixel rows
@@ -358,7 +366,7 @@ class StegoInterface:
             rows = code.reshape(B * G * G, self._C)
             if self._cluster_resolution == "pixel" and self._w_probe.shape[0] <= 32:
                 logits = ops.gemm_f32(rows if rows.is_contiguous() else rows.contiguous(), self._w_probe, self._b_probe)
-                lin = ops.table_bilerp_argmax(logits.reshape(B, G * G, -1), G, S)
+                lin = ops.table_bilerp_argmax(logits.reshape(B, G * G, -1), G, S, align_corners=self._code_ac)
                 self._linear_pred = (lin if H == S else ops.upsample_nearest_labels(lin, H))[None]
             else:
                 lin = self._probe_labels(rows, self._w_probe, self._b_probe, cosine=False)

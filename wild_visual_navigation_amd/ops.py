@@ -284,14 +284,18 @@ def kmeans_pixels_linear_supported(G: int, H: int, C: int, K: int) -> bool:
 
 
 def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int = 10, relabel: bool = True,
-                         return_centroids: bool = False, form: str = "linear"):
+                         return_centroids: bool = False, form: str = "linear", align_corners: bool = True):
     """code [B, G*G, C] fp32 patch codes -> (labels [B, H*H] int32, n_segments [B] int32): the k-means of ``kmeans_cosine`` over
     the H x H bilinearly up-sampled, normalised code pixels (the [B, H*H, C] array is never built).
     form="linear" (default, oracle/kmeans_linear.py): assignment from a per-pass similarity table interpolated per pixel, centroid
     sums from summed tap weights times the patch codes -- the same clustering at ~1/20 of the arithmetic; form="direct"
     (oracle/interfaces.py::kmeans_cosine_labels_pixels): every row re-created and multiplied out in every pass.  Both are
-    deterministic and bit-exact against their oracle; they differ from each other only where two similarities tie within fp32 rounding."""
+    deterministic and bit-exact against their oracle; they differ from each other only where two similarities tie within fp32 rounding.
+    align_corners=False (linear form only): the code pixels are the half-pixel (align_corners=False) bilinear interpolation of the patch codes --
+    the other reading of the absent STEGO package (include/wvn_hip.h: wvn_kmeans_cosine_pixels_linear_ac)."""
     require_cuda(code, "code")
+    if not align_corners and form != "linear":
+        raise _lib.WvnError("kmeans_cosine_pixels: align_corners=False exists in the linear form only")
     B, P, Cc = code.shape
     if P != G * G:
         raise _lib.WvnError(f"kmeans_cosine_pixels: {P} code rows for a {G} x {G} grid")
@@ -306,8 +310,8 @@ def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int 
             raise _lib.WvnError(f"kmeans_cosine_pixels(form='linear'): no instantiation for G={G}, H={H}, C={Cc}, K={K} "
                                 "(C in {16, 90}, K <= 32); use form='direct'")
         scratch = torch.empty(lib().wvn_kmeans_pixels_linear_scratch_bytes(B, G, H, Cc, K), dtype=torch.uint8, device=dev)
-        check(lib().wvn_kmeans_cosine_pixels_linear(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters,
-                                                    int(relabel), stream()), "wvn_kmeans_cosine_pixels_linear")
+        check(lib().wvn_kmeans_cosine_pixels_linear_ac(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters,
+                                                       int(relabel), int(bool(align_corners)), stream()), "wvn_kmeans_cosine_pixels_linear_ac")
     else:
         scratch = torch.empty(lib().wvn_kmeans_pixels_scratch_bytes(B, G, H, Cc, K), dtype=torch.uint8, device=dev)
         check(lib().wvn_kmeans_cosine_pixels(ptr(code), ptr(labels), ptr(nseg), ptr(scratch), B, G, H, Cc, K, iters, int(relabel),
@@ -317,9 +321,9 @@ def kmeans_cosine_pixels(code: torch.Tensor, G: int, H: int, K: int, iters: int 
     return labels, nseg
 
 
-def table_bilerp_argmax(table: torch.Tensor, G: int, H: int) -> torch.Tensor:
+def table_bilerp_argmax(table: torch.Tensor, G: int, H: int, align_corners: bool = True) -> torch.Tensor:
     """table [B, G*G, K] fp32 (K <= 32 scores per patch) -> labels [B, H, H] int32: per pixel the first-maximum argmax of the
-    bilinearly interpolated (align_corners=True, fixed operation order) scores -- a linear probe at pixel resolution."""
+    bilinearly interpolated (align_corners as given, fixed operation order) scores -- a linear probe at pixel resolution."""
     require_cuda(table, "table")
     B, P, K = table.shape
     if P != G * G:
@@ -330,7 +334,7 @@ def table_bilerp_argmax(table: torch.Tensor, G: int, H: int) -> torch.Tensor:
     t = table.float()
     t = torch.nn.functional.pad(t, (0, KP - K)).contiguous() if KP != K else t.contiguous()
     labels = torch.empty(B, H, H, dtype=torch.int32, device=table.device)
-    check(lib().wvn_table_bilerp_argmax(ptr(t), ptr(labels), B, G, H, K, stream()), "wvn_table_bilerp_argmax")
+    check(lib().wvn_table_bilerp_argmax_ac(ptr(t), ptr(labels), B, G, H, K, int(bool(align_corners)), stream()), "wvn_table_bilerp_argmax_ac")
     return labels
 
 
