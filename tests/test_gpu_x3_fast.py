@@ -111,7 +111,8 @@ def test_fast_block_kernels_inside_the_vit(dev, precision):
         b = VitBackbone(sd, 448, 8, 6, device=dev, precision=precision, max_chunk=4).forward_tokens(img.to(dev)).cpu()
     finally:
         os.environ.pop("WVN_NO_A384_X3", None)
-    assert (a - b).abs().max().item() < 2e-4
+    # ("mixed": a = the MX kernels (round 6), b = the tiled bf16 x 3 kernel: the correction terms' e5m2 operands separate them by ~1.5e-4)
+    assert (a - b).abs().max().item() < (3e-4 if precision == "mixed" else 2e-4)
     assert (a - want).abs().max().item() < (5e-4 if precision == "mixed" else 1e-4)
 
 
@@ -125,12 +126,16 @@ def test_layernorm_across_kernel_boundaries(dev, precision):
     img = torch.rand(4, 3, 448, 448, generator=g(2))
     want = OV.vit_tokens(sd, OI.normalize(img), 8, 6)[:, 1:]
     os.environ.pop("WVN_X3_DEBUG_BITS", None)
-    a = VitBackbone(sd, 448, 8, 6, device=dev, precision=precision, max_chunk=4).forward_tokens(img.to(dev)).cpu()
-    os.environ["WVN_X3_DEBUG_BITS"] = "512"
+    # (the hand-over of the bf16 x 3 kernels is what this test is about: "mixed" defaults to the MX kernels since round 6, which exist only WITH the
+    #  hand-over -- tests/test_gpu_mx.py covers their LayerNorm-on-load -- so both runs take the bf16 x 3 route here)
+    os.environ["WVN_NO_MX"] = "1"
     try:
+        a = VitBackbone(sd, 448, 8, 6, device=dev, precision=precision, max_chunk=4).forward_tokens(img.to(dev)).cpu()
+        os.environ["WVN_X3_DEBUG_BITS"] = "512"
         b = VitBackbone(sd, 448, 8, 6, device=dev, precision=precision, max_chunk=4).forward_tokens(img.to(dev)).cpu()
     finally:
         os.environ.pop("WVN_X3_DEBUG_BITS", None)
+        os.environ.pop("WVN_NO_MX", None)
     assert not torch.equal(a, b)                      # (the two routes really are different code)
     assert (a - b).abs().max().item() < 5e-5
     assert (a - want).abs().max().item() < (5e-4 if precision == "mixed" else 1e-4)
