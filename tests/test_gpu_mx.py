@@ -151,3 +151,28 @@ def test_mx_block_kernels_inside_the_vit(dev):
     print(f"tokens vs oracle: MX {(a - want).abs().max().item():.2e}, bf16 x 3 {(b - want).abs().max().item():.2e}; MX vs x3 {(a - b).abs().max().item():.2e}")
     assert (a - want).abs().max().item() < 5e-4
     assert (a - b).abs().max().item() < 4e-4
+
+
+def test_mx_with_layerscale_and_patch14(dev):
+    """DINOv2 ViT-S/14 (D = 384: the MX kernels apply; LayerScale on both branch outputs goes through the MX row-panel epilogue) at 518^2, 7 frames =
+    9632 token rows of 1376 per frame (a row stride that is not a multiple of 128), 3 blocks, precision "mixed": inside the gate against the CPU oracle
+    and close to the bf16 x 3 kernels."""
+    import os
+
+    from oracle import interfaces as OI, vit as OV
+    from wild_visual_navigation_amd.backbone import VitBackbone
+    sd = OV.make_dinov2_state_dict("vit_small", 14, pretrain_grid=37, seed=3, depth=3)
+    img = torch.rand(7, 3, 518, 518, generator=g(9))
+    want = OV.vit_tokens(sd, OI.normalize(img), 14, 6)[:, 1:]
+    os.environ.pop("WVN_NO_MX", None)
+    bb = VitBackbone(sd, 518, 14, 6, device=dev, precision="mixed", max_chunk=7)
+    assert bb.mx and bb.model.layers[1].proj_w_mx and bb.model.layers[1].ls1
+    a = bb.forward_tokens(img.to(dev)).cpu()
+    os.environ["WVN_NO_MX"] = "1"
+    try:
+        b = VitBackbone(sd, 518, 14, 6, device=dev, precision="mixed", max_chunk=7).forward_tokens(img.to(dev)).cpu()
+    finally:
+        os.environ.pop("WVN_NO_MX", None)
+    print(f"dinov2 ViT-S/14 518^2 x 7, mixed: MX {(a - want).abs().max().item():.2e}, bf16 x 3 {(b - want).abs().max().item():.2e}")
+    assert not torch.equal(a, b)
+    assert (a - want).abs().max().item() < 5e-4
