@@ -15,7 +15,8 @@ typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-__global__ void cvt_probe(const float* x, unsigned* o, float sc, int n) {
+__global__ void cvt_probe(const float* x, unsigned* o, float sc, int n, int ovfl) {
+  if (ovfl) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL (csrc/common.h: wvn_fp16_saturate)
   const int i = threadIdx.x;
   if (i >= n) return;
   s2 old = {0, 0};
@@ -97,8 +98,20 @@ int main() {
   float* dx; unsigned* dob;
   (void)hipMalloc(&dx, sizeof(xs)); (void)hipMalloc(&dob, 256 * 4);
   (void)hipMemcpy(dx, xs, sizeof(xs), hipMemcpyHostToDevice);
+  for (int ovfl : {1}) {   // what the library's kernels see: MODE.FP16_OVFL set
+    hipLaunchKernelGGL(cvt_probe, dim3(1), dim3(64), 0, 0, dx, dob, 1.0f, n, ovfl);
+    unsigned ho[256];
+    (void)hipMemcpy(ho, dob, sizeof(ho), hipMemcpyDeviceToHost);
+    printf("with MODE.FP16_OVFL = 1, scale operand 1:\n");
+    for (int i = 0; i < n; ++i)
+      for (int e = 0; e < 2; ++e)
+        if (fabsf(xs[2 * i + e]) >= 4096.f || xs[2 * i + e] == 1.0f) {
+          const unsigned char b0 = (ho[i] >> (8 * e)) & 255, b1 = (ho[64 + i] >> (8 * e)) & 255, b2 = (ho[128 + i] >> (8 * e)) & 255;
+          printf("  x %13.6g : scalef32_pk_bf8_f32 %02x = %-12g  scalef32_pk_bf8_f16 %02x = %-12g  pk_bf8_f32 %02x = %g\n", xs[2 * i + e], b0, bf8_to_f(b0), b1, bf8_to_f(b1), b2, bf8_to_f(b2));
+        }
+  }
   for (float sc : {1.0f, 1.0f / 4096, 4096.f}) {
-    hipLaunchKernelGGL(cvt_probe, dim3(1), dim3(64), 0, 0, dx, dob, sc, n);
+    hipLaunchKernelGGL(cvt_probe, dim3(1), dim3(64), 0, 0, dx, dob, sc, n, 0);
     unsigned ho[256];
     (void)hipMemcpy(ho, dob, sizeof(ho), hipMemcpyDeviceToHost);
     printf("scale operand %g:\n", sc);

@@ -89,7 +89,7 @@ def test_mx_block_mlp_every_row(dev, M):
     hv, h8v = _unfrag(hid[:n_h].view(torch.float16).reshape(R, F // 16, 64, 8), hid[n_h:n_h + n_8].reshape(R, F // 64, 2, 64, 16),
                       hid[n_h + n_8:].reshape(R, F // 64, 2, 64, 16), M, F)
     assert (hv - hidden).abs().max().item() < 2e-4                       # fc1 through the MX products, hidden = h + l8 / 4096
-    assert ((h8v - hidden).abs() <= 0.126 * hidden.abs() + 1e-4).all()   # the e5m2 image of the value itself
+    assert float(h8v.abs().max()) == 0.0                                 # (no h8 plane is written: the consumer derives e5m2(h) in registers)
     want = x0[:M].double().cpu() + hidden @ w2.double().T + b2.double()
     assert (xo[:M].double().cpu() - want).abs().max().item() < 4e-4
     assert torch.equal(xo[M:], x0[M:])

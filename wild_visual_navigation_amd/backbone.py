@@ -142,7 +142,8 @@ def pack_a384_mx(w: torch.Tensor) -> torch.Tensor:
 
 def mx_fragments(a: torch.Tensor):
     """A [M][K] fp32 -> the fragment-major MX planes the row-panel kernel reads (what the producers' epilogues write):
-    (h fp16 [R][K / 16][64][8], l8 uint8 [R][K / 64][2][64][16], h8 likewise), R = ceil(M / 32); lane = 32 hw + row, element j of k-step s =
+    (h fp16 [R][K / 16][64][8], l8 uint8 [R][K / 64][2][64][16], h8 likewise -- h8 is NOT read by the kernels any more: they derive e5m2(h) in
+    registers; kept for the tests' bookkeeping), R = ceil(M / 32); lane = 32 hw + row, element j of k-step s =
     A[32 R + row, 16 s + swap23(8 hw + j)], byte (sp, j) of half x of 64-k step c = A8[.., 16 (4c + 2x + sp) + swap23(8 hw + j)].  Rows past M: 0."""
     M, K = a.shape
     R = (M + 31) // 32
@@ -160,7 +161,8 @@ def mx_fragments(a: torch.Tensor):
 
 def mx_matmul_reference(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """float64 statement of what an MX kernel computes for a [M][K] x w [N][K]^T (the operand roundings exactly, the sums in float64)."""
-    ah, al8, ah8 = mx_split(a)
+    ah, al8, _ = mx_split(a)
+    ah8 = _e5m2_bytes(ah.float())                      # the activation's h8 operand is derived from its fp16 image in registers (gemm_n384_x3.hip: derive_h8)
     wh, wl8, wh8 = mx_split(w)
     f = lambda b: b.view(torch.float8_e5m2).double()   # noqa: E731
     return ah.double() @ wh.double().T + (f(ah8) @ f(wl8).T + f(al8) @ f(wh8).T) / MX_RES_SCALE

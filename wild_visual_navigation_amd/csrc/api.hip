@@ -349,10 +349,8 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     const bool mx = mix && x3_fast && ln_fuse && d.H * 64 == d.D && (d.F % 128) == 0 && L.qkv_w_mx && L.proj_w_mx && L.fc1_w_mx && L.fc2_w_mx &&
                     !(m->flags & WVN_VIT_NO_MX);
     const size_t mpad32 = (size_t)((d.M + 31) / 32 * 32);
-    unsigned char* xn_l8 = (unsigned char*)w.xn + mpad32 * d.D * 2;     // MX planes of the attention output: fp16 fragments | l8 | h8
-    unsigned char* xn_h8 = xn_l8 + mpad32 * d.D;
+    unsigned char* xn_l8 = (unsigned char*)w.xn + mpad32 * d.D * 2;     // MX planes of the attention output: fp16 fragments | l8 (h8 = e5m2(h) is derived by the consumer)
     unsigned char* hid_l8 = (unsigned char*)w.hid + mpad32 * d.F * 2;   // ... and of the hidden activation
-    unsigned char* hid_h8 = hid_l8 + mpad32 * d.F;
     // the two-plane q in the leading blocks only (include/wvn_hip.h: WVN_VIT_QSPLIT_BLOCKS)
     const int qs_field = (m->flags >> 16) & 63;
     const bool qsplit = mix && l < (qs_field ? qs_field - 1 : WVN_VIT_QSPLIT_DEFAULT);
@@ -437,7 +435,7 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     bool ln2_stats = false;   // w.ln_stats holds the statistics of w.x for this block's norm2
     if (mx) {   // the attention output arrived as MX operand planes: the projection on the MX row-panel kernel
       GemmBf16Params pp{};
-      pp.A = (const bf16_t*)w.xn; pp.A_lo = (const bf16_t*)xn_l8; pp.A_h8 = xn_h8; pp.lda = d.D; pp.W = (const bf16_t*)L.proj_w_mx; pp.ldw = d.D; pp.bias = L.proj_b; pp.ls = L.ls1;
+      pp.A = (const bf16_t*)w.xn; pp.A_lo = (const bf16_t*)xn_l8; pp.lda = d.D; pp.W = (const bf16_t*)L.proj_w_mx; pp.ldw = d.D; pp.bias = L.proj_b; pp.ls = L.ls1;
       pp.C = w.x; pp.ldc = d.D; pp.M = M; pp.N = d.D; pp.K = d.D;
       pp.ln_stats_out = w.ln_stats; pp.ln_eps = 1e-6f;
       Span s(5, st);
@@ -470,11 +468,11 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     if (mx && ln2_stats) {   // LayerNorm-on-load fc1 + GELU -> MX operand planes -> MX row-panel fc2 (+ the next block's LayerNorm statistics)
       GemmBf16Params p1{};
       p1.W = (const bf16_t*)L.fc1_w_mx; p1.W_lo = (const bf16_t*)L.fc1_w_mx + (size_t)d.F * d.D; p1.ldw = d.D; p1.bias = L.fc1_b;
-      p1.C = w.hid; p1.C_lo = hid_l8; p1.C_h8 = hid_h8; p1.ldc = d.F; p1.M = M; p1.N = d.F; p1.K = d.D;
+      p1.C = w.hid; p1.C_lo = hid_l8; p1.ldc = d.F; p1.M = M; p1.N = d.F; p1.K = d.D;
       p1.ln_x = w.x; p1.ln_ldx = d.D; p1.ln_stats = w.ln_stats; p1.ln_g = L.ln2_g; p1.ln_b = L.ln2_b;
       { Span s(6, st); RET_IF(wvn_gemm_a384_mx_launch(p1, EPI_GELU_FRAG, st)); }
       GemmBf16Params p2{};
-      p2.A = (const bf16_t*)w.hid; p2.A_lo = (const bf16_t*)hid_l8; p2.A_h8 = hid_h8; p2.lda = d.F; p2.W = (const bf16_t*)L.fc2_w_mx; p2.ldw = d.F; p2.bias = L.fc2_b;
+      p2.A = (const bf16_t*)w.hid; p2.A_lo = (const bf16_t*)hid_l8; p2.lda = d.F; p2.W = (const bf16_t*)L.fc2_w_mx; p2.ldw = d.F; p2.bias = L.fc2_b;
       p2.ls = L.ls2; p2.C = w.x; p2.ldc = d.D; p2.M = M; p2.N = d.D; p2.K = d.F;
       const bool want = l + 1 < m->depth;   // the next block's norm1
       if (want) { p2.ln_stats_out = w.ln_stats; p2.ln_eps = 1e-6f; }

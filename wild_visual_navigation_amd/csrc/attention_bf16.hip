@@ -499,8 +499,8 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
   const int qi = q0 + l31;
   if (out_lo && out_frag == 2) {
     // (uniform) the MX operand planes of the projection (csrc/gemm_n384_x3.hip, gemm_n384_mx_pair_kernel): per element h = fp16(o) as FRAGMENT-MAJOR
-    // fp16 (out: the layout of the branch below), l8 = e5m2((o - h) * 2^12) and h8 = e5m2(o) as [row group][head = 64-k step][half dt][64 lanes][16 bytes]
-    // (out_lo: l8; h8 behind it, ceil32(rows) * heads * 64 bytes further) -- byte (u, j) of half dt = column 16 (2 dt + u) + swap23(8 hi + j) of the head,
+    // fp16 (out: the layout of the branch below) and l8 = e5m2((o - h) * 2^12) as [row group][head = 64-k step][half dt][64 lanes][16 bytes] (out_lo; the
+    // consumer derives h8 = e5m2(h) itself) -- byte (u, j) of half dt = column 16 (2 dt + u) + swap23(8 hi + j) of the head,
     // exactly what this lane's accumulators hold.  The padding queries of a frame (ntok <= q < ntok_s) are written as ZEROS: stale bytes
     // reinterpreted as e5m2 would be NaN / inf one time in 32, and the padding rows feed the next block's (masked, but multiplied) K / V^T.
     if (qi < ntok_s) {
@@ -509,13 +509,11 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
       const float keep = qi < ntok ? inv : 0.f;
       const size_t m = (size_t)b * ntok_s + qi;
       const int nks = heads * 4;
-      const size_t rows_pad = ((size_t)(nbh / heads) * ntok_s + 31) / 32 * 32;
       op16_t* fb = out + (((m >> 5) * nks + head * 4) * 64 + hi * 32 + (m & 31)) * 8;
       unsigned char* l8 = (unsigned char*)out_lo + (((m >> 5) * heads + head) * 2 * 64 + hi * 32 + (m & 31)) * 16;
-      unsigned char* h8 = l8 + rows_pad * (size_t)(heads * DH);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        u32x4_t o8l = {0, 0, 0, 0}, o8h = {0, 0, 0, 0};
+        u32x4_t o8l = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           u32x4_t oh;
@@ -528,19 +526,13 @@ __global__ __launch_bounds__(256, OCC) void attention_bf16_kernel(const op16_t* 
             const h2_t hh = __builtin_bit_cast(h2_t, hb);
             const int d = 2 * u + (e >> 1);
             // (the old value travels as a SCALAR: clang's bit_cast of a vector element reads element 0)
-            const uint32_t oh8 = o8h[d], ol8 = o8l[d];
-            if (e & 1) {
-              o8h[d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(s16x2_t, oh8), a, c, 1.0f, true));
-              o8l[d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(s16x2_t, ol8), a - (float)hh[0], c - (float)hh[1], 1.0f / 4096.0f, true));
-            } else {
-              o8h[d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(s16x2_t, oh8), a, c, 1.0f, false));
-              o8l[d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(s16x2_t, ol8), a - (float)hh[0], c - (float)hh[1], 1.0f / 4096.0f, false));
-            }
+            const uint32_t ol8 = o8l[d];
+            if (e & 1) o8l[d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(s16x2_t, ol8), a - (float)hh[0], c - (float)hh[1], 1.0f / 4096.0f, true));
+            else o8l[d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(s16x2_t, ol8), a - (float)hh[0], c - (float)hh[1], 1.0f / 4096.0f, false));
           }
           *(u32x4_t*)(fb + (2 * dt + u) * 512) = oh;
         }
         *(u32x4_t*)(l8 + dt * 1024) = o8l;
-        *(u32x4_t*)(h8 + dt * 1024) = o8h;
       }
     }
   } else if (qi < ntok) {

@@ -301,7 +301,6 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
                                              : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c2 = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base_lo ? p.qkv_base_lo : p.qkv_base, 0, p.qkv_bytes, 0x00020000)
                                               : __builtin_amdgcn_make_buffer_rsrc(p.C_lo ? p.C_lo : p.C, 0, MX ? c_bytes / 2 : c_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_c3 = __builtin_amdgcn_make_buffer_rsrc(MX && p.C_h8 ? p.C_h8 : (void*)p.W, 0, MX && p.C_h8 ? c_bytes / 2 : 0u, 0x00020000);   // MX fc1: the h8 plane
   auto qkv_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int hblk = 0; hblk < 2; ++hblk) {
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   bf16x8_t wh[2][2], wl[2][2];   // [k-step parity][column half]
   u32x4_t resid_q[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   u32x4_t fragh = {0, 0, 0, 0}, fragl = {0, 0, 0, 0};   // X_GELU_FRAG: the fragment being assembled
-  u32x4_t frag8h = {0, 0, 0, 0}, frag8l = {0, 0, 0, 0};  // MX: the 16-byte half of the e5m2 operands being assembled
+  u32x4_t frag8l = {0, 0, 0, 0};  // MX: the 16-byte half of the l8 plane being assembled
   u32x4_t wq[2][2], w8[2][2];   // MX: [k-step parity][column half] fp16 fragments; [k-step parity][half] of the region's e5m2 operand
   auto frag_read = [&](int slot, int s, int par) __attribute__((always_inline)) {
     const unsigned char* base = smem + slot * SLICE_BYTES + rd_base;
@@ -411,8 +410,12 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
           const uint32_t h = pack_f16x2(v0, v1);
           const h2_t hh = __builtin_bit_cast(h2_t, h);
           fragh[2 * (g & 1) + (h2 >> 1)] = h;
-          frag8h[s >> 1] = mx_pk8(frag8h[s >> 1], v0, v1, 1.0f, s & 1);
-          frag8l[s >> 1] = mx_pk8(frag8l[s >> 1], v0 - (float)hh[0], v1 - (float)hh[1], MX_RES_INV, s & 1);
+          // (no h8 plane: the consumer derives e5m2(h) from the fp16 fragments in registers -- gemm_n384_x3.hip: derive_h8)
+          {
+            typedef __attribute__((ext_vector_type(2))) float f2_t;
+            const f2_t res = f2_t{v0, v1} - f2_t{(float)hh[0], (float)hh[1]};   // one v_pk_add_f32 for the two residues
+            frag8l[s >> 1] = mx_pk8(frag8l[s >> 1], res[0], res[1], MX_RES_INV, s & 1);
+          }
           if ((s & 3) == 3) {
             const unsigned so = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 4)) + 4 * jp + 2 * t + (g >> 1)) * 1024);
             wvn_store_b128_guarded(fragh, rs_c, lane * 16, so);
@@ -420,7 +423,6 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
           if (s == 7) {
             const unsigned so8 = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 6)) + jp) * 2048 + t * 1024);
             wvn_store_b128_guarded(frag8l, rs_c2, lane * 16, so8);
-            wvn_store_b128_guarded(frag8h, rs_c3, lane * 16, so8);
           }
           return;
         }
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   // operations to stay outstanding than were issued would let DMA(i) itself slip through the wait).  ST2: the stores (and row fetches)
   // of part 2, in a ks == 2 period; ST01: the fragment stores of X_GELU_FRAG in the ks == 0 / 1 periods.
   constexpr int ST2 = EPI == X_RESID ? 14 : (EPI == X_GELU || EPI == X_PLANES ? 8 : (EPI == X_GELU_FRAG ? 0 : (F16OUT ? 4 : 8)));   // (QK fp16: 4 stores are the lower bound, a two-plane q issues 8)
-  constexpr int ST01 = EPI == X_GELU_FRAG ? 4 : 0;
+  constexpr int ST01 = EPI == X_GELU_FRAG ? (MX ? 3 : 4) : 0;   // (MX: two fp16 fragments + one l8 half per column half)
   long long t_wait = 0, t_iss = 0, t_mfma = 0;
   const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
   auto period = [&](int i, int ks, int j, bool stores_in_window, auto mtr, auto etr, auto epi_tag) __attribute__((always_inline)) {
@@ -816,7 +818,7 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
 }
 
 // MX form (LayerNorm on load only): W = backbone.pack_a384_mx (plane 0 fp16 [N][384] at g.W, plane 1 bytes [N][768] at g.W_lo); EPI_GELU_FRAG writes the
-// MX operand planes of gemm_n384_x3.hip's MX kernel (g.C fp16 fragments, g.C_lo = l8, g.C_h8 = h8), EPI_QKV the fp16 q (| q_lo) | k | v^T planes.
+// MX operand planes of gemm_n384_x3.hip's MX kernel (g.C fp16 fragments, g.C_lo = l8; h8 is derived by the consumer), EPI_QKV the fp16 q (| q_lo) | k | v^T planes.
 int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   if (!g.ln_x || g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.W || !g.W_lo) return WVN_ERR_ARG;
   if (((uintptr_t)g.W | (uintptr_t)g.W_lo) & 15) return WVN_ERR_ARG;
@@ -829,7 +831,7 @@ int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   p.ln_x = g.ln_x; p.ln_ldx = g.ln_ldx; p.ln_stats = g.ln_stats; p.ln_g = g.ln_g; p.ln_b = g.ln_b;
   switch (epi) {
     case EPI_GELU_FRAG:
-      if (!g.C || !g.C_lo || !g.C_h8 || g.ldc != g.N || (g.N % 64) || (((uintptr_t)g.C | (uintptr_t)g.C_lo | (uintptr_t)g.C_h8) & 15) || ((size_t)g.M + 32) * g.ldc * 2 >= (1ull << 31))
+      if (!g.C || !g.C_lo || g.ldc != g.N || (g.N % 64) || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || ((size_t)g.M + 32) * g.ldc * 2 >= (1ull << 31))
         return WVN_ERR_ARG;
       return launch_mx<X_GELU_FRAG>(p, st);
     case EPI_QKV: {

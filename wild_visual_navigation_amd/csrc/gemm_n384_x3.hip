@@ -663,7 +663,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 constexpr int MXD = 2;                            // 64-k steps of A in flight
 constexpr int MX_SC_ONE = 0x7f7f7f7f, MX_SC_RES = 0x73737373;   // E8M0 scale bytes: 2^0, 2^-12 (all four bytes alike: op_sel never matters)
 
-struct N384MXExtra { unsigned a_l8_off, a_h8_off; };   // byte offsets of the two 8-bit planes behind the fp16 plane (one buffer descriptor)
+struct N384MXExtra { unsigned a_l8_off; };   // byte offset of the l8 plane behind the fp16 plane (one buffer descriptor)
 
 // VAR (timing experiments only, results are garbage for VAR != 0): 1 = no W DMA inside the loop, 2 = no A loads inside the loop, 3 = neither,
 // 4 = no barrier / wait at the stage boundaries
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_mx_pair_kernel(N384X3Params 
   }
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)4 * NN * p.K), 0x00020000);
   const size_t mpad = (size_t)(p.M + 31) / 32 * 32;
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)(ex.a_h8_off + mpad * p.K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (unsigned)(ex.a_l8_off + mpad * p.K), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (unsigned)((size_t)p.M * p.ldc * 4), 0x00020000);
   const unsigned wv0 = (unsigned)(wave * PFW * 1024 + lane * 16);
   const unsigned rdw = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4) + ch * 6 * 1024;  // + x * W_PLANE + t * 1024: this wave's six column tiles
@@ -708,11 +708,29 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_mx_pair_kernel(N384X3Params 
       for (int s = 0; s < 4; ++s)
         ah[slot][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, __builtin_amdgcn_readfirstlane(a_base + (unsigned)(c * 4 + s) * 1024), 0);
     };
-    auto load_a8 = [&](int c, int slot, int which) {
-      const unsigned off = which ? ex.a_l8_off : ex.a_h8_off;
+    auto load_a8 = [&](int c, int slot) {   // the l8 plane (the h8 operand is derived from the fp16 fragments: derive_h8)
 #pragma unroll
       for (int x = 0; x < 2; ++x)
-        a8[slot][which][x] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, __builtin_amdgcn_readfirstlane(a8_base + off + (unsigned)(c * 2 + x) * 1024), 0);
+        a8[slot][1][x] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane * 16, __builtin_amdgcn_readfirstlane(a8_base + ex.a_l8_off + (unsigned)(c * 2 + x) * 1024), 0);
+    };
+    // a_h8 = e5m2(a_h): sixteen v_cvt_scalef32_pk_bf8_f16 per 64 k and lane, in VALU slots this kernel does not use otherwise -- instead of a third plane
+    // in HBM (a quarter of the A stream, which is what the stage waits for: profiles/r06_mx_kernels.md) and a conversion + two stores per tile in the producers
+    auto derive_h8 = [&](int slot) {
+      typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+      typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+#pragma unroll
+      for (int sfr = 0; sfr < 4; ++sfr) {
+        uint32_t d[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t pr = ah[slot][sfr][e];   // (scalar copy: clang's bit_cast of a vector element reads element 0)
+          const s16x2_t o = __builtin_bit_cast(s16x2_t, d[e >> 1]);
+          d[e >> 1] = __builtin_bit_cast(uint32_t, (e & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, true)
+                                                           : __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, false));
+        }
+        a8[slot][0][sfr >> 1][2 * (sfr & 1)] = d[0];
+        a8[slot][0][sfr >> 1][2 * (sfr & 1) + 1] = d[1];
+      }
     };
     __syncthreads();  // the previous row block's staging / statistics reads are done (and the bias table is visible) before DMA reuses the LDS
     // (the order is pinned: hipcc counts the operations behind a register load to size the vmcnt wait in front of its first use, and takes the
@@ -722,9 +740,7 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_mx_pair_kernel(N384X3Params 
     for (int c = 0; c < MXD; ++c) {
       load_ah(c, c);
       __builtin_amdgcn_sched_barrier(0);
-      load_a8(c, c, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_a8(c, c, 1);
+      load_a8(c, c);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -760,15 +776,17 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_mx_pair_kernel(N384X3Params 
         // buffer and return zeros into registers nobody reads -- so that the count is a constant of the stage kind: waiting for "all but nine"
         // also waited for A fragments requested from HBM two stages earlier, 125 cycles per stage)
         if constexpr (VAR != 4) {
-          // A loads of the three stages before a stage of kind 0 / 1 / 2 / 3: 8 / 4 / 6 / 6 -- behind the prologue (whose A loads all precede its
-          // pieces) stages 0 / 1 / 2 see 0 / 0 / 4 (uniform branches at a stage boundary, where the barrier ends the scheduling region anyway)
+          // A loads per stage kind: 0 / 4 (fp16 fragments) / 0 / 2 (l8 halves); of the three stages before a stage of kind 0 / 1 / 2 / 3: 6 / 2 / 6 / 4 -- behind
+          // the prologue (whose A loads all precede its pieces) stages 0 / 1 / 2 see 0 / 0 / 4 (uniform branches at a stage boundary, where the barrier ends
+          // the scheduling region anyway)
           constexpr int W3 = (PNS - 3) * PFW;
-          if (jj == 0) { if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 8) : "memory"); }
-          else if (jj == 1) { if (i == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 4) : "memory"); }
+          if (jj == 0) { if (i == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 6) : "memory"); }
+          else if (jj == 1) { if (i == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 2) : "memory"); }
           else if (jj == 2) { if (i == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 4) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 6) : "memory"); }
-          else if ((jj & 3) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 8) : "memory");
-          else if ((jj & 3) == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 4) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 6) : "memory");
+          else if ((jj & 3) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 6) : "memory");
+          else if ((jj & 3) == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 2) : "memory");
+          else if ((jj & 3) == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 6) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W3 + 4) : "memory");
           __builtin_amdgcn_s_barrier();
         }
         if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
@@ -785,6 +803,7 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_mx_pair_kernel(N384X3Params 
           for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int t = 0; t < 2; ++t) wq[nx][x][t] = *(const u32x4_t*)(src + rdw + x * W_PLANE + t * 1024);
+          if (kind == 1 && pr == 0) derive_h8(slot);   // (the fp16 fragments of this 64-k step are in: stage kind 0 has used them; VALU work beside this stage's MFMAs)
           if (kind < 2) {
 #pragma unroll
             for (int x = 0; x < 2; ++x)
@@ -824,8 +843,7 @@ __global__ __launch_bounds__(512, 1) void gemm_n384_mx_pair_kernel(N384X3Params 
         const int c2 = (i >> 2) + MXD;
         if constexpr (!(VAR & 2) || VAR == 4) {
           if (kind == 1) load_ah(c2, slot);
-          if (kind == 2) load_a8(c2, slot, 0);
-          if (kind == 3) load_a8(c2, slot, 1);
+          if (kind == 3) load_a8(c2, slot);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TIMING) { t_wait += c1 - c0; t_steps += (long long)__builtin_amdgcn_s_memtime() - c1; }
@@ -915,21 +933,21 @@ int wvn_gemm_n384_x3_frag_launch(const GemmBf16Params& g, int epi, hipStream_t s
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
-// MX form (see gemm_n384_mx_pair_kernel): A = fragment-major fp16 plane (g.A) + the two 8-bit planes (g.A_lo = l8, g.A_h8 = h8, both behind g.A
-// within 4 GB); W = backbone.pack_n384_mx's stage list (4 * 384 * K bytes).  K % 128 == 0.
+// MX form (see gemm_n384_mx_pair_kernel): A = fragment-major fp16 plane (g.A) + the l8 plane (g.A_lo, behind g.A within 4 GB; the h8 operand is derived in
+// registers); W = backbone.pack_n384_mx's stage list (4 * 384 * K bytes).  K % 128 == 0.
 int wvn_gemm_n384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   if (epi != EPI_RESID_F32 && epi != EPI_ACCUM_F32) return WVN_ERR_ARG;
-  if (g.N != NN || g.K <= 0 || (g.K % 128) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.A_h8 || !g.W || !g.C || (g.ldc % 4)) return WVN_ERR_ARG;
-  if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.A_h8 | (uintptr_t)g.W | (uintptr_t)g.C) & 15) return WVN_ERR_ARG;
+  if (g.N != NN || g.K <= 0 || (g.K % 128) != 0 || g.M <= 0 || !g.A || !g.A_lo || !g.W || !g.C || (g.ldc % 4)) return WVN_ERR_ARG;
+  if (((uintptr_t)g.A | (uintptr_t)g.A_lo | (uintptr_t)g.W | (uintptr_t)g.C) & 15) return WVN_ERR_ARG;
   const size_t mpad = (size_t)(g.M + 31) / 32 * 32;
-  const uintptr_t a0 = (uintptr_t)g.A, al = (uintptr_t)g.A_lo, ah = (uintptr_t)g.A_h8;
-  if (al < a0 + mpad * g.K * 2 || ah < a0 + mpad * g.K * 2) return WVN_ERR_ARG;
-  const uintptr_t top = (al > ah ? al : ah) + mpad * g.K;
+  const uintptr_t a0 = (uintptr_t)g.A, al = (uintptr_t)g.A_lo;
+  if (al < a0 + mpad * g.K * 2) return WVN_ERR_ARG;
+  const uintptr_t top = al + mpad * g.K;
   if (top - a0 >= (1ull << 32) || (size_t)g.M * g.ldc * 4 >= (1ull << 32) || (size_t)4 * NN * g.K >= (1ull << 31)) return WVN_ERR_ARG;
   N384X3Params p{};
   p.A = g.A; p.a_plane = 0; p.lda = g.K; p.W = g.W; p.w_plane = 0; p.ldw = g.K; p.bias = g.bias; p.ls = g.ls;
   p.C = (float*)g.C; p.ldc = g.ldc; p.M = g.M; p.K = g.K; p.dbg = g.dbg; p.stats = g.ln_stats_out; p.eps = g.ln_eps;
-  N384MXExtra ex{(unsigned)(al - a0), (unsigned)(ah - a0)};
+  N384MXExtra ex{(unsigned)(al - a0)};
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(PAIR_LDS_BYTES, (const void*)gemm_n384_mx_pair_kernel<false>, (const void*)gemm_n384_mx_pair_kernel<true>,
                                 (const void*)gemm_n384_mx_pair_kernel<true, 1>, (const void*)gemm_n384_mx_pair_kernel<true, 2>,
