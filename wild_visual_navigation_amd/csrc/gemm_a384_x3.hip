@@ -111,12 +111,17 @@ __device__ inline void gelu_pair(float& x0, float& x1) {
 // h8 = e5m2(v) -- for both operands: per k-step region TWO fp16 MFMAs (hi * hi of the two column halves) and ONE scaled e5m2 MFMA of K = 64 (one of
 // the slice's eight correction products: 2 column halves x 2 64-k steps x {a_h8 w_l8, a_l8 w_h8}) = 128 matrix-pipe cycles instead of 192, the same
 // four ds_read_b128.  W: plane 0 = fp16 [N][384]; plane 1 = bytes [N][768] in the chunk order the kernel reads them (backbone.pack_a384_mx).
-// The row block's operands stay resident as before: 24 fp16 fragments + 6 + 6 eight-register e5m2 operands = the same 192 registers.
+// The row block's operands stay resident: 24 fp16 fragments + 6 eight-register l8 operands = 144 registers; a_h8 = e5m2(a_h) is derived from the fp16 fragments once per
+// (slice, 64-k step) -- 16 conversions for two regions -- which is also what the row-panel consumer does with ITS activations (one definition of h8 for activations: e5m2(fp16(v))).
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) short s16x2_t;
 constexpr int MX_SC_ONE = 0x7f7f7f7f, MX_SC_RES = 0x73737373;   // E8M0 scale bytes 2^0 / 2^-12 (every byte alike)
-constexpr float MX_RES_INV = 1.0f / 4096.0f;                    // v_cvt_scalef32_* DIVIDES by its scale operand (scripts/ubench/mx_formats.hip)
+constexpr float MX_RES_INV = 1.0f / 4096.0f;
+#ifndef WVN_MXG
+#define WVN_MXG 12
+#endif
+constexpr int MXG = WVN_MXG;   // k-steps of fp32 rows requested at a time by the MX LayerNorm-on-load prologue (12: two HBM round trips per row block)                    // v_cvt_scalef32_* DIVIDES by its scale operand (scripts/ubench/mx_formats.hip)
 __device__ inline uint32_t mx_pk8(uint32_t old, float a, float b, float inv_scale, bool hi_word) {
   const s16x2_t o = __builtin_bit_cast(s16x2_t, old);
   return __builtin_bit_cast(uint32_t, hi_word ? __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(o, a, b, inv_scale, true)
@@ -177,7 +182,8 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     for (int i = tid; i < 2 * KD; i += 256) ((float*)(smem + BIAS_OFF + p.N * 4))[i] = i < KD ? p.ln_g[i] : p.ln_b[i - KD];
   bf16x8_t xh[KD / 16], xl[KD / 16];
   u32x4_t mh[KD / 16];                    // MX: the fp16 fragments
-  u32x4_t m8[2][KD / 64][2];              // MX: [0 = h8 | 1 = l8][64-k step][half]: dword 2 (s & 1) + e of half (s >> 1) & 1 = bytes j = 4 e .. 4 e + 3 of k-step s
+  u32x4_t m8[KD / 64][2];                 // MX: the l8 operands [64-k step][half]: dword 2 (s & 1) + e of half (s >> 1) & 1 = bytes j = 4 e .. 4 e + 3 of k-step s
+  //                                          (the h8 operands are derived per use from mh: e5m2 of the fp16 image)
   auto load_a = [&]() __attribute__((always_inline)) {
     if constexpr (LNA && MX) {
       const int row = min(m0w + l31, p.M - 1);
@@ -185,17 +191,17 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
       const float a1 = st[1], a0 = -st[0] * st[1];
       const float* xr = p.ln_x + (size_t)row * p.ln_ldx + hi * 8;
 #pragma unroll
-      for (int s0 = 0; s0 < KD / 16; s0 += 12) {
-        f32x4_t u[24];
+      for (int s0 = 0; s0 < KD / 16; s0 += MXG) {
+        f32x4_t u[2 * MXG];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < MXG; ++i) {
           u[2 * i] = *(const f32x4_t*)(xr + (s0 + i) * 16);
           u[2 * i + 1] = *(const f32x4_t*)(xr + (s0 + i) * 16 + 4);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < MXG; ++i) {
           const int s = s0 + i;
           const f32x4_t g0 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8), g1 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8 + 4);
           const f32x4_t b0 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8), b1 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8 + 4);
@@ -206,23 +212,19 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
             y[4 + e] = fmaf(fmaf(u[2 * i + 1][e], a1, a0), g1[e], b1[e]);
           }
           u32x4_t hv;
-          uint32_t d8[2][2] = {{0, 0}, {0, 0}};   // [h8 | l8][dword]
+          uint32_t d8[2] = {0, 0};   // the l8 dwords of this k-step
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
             const uint32_t hb = pack_f16x2(y[2 * e], y[2 * e + 1]);   // (bit_cast of the SCALAR: clang reads element 0 when handed a vector element)
             hv[e] = hb;
             const h2_t hh = __builtin_bit_cast(h2_t, hb);
-            d8[0][e >> 1] = mx_pk8(d8[0][e >> 1], y[2 * e], y[2 * e + 1], 1.0f, e & 1);
-            d8[1][e >> 1] = mx_pk8(d8[1][e >> 1], y[2 * e] - (float)hh[0], y[2 * e + 1] - (float)hh[1], MX_RES_INV, e & 1);
+            d8[e >> 1] = mx_pk8(d8[e >> 1], y[2 * e] - (float)hh[0], y[2 * e + 1] - (float)hh[1], MX_RES_INV, e & 1);
           }
           asm volatile("" : "+v"(hv));
           mh[s] = hv;
-#pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            m8[w][s >> 2][(s >> 1) & 1][2 * (s & 1)] = d8[w][0];
-            m8[w][s >> 2][(s >> 1) & 1][2 * (s & 1) + 1] = d8[w][1];
-          }
+          m8[s >> 2][(s >> 1) & 1][2 * (s & 1)] = d8[0];
+          m8[s >> 2][(s >> 1) & 1][2 * (s & 1) + 1] = d8[1];
         }
       }
     } else if constexpr (LNA) {
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
   u32x4_t fragh = {0, 0, 0, 0}, fragl = {0, 0, 0, 0};   // X_GELU_FRAG: the fragment being assembled
   u32x4_t frag8l = {0, 0, 0, 0};  // MX: the 16-byte half of the l8 plane being assembled
   u32x4_t wq[2][2], w8[2][2];   // MX: [k-step parity][column half] fp16 fragments; [k-step parity][half] of the region's e5m2 operand
+  u32x4_t dh8[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // MX: a_h8 of the current 64-k step, derived from its four fp16 fragments (not resident: -48 registers)
   auto frag_read = [&](int slot, int s, int par) __attribute__((always_inline)) {
     const unsigned char* base = smem + slot * SLICE_BYTES + rd_base;
     if constexpr (MX) {
@@ -356,7 +359,23 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
     if constexpr (MX) {
       const int mm = s >> 2, which = (s >> 1) & 1, t8 = s & 1;
       const f16x8_t af = __builtin_bit_cast(f16x8_t, mh[ks * 8 + s]);
-      const u32x4_t a0 = m8[which][ks * 2 + mm][0], a1 = m8[which][ks * 2 + mm][1];
+      if (which == 0 && t8 == 0) {   // e5m2 of the fp16 image (what the row-panel consumer derives for ITS activations too), once per (slice, 64-k step): two regions use it
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+#pragma unroll
+        for (int sfr = 0; sfr < 4; ++sfr) {
+          uint32_t d[2] = {0, 0};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t pr = mh[ks * 8 + 4 * mm + sfr][e];   // (scalar copy before the bit_cast)
+            const s16x2_t o = __builtin_bit_cast(s16x2_t, d[e >> 1]);
+            d[e >> 1] = __builtin_bit_cast(uint32_t, (e & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, true)
+                                                             : __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, false));
+          }
+          dh8[sfr >> 1][2 * (sfr & 1)] = d[0];
+          dh8[sfr >> 1][2 * (sfr & 1) + 1] = d[1];
+        }
+      }
+      const u32x4_t a0 = which ? m8[ks * 2 + mm][0] : dh8[0], a1 = which ? m8[ks * 2 + mm][1] : dh8[1];
       const i32x8_t av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
       const u32x4_t w0 = w8[cur][0], w1 = w8[cur][1];
       const i32x8_t wv = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
