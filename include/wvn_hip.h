@@ -588,14 +588,14 @@ int wvn_debug_mlp_x3_frag(const void* xn, const void* xn_lo, const void* W1, con
 /* The MX form of the row-panel kernel (round 6; what WVN_PREC_MIX runs for fc2 and the attention projection by default): every operand as
  * an fp16 value h, the e5m2 image l8 of its rounding residue * 2^12 and the e5m2 image h8 of the value; the product = A_h W_h on fp16 MFMAs
  * + 2^-12 (A_h8 W_l8 + A_l8 W_h8) on scaled 8-bit MFMAs of K = 64 (csrc/gemm_n384_x3.hip: gemm_n384_mx_pair_kernel).  A_h: fragment-major
- * fp16 [ceil(M / 32)][K / 16][64 lanes][8]; A_l8 / A_h8: [ceil(M / 32)][K / 64][2 halves][64 lanes][16 bytes] (backbone.mx_fragments states
- * the element order), both behind A_h inside one 4 GB span; Wp: backbone.pack_n384_mx(W [384][K]); C [M][ldc] fp32 += (A W^T + bias) (* ls);
+ * fp16 [ceil(M / 32)][K / 16][64 lanes][8]; A_l8: [ceil(M / 32)][K / 64][2 halves][64 lanes][16 bytes] (backbone.mx_fragments states
+ * the element order), behind A_h inside one 4 GB span; A_h8 is ignored (may be NULL): the kernel derives e5m2(A_h) in registers; Wp: backbone.pack_n384_mx(W [384][K]); C [M][ldc] fp32 += (A W^T + bias) (* ls);
  * K % 128 == 0.  dbg as wvn_debug_gemm_n384_x3. */
 int wvn_debug_gemm_n384_mx(const void* A_h, const void* A_l8, const void* A_h8, const void* Wp, const float* bias, const float* ls, float* C,
                            int ldc, int M, int K, long long* dbg, void* stream);
 /* The block MLP of WVN_PREC_MIX in its MX form: hid = gelu(LayerNorm(x) W1^T + b1) by csrc/gemm_a384_x3.hip (LayerNorm formed on load from
- * ln_stats[m] = {mean, 1 / sqrt(var + eps)}; W1p = backbone.pack_a384_mx(fc1.weight)), written as the MX operand planes hid_h / hid_l8 / hid_h8
- * (fragment-major, ceil(M / 32) * 32 rows of F), then xout [M][384] fp32 += hid W2^T + b2 by the MX row-panel kernel (W2p =
+ * ln_stats[m] = {mean, 1 / sqrt(var + eps)}; W1p = backbone.pack_a384_mx(fc1.weight)), written as the MX operand planes hid_h / hid_l8 (hid_h8 is
+ * ignored and may be NULL) (fragment-major, ceil(M / 32) * 32 rows of F), then xout [M][384] fp32 += hid W2^T + b2 by the MX row-panel kernel (W2p =
  * backbone.pack_n384_mx(fc2.weight)).  W2p == NULL: fc1 only.  dbg1 / dbg2: per-wave cycle counters of the instrumented builds. */
 int wvn_debug_mlp_mx(const float* x, int ldx, const float* ln_stats, const float* ln_g, const float* ln_b, const void* W1p, const float* b1,
                      void* hid_h, void* hid_l8, void* hid_h8, const void* W2p, const float* b2, float* xout, int M, int F, long long* dbg1,
