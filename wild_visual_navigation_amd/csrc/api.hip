@@ -731,7 +731,11 @@ int wvn_debug_qkv_mx(const float* x, int ldx, const float* ln_stats, const float
   p.ln_x = x; p.ln_ldx = ldx; p.ln_stats = ln_stats; p.ln_g = ln_g; p.ln_b = ln_b;
   return wvn_gemm_a384_mx_launch(p, EPI_QKV, (hipStream_t)stream);
 }
-int wvn_debug_n384_pair(int on) { wvn_gemm_n384_x3_set_pair(on); return WVN_OK; }
+int wvn_debug_n384_pair(int on) {
+  if (on >= 32) { wvn_gemm_a384_mx_set_form(on - 32); return WVN_OK; }   // 33 / 34: form 1 / 2 of the A-stationary MX kernel
+  wvn_gemm_n384_x3_set_pair(on);
+  return WVN_OK;
+}
 int wvn_debug_kmeans_screen_stats(unsigned long long* out, int reset) { return out ? wvn_kmeans_pixels_screen_stats(out, reset) : WVN_ERR_ARG; }
 int wvn_debug_kmeans_assign_form(int form) { wvn_kmeans_pixels_set_assign_form(form); return WVN_OK; }
 int wvn_debug_attention_variant(int v) { wvn_attention_bf16_set_variant(v); wvn_attention_bf16_set_variant_f16(v); return WVN_OK; }

@@ -70,6 +70,7 @@ struct X384Params {
   // LNA: A = LayerNorm(ln_x) formed while the row block is loaded: ln_x fp32 [M][ln_ldx], ln_stats[m] = {mean, rstd} (left by the kernel
   // that wrote the rows: gemm_n384_x3.hip), gamma / beta [384]
   const float* ln_x; int ln_ldx; const float* ln_stats; const float* ln_g; const float* ln_b;
+  int stagger;                          // gemm_a384_mx2_kernel: the delay of a CU's second workgroup, in units of 64 shader cycles
 };
 
 __device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -710,6 +711,411 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
 }
 
 
+// ======================================================================================================================================
+// The MX form at TWO workgroups per CU (round 6, second half).  The kernel above keeps one wave per SIMD, and that wave issues everything
+// itself: per k-step region 128 cycles of MFMAs against ~240 of its own instruction stream (one 1 KB DMA piece = ~54 cycles of issue, a chunk
+// of the previous tile's GELU, four fragment reads and their waits).  Here the same work is cut so that TWO independent workgroups fit a CU
+// (<= 256 registers, <= 80 KB of LDS each) and one workgroup's DMA issue, LDS round trips, barriers, LayerNorm-on-load prologue and -- above
+// all -- epilogue run under the OTHER workgroup's MFMAs:
+//   * the ring holds slices of 64 (n) x 64 (k) = 16 KB as SIXTEEN CHUNK IMAGES [64 rows][16 B] (eight of the fp16 plane: k-step s, half hi -> image 2 s + hi;
+//     four of l8, four of h8), three slots; the weight is packed in exactly this order (backbone.pack_a384_mx, second image), so a slice is one contiguous
+//     16 KB block, a DMA piece is one contiguous kilobyte copied lane-linear, and a fragment read takes two contiguous 512-byte runs: no swizzle, one
+//     address register, every other offset an immediate;
+//   * a period = one slice = four regions (k-steps) of 2 fp16 MFMAs + 1 scaled MFMA; the correction products of a 64-k step: region 0 / 1 =
+//     W_l8 x a_h8 for column half 0 / 1, region 2 / 3 = W_h8 x a_l8;
+//   * no second accumulator set: the tile's epilogue runs serially behind its sixth period (nothing rides between the MFMAs, so the fragment
+//     reads are single-buffered through two alternating register sets and the schedule inside a region is left to the compiler);
+//   * resident: 24 fp16 fragments + 6 l8 operands (144 registers) + 32 accumulators + 2 x 16 of W fragments + a_h8 (8).
+constexpr int S2K = 64;
+constexpr int S2_NSL = KD / S2K;             // 6 slices per column tile
+constexpr int S2_NS = 3;
+constexpr int S2_SLICE = BNT * 256;          // 16 KB
+constexpr int S2_RING = S2_NS * S2_SLICE;    // 48 KB
+constexpr int S2_PIECES = S2_SLICE / 1024 / 4;   // 4 per wave and slice: one per region
+constexpr int S2_STG = 5120;                 // per wave (QKV): two fp16 images of a column half [32][80 B] (q | k: the plane and its residue), or one V^T half [32 n][80 B]
+static_assert(S2_PIECES == 4, "one DMA piece per region");
+
+template <int EPI, bool TIMING = false>
+__global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
+  static_assert(EPI == X_GELU_FRAG || EPI == X_QKV_F16, "fc1 + GELU -> MX planes, or q | k | v^T fp16");
+  constexpr bool IS_QKV = EPI == X_QKV_F16;
+  wvn_fp16_saturate();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int NT = p.N / BNT;
+  const int NRB = (p.M + BM - 1) / BM;
+  const long long U = (long long)NRB * NT;
+  const int u_begin = (int)(U * blockIdx.x / gridDim.x), u_end = (int)(U * (blockIdx.x + 1) / gridDim.x);
+  const int total = (u_end - u_begin) * S2_NSL;
+  constexpr int STG_OFF2 = S2_RING;
+  constexpr int BIAS_OFF2 = STG_OFF2 + (IS_QKV ? 4 * S2_STG : 0);
+  unsigned char* stg = smem + STG_OFF2 + wave * S2_STG;
+  const float* bias_l = (const float*)(smem + BIAS_OFF2);
+  const float* gam_l = (const float*)(smem + BIAS_OFF2 + p.N * 4);
+  int m0w = 0;
+
+  // ---- W ring producer: a slice = 16 contiguous kilobytes of the packed weight = sixteen chunk images [64 rows][16 B]; a piece = one chunk image, copied
+  // lane-linear (no swizzle: a fragment read takes 2 x 512 contiguous bytes) ----
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)p.N * KD * 4), 0x00020000);
+  const unsigned wvoff = lane * 16;
+  const int n_slices = NT * S2_NSL;
+  int iss_g = (u_begin % NT) * S2_NSL;    // the stream cursor: slice (tile j, k-slice) = j * 6 + sl, wrapping at the last tile
+  unsigned iss_soff = 0;
+  auto issue_begin = [&]() __attribute__((always_inline)) { iss_soff = __builtin_amdgcn_readfirstlane((unsigned)iss_g * (unsigned)S2_SLICE + wave * S2_PIECES * 1024); };
+  auto issue_piece = [&](int i, int u) __attribute__((always_inline)) {   // (u: compile-time constant -> the instruction's immediate offset, which the hardware adds to the LDS address too)
+    unsigned char* dst = smem + (i % S2_NS) * S2_SLICE + wave * S2_PIECES * 1024;
+    __attribute__((address_space(3))) void* d3 = (__attribute__((address_space(3))) void*)dst;
+    switch (u) {   // (the immediate must be a literal; u is a constant after unrolling and the switch folds)
+      case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 0, 0); break;
+      case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 1024, 0); break;
+      case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 2048, 0); break;
+      default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 3072, 0); break;
+    }
+  };
+  auto issue_end = [&]() __attribute__((always_inline)) { if (++iss_g == n_slices) iss_g = 0; };
+#pragma unroll
+  for (int i = 0; i < S2_NS - 1; ++i)
+    if (i < total) {
+      issue_begin();
+#pragma unroll
+      for (int u = 0; u < S2_PIECES; ++u) issue_piece(i, u);
+      issue_end();
+    }
+  for (int i = tid; i < p.N; i += 256) ((float*)(smem + BIAS_OFF2))[i] = p.bias ? p.bias[i] : 0.f;
+  for (int i = tid; i < 2 * KD; i += 256) ((float*)(smem + BIAS_OFF2 + p.N * 4))[i] = i < KD ? p.ln_g[i] : p.ln_b[i - KD];
+
+  u32x4_t mh[KD / 16];        // the row block's fp16 fragments
+  u32x4_t m8[KD / 64][2];     // its l8 operands [64-k step][half]
+  // LayerNorm on load: the prologue of the kernel above, six k-steps of fp32 rows in flight (the other workgroup covers the round trips)
+  auto load_a = [&]() __attribute__((always_inline)) {
+    const int row = min(m0w + l31, p.M - 1);
+    const wvn_f32x2_t st = *(const wvn_f32x2_t*)(p.ln_stats + 2 * (size_t)row);
+    const float a1 = st[1], a0 = -st[0] * st[1];
+    const float* xr = p.ln_x + (size_t)row * p.ln_ldx + hi * 8;
+    constexpr int G = 8;
+#pragma unroll
+    for (int s0 = 0; s0 < KD / 16; s0 += G) {
+      f32x4_t u[2 * G];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        u[2 * i] = *(const f32x4_t*)(xr + (s0 + i) * 16);
+        u[2 * i + 1] = *(const f32x4_t*)(xr + (s0 + i) * 16 + 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int s = s0 + i;
+        const f32x4_t g0 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8), g1 = *(const f32x4_t*)(gam_l + s * 16 + hi * 8 + 4);
+        const f32x4_t b0 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8), b1 = *(const f32x4_t*)(gam_l + KD + s * 16 + hi * 8 + 4);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = fmaf(fmaf(u[2 * i][e], a1, a0), g0[e], b0[e]);
+          y[4 + e] = fmaf(fmaf(u[2 * i + 1][e], a1, a0), g1[e], b1[e]);
+        }
+        u32x4_t hv;
+        uint32_t d8[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+          const uint32_t hb = pack_f16x2(y[2 * e], y[2 * e + 1]);   // (bit_cast of the SCALAR: clang reads element 0 when handed a vector element)
+          hv[e] = hb;
+          const h2_t hh = __builtin_bit_cast(h2_t, hb);
+          d8[e >> 1] = mx_pk8(d8[e >> 1], y[2 * e] - (float)hh[0], y[2 * e + 1] - (float)hh[1], MX_RES_INV, e & 1);
+        }
+        asm volatile("" : "+v"(hv), "+v"(d8[0]), "+v"(d8[1]));   // (pins the conversions HERE: left free they sink to their first use in the tile loop and the 192 fp32 values wait for them in scratch)
+        mh[s] = hv;
+        m8[s >> 2][(s >> 1) & 1][2 * (s & 1)] = d8[0];
+        m8[s >> 2][(s >> 1) & 1][2 * (s & 1) + 1] = d8[1];
+        __builtin_amdgcn_sched_barrier(0);   // (a k-step's residues are formed before the next one starts: left free, the scheduler parks all 192 fp32 values in scratch)
+      }
+    }
+  };
+
+  f32x16_t acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const unsigned rd_base = hi * 1024 + l31 * 16;   // chunk image (2 s + hi) of the slice, row l31 (+ 32 t: 512 B)
+
+  // ---- epilogue addressing ----
+  constexpr unsigned OOB = 0x80000000u;
+  const int nqk = IS_QKV ? 2 * p.heads : (1 << 30);
+  unsigned voff[2] = {0, 0};
+  unsigned vt_off = 0;
+  const unsigned c_bytes = IS_QKV ? 0u : (unsigned)((size_t)((p.M + 31) / 32 * 32) * p.ldc * 2);
+  const __amdgpu_buffer_rsrc_t rs_c = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base, 0, p.qkv_bytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c2 = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base_lo ? p.qkv_base_lo : p.qkv_base, 0, p.qkv_bytes, 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc(p.C_lo ? p.C_lo : p.C, 0, c_bytes / 2, 0x00020000);
+  auto qkv_offsets = [&]() __attribute__((always_inline)) {
+    // q | k half images: a row = 32 columns = 64 B = four lanes; a store instruction covers 16 rows
+#pragma unroll
+    for (int hblk = 0; hblk < 2; ++hblk) {
+      const int m = m0w + hblk * 16 + (lane >> 2);
+      const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
+      voff[hblk] = m < p.M ? (unsigned)((((size_t)b * p.heads * p.npad + tk) * 64 + (lane & 3) * 8) * 2) : OOB;
+    }
+    {
+      const int m = m0w + (lane & 3) * 8;
+      const int b = m / p.ntok_s, tk = m - b * p.ntok_s;
+      vt_off = m < p.M ? (unsigned)((((size_t)b * p.heads * 64 + (lane >> 2)) * p.npad + tk) * 2) : OOB;
+    }
+  };
+
+  // ONE set of W fragment registers per region, refilled in the order it is consumed: r0 (the fp16 fragment of the column half the region's FIRST MFMA takes),
+  // w8 (the region's e5m2 operand: second MFMA), r1 (the other fp16 fragment: third MFMA).  The read that refills a register is requested right behind the issue
+  // of the MFMA that consumed it (operands are read when an MFMA starts; the LDS data comes back a round trip later), so a register's turn-around is one LDS round
+  // trip, not a round trip plus the region's three MFMAs.
+  u32x4_t r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, w8[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  u32x4_t dh8[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  // region s of a slice: scaled MFMA on column half t8 = s & 1 (which = s >> 1: 0 = W_l8 x a_h8, 1 = W_h8 x a_l8); MFMA order: fp16 on half t8 ^ 1, scaled on t8, fp16 on t8
+  auto read_r0 = [&](int slot, int s) __attribute__((always_inline)) { r0 = *(const u32x4_t*)(smem + slot * S2_SLICE + rd_base + s * 2048 + ((s & 1) ^ 1) * 512); };
+  auto read_r1 = [&](int slot, int s) __attribute__((always_inline)) { r1 = *(const u32x4_t*)(smem + slot * S2_SLICE + rd_base + s * 2048 + (s & 1) * 512); };
+  auto read_w8 = [&](int slot, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) w8[x] = *(const u32x4_t*)(smem + slot * S2_SLICE + rd_base + 8192 + (s >> 1) * 4096 + x * 2048 + (s & 1) * 512);
+  };
+  auto derive_h8 = [&](int sl) __attribute__((always_inline)) {   // a_h8 = e5m2 of the fp16 image of this 64-k step (what the row-panel consumer derives for its activations too)
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+#pragma unroll
+    for (int sfr = 0; sfr < 4; ++sfr) {
+      uint32_t d[2] = {0, 0};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t pr = mh[sl * 4 + sfr][e];
+        const s16x2_t o = __builtin_bit_cast(s16x2_t, d[e >> 1]);
+        d[e >> 1] = __builtin_bit_cast(uint32_t, (e & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, true)
+                                                         : __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, false));
+      }
+      dh8[sfr >> 1][2 * (sfr & 1)] = d[0];
+      dh8[sfr >> 1][2 * (sfr & 1) + 1] = d[1];
+    }
+  };
+  auto mfma_f16 = [&](int sl, int s, int t, u32x4_t wreg, auto tr_tag) __attribute__((always_inline)) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const f16x8_t af = __builtin_bit_cast(f16x8_t, mh[sl * 4 + s]);
+    const f16x8_t wf = __builtin_bit_cast(f16x8_t, wreg);
+    if constexpr (TR) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[t], 0, 0, 0);
+    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, acc[t], 0, 0, 0);
+  };
+  auto mfma_s8 = [&](int sl, int s, auto tr_tag) __attribute__((always_inline)) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int which = s >> 1, t8 = s & 1;
+    const u32x4_t a0 = which ? m8[sl][0] : dh8[0], a1 = which ? m8[sl][1] : dh8[1];
+    const i32x8_t av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    const u32x4_t w0 = w8[0], w1 = w8[1];
+    const i32x8_t wv = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+    // which 0: W_l8 (carries 2^12) x a_h8;  which 1: W_h8 x a_l8 (carries 2^12)
+    if constexpr (TR) acc[t8] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc[t8], 1, 1, 0, which ? MX_SC_ONE : MX_SC_RES, 0, which ? MX_SC_RES : MX_SC_ONE);
+    else acc[t8] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, wv, acc[t8], 1, 1, 0, which ? MX_SC_RES : MX_SC_ONE, 0, which ? MX_SC_ONE : MX_SC_RES);
+  };
+
+  auto init_acc = [&](int j, auto tr_tag) __attribute__((always_inline)) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int n0 = j * BNT;
+    if constexpr (TR) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t b4 = *(const f32x4_t*)(bias_l + n0 + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b4[e];
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float b = bias_l[n0 + 32 * t + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b;
+      }
+    }
+  };
+
+  // ---- the tile's epilogue, serial (the CU's other workgroup has the matrix pipe meanwhile) ----
+  auto epilogue = [&](int jp, auto tr_tag) __attribute__((always_inline)) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int n0 = jp * BNT;
+    if constexpr (!IS_QKV) {
+      // TR accumulators: lane (row l31, half hi) holds columns 32 t + 8 g + 4 hi + e.  The consumer's 64-k step jp: fragment (k-step 4 jp + 2 t + (g >> 1)) element
+      // order = the accumulators' own; l8 half t = the 16 bytes of the lane in register order
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        u32x4_t frag8l = {0, 0, 0, 0};
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          u32x4_t fragh;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {   // chunk s = 4 gg + c of the interleaved form: g = s >> 1, h2 = (s & 1) * 2
+            const int s = 4 * gg + c, g = s >> 1, h2 = (s & 1) * 2;
+            float v0 = acc[t][4 * g + h2], v1 = acc[t][4 * g + h2 + 1];
+            gelu_pair(v0, v1);
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+            typedef __attribute__((ext_vector_type(2))) float f2_t;
+            const uint32_t h = pack_f16x2(v0, v1);
+            const h2_t hh = __builtin_bit_cast(h2_t, h);
+            fragh[2 * (g & 1) + (h2 >> 1)] = h;
+            const f2_t res = f2_t{v0, v1} - f2_t{(float)hh[0], (float)hh[1]};
+            frag8l[s >> 1] = mx_pk8(frag8l[s >> 1], res[0], res[1], MX_RES_INV, s & 1);
+            if (c & 1) __builtin_amdgcn_sched_barrier(0);   // (two pairs at a time: with more in flight -- or with one -- the register allocation of the tile loop no longer fits)
+          }
+          const unsigned so = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 4)) + 4 * jp + 2 * t + gg) * 1024);
+          wvn_store_b128_guarded(fragh, rs_c, lane * 16, so);
+        }
+        const unsigned so8 = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 6)) + jp) * 2048 + t * 1024);
+        wvn_store_b128_guarded(frag8l, rs_c2, lane * 16, so8);
+      }
+    } else if constexpr (TR) {
+      // a q | k tile = one head's 64 dims of 32 tokens: per column half an fp16 image [32 tokens][32 dims] (rows of 80 B) and the image of the rounding
+      // residues behind it; q pre-scaled.  Then 16 bytes per lane: 4 lanes per token row, 16 rows per store
+      const int D = p.heads * 64;
+      const int which = n0 / D, head = (n0 - which * D) >> 6;
+      const float qs = which == 0 ? p.q_scale : 1.f;
+      const bool keep_lo = which == 0 && p.q_lo_f16;
+      const unsigned so = __builtin_amdgcn_readfirstlane((which == 0 ? p.q_off : p.k_off) + head * p.npad * 64 * 2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int h2 = 0; h2 < 4; h2 += 2) {
+            uint32_t h, l;
+            wvn_split2_f16(acc[t][4 * g + h2] * qs, acc[t][4 * g + h2 + 1] * qs, h, l);
+            const int c = 8 * g + 4 * hi + h2;
+            *(uint32_t*)(stg + l31 * 80 + c * 2) = h;
+            *(uint32_t*)(stg + 2560 + l31 * 80 + c * 2) = l;
+          }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+          wvn_store_b128_guarded(val, rs_c, voff[it], so + t * 64);
+        }
+        if (keep_lo) {
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const u32x4_t val = *(const u32x4_t*)(stg + 2560 + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+            wvn_store_b128_guarded(val, rs_c2, voff[it], so + t * 64);
+          }
+        }
+      }
+    } else {
+      // V^T: lane (row n = l31 of half t, half hi) holds tokens 8 g + 4 hi + e; image [32 n][32 tokens] with bits 2 and 3 of the token index swapped inside
+      // aligned groups of 16 (the attention kernel's V^T fragment order), rows of 80 B; 4 lanes per row, 16 rows per store
+      const int head = (n0 - 2 * p.heads * 64) >> 6;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int h2 = 0; h2 < 4; h2 += 2) {
+            const int mloc = 16 * (g >> 1) + 8 * hi + 4 * (g & 1) + h2;
+            *(uint32_t*)(stg + l31 * 80 + mloc * 2) = pack_f16x2(acc[t][4 * g + h2], acc[t][4 * g + h2 + 1]);
+          }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+          const unsigned so = __builtin_amdgcn_readfirstlane(p.v_off + (head * 64 + 32 * t + it * 16) * p.npad * 2);
+          wvn_store_b128_guarded(val, rs_c, vt_off, so);
+        }
+      }
+    }
+  };
+
+  // ---- one slice period: barrier (every wave has waited for its pieces of slice i at the END of its previous period), the four regions with the DMA
+  // requests of slice i + 2 riding along, then the wait for this wave's pieces of slice i + 1 -- BEFORE the epilogue's stores are issued, so the queue at the
+  // wait is exactly DMA(i + 1), DMA(i + 2) whatever follows (pieces are requested unconditionally; past the workgroup's last slice the cursor wraps to valid
+  // rows and the data lands in a slot nobody reads again) ----
+  long long t_bar = 0, t_loop = 0, t_epi = 0, t_pro = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  auto period = [&](int i, int sl, auto tr_tag) __attribute__((always_inline)) {
+    long long c0 = 0, c1 = 0, c2 = 0;
+    if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
+    issue_begin();
+    read_r0(i % S2_NS, 0);
+    read_w8(i % S2_NS, 0);
+    read_r1(i % S2_NS, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int t8 = s & 1;
+      issue_piece(i + S2_NS - 1, s);
+      if (s == 0) derive_h8(sl);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_f16(sl, s, t8 ^ 1, r0, tr_tag);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < 4) read_r0(i % S2_NS, s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_s8(sl, s, tr_tag);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < 4) read_w8(i % S2_NS, s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_f16(sl, s, t8, r1, tr_tag);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < 4) read_r1(i % S2_NS, s + 1);
+    }
+    issue_end();
+    if constexpr (TIMING) c2 = (long long)__builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S2_PIECES) : "memory");
+    if constexpr (TIMING) { t_bar += c1 - c0 + (long long)__builtin_amdgcn_s_memtime() - c2; t_loop += c2 - c1; }
+  };
+  int si = 0;
+  auto tile = [&](int j, bool last, auto tr_tag, auto next_tr) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sl = 0; sl < S2_NSL; ++sl) period(si + sl, sl, tr_tag);
+    si += S2_NSL;
+    const long long e0 = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    epilogue(j, tr_tag);
+    if (!last) init_acc(j + 1, next_tr);
+    if constexpr (TIMING) t_epi += (long long)__builtin_amdgcn_s_memtime() - e0;
+  };
+
+  __syncthreads();
+  // Two workgroups with identical work that start together stay in phase: both in their MFMA periods (sharing the pipe), then both in their epilogues (the pipe
+  // idle) -- measured: a wave's regions took 2.2 x their MFMA time and its epilogues ran against the neighbour's.  The workgroup whose waves sit in the ODD wave
+  // slots of their SIMDs (the second one the CU received) starts half a tile late; in the fluid model of two waves sharing a pipe an offset persists.
+  if ((__builtin_amdgcn_s_getreg(0x1804) & 1) != 0)   // HW_REG_HW_ID, bits 3:0 = the wave's slot on its SIMD
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  for (int u = u_begin; u < u_end;) {
+    const int rb = u / NT, j0 = u - rb * NT, j1 = min(NT, j0 + (u_end - u));
+    m0w = rb * BM + wave * 32;
+    const long long l0 = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    load_a();
+    if constexpr (IS_QKV) qkv_offsets();
+    // (the first barrier of a row block: this wave's pieces of the next slice -- and everything else it has in flight -- have landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (TIMING) t_pro += (long long)__builtin_amdgcn_s_memtime() - l0;
+    using T = std::true_type; using F = std::false_type;
+    if constexpr (IS_QKV) {
+      if (j0 < nqk) init_acc(j0, T{}); else init_acc(j0, F{});
+      for (int j = j0; j < j1; ++j) {
+        if (j + 1 < nqk) tile(j, j + 1 == j1, T{}, T{});
+        else if (j < nqk) tile(j, j + 1 == j1, T{}, F{});
+        else tile(j, j + 1 == j1, F{}, F{});
+      }
+    } else {
+      init_acc(j0, T{});
+      for (int j = j0; j < j1; ++j) tile(j, j + 1 == j1, T{}, T{});
+    }
+    u += j1 - j0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (TIMING) {   // per wave {wait + barrier, row-block prologues, regions, total}; the epilogues = total - the three
+    if (lane == 0 && p.dbg) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+      d[0] = t_bar; d[1] = t_pro; d[2] = t_loop; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+      if (p.stagger < 0) { d[0] = __builtin_amdgcn_s_getreg(0xf804); d[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20); d[2] = t_start; }   // (probe: HW_ID, XCC_ID, start time)
+      (void)t_epi;
+    }
+  }
+}
+
+
 bool g_x384_split_qkv = getenv("WVN_X384_SPLIT_QKV") != nullptr;   // A/B: q | k and v^T as two launches (the form before the merged kernel)
 
 int x384_num_cus() {
@@ -746,6 +1152,30 @@ int launch_mx(const X384Params& p, hipStream_t st) {
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
+
+int g_a384_mx_stagger = [] { const char* e = getenv("WVN_A384_STAGGER"); return e ? atoi(e) : 56; }();   // x 64 cycles: about half a tile
+
+// (form 2: the two-workgroups-per-CU kernel; its weight image lies N * 1536 bytes behind the first one -- backbone.pack_a384_mx)
+template <int EPI>
+int launch_mx2(X384Params p, hipStream_t st) {
+  if (!p.ln_x || !p.ln_stats || !p.ln_g || !p.ln_b || (p.ln_ldx % 4) || ((uintptr_t)p.ln_x & 15) || ((uintptr_t)p.ln_stats & 7)) return WVN_ERR_ARG;
+  p.W = (const bf16_t*)((const unsigned char*)p.W + (size_t)p.N * KD * 4);
+  p.stagger = g_a384_mx_stagger;
+  const int lds = S2_RING + (EPI == X_QKV_F16 ? 4 * S2_STG : 0) + p.N * 4 + 2 * KD * 4;
+  if (lds > 80 * 1024) return WVN_ERR_ARG;
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(80 * 1024, (const void*)gemm_a384_mx2_kernel<EPI>, (const void*)gemm_a384_mx2_kernel<EPI, true>)) return rc;
+  const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
+  static const bool one_per_cu = getenv("WVN_A384_MX2_ONE") != nullptr;   // (experiment: one workgroup per CU -- what a wave does when it has its SIMD to itself)
+  const int cap = (one_per_cu ? 1 : 2) * x384_num_cus();
+  const int grid = (int)(units < cap ? units : cap);
+  if (p.dbg) hipLaunchKernelGGL((gemm_a384_mx2_kernel<EPI, true>), dim3(grid), dim3(256), lds, st, p);   // (dbg: 2 x CUs x 4 waves x 4 counters)
+  else hipLaunchKernelGGL((gemm_a384_mx2_kernel<EPI>), dim3(grid), dim3(256), lds, st, p);
+  WVN_LAUNCH_CHECK();
+  return WVN_OK;
+}
+
+int g_a384_mx_form = [] { const char* e = getenv("WVN_A384_MX_FORM"); return e && e[0] == '2' ? 2 : 1; }();
 
 template <int EPI>
 int launch(const X384Params& p, hipStream_t st) {
@@ -836,7 +1266,10 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   }
 }
 
-// MX form (LayerNorm on load only): W = backbone.pack_a384_mx (plane 0 fp16 [N][384] at g.W, plane 1 bytes [N][768] at g.W_lo); EPI_GELU_FRAG writes the
+void wvn_gemm_a384_mx_set_form(int form) { g_a384_mx_form = form == 1 ? 1 : 2; }
+
+// MX form (LayerNorm on load only): W = backbone.pack_a384_mx (plane 0 fp16 [N][384] at g.W, plane 1 bytes [N][768] at g.W_lo, the slice-major image of the
+// two-workgroups-per-CU kernel behind them; WVN_A384_MX_FORM=1 / wvn_gemm_a384_mx_set_form(1): the one-wave-per-SIMD kernel; a cycle-counter request takes it too); EPI_GELU_FRAG writes the
 // MX operand planes of gemm_n384_x3.hip's MX kernel (g.C fp16 fragments, g.C_lo = l8; h8 is derived by the consumer), EPI_QKV the fp16 q (| q_lo) | k | v^T planes.
 int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   if (!g.ln_x || g.K != KD || g.ldw != KD || (g.N % BNT) != 0 || g.M <= 0 || !g.W || !g.W_lo) return WVN_ERR_ARG;
@@ -852,7 +1285,7 @@ int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
     case EPI_GELU_FRAG:
       if (!g.C || !g.C_lo || g.ldc != g.N || (g.N % 64) || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || ((size_t)g.M + 32) * g.ldc * 2 >= (1ull << 31))
         return WVN_ERR_ARG;
-      return launch_mx<X_GELU_FRAG>(p, st);
+      return g_a384_mx_form == 2 ? launch_mx2<X_GELU_FRAG>(p, st) : launch_mx<X_GELU_FRAG>(p, st);
     case EPI_QKV: {
       if (!g.qkv_f16 || g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 16) || (g.M % 16) || (g.npad % 16)) return WVN_ERR_ARG;
       const uintptr_t lo = std::min({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
@@ -866,7 +1299,7 @@ int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
         p.qkv_base_lo = (bf16_t*)((uintptr_t)g.q_lo - p.q_off);
         p.q_lo_f16 = 1;
       }
-      return launch_mx<X_QKV_F16>(p, st);
+      return g_a384_mx_form == 2 ? launch_mx2<X_QKV_F16>(p, st) : launch_mx<X_QKV_F16>(p, st);
     }
     default: return WVN_ERR_ARG;
   }
