@@ -63,9 +63,19 @@ def _unfrag(h, l8, h8, M, K):
     return (hf.double() + outs[0] / MX_RES_SCALE)[:M], outs[1][:M]
 
 
-@pytest.mark.parametrize("M", [12608, 128 * 65 + 16])
-def test_mx_block_mlp_every_row(dev, M):
-    """LayerNorm-on-load fc1 + GELU writes the MX operand planes (fp16 fragments, l8, h8), the MX row-panel kernel consumes them."""
+@pytest.fixture(params=[2, 1], ids=["two-workgroups-per-cu", "one-wave-per-simd"])
+def a384_form(request):
+    """Both forms of the A-stationary MX kernel (csrc/gemm_a384_x3.hip: gemm_a384_mx2_kernel, the default, and gemm_a384_x3_kernel<..., MX>)."""
+    lib = _lib.lib()
+    lib.wvn_debug_n384_pair(32 + request.param)
+    yield request.param
+    lib.wvn_debug_n384_pair(32)
+
+
+@pytest.mark.parametrize("M", [12608, 128 * 65 + 16, 128 * 530 + 40])
+def test_mx_block_mlp_every_row(dev, M, a384_form):
+    """LayerNorm-on-load fc1 + GELU writes the MX operand planes (fp16 fragments, l8), the MX row-panel kernel consumes them.  (The largest M
+    gives the two-workgroups-per-CU form more than one row block per workgroup and row blocks shared between workgroups.)"""
     from wild_visual_navigation_amd.backbone import pack_a384_mx
     lib = _lib.lib()
     F = 1536
@@ -95,11 +105,12 @@ def test_mx_block_mlp_every_row(dev, M):
     assert torch.equal(xo[M:], x0[M:])
 
 
-def test_mx_qkv(dev):
+@pytest.mark.parametrize("B", [4, 22])
+def test_mx_qkv(dev, B, a384_form):
     """LayerNorm-on-load + q | k | v^T with the MX products: fp16 planes in the attention kernel's layouts (q pre-scaled, two planes)."""
     from wild_visual_navigation_amd.backbone import pack_a384_mx
     lib = _lib.lib()
-    B, ntok, heads = 4, 3137, 6
+    ntok, heads = 3137, 6
     ntok_s, npad = 3152, 3200
     M = B * ntok_s
     x = torch.randn(M, 384, generator=g(11)) * 1.3
@@ -107,9 +118,9 @@ def test_mx_qkv(dev):
     w, b = torch.randn(1152, 384, generator=g(1)) * 0.06, torch.randn(1152, generator=g(2)) * 0.02
     qs = 0.125 * 1.4426950408889634
     d = lambda t: t.to(dev).contiguous()   # noqa: E731
-    q = torch.zeros(2, B, heads, npad, 64, dtype=torch.float16, device=dev)
-    k = torch.zeros(B, heads, npad, 64, dtype=torch.float16, device=dev)
-    vt = torch.zeros(B, heads, 64, npad, dtype=torch.float16, device=dev)
+    per = B * heads * npad * 64
+    buf = torch.zeros(4 * per, dtype=torch.float16, device=dev)          # (one allocation: the kernel addresses q | k | v^T through one buffer descriptor)
+    q, k, vt = buf[:2 * per].view(2, B, heads, npad, 64), buf[2 * per:3 * per].view(B, heads, npad, 64), buf[3 * per:].view(B, heads, 64, npad)
     xd, sd_, gd, bd, wp, bb = d(x), d(_ln_stats(x)), d(gam), d(bet), pack_a384_mx(d(w)), d(b)
     _lib.check(lib.wvn_debug_qkv_mx(xd.data_ptr(), 384, sd_.data_ptr(), gd.data_ptr(), bd.data_ptr(), wp.data_ptr(), bb.data_ptr(), q[0].data_ptr(), q[1].data_ptr(),
                                     k.data_ptr(), vt.data_ptr(), heads, npad, ntok_s, qs, M, 0, _lib.stream()), "qkv_mx")

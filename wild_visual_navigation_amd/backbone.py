@@ -132,17 +132,17 @@ def pack_a384_mx(w: torch.Tensor) -> torch.Tensor:
     Image 0 (the one-wave-per-SIMD kernel): plane 0 = fp16(W) row-major, plane 1 = per 128-k slice ks sixteen 16-byte chunks, chunk 2 s'' + h with
     s'' = 4 which + 2 mm + x (which: 0 = l8, 1 = h8; mm: 64-k step of the slice; x: half of the lane's 32 bytes), byte (sp, j) of it =
     W8[n, 128 ks + 64 mm + 16 (2 x + sp) + 8 h + j] -- natural k order, the order the LayerNorm-on-load prologue fills the A operands in.
-    Image 1 (the two-workgroups-per-CU kernel, gemm_a384_mx2_kernel): [N / 64 tiles][6 slices of 64 k][16 chunk images][64 rows][16 B]; chunk images
-    0 - 7 = fp16 W[n, 64 sl + 8 c .. + 8], 8 - 15 = the 16-byte chunks 4 which + 2 x + h of the same bytes as above (mm folded into sl)."""
+    Image 1 (the two-workgroups-per-CU kernel, gemm_a384_mx2_kernel): [N / 32 tiles][3 slices of 128 k][32 chunk images][32 rows][16 B]; chunk images
+    0 - 15 = fp16 W[n, 128 ks + 8 c .. + 8], 16 - 31 = the 16-byte chunks 8 mm + 4 which + 2 x + h of the same bytes as above."""
     N, K = w.shape
     assert K == 384 and N % 64 == 0
     h, l8, h8 = mx_split(w)
     q = torch.stack([l8, h8], dim=1).reshape(N, 2, 3, 2, 2, 2, 2, 8)            # [n][which][ks][mm][x][sp][h][j]
     q0 = q.permute(0, 2, 1, 3, 4, 6, 5, 7).contiguous().reshape(N, 768)         # [n][ks][which][mm][x][h][sp][j]
     img0 = torch.stack([h.contiguous().view(torch.uint8).reshape(N, 768), q0])
-    hb = h.contiguous().view(torch.uint8).reshape(N // 64, 64, 6, 8, 16)        # [tile][row][sl][chunk 2 s + h][16 B]
-    q1 = q.permute(0, 2, 3, 1, 4, 6, 5, 7).contiguous().reshape(N // 64, 64, 6, 8, 16)   # [n][ks][mm][which][x][h][sp][j] -> [tile][row][sl = 2 ks + mm][chunk 4 which + 2 x + h][16 B]
-    img1 = torch.cat([hb, q1], dim=3).permute(0, 2, 3, 1, 4).contiguous()       # [tile][sl][chunk][row][16 B]
+    hb = h.contiguous().view(torch.uint8).reshape(N // 32, 32, 3, 16, 16)       # [tile][row][ks][image 2 s + h][16 B]
+    q1 = q.permute(0, 2, 3, 1, 4, 6, 5, 7).contiguous().reshape(N // 32, 32, 3, 16, 16)   # [n][ks][mm][which][x][h][sp][j] -> [tile][row][ks][image 8 mm + 4 which + 2 x + h][16 B]
+    img1 = torch.cat([hb, q1], dim=3).permute(0, 2, 3, 1, 4).contiguous()       # [tile][ks][image][row][16 B]
     return torch.stack([img0, img1.reshape(2, N, 768)]).contiguous()
 
 

@@ -70,7 +70,6 @@ struct X384Params {
   // LNA: A = LayerNorm(ln_x) formed while the row block is loaded: ln_x fp32 [M][ln_ldx], ln_stats[m] = {mean, rstd} (left by the kernel
   // that wrote the rows: gemm_n384_x3.hip), gamma / beta [384]
   const float* ln_x; int ln_ldx; const float* ln_stats; const float* ln_g; const float* ln_b;
-  int stagger;                          // gemm_a384_mx2_kernel: the delay of a CU's second workgroup, in units of 64 shader cycles
 };
 
 __device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -712,27 +711,34 @@ __global__ __launch_bounds__(256, 1) void gemm_a384_x3_kernel(X384Params p) {
 
 
 // ======================================================================================================================================
-// The MX form at TWO workgroups per CU (round 6, second half).  The kernel above keeps one wave per SIMD, and that wave issues everything
-// itself: per k-step region 128 cycles of MFMAs against ~240 of its own instruction stream (one 1 KB DMA piece = ~54 cycles of issue, a chunk
-// of the previous tile's GELU, four fragment reads and their waits).  Here the same work is cut so that TWO independent workgroups fit a CU
-// (<= 256 registers, <= 80 KB of LDS each) and one workgroup's DMA issue, LDS round trips, barriers, LayerNorm-on-load prologue and -- above
-// all -- epilogue run under the OTHER workgroup's MFMAs:
-//   * the ring holds slices of 64 (n) x 64 (k) = 16 KB as SIXTEEN CHUNK IMAGES [64 rows][16 B] (eight of the fp16 plane: k-step s, half hi -> image 2 s + hi;
-//     four of l8, four of h8), three slots; the weight is packed in exactly this order (backbone.pack_a384_mx, second image), so a slice is one contiguous
-//     16 KB block, a DMA piece is one contiguous kilobyte copied lane-linear, and a fragment read takes two contiguous 512-byte runs: no swizzle, one
-//     address register, every other offset an immediate;
-//   * a period = one slice = four regions (k-steps) of 2 fp16 MFMAs + 1 scaled MFMA; the correction products of a 64-k step: region 0 / 1 =
-//     W_l8 x a_h8 for column half 0 / 1, region 2 / 3 = W_h8 x a_l8;
-//   * no second accumulator set: the tile's epilogue runs serially behind its sixth period (nothing rides between the MFMAs, so the fragment
-//     reads are single-buffered through two alternating register sets and the schedule inside a region is left to the compiler);
-//   * resident: 24 fp16 fragments + 6 l8 operands (144 registers) + 32 accumulators + 2 x 16 of W fragments + a_h8 (8).
-constexpr int S2K = 64;
-constexpr int S2_NSL = KD / S2K;             // 6 slices per column tile
+// The MX form at TWO workgroups per CU (round 6, second half; the default of WVN_PREC_MIX's fc1 and q | k | v^T).  The kernel above keeps one wave per SIMD,
+// and that wave issues everything itself: per k-step region 128 cycles of MFMAs against ~240 of its own instruction stream (one 1 KB DMA piece = ~54 cycles of
+// issue, a chunk of the previous tile's GELU, four fragment reads and their waits).  Here the same work is cut so that TWO independent workgroups fit a CU
+// (<= 256 registers, <= 80 KB of LDS each) and one workgroup's DMA issue, LDS round trips, barriers, LayerNorm-on-load prologue and epilogue run under the
+// OTHER workgroup's MFMAs.  Measured (in-kernel counters, per wave and 64 output columns, fc1 at 403 456 rows): a wave alone on its SIMD 8.2 K cycles (regions
+// 4.8 K against 3.1 K of MFMAs, epilogue 1.9 K, prologue 1.0 K, barriers 0.4 K) -- the same kernel time as the form above with none of its scheduling; two
+// per SIMD 12.4 K each = 6.2 K per 64 columns and SIMD: fc1 1.21 -> 1.10 ms, q | k | v^T 0.87 -> 0.80 ms per 128 frame-passes, the step 1.8 ms shorter.
+// Each wave stays bound by its own dependent chain (one accumulator: every MFMA waits for the one before it) and two of them do not fill the pipe; delaying the
+// CU's second workgroup by half a tile (s_getreg HW_ID: its waves sit in the odd slots) changed nothing and is not in the code.
+//   * a column tile is 32 wide: ONE 16-register accumulator (the first build kept 64 columns = two accumulators and had no room to prefetch
+//     W fragments: a wave alone on its SIMD needed 219 cycles per 128 of MFMAs, two of them 286 each);
+//   * the ring holds slices of 32 (n) x 128 (k) = 16 KB as THIRTY-TWO CHUNK IMAGES [32 rows][16 B]: sixteen of the fp16 plane (k-step s, half
+//     hi -> image 2 s + hi: a fragment read is ONE contiguous kilobyte at lane * 16 + s * 1024), sixteen of the 8-bit planes (64-k step mm,
+//     which (l8 | h8), half x, hi -> image 16 + 8 mm + 4 which + 2 x + hi); three slots; the weight is packed in exactly this order
+//     (backbone.pack_a384_mx, second image): a slice is one contiguous 16 KB block, a DMA piece one contiguous kilobyte copied lane-linear,
+//     no swizzle, one address register, every other offset an immediate;
+//   * a period = one slice = four regions of 2 fp16 MFMAs (k-steps 2 r, 2 r + 1) + 1 scaled MFMA (64-k step mm = r >> 1; r even: W_l8 x
+//     a_h8, r odd: W_h8 x a_l8) = 128 matrix-pipe cycles; region r + 1's four fragment reads are requested before region r's MFMAs (two
+//     register sets);
+//   * no second accumulator set: the tile's epilogue (16 values per lane) runs serially behind its third period;
+//   * resident: 24 fp16 fragments + 6 l8 operands (144 registers) + 16 accumulators + 2 x 16 of W fragments + a_h8 (8).
+constexpr int S2_BN = 32;                    // columns per tile
+constexpr int S2_NSL = 3;                    // slices (of 128 k) per column tile
 constexpr int S2_NS = 3;
-constexpr int S2_SLICE = BNT * 256;          // 16 KB
+constexpr int S2_SLICE = 16384;
 constexpr int S2_RING = S2_NS * S2_SLICE;    // 48 KB
 constexpr int S2_PIECES = S2_SLICE / 1024 / 4;   // 4 per wave and slice: one per region
-constexpr int S2_STG = 5120;                 // per wave (QKV): two fp16 images of a column half [32][80 B] (q | k: the plane and its residue), or one V^T half [32 n][80 B]
+constexpr int S2_STG = 5120;                 // per wave (QKV): two fp16 images of a tile [32][80 B] (q | k: the plane and its residue), or one V^T tile [32 n][80 B]
 static_assert(S2_PIECES == 4, "one DMA piece per region");
 
 template <int EPI, bool TIMING = false>
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int NT = p.N / BNT;
+  const int NT = p.N / S2_BN;
   const int NRB = (p.M + BM - 1) / BM;
   const long long U = (long long)NRB * NT;
   const int u_begin = (int)(U * blockIdx.x / gridDim.x), u_end = (int)(U * (blockIdx.x + 1) / gridDim.x);
@@ -756,22 +762,21 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
   const float* gam_l = (const float*)(smem + BIAS_OFF2 + p.N * 4);
   int m0w = 0;
 
-  // ---- W ring producer: a slice = 16 contiguous kilobytes of the packed weight = sixteen chunk images [64 rows][16 B]; a piece = one chunk image, copied
-  // lane-linear (no swizzle: a fragment read takes 2 x 512 contiguous bytes) ----
+  // ---- W ring producer: a slice = 16 contiguous kilobytes of the packed weight; a piece = two chunk images, copied lane-linear ----
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)p.N * KD * 4), 0x00020000);
-  const unsigned wvoff = lane * 16;
+  const unsigned l16 = lane * 16;
   const int n_slices = NT * S2_NSL;
-  int iss_g = (u_begin % NT) * S2_NSL;    // the stream cursor: slice (tile j, k-slice) = j * 6 + sl, wrapping at the last tile
+  int iss_g = (u_begin % NT) * S2_NSL;    // the stream cursor: slice (tile j, k-slice) = j * 3 + ks, wrapping at the last tile
   unsigned iss_soff = 0;
   auto issue_begin = [&]() __attribute__((always_inline)) { iss_soff = __builtin_amdgcn_readfirstlane((unsigned)iss_g * (unsigned)S2_SLICE + wave * S2_PIECES * 1024); };
   auto issue_piece = [&](int i, int u) __attribute__((always_inline)) {   // (u: compile-time constant -> the instruction's immediate offset, which the hardware adds to the LDS address too)
     unsigned char* dst = smem + (i % S2_NS) * S2_SLICE + wave * S2_PIECES * 1024;
     __attribute__((address_space(3))) void* d3 = (__attribute__((address_space(3))) void*)dst;
     switch (u) {   // (the immediate must be a literal; u is a constant after unrolling and the switch folds)
-      case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 0, 0); break;
-      case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 1024, 0); break;
-      case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 2048, 0); break;
-      default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, wvoff, iss_soff, 3072, 0); break;
+      case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, l16, iss_soff, 0, 0); break;
+      case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, l16, iss_soff, 1024, 0); break;
+      case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, l16, iss_soff, 2048, 0); break;
+      default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, d3, 16, l16, iss_soff, 3072, 0); break;
     }
   };
   auto issue_end = [&]() __attribute__((always_inline)) { if (++iss_g == n_slices) iss_g = 0; };
@@ -788,13 +793,13 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
 
   u32x4_t mh[KD / 16];        // the row block's fp16 fragments
   u32x4_t m8[KD / 64][2];     // its l8 operands [64-k step][half]
-  // LayerNorm on load: the prologue of the kernel above, six k-steps of fp32 rows in flight (the other workgroup covers the round trips)
+  // LayerNorm on load: the prologue of the kernel above, eight k-steps of fp32 rows in flight (the other workgroup covers the round trips)
   auto load_a = [&]() __attribute__((always_inline)) {
     const int row = min(m0w + l31, p.M - 1);
     const wvn_f32x2_t st = *(const wvn_f32x2_t*)(p.ln_stats + 2 * (size_t)row);
     const float a1 = st[1], a0 = -st[0] * st[1];
     const float* xr = p.ln_x + (size_t)row * p.ln_ldx + hi * 8;
-    constexpr int G = 8;
+    constexpr int G = 8;   // k-steps of fp32 rows requested at a time (twelve: the same step time)
 #pragma unroll
     for (int s0 = 0; s0 < KD / 16; s0 += G) {
       f32x4_t u[2 * G];
@@ -835,16 +840,13 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
     }
   };
 
-  f32x16_t acc[2];
+  f32x16_t acc;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const unsigned rd_base = hi * 1024 + l31 * 16;   // chunk image (2 s + hi) of the slice, row l31 (+ 32 t: 512 B)
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   // ---- epilogue addressing ----
   constexpr unsigned OOB = 0x80000000u;
-  const int nqk = IS_QKV ? 2 * p.heads : (1 << 30);
+  const int nqk = IS_QKV ? 4 * p.heads : (1 << 30);      // QKV: the 32-column tiles below nqk are q | k (half a head each), the rest v^T
   unsigned voff[2] = {0, 0};
   unsigned vt_off = 0;
   const unsigned c_bytes = IS_QKV ? 0u : (unsigned)((size_t)((p.M + 31) / 32 * 32) * p.ldc * 2);
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
   const __amdgpu_buffer_rsrc_t rs_c2 = IS_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base_lo ? p.qkv_base_lo : p.qkv_base, 0, p.qkv_bytes, 0x00020000)
                                               : __builtin_amdgcn_make_buffer_rsrc(p.C_lo ? p.C_lo : p.C, 0, c_bytes / 2, 0x00020000);
   auto qkv_offsets = [&]() __attribute__((always_inline)) {
-    // q | k half images: a row = 32 columns = 64 B = four lanes; a store instruction covers 16 rows
+    // q | k tile images: a row = 32 columns = 64 B = four lanes; a store instruction covers 16 rows
 #pragma unroll
     for (int hblk = 0; hblk < 2; ++hblk) {
       const int m = m0w + hblk * 16 + (lane >> 2);
@@ -867,27 +869,23 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
     }
   };
 
-  // ONE set of W fragment registers per region, refilled in the order it is consumed: r0 (the fp16 fragment of the column half the region's FIRST MFMA takes),
-  // w8 (the region's e5m2 operand: second MFMA), r1 (the other fp16 fragment: third MFMA).  The read that refills a register is requested right behind the issue
-  // of the MFMA that consumed it (operands are read when an MFMA starts; the LDS data comes back a round trip later), so a register's turn-around is one LDS round
-  // trip, not a round trip plus the region's three MFMAs.
-  u32x4_t r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, w8[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  u32x4_t wq[2][2], w8[2][2];   // [register set][k-step parity] fp16 fragments; [register set][half] of the region's e5m2 operand
   u32x4_t dh8[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-  // region s of a slice: scaled MFMA on column half t8 = s & 1 (which = s >> 1: 0 = W_l8 x a_h8, 1 = W_h8 x a_l8); MFMA order: fp16 on half t8 ^ 1, scaled on t8, fp16 on t8
-  auto read_r0 = [&](int slot, int s) __attribute__((always_inline)) { r0 = *(const u32x4_t*)(smem + slot * S2_SLICE + rd_base + s * 2048 + ((s & 1) ^ 1) * 512); };
-  auto read_r1 = [&](int slot, int s) __attribute__((always_inline)) { r1 = *(const u32x4_t*)(smem + slot * S2_SLICE + rd_base + s * 2048 + (s & 1) * 512); };
-  auto read_w8 = [&](int slot, int s) __attribute__((always_inline)) {
+  auto frag_read = [&](int slot, int r, int par) __attribute__((always_inline)) {
+    const unsigned char* base = smem + slot * S2_SLICE + l16;
 #pragma unroll
-    for (int x = 0; x < 2; ++x) w8[x] = *(const u32x4_t*)(smem + slot * S2_SLICE + rd_base + 8192 + (s >> 1) * 4096 + x * 2048 + (s & 1) * 512);
+    for (int x = 0; x < 2; ++x) wq[par][x] = *(const u32x4_t*)(base + (2 * r + x) * 1024);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) w8[par][x] = *(const u32x4_t*)(base + 8192 + (8 * (r >> 1) + 4 * (r & 1) + 2 * x) * 512);
   };
-  auto derive_h8 = [&](int sl) __attribute__((always_inline)) {   // a_h8 = e5m2 of the fp16 image of this 64-k step (what the row-panel consumer derives for its activations too)
+  auto derive_h8 = [&](int c) __attribute__((always_inline)) {   // a_h8 = e5m2 of the fp16 image of 64-k step c (what the row-panel consumer derives for its activations too)
     typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
 #pragma unroll
     for (int sfr = 0; sfr < 4; ++sfr) {
       uint32_t d[2] = {0, 0};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const uint32_t pr = mh[sl * 4 + sfr][e];
+        const uint32_t pr = mh[c * 4 + sfr][e];
         const s16x2_t o = __builtin_bit_cast(s16x2_t, d[e >> 1]);
         d[e >> 1] = __builtin_bit_cast(uint32_t, (e & 1) ? __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, true)
                                                          : __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(o, __builtin_bit_cast(h2_t, pr), 1.0f, false));
@@ -896,132 +894,118 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
       dh8[sfr >> 1][2 * (sfr & 1) + 1] = d[1];
     }
   };
-  auto mfma_f16 = [&](int sl, int s, int t, u32x4_t wreg, auto tr_tag) __attribute__((always_inline)) {
+  auto mfma_region = [&](int ks, int r, int par, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
-    const f16x8_t af = __builtin_bit_cast(f16x8_t, mh[sl * 4 + s]);
-    const f16x8_t wf = __builtin_bit_cast(f16x8_t, wreg);
-    if constexpr (TR) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[t], 0, 0, 0);
-    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, acc[t], 0, 0, 0);
-  };
-  auto mfma_s8 = [&](int sl, int s, auto tr_tag) __attribute__((always_inline)) {
-    constexpr bool TR = decltype(tr_tag)::value;
-    const int which = s >> 1, t8 = s & 1;
-    const u32x4_t a0 = which ? m8[sl][0] : dh8[0], a1 = which ? m8[sl][1] : dh8[1];
+    const int c = 2 * ks + (r >> 1), which = r & 1;   // the 64-k step; 0: W_l8 (carries 2^12) x a_h8, 1: W_h8 x a_l8 (carries 2^12)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const f16x8_t af = __builtin_bit_cast(f16x8_t, mh[ks * 8 + 2 * r + x]);
+      const f16x8_t wf = __builtin_bit_cast(f16x8_t, wq[par][x]);
+      if constexpr (TR) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, acc, 0, 0, 0);
+    }
+    const u32x4_t a0 = which ? m8[c][0] : dh8[0], a1 = which ? m8[c][1] : dh8[1];
     const i32x8_t av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
-    const u32x4_t w0 = w8[0], w1 = w8[1];
+    const u32x4_t w0 = w8[par][0], w1 = w8[par][1];
     const i32x8_t wv = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
-    // which 0: W_l8 (carries 2^12) x a_h8;  which 1: W_h8 x a_l8 (carries 2^12)
-    if constexpr (TR) acc[t8] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc[t8], 1, 1, 0, which ? MX_SC_ONE : MX_SC_RES, 0, which ? MX_SC_RES : MX_SC_ONE);
-    else acc[t8] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, wv, acc[t8], 1, 1, 0, which ? MX_SC_RES : MX_SC_ONE, 0, which ? MX_SC_ONE : MX_SC_RES);
+    if constexpr (TR) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc, 1, 1, 0, which ? MX_SC_ONE : MX_SC_RES, 0, which ? MX_SC_RES : MX_SC_ONE);
+    else acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, wv, acc, 1, 1, 0, which ? MX_SC_RES : MX_SC_ONE, 0, which ? MX_SC_ONE : MX_SC_RES);
   };
 
   auto init_acc = [&](int j, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
-    const int n0 = j * BNT;
+    const int n0 = j * S2_BN;
     if constexpr (TR) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t b4 = *(const f32x4_t*)(bias_l + n0 + 8 * g + 4 * hi);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4_t b4 = *(const f32x4_t*)(bias_l + n0 + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b4[e];
-        }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float b = bias_l[n0 + 32 * t + l31];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = b;
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = b4[e];
       }
+    } else {
+      const float b = bias_l[n0 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = b;
     }
   };
 
   // ---- the tile's epilogue, serial (the CU's other workgroup has the matrix pipe meanwhile) ----
-  auto epilogue = [&](int jp, auto tr_tag) __attribute__((always_inline)) {
+  auto epilogue = [&](int j, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
-    const int n0 = jp * BNT;
+    const int n0 = j * S2_BN;
     if constexpr (!IS_QKV) {
-      // TR accumulators: lane (row l31, half hi) holds columns 32 t + 8 g + 4 hi + e.  The consumer's 64-k step jp: fragment (k-step 4 jp + 2 t + (g >> 1)) element
-      // order = the accumulators' own; l8 half t = the 16 bytes of the lane in register order
+      // TR accumulators: lane (row l31, half hi) holds columns 8 g + 4 hi + e of the tile.  The consumer's 64-k step jp = j >> 1, half t = j & 1: fragment (k-step
+      // 4 jp + 2 t + (g >> 1)) in the accumulators' own element order; l8 half t = the 16 bytes of the lane in register order
+      const int jp = j >> 1, t = j & 1;
+      u32x4_t frag8l = {0, 0, 0, 0};
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        u32x4_t frag8l = {0, 0, 0, 0};
+      for (int gg = 0; gg < 2; ++gg) {
+        u32x4_t fragh;
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-          u32x4_t fragh;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {   // chunk s = 4 gg + c of the interleaved form: g = s >> 1, h2 = (s & 1) * 2
-            const int s = 4 * gg + c, g = s >> 1, h2 = (s & 1) * 2;
-            float v0 = acc[t][4 * g + h2], v1 = acc[t][4 * g + h2 + 1];
-            gelu_pair(v0, v1);
-            typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
-            typedef __attribute__((ext_vector_type(2))) float f2_t;
-            const uint32_t h = pack_f16x2(v0, v1);
-            const h2_t hh = __builtin_bit_cast(h2_t, h);
-            fragh[2 * (g & 1) + (h2 >> 1)] = h;
-            const f2_t res = f2_t{v0, v1} - f2_t{(float)hh[0], (float)hh[1]};
-            frag8l[s >> 1] = mx_pk8(frag8l[s >> 1], res[0], res[1], MX_RES_INV, s & 1);
-            if (c & 1) __builtin_amdgcn_sched_barrier(0);   // (two pairs at a time: with more in flight -- or with one -- the register allocation of the tile loop no longer fits)
-          }
-          const unsigned so = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 4)) + 4 * jp + 2 * t + gg) * 1024);
-          wvn_store_b128_guarded(fragh, rs_c, lane * 16, so);
+        for (int c = 0; c < 4; ++c) {   // chunk s = 4 gg + c: g = s >> 1, h2 = (s & 1) * 2
+          const int s = 4 * gg + c, g = s >> 1, h2 = (s & 1) * 2;
+          float v0 = acc[4 * g + h2], v1 = acc[4 * g + h2 + 1];
+          gelu_pair(v0, v1);
+          typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+          typedef __attribute__((ext_vector_type(2))) float f2_t;
+          const uint32_t h = pack_f16x2(v0, v1);
+          const h2_t hh = __builtin_bit_cast(h2_t, h);
+          fragh[2 * (g & 1) + (h2 >> 1)] = h;
+          const f2_t res = f2_t{v0, v1} - f2_t{(float)hh[0], (float)hh[1]};
+          frag8l[s >> 1] = mx_pk8(frag8l[s >> 1], res[0], res[1], MX_RES_INV, s & 1);
         }
-        const unsigned so8 = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 6)) + jp) * 2048 + t * 1024);
-        wvn_store_b128_guarded(frag8l, rs_c2, lane * 16, so8);
+        const unsigned so = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 4)) + 4 * jp + 2 * t + gg) * 1024);
+        wvn_store_b128_guarded(fragh, rs_c, l16, so);
       }
+      const unsigned so8 = __builtin_amdgcn_readfirstlane((((m0w >> 5) * (p.N >> 6)) + jp) * 2048 + t * 1024);
+      wvn_store_b128_guarded(frag8l, rs_c2, l16, so8);
     } else if constexpr (TR) {
-      // a q | k tile = one head's 64 dims of 32 tokens: per column half an fp16 image [32 tokens][32 dims] (rows of 80 B) and the image of the rounding
-      // residues behind it; q pre-scaled.  Then 16 bytes per lane: 4 lanes per token row, 16 rows per store
+      // a q | k tile = half a head's dims of 32 tokens: an fp16 image [32 tokens][32 dims] (rows of 80 B) and the image of the rounding residues behind it; q
+      // pre-scaled.  Then 16 bytes per lane: 4 lanes per token row, 16 rows per store
       const int D = p.heads * 64;
-      const int which = n0 / D, head = (n0 - which * D) >> 6;
+      const int which = n0 / D, head = (n0 - which * D) >> 6, t = (n0 >> 5) & 1;
       const float qs = which == 0 ? p.q_scale : 1.f;
       const bool keep_lo = which == 0 && p.q_lo_f16;
-      const unsigned so = __builtin_amdgcn_readfirstlane((which == 0 ? p.q_off : p.k_off) + head * p.npad * 64 * 2);
+      const unsigned so = __builtin_amdgcn_readfirstlane((which == 0 ? p.q_off : p.k_off) + head * p.npad * 64 * 2 + t * 64);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int h2 = 0; h2 < 4; h2 += 2) {
+          uint32_t h, l;
+          wvn_split2_f16(acc[4 * g + h2] * qs, acc[4 * g + h2 + 1] * qs, h, l);
+          const int c = 8 * g + 4 * hi + h2;
+          *(uint32_t*)(stg + l31 * 80 + c * 2) = h;
+          *(uint32_t*)(stg + 2560 + l31 * 80 + c * 2) = l;
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-          for (int h2 = 0; h2 < 4; h2 += 2) {
-            uint32_t h, l;
-            wvn_split2_f16(acc[t][4 * g + h2] * qs, acc[t][4 * g + h2 + 1] * qs, h, l);
-            const int c = 8 * g + 4 * hi + h2;
-            *(uint32_t*)(stg + l31 * 80 + c * 2) = h;
-            *(uint32_t*)(stg + 2560 + l31 * 80 + c * 2) = l;
-          }
+      for (int it = 0; it < 2; ++it) {
+        const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+        wvn_store_b128_guarded(val, rs_c, voff[it], so);
+      }
+      if (keep_lo) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
-          wvn_store_b128_guarded(val, rs_c, voff[it], so + t * 64);
-        }
-        if (keep_lo) {
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const u32x4_t val = *(const u32x4_t*)(stg + 2560 + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
-            wvn_store_b128_guarded(val, rs_c2, voff[it], so + t * 64);
-          }
+          const u32x4_t val = *(const u32x4_t*)(stg + 2560 + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+          wvn_store_b128_guarded(val, rs_c2, voff[it], so);
         }
       }
     } else {
-      // V^T: lane (row n = l31 of half t, half hi) holds tokens 8 g + 4 hi + e; image [32 n][32 tokens] with bits 2 and 3 of the token index swapped inside
+      // V^T: lane (row n = l31 of the tile, half hi) holds tokens 8 g + 4 hi + e; image [32 n][32 tokens] with bits 2 and 3 of the token index swapped inside
       // aligned groups of 16 (the attention kernel's V^T fragment order), rows of 80 B; 4 lanes per row, 16 rows per store
-      const int head = (n0 - 2 * p.heads * 64) >> 6;
+      const int nv = n0 - 2 * p.heads * 64;     // row of V^T = head * 64 + dim
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int h2 = 0; h2 < 4; h2 += 2) {
-            const int mloc = 16 * (g >> 1) + 8 * hi + 4 * (g & 1) + h2;
-            *(uint32_t*)(stg + l31 * 80 + mloc * 2) = pack_f16x2(acc[t][4 * g + h2], acc[t][4 * g + h2 + 1]);
-          }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
-          const unsigned so = __builtin_amdgcn_readfirstlane(p.v_off + (head * 64 + 32 * t + it * 16) * p.npad * 2);
-          wvn_store_b128_guarded(val, rs_c, vt_off, so);
+        for (int h2 = 0; h2 < 4; h2 += 2) {
+          const int mloc = 16 * (g >> 1) + 8 * hi + 4 * (g & 1) + h2;
+          *(uint32_t*)(stg + l31 * 80 + mloc * 2) = pack_f16x2(acc[4 * g + h2], acc[4 * g + h2 + 1]);
         }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const u32x4_t val = *(const u32x4_t*)(stg + ((lane >> 2) + it * 16) * 80 + (lane & 3) * 16);
+        const unsigned so = __builtin_amdgcn_readfirstlane(p.v_off + (nv + it * 16) * p.npad * 2);
+        wvn_store_b128_guarded(val, rs_c, vt_off, so);
       }
     }
   };
@@ -1032,32 +1016,21 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
   // rows and the data lands in a slot nobody reads again) ----
   long long t_bar = 0, t_loop = 0, t_epi = 0, t_pro = 0;
   const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  auto period = [&](int i, int sl, auto tr_tag) __attribute__((always_inline)) {
+  auto period = [&](int i, int ks, auto tr_tag) __attribute__((always_inline)) {
     long long c0 = 0, c1 = 0, c2 = 0;
     if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
     if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
     issue_begin();
-    read_r0(i % S2_NS, 0);
-    read_w8(i % S2_NS, 0);
-    read_r1(i % S2_NS, 0);
+    frag_read(i % S2_NS, 0, 0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int t8 = s & 1;
-      issue_piece(i + S2_NS - 1, s);
-      if (s == 0) derive_h8(sl);
+    for (int r = 0; r < 4; ++r) {
+      if (r + 1 < 4) frag_read(i % S2_NS, r + 1, (r & 1) ^ 1);
+      issue_piece(i + S2_NS - 1, r);
+      if ((r & 1) == 0) derive_h8(2 * ks + (r >> 1));
       __builtin_amdgcn_sched_barrier(0);
-      mfma_f16(sl, s, t8 ^ 1, r0, tr_tag);
+      mfma_region(ks, r, r & 1, tr_tag);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < 4) read_r0(i % S2_NS, s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_s8(sl, s, tr_tag);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < 4) read_w8(i % S2_NS, s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_f16(sl, s, t8, r1, tr_tag);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < 4) read_r1(i % S2_NS, s + 1);
     }
     issue_end();
     if constexpr (TIMING) c2 = (long long)__builtin_amdgcn_s_memtime();
@@ -1067,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
   int si = 0;
   auto tile = [&](int j, bool last, auto tr_tag, auto next_tr) __attribute__((always_inline)) {
 #pragma unroll
-    for (int sl = 0; sl < S2_NSL; ++sl) period(si + sl, sl, tr_tag);
+    for (int ks = 0; ks < S2_NSL; ++ks) period(si + ks, ks, tr_tag);
     si += S2_NSL;
     const long long e0 = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
     epilogue(j, tr_tag);
@@ -1076,11 +1049,6 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
   };
 
   __syncthreads();
-  // Two workgroups with identical work that start together stay in phase: both in their MFMA periods (sharing the pipe), then both in their epilogues (the pipe
-  // idle) -- measured: a wave's regions took 2.2 x their MFMA time and its epilogues ran against the neighbour's.  The workgroup whose waves sit in the ODD wave
-  // slots of their SIMDs (the second one the CU received) starts half a tile late; in the fluid model of two waves sharing a pipe an offset persists.
-  if ((__builtin_amdgcn_s_getreg(0x1804) & 1) != 0)   // HW_REG_HW_ID, bits 3:0 = the wave's slot on its SIMD
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
   for (int u = u_begin; u < u_end;) {
     const int rb = u / NT, j0 = u - rb * NT, j1 = min(NT, j0 + (u_end - u));
     m0w = rb * BM + wave * 32;
@@ -1092,11 +1060,16 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
     if constexpr (TIMING) t_pro += (long long)__builtin_amdgcn_s_memtime() - l0;
     using T = std::true_type; using F = std::false_type;
     if constexpr (IS_QKV) {
-      if (j0 < nqk) init_acc(j0, T{}); else init_acc(j0, F{});
-      for (int j = j0; j < j1; ++j) {
-        if (j + 1 < nqk) tile(j, j + 1 == j1, T{}, T{});
-        else if (j < nqk) tile(j, j + 1 == j1, T{}, F{});
-        else tile(j, j + 1 == j1, F{}, F{});
+      // the q | k tiles, then the v^T tiles, as two loops (one loop over three tile variants: 36 registers in scratch)
+      if (j0 < nqk) {
+        const int je = min(j1, nqk);
+        init_acc(j0, T{});
+        for (int j = j0; j < je; ++j) tile(j, j + 1 == je, T{}, T{});
+      }
+      if (j1 > nqk) {
+        const int jb = max(j0, nqk);
+        init_acc(jb, F{});
+        for (int j = jb; j < j1; ++j) tile(j, j + 1 == j1, F{}, F{});
       }
     } else {
       init_acc(j0, T{});
@@ -1109,12 +1082,10 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
     if (lane == 0 && p.dbg) {
       long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
       d[0] = t_bar; d[1] = t_pro; d[2] = t_loop; d[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;
-      if (p.stagger < 0) { d[0] = __builtin_amdgcn_s_getreg(0xf804); d[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20); d[2] = t_start; }   // (probe: HW_ID, XCC_ID, start time)
       (void)t_epi;
     }
   }
 }
-
 
 bool g_x384_split_qkv = getenv("WVN_X384_SPLIT_QKV") != nullptr;   // A/B: q | k and v^T as two launches (the form before the merged kernel)
 
@@ -1153,19 +1124,16 @@ int launch_mx(const X384Params& p, hipStream_t st) {
   return WVN_OK;
 }
 
-int g_a384_mx_stagger = [] { const char* e = getenv("WVN_A384_STAGGER"); return e ? atoi(e) : 56; }();   // x 64 cycles: about half a tile
-
 // (form 2: the two-workgroups-per-CU kernel; its weight image lies N * 1536 bytes behind the first one -- backbone.pack_a384_mx)
 template <int EPI>
 int launch_mx2(X384Params p, hipStream_t st) {
   if (!p.ln_x || !p.ln_stats || !p.ln_g || !p.ln_b || (p.ln_ldx % 4) || ((uintptr_t)p.ln_x & 15) || ((uintptr_t)p.ln_stats & 7)) return WVN_ERR_ARG;
   p.W = (const bf16_t*)((const unsigned char*)p.W + (size_t)p.N * KD * 4);
-  p.stagger = g_a384_mx_stagger;
   const int lds = S2_RING + (EPI == X_QKV_F16 ? 4 * S2_STG : 0) + p.N * 4 + 2 * KD * 4;
   if (lds > 80 * 1024) return WVN_ERR_ARG;
   static LdsOptIn lds_opt_in;
   if (const int rc = lds_opt_in(80 * 1024, (const void*)gemm_a384_mx2_kernel<EPI>, (const void*)gemm_a384_mx2_kernel<EPI, true>)) return rc;
-  const long long units = (long long)ceil_div(p.M, BM) * (p.N / BNT);
+  const long long units = (long long)ceil_div(p.M, BM) * (p.N / S2_BN);
   static const bool one_per_cu = getenv("WVN_A384_MX2_ONE") != nullptr;   // (experiment: one workgroup per CU -- what a wave does when it has its SIMD to itself)
   const int cap = (one_per_cu ? 1 : 2) * x384_num_cus();
   const int grid = (int)(units < cap ? units : cap);
@@ -1175,7 +1143,8 @@ int launch_mx2(X384Params p, hipStream_t st) {
   return WVN_OK;
 }
 
-int g_a384_mx_form = [] { const char* e = getenv("WVN_A384_MX_FORM"); return e && e[0] == '2' ? 2 : 1; }();
+// 0 (default) / 2: the two-workgroups-per-CU kernel (fc1 9 %, q | k | v^T 5 - 8 % faster); 1: the one-wave-per-SIMD kernel
+int g_a384_mx_form = [] { const char* e = getenv("WVN_A384_MX_FORM"); return e && e[0] == '2' ? 2 : (e && e[0] == '1' ? 1 : 0); }();
 
 template <int EPI>
 int launch(const X384Params& p, hipStream_t st) {
@@ -1266,7 +1235,7 @@ int wvn_gemm_a384_x3_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
   }
 }
 
-void wvn_gemm_a384_mx_set_form(int form) { g_a384_mx_form = form == 1 ? 1 : 2; }
+void wvn_gemm_a384_mx_set_form(int form) { g_a384_mx_form = form == 1 || form == 2 ? form : 0; }
 
 // MX form (LayerNorm on load only): W = backbone.pack_a384_mx (plane 0 fp16 [N][384] at g.W, plane 1 bytes [N][768] at g.W_lo, the slice-major image of the
 // two-workgroups-per-CU kernel behind them; WVN_A384_MX_FORM=1 / wvn_gemm_a384_mx_set_form(1): the one-wave-per-SIMD kernel; a cycle-counter request takes it too); EPI_GELU_FRAG writes the
@@ -1285,7 +1254,7 @@ int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
     case EPI_GELU_FRAG:
       if (!g.C || !g.C_lo || g.ldc != g.N || (g.N % 64) || (((uintptr_t)g.C | (uintptr_t)g.C_lo) & 15) || ((size_t)g.M + 32) * g.ldc * 2 >= (1ull << 31))
         return WVN_ERR_ARG;
-      return g_a384_mx_form == 2 ? launch_mx2<X_GELU_FRAG>(p, st) : launch_mx<X_GELU_FRAG>(p, st);
+      return g_a384_mx_form != 1 ? launch_mx2<X_GELU_FRAG>(p, st) : launch_mx<X_GELU_FRAG>(p, st);
     case EPI_QKV: {
       if (!g.qkv_f16 || g.N != 3 * g.heads * 64 || !g.q || !g.k || !g.vt || (g.ntok_s % 16) || (g.M % 16) || (g.npad % 16)) return WVN_ERR_ARG;
       const uintptr_t lo = std::min({(uintptr_t)g.q, (uintptr_t)g.k, (uintptr_t)g.vt});
@@ -1299,7 +1268,7 @@ int wvn_gemm_a384_mx_launch(const GemmBf16Params& g, int epi, hipStream_t st) {
         p.qkv_base_lo = (bf16_t*)((uintptr_t)g.q_lo - p.q_off);
         p.q_lo_f16 = 1;
       }
-      return g_a384_mx_form == 2 ? launch_mx2<X_QKV_F16>(p, st) : launch_mx<X_QKV_F16>(p, st);
+      return g_a384_mx_form != 1 ? launch_mx2<X_QKV_F16>(p, st) : launch_mx<X_QKV_F16>(p, st);
     }
     default: return WVN_ERR_ARG;
   }

@@ -206,7 +206,7 @@ int wvn_kmeans_pixels_linear_launch(const float* code, int* labels, int* nseg, f
                                     int iters, int relabel, hipStream_t st, int align_corners = 1);
 int wvn_f16_saturate_probe_launch(const float* in, uint16_t* out, int n, hipStream_t st);
 void wvn_gemm_n384_x3_set_pair(int on);
-void wvn_gemm_a384_mx_set_form(int form);   // 1: one wave per SIMD (gemm_a384_x3_kernel<..., MX>), 2: two workgroups per CU (gemm_a384_mx2_kernel)
+void wvn_gemm_a384_mx_set_form(int form);   // 1: one wave per SIMD (gemm_a384_x3_kernel<..., MX>), 2: two workgroups per CU (gemm_a384_mx2_kernel), 0: the default (fc1 on 2, QKV on 1)
 int wvn_table_slots(int K);
 int wvn_table_bilerp_argmax_launch(const float* table, int* labels, int B, int G, int H, int K, hipStream_t st, int align_corners = 1);
 void wvn_kmeans_pixels_set_assign_form(int form);
