@@ -264,6 +264,13 @@ int wvn_layernorm_fp8(const float* x, const float* gamma, const float* beta, voi
                       float eps, void* stream);
 int wvn_gemm_fp8(const void* A_q, int lda, const void* W_q, int ldw, const float* sa, const float* sw, const float* bias,
                  void* C, int ldc, int M, int N, int K, int epi, void* stream);
+/* The A-stationary form of the same product for K == 768 (csrc/gemm_a768_fp8.hip; what WVN_PREC_FP8 runs for the QKV, projection and fc1 linears of
+ * ViT-Base from 4096 rows on -- the layer's qkv_w_mx / proj_w_mx / fc1_w_mx fields carry the packed weights in that precision): a workgroup keeps 128 rows of
+ * A in registers and streams 32-column tiles of the weight, packed by backbone.pack_a768_fp8 as [N / 32][12 k-steps][2 halves][64 lanes][16 B].
+ * epi (the numbers of wvn_gemm_fp8): 0 | 1 (C bf16 [M][ldc], 1 = gelu), 4 (C fp32 += ls * (...), ls optional), 7 (q | k | v^T bf16 in the
+ * layouts of wvn_attention_bf16, inside one 2 GB span; q scaled by q_scale when it is not 0).  N % 32 == 0; WVN_ERR_ARG for any other shape. */
+int wvn_gemm_a768_fp8(const void* A_q, int lda, const void* W_packed, const float* sa, const float* sw, const float* bias, const float* ls, void* C, int ldc,
+                      int M, int N, int epi, void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, void* stream);
 /* fp32 [rows, lds] -> hi = bf16(x), lo = bf16(x - hi), both [rows, ldd] */
 int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream);
 /* exact-mode attention: q / k planes [B,h,npad,64], V^T planes [B,h,64,npad] (token permutation of the bf16 path),

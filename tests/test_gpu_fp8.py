@@ -105,3 +105,72 @@ def test_layernorm_fp8_direct(dev, D):
     # and the statistics themselves: the dequantised rows have the LayerNorm's mean / variance, not a shrunk one
     z = (got - beta.double()) / gamma.double()
     assert z.mean(1).abs().max().item() < 0.02 and (z.var(1, unbiased=False) - 1).abs().max().item() < 0.03
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The A-stationary K = 768 kernel (csrc/gemm_a768_fp8.hip): fp64 math on the quantised operands, every row
+# ---------------------------------------------------------------------------------------------------------------------------
+def _a768_operands(dev, M, N, seed=2):
+    from wild_visual_navigation_amd.backbone import pack_a768_fp8
+    a = torch.randn(M, 768, generator=g(seed)) * torch.logspace(-1, 1, M)[:, None]
+    w = torch.randn(N, 768, generator=g(seed + 1)) * 0.05 * torch.logspace(-1, 0.5, N)[:, None]
+    bias = (torch.randn(N, generator=g(seed + 2)) * 0.1).to(dev)
+    aq, sa = ops.quantize_rows_fp8(a.to(dev))
+    wq, sw = ops.quantize_rows_fp8(w.to(dev))
+    ref = (aq.double() * sa.double()[:, None]) @ (wq.double() * sw.double()[:, None]).T + bias.double()
+    mag = (aq.double().abs() * sa.double()[:, None]) @ (wq.double().abs() * sw.double()[:, None]).T + 1.0
+    return aq, sa, wq, sw, pack_a768_fp8(wq), bias, ref, mag
+
+
+@pytest.mark.parametrize("M,N", [(4096 + 37, 768), (128 * 70 + 16, 3072), (200, 96)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "resid", "resid_ls"])
+def test_gemm_a768_fp8_every_row(dev, M, N, epi):
+    lib = _lib.lib()
+    aq, sa, wq, sw, wp, bias, ref, mag = _a768_operands(dev, M, N)
+    st = _lib.stream()
+    if epi in ("bf16", "gelu"):
+        out = torch.full((M + 8, N), 7.0, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.wvn_gemm_a768_fp8(aq.data_ptr(), 768, wp.data_ptr(), sa.data_ptr(), sw.data_ptr(), bias.data_ptr(), 0, out.data_ptr(), N, M, N,
+                                         _lib.EPI_BF16 if epi == "bf16" else _lib.EPI_GELU_BF16, 0, 0, 0, 0, 0, 0, 0.0, st), "a768")
+        if epi == "gelu":
+            ref = torch.nn.functional.gelu(ref)
+        assert ((out[:M].double() - ref).abs() / mag).max().item() < 2.0 ** -8
+        assert (out[M:] == 7.0).all()                      # nothing past row M
+    else:
+        ls = (0.5 + torch.rand(N, generator=g(9))).to(dev) if epi == "resid_ls" else None
+        c0 = torch.randn(M + 8, N, generator=g(5)).to(dev)
+        out = c0.clone()
+        _lib.check(lib.wvn_gemm_a768_fp8(aq.data_ptr(), 768, wp.data_ptr(), sa.data_ptr(), sw.data_ptr(), bias.data_ptr(), ls.data_ptr() if ls is not None else 0,
+                                         out.data_ptr(), N, M, N, _lib.EPI_RESID_F32, 0, 0, 0, 0, 0, 0, 0.0, st), "a768")
+        want = c0[:M].double() + (ref * ls.double() if ls is not None else ref)
+        assert ((out[:M].double() - want).abs() / mag).max().item() < 2e-5
+        assert torch.equal(out[M:], c0[M:])
+    # the tiled kernel on the same operands: the same numbers up to accumulation order
+    if epi == "bf16":
+        tiled = ops.gemm_fp8(aq, sa, wq, sw, bias, _lib.EPI_BF16).double()
+        assert ((out[:M].double() - tiled).abs() / mag).max().item() < 2.0 ** -7
+
+
+@pytest.mark.parametrize("B,ntok,heads", [(3, 1370, 12), (5, 785, 12)])
+def test_gemm_a768_fp8_qkv_layouts(dev, B, ntok, heads):
+    """q | k (pre-scaled q) as [B, heads, npad, 64] bf16 and v^T as [B, heads, 64, npad] with the attention kernel's token permutation."""
+    lib = _lib.lib()
+    ntok_s = (ntok + 15) // 16 * 16
+    npad = (ntok + 63) // 64 * 64
+    M, N = B * ntok_s, 3 * heads * 64
+    aq, sa, wq, sw, wp, bias, ref, mag = _a768_operands(dev, M, N, seed=11)
+    per = B * heads * npad * 64
+    buf = torch.zeros(3 * per, dtype=torch.bfloat16, device=dev)
+    q, k, vt = buf[:per].view(B, heads, npad, 64), buf[per:2 * per].view(B, heads, npad, 64), buf[2 * per:].view(B, heads, 64, npad)
+    qs = 0.125 * 1.4426950408889634
+    _lib.check(lib.wvn_gemm_a768_fp8(aq.data_ptr(), 768, wp.data_ptr(), sa.data_ptr(), sw.data_ptr(), bias.data_ptr(), 0, 0, 0, M, N, _lib.EPI_QKV,
+                                     q.data_ptr(), k.data_ptr(), vt.data_ptr(), heads, npad, ntok_s, qs, _lib.stream()), "a768 qkv")
+    r = ref.reshape(B, ntok_s, 3, heads, 64).cpu()
+    mg = mag.reshape(B, ntok_s, 3, heads, 64).cpu()
+    assert (((q.double().cpu()[:, :, :ntok_s] - r[:, :, 0].permute(0, 2, 1, 3) * qs).abs()) / mg[:, :, 0].permute(0, 2, 1, 3)).max().item() < 2.0 ** -8
+    assert (((k.double().cpu()[:, :, :ntok_s] - r[:, :, 1].permute(0, 2, 1, 3)).abs()) / mg[:, :, 1].permute(0, 2, 1, 3)).max().item() < 2.0 ** -8
+    t = torch.arange(ntok_s)
+    perm = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    vg = vt.double().cpu()[:, :, :, :ntok_s][..., perm]
+    assert (((vg - r[:, :, 2].permute(0, 2, 3, 1)).abs()) / mg[:, :, 2].permute(0, 2, 3, 1)).max().item() < 2.0 ** -8
+    assert float(q[:, :, ntok_s:].abs().max()) == 0.0 and float(vt[..., ntok_s:].abs().max()) == 0.0

@@ -191,6 +191,20 @@ def test_reference_448_frame_through_the_full_backbone(dev, golden):
     assert torch.equal(bb.forward_tokens(u8[None].to(dev)).cpu(), got)          # uint8 ingest: bit-identical
 
 
+def test_vit_base_8_mixed_at_448_within_1e3(dev, golden):
+    """ViT-Base/8 (D = 768, 12 heads, 12 blocks: the backbone of the reference's released STEGO checkpoint, stego_interface.py:23) on the reference's
+    real 448 x 448 frame in the <= 1e-3 mode (class default).  D = 768 has no row-panel / A-stationary kernels: the linears run on the tiled
+    split-operand kernel (csrc/gemm_x3.hip), attention on the fp16 kernel with the two-plane q of the first six blocks."""
+    u8 = golden("graph_img_448.pt")["frame_u8"]
+    img = (u8.float() / 255)[None]
+    sd = OV.make_vit_state_dict("vit_base", 8, pretrain_grid=28, seed=2)
+    want = OV.vit_tokens(sd, OI.normalize(img), 8, 12)[:, 1:]
+    got = VitBackbone(sd, 448, 8, 12, device=dev, precision="mixed").forward_tokens(img.to(dev)).cpu()
+    err = (got - want).abs().max().item()
+    print(f"img.png 448^2 ViT-Base/8 mixed: max|err| = {err:.3e}")
+    assert err < 1e-3
+
+
 def test_bf16_shipped_instantiations_at_448(dev):
     """bf16 path exactly as bench.py drives it, scaled down in depth only: 448^2 (25 query blocks, 50 key tiles, masked tail),
     B = 16 frames in ONE launch sequence -> (frame, head) count 96 = XCD-ordered attention, pre-scaled-q kernel; 50,432 token

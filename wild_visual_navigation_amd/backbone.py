@@ -146,6 +146,15 @@ def pack_a384_mx(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([img0, img1.reshape(2, N, 768)]).contiguous()
 
 
+def pack_a768_fp8(wq: torch.Tensor) -> torch.Tensor:
+    """e4m3 weight bytes [N][768] (uint8 or float8_e4m3fn) -> the operand of the A-stationary fp8 kernel (csrc/gemm_a768_fp8.hip): uint8
+    [N / 32 tiles][12 k-steps][2 halves x][64 lanes = (hi, row)][16 B]; byte j of lane (hi, row) in (s, x) = W[32 tile + row, 64 s + 32 hi + 16 x + j]."""
+    N, K = wq.shape
+    assert K == 768 and N % 32 == 0
+    b = wq.contiguous().view(torch.uint8).reshape(N // 32, 32, 12, 2, 2, 16)     # [tile][row][s][hi][x][16]
+    return b.permute(0, 2, 4, 3, 1, 5).contiguous()                              # [tile][s][x][hi][row][16]
+
+
 def mx_fragments(a: torch.Tensor):
     """A [M][K] fp32 -> the fragment-major MX planes the row-panel kernel reads (what the producers' epilogues write):
     (h fp16 [R][K / 16][64][8], l8 uint8 [R][K / 64][2][64][16], h8 likewise -- h8 is NOT read by the kernels any more: they derive e5m2(h) in
@@ -279,6 +288,11 @@ class VitBackbone:
             qw = (t / s[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(self.device).contiguous()
             s = s.to(self.device).contiguous()
             self._keep += [qw, s]
+            if t.shape[1] == 768 and t.shape[0] % 32 == 0:   # the A-stationary kernel's packed image rides behind in _pack8 (csrc/gemm_a768_fp8.hip)
+                self._pack8 = pack_a768_fp8(qw)
+                self._keep.append(self._pack8)
+            else:
+                self._pack8 = None
             return qw.data_ptr(), s.data_ptr()
 
         def vec(t):
@@ -315,9 +329,13 @@ class VitBackbone:
             p = f"blocks.{i}."
             L = m.layers[i]
             if self.precision == _lib.PREC_FP8:
+                # (the *_w_mx fields carry the packed images of the K = 768 linears in this precision: include/wvn_hip.h)
                 L.qkv_w, L.qkv_s = mat8(sd[p + "attn.qkv.weight"])
+                L.qkv_w_mx = self._pack8.data_ptr() if self._pack8 is not None else 0
                 L.proj_w, L.proj_s = mat8(sd[p + "attn.proj.weight"])
+                L.proj_w_mx = self._pack8.data_ptr() if self._pack8 is not None else 0
                 L.fc1_w, L.fc1_s = mat8(sd[p + "mlp.fc1.weight"])
+                L.fc1_w_mx = self._pack8.data_ptr() if self._pack8 is not None else 0
                 L.fc2_w, L.fc2_s = mat8(sd[p + "mlp.fc2.weight"])
             else:
                 L.qkv_w = mat(sd[p + "attn.qkv.weight"])

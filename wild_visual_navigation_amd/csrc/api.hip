@@ -296,13 +296,18 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
     RET_IF(linear(w.patches, pl_pat, d.KPs, m->patch_w, m->patch_b, w.x, 0, d.D, Mp, d.D, d.KPs, EPI_PATCH, nullptr, &e));
   }
   // fp8: quantise-then-GEMM for the four linears of a block (A rows -> e4m3 + per-token scale in ws.xq / ws.hq / ws.sa)
-  auto linear_fp8 = [&](const unsigned char* Aq, int K, const void* W, const float* sw, const float* bias, void* C, int ldc, int N,
+  // (Wp: the packed image of a K = 768 weight for the A-stationary kernel, from 4096 rows on; elsewhere, or where that kernel declines, the tiled kernel)
+  auto linear_fp8 = [&](const unsigned char* Aq, int K, const void* W, const void* Wp, const float* sw, const float* bias, void* C, int ldc, int N,
                         int epi, const float* ls, const GemmBf16Params* extra) -> int {
     GemmFp8Params p{};
     p.A = Aq; p.lda = K; p.W = (const unsigned char*)W; p.ldw = K; p.sa = w.sa; p.sw = sw; p.bias = bias; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.ls = ls;
     if (extra) { p.q = extra->q; p.k = extra->k; p.vt = extra->vt; p.heads = extra->heads; p.npad = extra->npad; p.ntok = extra->ntok;
                  p.ntok_s = extra->ntok_s; p.q_scale = extra->q_scale; }
+    if (Wp && K == 768 && M >= 4096) {
+      const int rc = wvn_gemm_a768_fp8_launch(p, Wp, epi, st);
+      if (rc != WVN_ERR_ARG) return rc;
+    }
     return wvn_gemm_fp8_launch(p, epi, st);
   };
   // the split-operand block kernels (A-stationary K = 384 with the LayerNorm in its prologue, fragment-major MLP): from 8192 rows on
@@ -324,20 +329,20 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
         GemmBf16Params e{};
         e.q = (bf16_t*)w.q; e.k = (bf16_t*)w.k; e.vt = (bf16_t*)w.v; e.heads = d.H; e.npad = d.npad; e.ntok = d.ntok; e.ntok_s = d.ntok_s;
         e.q_scale = scale * 1.44269504088896340736f;
-        RET_IF(linear_fp8(w.xq, d.D, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, 0, 3 * d.D, EPI_QKV, nullptr, &e));
+        RET_IF(linear_fp8(w.xq, d.D, L.qkv_w, L.qkv_w_mx, L.qkv_s, L.qkv_b, nullptr, 0, 3 * d.D, EPI_QKV, nullptr, &e));
       }
       { Span s(4, st); RET_IF(wvn_attention_bf16_launch((const bf16_t*)w.q, (const bf16_t*)w.k, (const bf16_t*)w.v, (bf16_t*)w.xn, d.B, d.H, d.ntok, d.ntok_s, d.npad, 0.f, st, nullptr)); }
       {
         Span s(5, st);
         RET_IF(wvn_quantize_rows_fp8_launch(w.xn, 1, d.D, w.xq, d.D, w.sa, M, d.D, st));
-        RET_IF(linear_fp8(w.xq, d.D, L.proj_w, L.proj_s, L.proj_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr));
+        RET_IF(linear_fp8(w.xq, d.D, L.proj_w, L.proj_w_mx, L.proj_s, L.proj_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr));
       }
       { Span s(2, st); RET_IF(wvn_layernorm_fp8_launch(w.x, L.ln2_g, L.ln2_b, w.xq, d.D, w.sa, M, d.D, 1e-6f, st)); }
-      { Span s(6, st); RET_IF(linear_fp8(w.xq, d.D, L.fc1_w, L.fc1_s, L.fc1_b, w.hid, d.F, d.F, EPI_GELU_BF16, nullptr, nullptr)); }
+      { Span s(6, st); RET_IF(linear_fp8(w.xq, d.D, L.fc1_w, L.fc1_w_mx, L.fc1_s, L.fc1_b, w.hid, d.F, d.F, EPI_GELU_BF16, nullptr, nullptr)); }
       {
         Span s(7, st);
         RET_IF(wvn_quantize_rows_fp8_launch(w.hid, 1, d.F, w.hq, d.F, w.sa, M, d.F, st));
-        RET_IF(linear_fp8(w.hq, d.F, L.fc2_w, L.fc2_s, L.fc2_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls2, nullptr));
+        RET_IF(linear_fp8(w.hq, d.F, L.fc2_w, nullptr, L.fc2_s, L.fc2_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls2, nullptr));
       }
       continue;
     }
@@ -643,6 +648,13 @@ int wvn_gemm_fp8(const void* A_q, int lda, const void* W_q, int ldw, const float
   p.A = (const unsigned char*)A_q; p.lda = lda; p.W = (const unsigned char*)W_q; p.ldw = ldw; p.sa = sa; p.sw = sw; p.bias = bias;
   p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   return wvn_gemm_fp8_launch(p, epi, (hipStream_t)stream);
+}
+int wvn_gemm_a768_fp8(const void* A_q, int lda, const void* W_packed, const float* sa, const float* sw, const float* bias, const float* ls, void* C, int ldc,
+                      int M, int N, int epi, void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, void* stream) {
+  GemmFp8Params p{};
+  p.A = (const unsigned char*)A_q; p.lda = lda; p.sa = sa; p.sw = sw; p.bias = bias; p.ls = ls; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = 768;
+  p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.heads = heads; p.npad = npad; p.ntok_s = ntok_s; p.q_scale = q_scale;
+  return wvn_gemm_a768_fp8_launch(p, W_packed, epi, (hipStream_t)stream);
 }
 int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream) {
   return wvn_split_planes_launch(src, lds, (bf16_t*)hi, (bf16_t*)lo, ldd, rows, cols, (hipStream_t)stream);

@@ -111,6 +111,9 @@ struct GemmFp8Params {
   const float* ls;                                                            // EPI_RESID_F32: optional LayerScale
 };
 int wvn_gemm_fp8_launch(const GemmFp8Params& p, int epi, hipStream_t st);
+// the A-stationary form for K == 768 (gemm_a768_fp8.hip): Wp = backbone.pack_a768_fp8 of the e4m3 weight; EPI_BF16 / EPI_GELU_BF16 / EPI_RESID_F32 / EPI_QKV;
+// WVN_ERR_ARG where the shape is not its (the caller falls back to wvn_gemm_fp8_launch)
+int wvn_gemm_a768_fp8_launch(const GemmFp8Params& p, const void* Wp, int epi, hipStream_t st);
 // rows of src (fp32 or bf16, leading dimension lds_) -> e4m3 rows (leading dimension ldq, bytes) + scale[rows] = amax / 448
 int wvn_quantize_rows_fp8_launch(const void* src, int src_bf16, int lds_, unsigned char* q, int ldq, float* scale, int rows,
                                  int cols, hipStream_t st);
