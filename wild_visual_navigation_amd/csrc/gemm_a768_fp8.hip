@@ -10,11 +10,16 @@
 //     fragment reads take them: a tile is one contiguous 24 KB block, a DMA piece (buffer_load ... lds) one contiguous kilobyte copied lane-linear, a fragment
 //     read one contiguous kilobyte at lane * 16 + immediate: no swizzle, no address arithmetic;
 //   * two LDS slots: tile j + 1 lands while tile j is multiplied (12 scaled MFMAs = 768 matrix-pipe cycles per wave, two accumulators alternating, fragments
-//     one k-step ahead in registers); one barrier per tile;
-//   * <= 128 registers, 52 KB of LDS: THREE workgroups per CU, whose DMA round trips, barriers and epilogues cover one another;
-//   * epilogues: bf16 rows (+ exact-erf GELU) and the q | k | v^T layouts of attention_bf16.hip through a 2 KB wave-private LDS image (16-byte stores of 64-byte
-//     row pieces), fp32 residual rows (+ LayerScale) read-modified-written directly in 16-byte pieces.
+//     two k-steps ahead in registers); one barrier per tile;
+//   * NOTHING in a tile waits for memory it asked for in that tile: the per-column scales, the bias and the LayerScale vector sit in LDS (loaded once per
+//     workgroup), the residual rows of a tile are requested before its MFMAs, and the wait at the end of a tile lets that tile's own stores stay in flight
+//     (the first build fetched scales and bias inside the epilogue: every tile then waited for its loads BEHIND the next tile's DMA pieces and the previous
+//     tile's stores -- 5.5 us per 0.4 us of MFMAs);
+//   * <= 256 registers, <= 80 KB of LDS: two workgroups per CU, whose barriers and epilogues cover one another;
+//   * epilogues: bf16 rows (+ exact-erf GELU) and the q | k | v^T layouts of attention_bf16.hip through a 1 KB wave-private LDS image, half a tile at a time
+//     (16-byte stores of 64-byte row pieces), fp32 residual rows (+ LayerScale) read-modified-written directly in 16-byte pieces.
 // K != 768, N % 32 != 0 or an un-packed weight: WVN_ERR_ARG (the caller uses gemm_fp8_kernel).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -34,7 +39,7 @@ constexpr int TILE_BYTES = BN * KD;          // 24 KB
 constexpr int NS = 2;                        // LDS slots
 constexpr int PIECES = TILE_BYTES / 1024 / 4;   // 6 per wave and tile
 constexpr int STG = 1024;                    // per wave: HALF a bf16 tile image [16 rows][64 B], 16-byte chunks XOR-swizzled by (row >> 2) & 3
-constexpr int LDS_BYTES = NS * TILE_BYTES + 4 * STG;   // 52 KB: three workgroups per CU
+constexpr int VEC_OFF = NS * TILE_BYTES + 4 * STG;     // sw [N] | bias [N] | ls [N] (floats) behind the ring and the staging images
 static_assert(PIECES == 6, "six DMA pieces per wave and tile");
 
 // erf GELU to fp32 rounding with one transcendental (gemm_a384_x3.hip: gelu_pair; tests/test_host_logic.py pins its 2.8e-7 bound)
@@ -56,6 +61,13 @@ __device__ inline void gelu_pair8(float& x0, float& x1) {
   x0 = g[0]; x1 = g[1];
 }
 
+// (Non-temporal stores and A loads were tried: the weight then stays in the XCD's L2 -- fc1's HBM reads 248 -> 92 MB -- and every kernel is a third SLOWER.
+//  Same data-register guard as wvn_store_b128_guarded, common.h.)
+__device__ inline void store_b128_nt(u32x4_t v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+  asm volatile("s_nop 1" ::"v"(v));
+}
+
 struct A768Params {
   const unsigned char* A; int lda; const float* sa;
   const unsigned char* Wp;              // backbone.pack_a768_fp8: [N / 32 tiles][12 k-steps][2 halves][64 lanes][16 B]
@@ -70,7 +82,7 @@ struct A768Params {
 enum { E_BF16 = 0, E_GELU = 1, E_RESID = 2, E_QKV = 3 };
 
 template <int EPI>
-__global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
+__global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,6 +94,14 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
   unsigned char* stg = smem + NS * TILE_BYTES + wave * STG;
   const unsigned l16 = lane * 16;
   int m0w = 0;
+  float* sw_l = (float*)(smem + VEC_OFF);
+  float* bias_l = sw_l + p.N;
+  float* ls_l = bias_l + p.N;
+  for (int i = tid; i < p.N; i += 256) {
+    sw_l[i] = p.sw[i];
+    bias_l[i] = p.bias ? p.bias[i] : 0.f;
+    if constexpr (EPI == E_RESID) ls_l[i] = p.ls ? p.ls[i] : 1.f;
+  }
 
   // ---- W producer ----
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (unsigned)((size_t)p.N * KD), 0x00020000);
@@ -157,6 +177,7 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
     }
   };
 
+  u32x4_t resid[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // E_RESID: the tile's residual rows, requested before its MFMAs
   f32x16_t acc[2];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -181,8 +202,8 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
       }
       const int row = lane >> 2;
       const u32x4_t val = *(const u32x4_t*)(stg + row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
-      if (!vt_layout) wvn_store_b128_guarded(val, rs_c, voff[it], so);
-      else wvn_store_b128_guarded(val, rs_c, vt_off, __builtin_amdgcn_readfirstlane(so + (unsigned)((nv + it * 16) * p.npad * 2)));
+      if (!vt_layout) store_b128_nt(val, rs_c, voff[it], so);
+      else store_b128_nt(val, rs_c, vt_off, __builtin_amdgcn_readfirstlane(so + (unsigned)((nv + it * 16) * p.npad * 2)));
     }
   };
   auto epilogue = [&](int j, auto tr_tag) __attribute__((always_inline)) {
@@ -195,9 +216,7 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
       // lane = row m (scale sa_l), register 4 g + e = column n0 + 8 g + 4 hi + e
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4_t s4 = *(const f32x4_t*)(p.sw + n0 + 8 * g + 4 * hi);
-        f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *(const f32x4_t*)(p.bias + n0 + 8 * g + 4 * hi);
+        const f32x4_t s4 = *(const f32x4_t*)(sw_l + n0 + 8 * g + 4 * hi), b4 = *(const f32x4_t*)(bias_l + n0 + 8 * g + 4 * hi);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(v[4 * g + e], sa_l * s4[e], b4[e]);
       }
@@ -205,13 +224,13 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4_t o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-          if (p.ls) o *= *(const f32x4_t*)(p.ls + n0 + 8 * g + 4 * hi);
+          o *= *(const f32x4_t*)(ls_l + n0 + 8 * g + 4 * hi);
           const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((n0 + 8 * g) * 4));
-          const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs_c, roff, so, 0);
+          const u32x4_t r = resid[g];
           u32x4_t w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(o[e] + __uint_as_float(r[e]));
-          wvn_store_b128_guarded(w, rs_c, roff, so);
+          store_b128_nt(w, rs_c, roff, so);
         }
       } else {
         float qs = 1.f;
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
       }
     } else {
       // V^T: lane = column n = n0 + l31 (scale sw, bias), register 4 g + e = row m0w + 8 g + 4 hi + e (scale sa_r)
-      const float sl = p.sw[n0 + l31], bl = p.bias ? p.bias[n0 + l31] : 0.f;
+      const float sl = sw_l[n0 + l31], bl = bias_l[n0 + l31];
       uint32_t h[8];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -250,7 +269,8 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
 
   // ---- one tile: barrier (every wave has waited for its pieces of this tile at the end of the previous one), the DMA requests of the next tile riding between
   // the twelve MFMAs, the wait for them, the epilogue ----
-  i32x8_t wf[2];
+  i32x8_t wf[3];
+  constexpr int NST = EPI == E_RESID ? 4 : 2;   // stores of one epilogue per lane
   auto frag_read = [&](int slot, int s, int set) __attribute__((always_inline)) {
     const unsigned char* base = smem + slot * TILE_BYTES + l16 + s * 2048;
     const u32x4_t lo = *(const u32x4_t*)base, h4 = *(const u32x4_t*)(base + 1024);
@@ -261,24 +281,32 @@ __global__ __launch_bounds__(256, 3) void gemm_a768_fp8_kernel(A768Params p) {
     constexpr bool TR = decltype(tr_tag)::value;
     __builtin_amdgcn_s_barrier();
     issue_tile_begin();
+    if constexpr (EPI == E_RESID) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) resid[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, roff, __builtin_amdgcn_readfirstlane((unsigned)((j * BN + 8 * g) * 4)), 0);
+    }
     frag_read(ti % NS, 0, 0);
+    frag_read(ti % NS, 1, 1);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) frag_read(ti % NS, s + 1, (s + 1) & 1);
+      if (s + 2 < KS) frag_read(ti % NS, s + 2, (s + 2) % 3);
       if ((s & 1) == 0) issue(ti + 1, s >> 1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (TR) acc[s & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[s & 1], af[s], acc[s & 1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-      else acc[s & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[s], wf[s & 1], acc[s & 1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      if constexpr (TR) acc[s & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[s % 3], af[s], acc[s & 1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      else acc[s & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[s], wf[s % 3], acc[s & 1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       asm volatile("" : "+v"(acc[s & 1]));   // (pins the MFMA here: its only use is the epilogue, and left free all twelve sink behind the wait below -- with all twelve W fragments live)
       __builtin_amdgcn_sched_barrier(0);
     }
     issue_end();
     ++ti;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces (requested a tile ago) have landed -- before the epilogue's stores enter the queue
     epilogue(j, tr_tag);
     zero_acc();
+    // the next tile's pieces have landed: everything but this epilogue's own stores (the youngest NST operations of the queue: the previous tile's stores, this
+    // tile's residual rows -- consumed above -- and the DMA pieces are older)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
   };
 
+  __syncthreads();
   for (int u = u_begin; u < u_end;) {
     const int rb = u / NT, j0 = u - rb * NT, j1 = min(NT, j0 + (u_end - u));
     m0w = rb * BM + wave * 32;
@@ -314,10 +342,20 @@ int num_cus() {
 template <int EPI>
 int launch(const A768Params& p, hipStream_t st) {
   const long long units = (long long)ceil_div(p.M, BM) * (p.N / BN);
-  static const int per_cu = [] { const char* e = getenv("WVN_A768_WG_PER_CU"); const int v = e ? atoi(e) : 3; return v >= 1 && v <= 3 ? v : 3; }();
+  static const int per_cu = [] { const char* e = getenv("WVN_A768_WG_PER_CU"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 2 ? v : 2; }();
   const long long cap = (long long)per_cu * num_cus();
   const int grid = (int)(units < cap ? units : cap);
-  hipLaunchKernelGGL((gemm_a768_fp8_kernel<EPI>), dim3(grid), dim3(256), LDS_BYTES, st, p);
+  const int lds = VEC_OFF + (EPI == E_RESID ? 3 : 2) * p.N * 4;
+  if (lds > 80 * 1024) return WVN_ERR_ARG;
+  static LdsOptIn lds_opt_in;
+  if (const int rc = lds_opt_in(80 * 1024, (const void*)gemm_a768_fp8_kernel<EPI>)) return rc;
+  static const bool dbg = getenv("WVN_A768_DEBUG") != nullptr;
+  if (dbg) {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm_a768_fp8_kernel<EPI>, 256, lds);
+    fprintf(stderr, "gemm_a768_fp8<%d>: M %d N %d grid %d lds %d -> %d workgroups per CU\n", EPI, p.M, p.N, grid, lds, nb);
+  }
+  hipLaunchKernelGGL((gemm_a768_fp8_kernel<EPI>), dim3(grid), dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
