@@ -117,10 +117,13 @@ typedef struct wvn_vit_layer {
                             * split-operand form.  With it, WVN_PREC_MIX's attention kernel writes its output as MFMA operand fragments
                             * and the projection runs on the fragment form of csrc/gemm_n384_x3.hip.  NULL: the row-major projection */
   /* WVN_PREC_MIX, D = 384 (optional, all four or none): the weights in the MX operand representation -- per element h = fp16(w), l8 = e5m2((w - h) * 2^12),
-   * h8 = e5m2(w) -- packed for the MX kernels (round 6): qkv / fc1 by backbone.pack_a384_mx ([2 planes][N][768 bytes], csrc/gemm_a384_x3.hip), proj / fc2 by
+   * h8 = e5m2(w) -- packed for the MX kernels (round 6): qkv / fc1 by backbone.pack_a384_mx (TWO images of N * 1536 bytes each, back to back: the planes of the
+   * one-wave-per-SIMD kernel, then the chunk images of the two-workgroups-per-CU kernel that runs by default -- csrc/gemm_a384_x3.hip), proj / fc2 by
    * backbone.pack_n384_mx ([K / 64][4 stages][24 KB], csrc/gemm_n384_x3.hip).  With them every block linear from block 1 on (block 0's QKV has no producer
    * of LayerNorm statistics in front of it) computes a w = a_h w_h (fp16 MFMAs) + 2^-12 (a_h8 w_l8 + a_l8 w_h8) (scaled e5m2 MFMAs of K = 64): two thirds of
-   * the matrix-pipe time of the bf16 x 3 products; the activations travel between the kernels in the same three-plane form */
+   * the matrix-pipe time of the bf16 x 3 products; the activations travel between the kernels as the h and l8 planes (h8 is derived in registers).
+   * WVN_PREC_FP8, D = 768 (optional, each on its own): qkv_w_mx / proj_w_mx / fc1_w_mx = backbone.pack_a768_fp8 of the e4m3 weight -- with them these three
+   * linears run on the A-stationary kernel (csrc/gemm_a768_fp8.hip) from 4096 rows on; fc2_w_mx is not read in this precision */
   const void* qkv_w_mx;
   const void* proj_w_mx;
   const void* fc1_w_mx;
