@@ -443,19 +443,22 @@ __global__ __launch_bounds__(256) void km_lin_relabel_kernel(int* __restrict__ l
   const unsigned m = used[b];
   if (part == 0 && threadIdx.x == 0) nseg[b] = __builtin_popcount(m);
   if (!relabel) return;
-  int4* lab = (int4*)(labels + (size_t)b * P);
-  const long long n4 = P / 4;
+  // the frame's labels start at element b * P of the buffer: 16-byte aligned only when that is a multiple of four (odd H: not for b >= 1).  A scalar head of
+  // 0 - 3 labels up to the next aligned element, the aligned body as int4, a scalar tail
+  int* base = labels + (size_t)b * P;
+  const long long head = min((long long)((4 - (((uintptr_t)base >> 2) & 3)) & 3), P);
+  int4* lab = (int4*)(base + head);
+  const long long n4 = (P - head) / 4;
   for (long long i = (long long)part * blockDim.x + threadIdx.x; i < n4; i += (long long)nblk * blockDim.x) {
     int4 v = lab[i];
     v.x = __builtin_popcount(m & ((1u << v.x) - 1u)); v.y = __builtin_popcount(m & ((1u << v.y) - 1u));
     v.z = __builtin_popcount(m & ((1u << v.z) - 1u)); v.w = __builtin_popcount(m & ((1u << v.w) - 1u));
     lab[i] = v;
   }
-  if (part == 0)
-    for (long long p = n4 * 4 + threadIdx.x; p < P; p += blockDim.x) {
-      int* l = labels + (size_t)b * P + p;
-      *l = __builtin_popcount(m & ((1u << *l) - 1u));
-    }
+  if (part == 0) {
+    for (long long p = threadIdx.x; p < head; p += blockDim.x) base[p] = __builtin_popcount(m & ((1u << base[p]) - 1u));
+    for (long long p = head + n4 * 4 + threadIdx.x; p < P; p += blockDim.x) base[p] = __builtin_popcount(m & ((1u << base[p]) - 1u));
+  }
 }
 
 struct LinScratch { float *cent0, *cent1, *rinv, *S, *Pg, *Q; int* cntp; unsigned* used; size_t floats; };
