@@ -365,7 +365,7 @@ int launch(const A768Params& p, hipStream_t st) {
 // Eligibility: K == 768 (lda == 768 bytes a row or more), N % 32 == 0 (QKV: (N / 3) % 64 == 0), Wp = backbone.pack_a768_fp8 of the e4m3 weight, 16-byte aligned
 // operands; WVN_ERR_ARG otherwise.  Worth it from a few thousand rows on.
 int wvn_gemm_a768_fp8_launch(const GemmFp8Params& g, const void* Wp, int epi, hipStream_t st) {
-  static const bool off = getenv("WVN_NO_A768_FP8") != nullptr;
+  const bool off = getenv("WVN_NO_A768_FP8") != nullptr;   // (read per launch: tests/test_gpu_fp8.py switches it inside one process)
   if (off || !Wp || g.K != KD || (g.N % BN) != 0 || g.M <= 0 || !g.A || !g.sa || !g.sw || (g.lda % 16) != 0 || (((uintptr_t)g.A | (uintptr_t)Wp) & 15)) return WVN_ERR_ARG;
   if (((uintptr_t)g.sw & 15) || (g.bias && ((uintptr_t)g.bias & 15)) || (g.ls && ((uintptr_t)g.ls & 15))) return WVN_ERR_ARG;
   A768Params p{};
