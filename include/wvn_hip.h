@@ -271,9 +271,15 @@ int wvn_gemm_fp8(const void* A_q, int lda, const void* W_q, int ldw, const float
  * ViT-Base from 4096 rows on -- the layer's qkv_w_mx / proj_w_mx / fc1_w_mx fields carry the packed weights in that precision): a workgroup keeps 128 rows of
  * A in registers and streams 32-column tiles of the weight, packed by backbone.pack_a768_fp8 as [N / 32][12 k-steps][2 halves][64 lanes][16 B].
  * epi (the numbers of wvn_gemm_fp8): 0 | 1 (C bf16 [M][ldc], 1 = gelu), 4 (C fp32 += ls * (...), ls optional), 7 (q | k | v^T bf16 in the
- * layouts of wvn_attention_bf16, inside one 2 GB span; q scaled by q_scale when it is not 0).  N % 32 == 0; WVN_ERR_ARG for any other shape. */
+ * layouts of wvn_attention_bf16, inside one 2 GB span; q scaled by q_scale when it is not 0), 9 (gelu -> C = e4m3 [M][ldc] with MX block scales: one E8M0 byte per
+ * (row, 32 columns) written to q [M][N / 32] -- the A operand of wvn_gemm_fp8_mx).  N % 32 == 0; WVN_ERR_ARG for any other shape. */
 int wvn_gemm_a768_fp8(const void* A_q, int lda, const void* W_packed, const float* sa, const float* sw, const float* bias, const float* ls, void* C, int ldc,
                       int M, int N, int epi, void* q, void* k, void* vt, int heads, int npad, int ntok_s, float q_scale, void* stream);
+/* wvn_gemm_fp8 with MX block scales on the A operand: A_q e4m3 [M][lda], a_scales [M][K / 32] E8M0 bytes (value = q * 2^(byte - 127) per 32 consecutive k; what epi 9
+ * above writes), W_q with one fp32 scale per row as before; epi 3 (C fp32 =) | 4 (C fp32 += ls * (...)).  K % 128 == 0.  WVN_PREC_FP8 runs ViT-Base's fc2 this way
+ * behind the A-stationary fc1 (no row quantiser between them; WVN_NO_FP8_MX=1 in the environment: the bf16 hidden activation and the row quantiser again) */
+int wvn_gemm_fp8_mx(const void* A_q, int lda, const void* a_scales, const void* W_q, int ldw, const float* sw, const float* bias, const float* ls,
+                    void* C, int ldc, int M, int N, int K, int epi, void* stream);
 /* fp32 [rows, lds] -> hi = bf16(x), lo = bf16(x - hi), both [rows, ldd] */
 int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream);
 /* exact-mode attention: q / k planes [B,h,npad,64], V^T planes [B,h,64,npad] (token permutation of the bf16 path),

@@ -88,26 +88,31 @@ def test_backbone_fp8_accuracy_gate(dev, arch, patch, heads, S, depth, B):
 
 
 def test_backbone_fp8_on_the_a_stationary_kernel(dev, monkeypatch):
-    """DINOv2 ViT-B/14 at 518^2, 4 frames = 5504 rows: from 4096 rows on the QKV, projection and fc1 of every block run on csrc/gemm_a768_fp8.hip.  The same
-    forward with WVN_NO_A768_FP8 (the tiled kernel everywhere) multiplies the same quantised operands in its first product; both sit inside the mode's gate against the oracle and closer to
-    each other than to it."""
+    """DINOv2 ViT-B/14 at 518^2, 4 frames = 5504 rows: from 4096 rows on the QKV, projection and fc1 of every block run on csrc/gemm_a768_fp8.hip, and the hidden
+    activation travels from fc1 to fc2 as e4m3 with MX block scales.  Three forwards: the default; WVN_NO_FP8_MX (the A-stationary kernel with the bf16 hidden
+    activation and the row quantiser of round 5); WVN_NO_A768_FP8 (the tiled kernel everywhere).  All inside the mode's gate against the oracle; the second and the
+    third quantise the same way and sit closer to each other than to the oracle; the block-scaled form is no worse than the per-row form."""
     sd = OV.make_dinov2_state_dict("vit_base", 14, pretrain_grid=37, seed=5, depth=3)
     img = torch.rand(4, 3, 518, 518, generator=g(10))
     want = OV.vit_tokens(sd, OI.normalize(img), 14, 12)[:, 1:]
     bb = VitBackbone(sd, 518, 14, 12, device=dev, precision="fp8", max_chunk=4)
     got = bb.forward_tokens(img.to(dev)).cpu()
+    assert torch.equal(got, bb.forward_tokens(img.to(dev)).cpu())           # deterministic
+    monkeypatch.setenv("WVN_NO_FP8_MX", "1")
+    rowq = bb.forward_tokens(img.to(dev)).cpu()
     monkeypatch.setenv("WVN_NO_A768_FP8", "1")
     tiled = bb.forward_tokens(img.to(dev)).cpu()
     monkeypatch.delenv("WVN_NO_A768_FP8")
-    again = bb.forward_tokens(img.to(dev)).cpu()
-    assert torch.equal(got, again)                                           # deterministic
-    assert not torch.equal(got, tiled)                                       # (the switch switches)
+    monkeypatch.delenv("WVN_NO_FP8_MX")
+    assert not torch.equal(got, rowq) and not torch.equal(rowq, tiled)       # (the switches switch)
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()                    # noqa: E731
-    print(f"ViT-B/14 518^2 x 4, 3 blocks, fp8: rel-L2 vs oracle {rel(got, want):.3e} (tiled kernel {rel(tiled, want):.3e}), between the two {rel(got, tiled):.3e}")
-    assert rel(got, want) < 0.10 and rel(tiled, want) < 0.10
+    print(f"ViT-B/14 518^2 x 4, 3 blocks, fp8: rel-L2 vs oracle: MX hidden {rel(got, want):.3e}, per-row hidden {rel(rowq, want):.3e}, tiled kernels {rel(tiled, want):.3e}; "
+          f"per-row vs tiled {rel(rowq, tiled):.3e}")
+    assert rel(got, want) < 0.10 and rel(rowq, want) < 0.10 and rel(tiled, want) < 0.10
     # (a last-bit difference in a bf16 intermediate moves some e4m3 codes of the next product's operand by a whole 6 - 12 % step: measured 1.5e-2 between the two
-    #  forwards against 4.2e-2 of either from the oracle)
-    assert rel(got, tiled) < 0.6 * rel(got, want)
+    #  per-row forwards against 4.2e-2 of either from the oracle)
+    assert rel(rowq, tiled) < 0.6 * rel(rowq, want)
+    assert rel(got, want) < 1.15 * rel(rowq, want)
 
 
 @pytest.mark.parametrize("D", [384, 768, 128])
@@ -199,3 +204,61 @@ def test_gemm_a768_fp8_qkv_layouts(dev, B, ntok, heads):
     vg = vt.double().cpu()[:, :, :, :ntok_s][..., perm]
     assert (((vg - r[:, :, 2].permute(0, 2, 3, 1)).abs()) / mg[:, :, 2].permute(0, 2, 3, 1)).max().item() < 2.0 ** -8
     assert float(q[:, :, ntok_s:].abs().max()) == 0.0 and float(vt[..., ntok_s:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# MX block scales between fc1 and fc2 (round 6): epi 9 of the A-stationary kernel writes e4m3 + one E8M0 byte per (row, 32 columns),
+# wvn_gemm_fp8_mx multiplies with them
+# ---------------------------------------------------------------------------------------------------------------------------
+def _mx_dequant(q_bytes, scales):
+    """e4m3 bytes [M][N] + E8M0 bytes [M][N / 32] -> float64 values."""
+    q = q_bytes.view(torch.float8_e4m3fn).double()
+    sc = torch.pow(2.0, scales.double() - 127.0)
+    return q * sc.repeat_interleave(32, dim=1)
+
+
+@pytest.mark.parametrize("M,N", [(4096 + 37, 3072), (200, 96)])
+def test_a768_gelu_epilogue_writes_mx_blocks(dev, M, N):
+    lib = _lib.lib()
+    aq, sa, wq, sw, wp, bias, ref, mag = _a768_operands(dev, M, N, seed=21)
+    out = torch.full((M + 4, N), 0x11, dtype=torch.uint8, device=dev)
+    scales = torch.full((M + 4, N // 32), 0x22, dtype=torch.uint8, device=dev)
+    _lib.check(lib.wvn_gemm_a768_fp8(aq.data_ptr(), 768, wp.data_ptr(), sa.data_ptr(), sw.data_ptr(), bias.data_ptr(), 0, out.data_ptr(), N, M, N,
+                                     _lib.EPI_GELU_MX8, scales.data_ptr(), 0, 0, 0, 0, 0, 0.0, _lib.stream()), "a768 mx8")
+    want = torch.nn.functional.gelu(ref)
+    got = _mx_dequant(out[:M], scales[:M])
+    # the scale of a block is 2^(floor(log2 amax) - 8) and the elements are the nearest e4m3 values (saturating at 448): the error of an element is at most half
+    # an e4m3 step of the block's largest binade, 2^-4 of the block's amax (values inside [amax / 2, amax] carry 3 mantissa bits; the clamp costs at most 12.5 %)
+    blk = want.abs().reshape(M, N // 32, 32).amax(dim=2)
+    exp_want = torch.floor(torch.log2(blk.clamp_min(1e-30)))
+    sb = scales[:M].double() - 127.0
+    nz = blk > 1e-6
+    assert ((sb - (exp_want - 8)).abs()[nz] <= 1).all()                      # (the GPU's GELU differs from torch's in the last fp32 bits: the exponent may sit on a boundary)
+    tol = (blk / 8.0 + 2e-3 * mag.reshape(M, N // 32, 32).amax(dim=2)).repeat_interleave(32, dim=1)
+    assert ((got - want).abs() <= tol).all()
+    assert (out[M:] == 0x11).all() and (scales[M:] == 0x22).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(515, 768, 3072), (130, 256, 128), (4133, 768, 768)])
+@pytest.mark.parametrize("epi", ["f32", "resid"])
+def test_gemm_fp8_mx_block_scales_against_fp64(dev, M, N, K, epi):
+    """A as e4m3 with one E8M0 scale per (row, 32 k) -- random exponents per block -- against fp64 math on the same operands: pins which 32 elements of the
+    instruction's K = 64 a scale byte covers and which lane supplies it."""
+    lib = _lib.lib()
+    a8 = (torch.randn(M, K, generator=g(31)) * 40).clamp(-448, 448).to(torch.float8_e4m3fn).to(dev)
+    a_sc = torch.randint(118, 132, (M, K // 32), generator=g(32), dtype=torch.uint8).to(dev)
+    w = torch.randn(N, K, generator=g(33)) * 0.05
+    wq, sw = ops.quantize_rows_fp8(w.to(dev))
+    bias = (torch.randn(N, generator=g(34)) * 0.1).to(dev)
+    av = _mx_dequant(a8.view(torch.uint8), a_sc)
+    wv = wq.double() * sw.double()[:, None]
+    ref = av @ wv.T + bias.double()
+    mag = av.abs() @ wv.abs().T + 1.0
+    c0 = torch.randn(M, N, generator=g(35)).to(dev)
+    out = c0.clone()
+    _lib.check(lib.wvn_gemm_fp8_mx(a8.data_ptr(), K, a_sc.data_ptr(), wq.data_ptr(), K, sw.data_ptr(), bias.data_ptr(), 0, out.data_ptr(), N, M, N, K,
+                                   _lib.EPI_F32 if epi == "f32" else _lib.EPI_RESID_F32, _lib.stream()), "gemm_fp8_mx")
+    want = ref if epi == "f32" else ref + c0.double()
+    # (the instruction's internal accumulation of its 64 products is narrower than fp32: 1.3e-5 of the magnitude sum with unit scales on these operands, 3.5 - 4.5e-5
+    #  with fourteen octaves between neighbouring blocks -- scripts/dev/dbg_fp8_mx.py; a wrong block <-> byte mapping is wrong by factors of two)
+    assert ((out.double() - want).abs() / mag).max().item() < 1e-4

@@ -38,6 +38,7 @@ PROF_CATS = ("patchify", "patch_gemm", "layernorm", "qkv_gemm", "attention", "pr
 # epilogue codes (wvn_internal.h)
 EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_F32, EPI_RESID_F32, EPI_ACCUM_F32 = range(6)
 EPI_QKV = 7   # (q | k | v^T in the attention kernels' layouts: wvn_gemm_a768_fp8)
+EPI_GELU_MX8 = 9   # (gelu -> e4m3 with MX block scales: wvn_gemm_a768_fp8 -> wvn_gemm_fp8_mx)
 F32_NONE, F32_RELU, F32_GELU, F32_RESID, F32_SIGMOID0, F32_RELUMASK = range(6)
 
 
@@ -110,6 +111,7 @@ _SIGNATURES = {
     "wvn_layernorm_fp8": ([_p, _p, _p, _p, _i, _p, _i, _i, _f, _p], _i),
     "wvn_gemm_fp8": ([_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_gemm_a768_fp8": ([_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _f, _p], _i),
+    "wvn_gemm_fp8_mx": ([_p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p], _i),
     "wvn_split_planes": ([_p, _i, _p, _p, _i, _i, _i, _p], _i),
     "wvn_attention_x3": ([_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "wvn_gemm_f32": ([_p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p], _i),

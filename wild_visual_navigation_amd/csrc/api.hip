@@ -338,11 +338,33 @@ static int vit_forward_impl(const wvn_vit_model* m, const void* img, int img_u8,
         RET_IF(linear_fp8(w.xq, d.D, L.proj_w, L.proj_w_mx, L.proj_s, L.proj_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls1, nullptr));
       }
       { Span s(2, st); RET_IF(wvn_layernorm_fp8_launch(w.x, L.ln2_g, L.ln2_b, w.xq, d.D, w.sa, M, d.D, 1e-6f, st)); }
-      { Span s(6, st); RET_IF(linear_fp8(w.xq, d.D, L.fc1_w, L.fc1_w_mx, L.fc1_s, L.fc1_b, w.hid, d.F, d.F, EPI_GELU_BF16, nullptr, nullptr)); }
+      // fc1 -> fc2 in the MX operand form where the A-stationary kernel runs fc1 (round 6): its GELU epilogue writes the hidden activation as e4m3 with ONE E8M0 block
+      // scale per (row, 32 columns) -- a 32-column tile of fc1 is one scale block of fc2's K -- and fc2 multiplies with those block scales on its A operand: no row
+      // quantiser (and no bf16 copy of the hidden activation) between the two.  The scales sit in w.hid, which this form does not use otherwise.
+      bool hid_mx = false;
+      {
+        Span s(6, st);
+        if (L.fc1_w_mx && d.D == 768 && M >= 4096 && (d.F % 128) == 0 && !getenv("WVN_NO_FP8_MX")) {
+          GemmFp8Params p{};
+          p.A = w.xq; p.lda = d.D; p.sa = w.sa; p.sw = L.fc1_s; p.bias = L.fc1_b; p.C = w.hq; p.ldc = d.F; p.c_scales = (unsigned char*)w.hid;
+          p.M = M; p.N = d.F; p.K = d.D;
+          const int rc = wvn_gemm_a768_fp8_launch(p, L.fc1_w_mx, EPI_GELU_MX8, st);
+          if (rc != WVN_OK && rc != WVN_ERR_ARG) return rc;
+          hid_mx = rc == WVN_OK;
+        }
+        if (!hid_mx) RET_IF(linear_fp8(w.xq, d.D, L.fc1_w, L.fc1_w_mx, L.fc1_s, L.fc1_b, w.hid, d.F, d.F, EPI_GELU_BF16, nullptr, nullptr));
+      }
       {
         Span s(7, st);
-        RET_IF(wvn_quantize_rows_fp8_launch(w.hid, 1, d.F, w.hq, d.F, w.sa, M, d.F, st));
-        RET_IF(linear_fp8(w.hq, d.F, L.fc2_w, nullptr, L.fc2_s, L.fc2_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls2, nullptr));
+        if (hid_mx) {
+          GemmFp8Params p{};
+          p.A = w.hq; p.lda = d.F; p.a_scales = (const unsigned char*)w.hid; p.W = (const unsigned char*)L.fc2_w; p.ldw = d.F; p.sw = L.fc2_s; p.bias = L.fc2_b;
+          p.C = w.x; p.ldc = d.D; p.M = M; p.N = d.D; p.K = d.F; p.ls = L.ls2;
+          RET_IF(wvn_gemm_fp8_launch(p, EPI_RESID_F32, st));
+        } else {
+          RET_IF(wvn_quantize_rows_fp8_launch(w.hid, 1, d.F, w.hq, d.F, w.sa, M, d.F, st));
+          RET_IF(linear_fp8(w.hq, d.F, L.fc2_w, nullptr, L.fc2_s, L.fc2_b, w.x, d.D, d.D, EPI_RESID_F32, L.ls2, nullptr));
+        }
       }
       continue;
     }
@@ -654,7 +676,16 @@ int wvn_gemm_a768_fp8(const void* A_q, int lda, const void* W_packed, const floa
   GemmFp8Params p{};
   p.A = (const unsigned char*)A_q; p.lda = lda; p.sa = sa; p.sw = sw; p.bias = bias; p.ls = ls; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = 768;
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.vt = (bf16_t*)vt; p.heads = heads; p.npad = npad; p.ntok_s = ntok_s; p.q_scale = q_scale;
+  if (epi == EPI_GELU_MX8) p.c_scales = (unsigned char*)q;   // (epi 9: C = e4m3 [M][ldc], q = its E8M0 block scales [M][N / 32])
   return wvn_gemm_a768_fp8_launch(p, W_packed, epi, (hipStream_t)stream);
+}
+int wvn_gemm_fp8_mx(const void* A_q, int lda, const void* a_scales, const void* W_q, int ldw, const float* sw, const float* bias, const float* ls,
+                    void* C, int ldc, int M, int N, int K, int epi, void* stream) {
+  if (!a_scales || (epi != EPI_F32 && epi != EPI_RESID_F32)) return WVN_ERR_ARG;
+  GemmFp8Params p{};
+  p.A = (const unsigned char*)A_q; p.lda = lda; p.a_scales = (const unsigned char*)a_scales; p.W = (const unsigned char*)W_q; p.ldw = ldw; p.sw = sw; p.bias = bias;
+  p.ls = ls; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  return wvn_gemm_fp8_launch(p, epi, (hipStream_t)stream);
 }
 int wvn_split_planes(const float* src, int lds, void* hi, void* lo, int ldd, int rows, int cols, void* stream) {
   return wvn_split_planes_launch(src, lds, (bf16_t*)hi, (bf16_t*)lo, ldd, rows, cols, (hipStream_t)stream);

@@ -16,7 +16,7 @@
 //     (the first build fetched scales and bias inside the epilogue: every tile then waited for its loads BEHIND the next tile's DMA pieces and the previous
 //     tile's stores -- 5.5 us per 0.4 us of MFMAs);
 //   * <= 256 registers, <= 80 KB of LDS: two workgroups per CU, whose barriers and epilogues cover one another;
-//   * epilogues: bf16 rows (+ exact-erf GELU) and the q | k | v^T layouts of attention_bf16.hip through a 1 KB wave-private LDS image, half a tile at a time
+//   * epilogues: e4m3 rows with MX block scales (GELU -> the A operand of fc2: EPI_GELU_MX8, no row quantiser between fc1 and fc2), bf16 rows (+ exact-erf GELU) and the q | k | v^T layouts of attention_bf16.hip through a 1 KB wave-private LDS image, half a tile at a time
 //     (16-byte stores of 64-byte row pieces), fp32 residual rows (+ LayerScale) read-modified-written directly in 16-byte pieces.
 // K != 768, N % 32 != 0 or an un-packed weight: WVN_ERR_ARG (the caller uses gemm_fp8_kernel).
 #include <stdio.h>
@@ -75,11 +75,12 @@ struct A768Params {
   void* C; int ldc;
   int M, N;
   const float* ls;
+  unsigned char* c_scales;              // E_GELU_MX8: [M][N / 32] E8M0 bytes
   bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;   // one buffer descriptor over q / k / v^T
   int heads, npad, ntok_s; float q_scale;
 };
 
-enum { E_BF16 = 0, E_GELU = 1, E_RESID = 2, E_QKV = 3 };
+enum { E_BF16 = 0, E_GELU = 1, E_RESID = 2, E_QKV = 3, E_GELU_MX8 = 4 };
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
@@ -151,7 +152,9 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
   // ---- epilogue addressing ----
   constexpr unsigned OOB = 0x80000000u;
   const int nqk = EPI == E_QKV ? 2 * (p.N / 3) / BN : (1 << 30);   // QKV: tiles below nqk are q | k (TR), the rest v^T
-  const unsigned c_bytes = EPI == E_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == E_RESID ? 4 : 2));
+  const unsigned c_bytes = EPI == E_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == E_RESID ? 4 : (EPI == E_GELU_MX8 ? 1 : 2)));
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(EPI == E_GELU_MX8 ? (void*)p.c_scales : (void*)p.Wp, 0, EPI == E_GELU_MX8 ? (unsigned)((size_t)p.M * (p.N / 32)) : 0u, 0x00020000);
+  unsigned soff_row = 0;   // E_GELU_MX8: the lane's row in the scale array
   const __amdgpu_buffer_rsrc_t rs_c = EPI == E_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base, 0, p.qkv_bytes, 0x00020000)
                                                    : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
   unsigned voff[2] = {0, 0}, vt_off = 0, roff = 0;
@@ -168,6 +171,10 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
       vt_off = m < p.M ? (unsigned)((((size_t)b * p.heads * 64 + (lane >> 2)) * p.npad + tk) * 2) : OOB;
     } else if constexpr (EPI == E_RESID) {
       roff = m0w + l31 < p.M ? (unsigned)(((size_t)(m0w + l31) * p.ldc + 4 * hi) * 4) : OOB;
+    } else if constexpr (EPI == E_GELU_MX8) {   // e4m3 rows: 32 bytes a tile = two lanes per row
+      const int m = m0w + (lane >> 1);
+      voff[0] = m < p.M ? (unsigned)((size_t)m * p.ldc + (lane & 1) * 16) : OOB;
+      soff_row = m0w + l31 < p.M ? (unsigned)((size_t)(m0w + l31) * (p.N / 32)) : OOB;
     } else {
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
@@ -232,6 +239,32 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
           for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(o[e] + __uint_as_float(r[e]));
           store_b128_nt(w, rs_c, roff, so);
         }
+      } else if constexpr (EPI == E_GELU_MX8) {
+        // the tile's 32 columns of a row = ONE MX block of the next product's K: E8M0 scale 2^(floor(log2 amax) - 8) (OCP MX: e4m3's largest exponent is 8, elements
+        // above 448 x scale saturate), elements e4m3 by the hardware converter; the row's two lanes (hi = 0 | 1) hold 16 values each
+        float am = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float x0 = v[2 * k], x1 = v[2 * k + 1];
+          gelu_pair8(x0, x1);
+          v[2 * k] = x0; v[2 * k + 1] = x1;
+          am = fmaxf(am, fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
+        }
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const int sb = max((int)((__float_as_uint(am) >> 23) & 0xff) - 8, 0);     // the scale byte: 2^(sb - 127)
+        const float inv = __uint_as_float((unsigned)(254 - sb) << 23);             // 2^(127 - sb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float x[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_fmed3f(v[4 * g + e] * inv, -448.f, 448.f);
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w, true);
+          *(int*)(stg + l31 * 32 + 8 * g + 4 * hi) = w;
+        }
+        const u32x4_t val = *(const u32x4_t*)(stg + (lane >> 1) * 32 + (lane & 1) * 16);
+        store_b128_nt(val, rs_c, voff[0], __builtin_amdgcn_readfirstlane((unsigned)n0));
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_s, hi == 0 ? soff_row : OOB, __builtin_amdgcn_readfirstlane((unsigned)j), 0);
       } else {
         float qs = 1.f;
         unsigned so;
@@ -375,6 +408,10 @@ int wvn_gemm_a768_fp8_launch(const GemmFp8Params& g, const void* Wp, int epi, hi
     case EPI_GELU_BF16:
       if (!g.C || (g.ldc % 8) != 0 || ((uintptr_t)g.C & 15) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return WVN_ERR_ARG;
       return epi == EPI_BF16 ? launch<E_BF16>(p, st) : launch<E_GELU>(p, st);
+    case EPI_GELU_MX8:
+      if (!g.C || !g.c_scales || (g.ldc % 16) != 0 || ((uintptr_t)g.C & 15) || (size_t)g.M * g.ldc >= (1ull << 31)) return WVN_ERR_ARG;
+      p.c_scales = g.c_scales;
+      return launch<E_GELU_MX8>(p, st);
     case EPI_RESID_F32:
       if (!g.C || (g.ldc % 4) != 0 || ((uintptr_t)g.C & 15) || (size_t)g.M * g.ldc * 4 >= (1ull << 31)) return WVN_ERR_ARG;
       return launch<E_RESID>(p, st);

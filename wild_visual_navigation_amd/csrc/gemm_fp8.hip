@@ -10,7 +10,11 @@
 // Byte-for-byte the tile geometry of gemm_bf16.hip: 128 (M) x 128 (N) x 128 (K) tile = 128-byte operand rows, 4 waves (2 x 2),
 // each wave 64 x 64 = 2 x 2 MFMA tiles, LDS 2 stages x (A + W) x 128 rows x 144 B = 73,728 B (2 workgroups / CU), register
 // prefetch of the next K-tile, XCD-aware tile order, epilogue staged through the operand LDS as a row-major image and written
-// with 16-byte coalesced stores.  A fragment = the lane's row, 32 consecutive k (bytes 32 hi .. 32 hi + 31 of each 64-k step).
+// with 16-byte coalesced stores.  A fragment = the lane's row, bytes [16 hi, 16 hi + 16) and [32 + 16 hi, 32 + 16 hi + 16) of each 64-k step: the hardware's scale block 0 of
+// the instruction is registers 0 - 3 of BOTH half-waves, so this is the mapping under which block kb = k [32 kb, 32 kb + 32) (scripts/ubench/mx_formats.hip).
+// AMX (round 6): the A operand carries MX block scales -- one E8M0 byte per (row, 32 k), p.a_scales [M][K / 32] -- instead of the per-row fp32 scale sa: what the fc1
+// epilogue of gemm_a768_fp8.hip writes (a 32-column tile of the hidden activation IS one scale block of fc2's K), so no row quantiser runs between fc1 and fc2.
+// The lane (row, hi) supplies the scale of its row's block hi in byte 0 of the scale operand.
 #include "common.h"
 #include "wvn_internal.h"
 
@@ -22,6 +26,8 @@ constexpr int BM = 128, BN = 128, BK = 128;   // BK in fp8 elements = bytes
 constexpr int LDS_STRIDE = BK + 16;                      // bytes per LDS row (144 B)
 constexpr int STAGE_ELEMS = (BM + BN) * LDS_STRIDE;      // per stage
 constexpr int GEMM_LDS_BYTES = 2 * STAGE_ELEMS;          // 73,728 B
+constexpr int SCALE_LDS_OFF = GEMM_LDS_BYTES;            // AMX: 2 stages x 128 rows x 4 scale bytes of the K-tile
+constexpr int GEMM_LDS_BYTES_AMX = GEMM_LDS_BYTES + 2 * BM * 4;
 constexpr int CT_BF16_STRIDE = 128 + 8;                  // output-tile image, bf16 elements per row (272 B)
 constexpr int CT_F32_STRIDE = 128 + 4;                   // output-tile image, floats per row (528 B)
 static_assert(128 * CT_F32_STRIDE * 4 <= GEMM_LDS_BYTES, "fp32 tile image must fit in the operand LDS");
@@ -52,7 +58,7 @@ constexpr bool out_is_bf16() {
 
 // TR = true : accumulators hold C^T (lane = row m, regs = cols n)  -> LDS image [m][n]
 // TR = false: accumulators hold C   (lane = col n, regs = rows m)  -> LDS image [n][m]   (V^T tiles)
-template <int EPI, bool TR>
+template <int EPI, bool TR, bool AMX = false>
 __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, unsigned char* smem) {
   unsigned char* lds = smem;
   const int tid = threadIdx.x;
@@ -66,6 +72,7 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
   // Loads are branch-free: rows past M / N are clamped to the last valid row (their results are never stored; an output
   // element depends only on its own A row and its own W row).
   u32x4_t ra[2][4], rb[2][4];
+  unsigned rsc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // AMX: the four scale bytes of the K-tile for the thread's four staging rows
   const int srow = tid >> 3, skc = tid & 7;
   const unsigned char* pa[4];
   const unsigned char* pb[4];
@@ -74,14 +81,16 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
     pa[i] = p.A + (size_t)min(m0 + srow + 32 * i, p.M - 1) * p.lda + skc * 16;
     pb[i] = p.W + (size_t)min(n0 + srow + 32 * i, p.N - 1) * p.ldw + skc * 16;
   }
-  auto load_regs = [&](int kt, u32x4_t (&a)[4], u32x4_t (&b)[4]) {
+  const int nblk = p.K / 32;   // AMX: scale bytes per row
+  auto load_regs = [&](int kt, u32x4_t (&a)[4], u32x4_t (&b)[4], unsigned (&sc)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       a[i] = *(const u32x4_t*)(pa[i] + kt * BK);
       b[i] = *(const u32x4_t*)(pb[i] + kt * BK);
+      if constexpr (AMX) sc[i] = *(const unsigned*)(p.a_scales + (size_t)min(m0 + srow + 32 * i, p.M - 1) * nblk + kt * 4);   // (eight threads per row: one request)
     }
   };
-  auto store_regs = [&](int stage, const u32x4_t (&a)[4], const u32x4_t (&b)[4]) {
+  auto store_regs = [&](int stage, const u32x4_t (&a)[4], const u32x4_t (&b)[4], const unsigned (&sc)[4]) {
     unsigned char* As = lds + stage * STAGE_ELEMS;
     unsigned char* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
@@ -89,6 +98,7 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
       int row = srow + 32 * i;
       *(u32x4_t*)(As + row * LDS_STRIDE + skc * 16) = a[i];
       *(u32x4_t*)(Bs + row * LDS_STRIDE + skc * 16) = b[i];
+      if constexpr (AMX) { if (skc == 0) *(unsigned*)(smem + SCALE_LDS_OFF + (stage * BM + row) * 4) = sc[i]; }
     }
   };
 
@@ -103,28 +113,35 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
   auto compute = [&](int stage) {
     const unsigned char* As = lds + stage * STAGE_ELEMS;
     const unsigned char* Bs = As + BM * LDS_STRIDE;
-    const unsigned char* a_base = As + (wm * 64 + l31) * LDS_STRIDE + hi * 32;
-    const unsigned char* b_base = Bs + (wn * 64 + l31) * LDS_STRIDE + hi * 32;
+    const unsigned char* a_base = As + (wm * 64 + l31) * LDS_STRIDE + hi * 16;
+    const unsigned char* b_base = Bs + (wn * 64 + l31) * LDS_STRIDE + hi * 16;
+    unsigned scw[2] = {0x7f7f7f7fu, 0x7f7f7f7fu};   // AMX: the K-tile's four scale bytes of the lane's row (per i)
+    if constexpr (AMX) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) scw[i] = *(const unsigned*)(smem + SCALE_LDS_OFF + (stage * BM + wm * 64 + i * 32 + l31) * 4);
+    }
 #pragma unroll
     for (int s = 0; s < BK / 64; ++s) {
       i32x8_t af[2], bfr[2];
+      int sca[2] = {0x7f7f7f7f, 0x7f7f7f7f};
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const u32x4_t lo = *(const u32x4_t*)(a_base + i * 32 * LDS_STRIDE + s * 64), hi4 = *(const u32x4_t*)(a_base + i * 32 * LDS_STRIDE + s * 64 + 16);
+        const u32x4_t lo = *(const u32x4_t*)(a_base + i * 32 * LDS_STRIDE + s * 64), hi4 = *(const u32x4_t*)(a_base + i * 32 * LDS_STRIDE + s * 64 + 32);
         af[i] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        if constexpr (AMX) sca[i] = (int)(scw[i] >> (8 * (2 * s + hi)));   // byte 0 = the scale of block 2 s + hi of the K-tile (the instruction reads byte 0 of lane (row, hi) for block hi)
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const u32x4_t lo = *(const u32x4_t*)(b_base + j * 32 * LDS_STRIDE + s * 64), hi4 = *(const u32x4_t*)(b_base + j * 32 * LDS_STRIDE + s * 64 + 16);
+        const u32x4_t lo = *(const u32x4_t*)(b_base + j * 32 * LDS_STRIDE + s * 64), hi4 = *(const u32x4_t*)(b_base + j * 32 * LDS_STRIDE + s * 64 + 32);
         bfr[j] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          // cbsz = blgp = 0: both operands e4m3; block scales 127 = 2^0 (the per-row scales are applied in the epilogue)
+          // cbsz = blgp = 0: both operands e4m3; block scales 127 = 2^0 (the per-row scales are applied in the epilogue) -- AMX: the activation's E8M0 block scales
           if constexpr (TR)
-            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, sca[i]);
           else
             acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bfr[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
@@ -135,20 +152,20 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
   // only for the tile it is about to move to LDS); the loop is unrolled by two so register slots and LDS stages are
   // compile-time.  (Fully unrolled K pipelines as in gemm_bf16.hip spilled 176 VGPRs here: the 8-VGPR fragments.)
   const int nk = p.K / BK;
-  auto load_c = [&](int kt, u32x4_t (&a)[4], u32x4_t (&b)[4]) { load_regs(min(kt, nk - 1), a, b); };
-  load_c(0, ra[0], rb[0]);
-  load_c(1, ra[1], rb[1]);
-  store_regs(0, ra[0], rb[0]);
-  load_c(2, ra[0], rb[0]);
+  auto load_c = [&](int kt, u32x4_t (&a)[4], u32x4_t (&b)[4], unsigned (&sc)[4]) { load_regs(min(kt, nk - 1), a, b, sc); };
+  load_c(0, ra[0], rb[0], rsc[0]);
+  load_c(1, ra[1], rb[1], rsc[1]);
+  store_regs(0, ra[0], rb[0], rsc[0]);
+  load_c(2, ra[0], rb[0], rsc[0]);
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
     compute(0);                              // tile kt
-    store_regs(1, ra[1], rb[1]);             // tile kt + 1 (or a clamped re-load of the last tile: then never read)
-    load_c(kt + 3, ra[1], rb[1]);
+    store_regs(1, ra[1], rb[1], rsc[1]);     // tile kt + 1 (or a clamped re-load of the last tile: then never read)
+    load_c(kt + 3, ra[1], rb[1], rsc[1]);
     __syncthreads();
     if (kt + 1 < nk) compute(1);             // tile kt + 1 (block-uniform)
-    store_regs(0, ra[0], rb[0]);             // tile kt + 2
-    load_c(kt + 4, ra[0], rb[0]);
+    store_regs(0, ra[0], rb[0], rsc[0]);     // tile kt + 2
+    load_c(kt + 4, ra[0], rb[0], rsc[0]);
     __syncthreads();                         // also: after the last K-tile every wave is done with the operand LDS
   }
 
@@ -164,7 +181,7 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
       float bl = 0.f, sl = 1.f;   // lane-dimension bias / scale: TR: sa of the lane's row; !TR: sw and bias of the lane's column
       if constexpr (!TR) {
         if (n0 + lane_dim < p.N) { bl = p.bias ? p.bias[n0 + lane_dim] : 0.f; sl = p.sw[n0 + lane_dim]; }
-      } else {
+      } else if constexpr (!AMX) {
         sl = p.sa[min(m0 + lane_dim, p.M - 1)];
       }
 #pragma unroll
@@ -276,7 +293,7 @@ __device__ inline void gemm_fp8_tile(const GemmFp8Params& p, int tm, int tn, uns
   }
 }
 
-template <int EPI>
+template <int EPI, bool AMX = false>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmFp8Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -289,15 +306,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmFp8Params p) {
       return;
     }
   }
-  gemm_fp8_tile<EPI, true>(p, tm, tn, smem);
+  gemm_fp8_tile<EPI, true, AMX>(p, tm, tn, smem);
 }
 
-template <int EPI>
+template <int EPI, bool AMX = false>
 int launch_epi(const GemmFp8Params& p, hipStream_t st) {
+  constexpr int LDS = AMX ? GEMM_LDS_BYTES_AMX : GEMM_LDS_BYTES;
   static LdsOptIn lds_opt_in;   // per device (common.h)
-  if (const int rc = lds_opt_in(GEMM_LDS_BYTES, (const void*)gemm_fp8_kernel<EPI>)) return rc;
+  if (const int rc = lds_opt_in(LDS, (const void*)gemm_fp8_kernel<EPI, AMX>)) return rc;
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL((gemm_fp8_kernel<EPI>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_fp8_kernel<EPI, AMX>), dim3(tiles), dim3(256), LDS, st, p);
   WVN_LAUNCH_CHECK();
   return WVN_OK;
 }
@@ -305,6 +323,13 @@ int launch_epi(const GemmFp8Params& p, hipStream_t st) {
 }  // namespace
 
 int wvn_gemm_fp8_launch(const GemmFp8Params& p, int epi, hipStream_t st) {
+  if (p.a_scales) {   // MX block scales on the A operand (what gemm_a768_fp8.hip's GELU epilogue writes): the residual epilogue of fc2
+    if (!p.A || !p.W || !p.sw || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 16) != 0 || (p.ldw % 16) != 0) return WVN_ERR_ARG;
+    if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.a_scales & 3)) return WVN_ERR_ARG;
+    if (epi == EPI_RESID_F32) return p.C ? launch_epi<EPI_RESID_F32, true>(p, st) : WVN_ERR_ARG;
+    if (epi == EPI_F32) return p.C ? launch_epi<EPI_F32, true>(p, st) : WVN_ERR_ARG;
+    return WVN_ERR_ARG;
+  }
   if (!p.A || !p.W || !p.sa || !p.sw || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 16) != 0 || (p.ldw % 16) != 0)
     return WVN_ERR_ARG;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return WVN_ERR_ARG;

@@ -13,6 +13,7 @@ enum GemmEpilogue {
   EPI_ACCUM_F32 = 5,  // C(f32)  += acc + bias                  (same arithmetic; second GEMM of a sum)
   EPI_PATCH = 6,      // patch-embed: row remap (b,p) -> b*ntok+1+p, + pos[1+p]
   EPI_QKV = 7,        // scatter to q/k [b,h,npad,64] and v^T [b,h,64,npad]
+  EPI_GELU_MX8 = 9,   // gemm_a768_fp8 only: gelu(acc + bias) as e4m3 with one E8M0 block scale per (row, 32 columns): the MX operand of the next product (gemm_fp8.hip AMX)
   EPI_GELU_FRAG = 8,  // gemm_a384_x3 only: gelu(acc + bias) as fragment-major hi / lo planes (the A operand of gemm_n384_x3's AFRAG form)
 };
 
@@ -109,6 +110,8 @@ struct GemmFp8Params {
   const float* pos; int npatch; int ntok; int ntok_s;                         // (EPI_PATCH is not instantiated for fp8)
   bf16_t* q; bf16_t* k; bf16_t* vt; int heads; int npad; float q_scale;      // EPI_QKV (bf16 outputs for attention_bf16.hip)
   const float* ls;                                                            // EPI_RESID_F32: optional LayerScale
+  const unsigned char* a_scales;     // optional: MX block scales of A, one E8M0 byte per (row, 32 k): [M][K / 32]; sa is then not read (EPI_F32 / EPI_RESID_F32)
+  unsigned char* c_scales;           // gemm_a768_fp8.hip, EPI_GELU_MX8: the block scales of the e4m3 output C [M][ldc], [M][N / 32]
 };
 int wvn_gemm_fp8_launch(const GemmFp8Params& p, int epi, hipStream_t st);
 // the A-stationary form for K == 768 (gemm_a768_fp8.hip): Wp = backbone.pack_a768_fp8 of the e4m3 weight; EPI_BF16 / EPI_GELU_BF16 / EPI_RESID_F32 / EPI_QKV;
