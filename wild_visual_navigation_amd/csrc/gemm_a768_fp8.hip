@@ -155,6 +155,8 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
   const unsigned c_bytes = EPI == E_QKV ? 0u : (unsigned)((size_t)p.M * p.ldc * (EPI == E_RESID ? 4 : (EPI == E_GELU_MX8 ? 1 : 2)));
   const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(EPI == E_GELU_MX8 ? (void*)p.c_scales : (void*)p.Wp, 0, EPI == E_GELU_MX8 ? (unsigned)((size_t)p.M * (p.N / 32)) : 0u, 0x00020000);
   unsigned soff_row = 0;   // E_GELU_MX8: the lane's row in the scale array
+  unsigned sc_acc = 0;     // ... and the scale bytes of the current group of four tiles (one dword store per group: a byte store costs a whole memory sector)
+  int run_lo = 0, run_hi = 0;   // the tiles [run_lo, run_hi) this workgroup computes of the current row block
   const __amdgpu_buffer_rsrc_t rs_c = EPI == E_QKV ? __builtin_amdgcn_make_buffer_rsrc(p.qkv_base, 0, p.qkv_bytes, 0x00020000)
                                                    : __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
   unsigned voff[2] = {0, 0}, vt_off = 0, roff = 0;
@@ -264,7 +266,20 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
         }
         const u32x4_t val = *(const u32x4_t*)(stg + (lane >> 1) * 32 + (lane & 1) * 16);
         store_b128_nt(val, rs_c, voff[0], __builtin_amdgcn_readfirstlane((unsigned)n0));
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_s, hi == 0 ? soff_row : OOB, __builtin_amdgcn_readfirstlane((unsigned)j), 0);
+        // the scale bytes of four consecutive tiles leave as ONE dword (2.1 million byte stores per launch cost 67 - 135 MB of sector traffic and their issue slots); a
+        // group the run covers only partly leaves as bytes.  Every tile issues at least one scale store instruction (an out-of-range one where the group is not
+        // complete yet): the end-of-tile wait counts on two stores per epilogue
+        if ((j & 3) == 0 || j == run_lo) sc_acc = 0;
+        sc_acc |= (unsigned)sb << (8 * (j & 3));
+        const unsigned srow = hi == 0 ? soff_row : OOB;
+        if ((j & 3) == 3 && j - 3 >= run_lo && ((p.N / 32) & 3) == 0) {   // (rows of the scale array a multiple of four bytes long: the dword is aligned)
+          __builtin_amdgcn_raw_buffer_store_b32(sc_acc, rs_s, srow, __builtin_amdgcn_readfirstlane((unsigned)(j - 3)), 0);
+        } else if ((j & 3) == 3 || j + 1 == run_hi) {
+          for (int t = max(j & ~3, run_lo); t <= j; ++t)
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(sc_acc >> (8 * (t & 3))), rs_s, srow, __builtin_amdgcn_readfirstlane((unsigned)t), 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, rs_s, OOB, 0, 0);
+        }
       } else {
         float qs = 1.f;
         unsigned so;
@@ -350,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
     using T = std::true_type; using F = std::false_type;
     if (j0 < nqk) {
       const int je = min(j1, nqk);
+      run_lo = j0; run_hi = je;
       for (int j = j0; j < je; ++j) tile(j, T{});
     }
     if constexpr (EPI == E_QKV) {
