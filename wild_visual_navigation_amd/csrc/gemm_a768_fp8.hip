@@ -9,10 +9,10 @@
 //   * a column tile is 32 wide x the whole K = 24 KB of W, packed on the host (backbone.pack_a768_fp8) as 24 chunk images [64 lanes][16 B] in the order the
 //     fragment reads take them: a tile is one contiguous 24 KB block, a DMA piece (buffer_load ... lds) one contiguous kilobyte copied lane-linear, a fragment
 //     read one contiguous kilobyte at lane * 16 + immediate: no swizzle, no address arithmetic;
-//   * two LDS slots: tile j + 1 lands while tile j is multiplied (12 scaled MFMAs = 768 matrix-pipe cycles per wave, two accumulators alternating, fragments
-//     two k-steps ahead in registers); one barrier per tile;
-//   * NOTHING in a tile waits for memory it asked for in that tile: the per-column scales, the bias and the LayerScale vector sit in LDS (loaded once per
-//     workgroup), the residual rows of a tile are requested before its MFMAs, and the wait at the end of a tile lets that tile's own stores stay in flight
+//   * three LDS slots: tile j + 2 is requested while tile j is multiplied (12 scaled MFMAs = 768 matrix-pipe cycles per wave, two accumulators alternating,
+//     fragments two k-steps ahead in registers) -- with two slots a tile of 0.4 us of MFMAs waited for a weight tile requested 0.4 us earlier; one barrier per tile;
+//   * NOTHING in a tile waits for memory it asked for in that tile: the tile's per-column scales, bias, LayerScale and residual rows are requested before its
+//     MFMAs, and the wait at the end of a tile lets that tile's own stores and the next-but-one tile's pieces stay in flight
 //     (the first build fetched scales and bias inside the epilogue: every tile then waited for its loads BEHIND the next tile's DMA pieces and the previous
 //     tile's stores -- 5.5 us per 0.4 us of MFMAs);
 //   * <= 256 registers, <= 80 KB of LDS: two workgroups per CU, whose barriers and epilogues cover one another;
@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "wvn_internal.h"
@@ -36,10 +37,10 @@ constexpr int KS = KD / 64;                  // 12 MFMA k-steps
 constexpr int BN = 32;                       // columns per tile
 constexpr int BM = 128;
 constexpr int TILE_BYTES = BN * KD;          // 24 KB
-constexpr int NS = 2;                        // LDS slots
+constexpr int NS = 3;                        // LDS slots
 constexpr int PIECES = TILE_BYTES / 1024 / 4;   // 6 per wave and tile
 constexpr int STG = 1024;                    // per wave: HALF a bf16 tile image [16 rows][64 B], 16-byte chunks XOR-swizzled by (row >> 2) & 3
-constexpr int VEC_OFF = NS * TILE_BYTES + 4 * STG;     // sw [N] | bias [N] | ls [N] (floats) behind the ring and the staging images
+constexpr int LDS_BYTES = NS * TILE_BYTES + 4 * STG;   // 76 KB: two workgroups per CU
 static_assert(PIECES == 6, "six DMA pieces per wave and tile");
 
 // erf GELU to fp32 rounding with one transcendental (gemm_a384_x3.hip: gelu_pair; tests/test_host_logic.py pins its 2.8e-7 bound)
@@ -78,11 +79,12 @@ struct A768Params {
   unsigned char* c_scales;              // E_GELU_MX8: [M][N / 32] E8M0 bytes
   bf16_t* qkv_base; unsigned q_off, k_off, v_off, qkv_bytes;   // one buffer descriptor over q / k / v^T
   int heads, npad, ntok_s; float q_scale;
+  long long* dbg;                       // TIMING build: per wave {barrier, MFMA loop, epilogue, end-of-tile wait, row-block prologue, total} shader cycles
 };
 
 enum { E_BF16 = 0, E_GELU = 1, E_RESID = 2, E_QKV = 3, E_GELU_MX8 = 4 };
 
-template <int EPI>
+template <int EPI, bool TIMING = false>
 __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -95,15 +97,6 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
   unsigned char* stg = smem + NS * TILE_BYTES + wave * STG;
   const unsigned l16 = lane * 16;
   int m0w = 0;
-  float* sw_l = (float*)(smem + VEC_OFF);
-  float* bias_l = sw_l + p.N;
-  float* ls_l = bias_l + p.N;
-  for (int i = tid; i < p.N; i += 256) {
-    sw_l[i] = p.sw[i];
-    bias_l[i] = p.bias ? p.bias[i] : 0.f;
-    if constexpr (EPI == E_RESID) ls_l[i] = p.ls ? p.ls[i] : 1.f;
-  }
-
   // ---- W producer ----
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (unsigned)((size_t)p.N * KD), 0x00020000);
   int iss_j = u_begin % NT;
@@ -123,10 +116,15 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
   };
   auto issue_tile_begin = [&]() __attribute__((always_inline)) { issue_begin(); iss_soff_b = iss_soff + 3072; };
   auto issue_end = [&]() __attribute__((always_inline)) { if (++iss_j == NT) iss_j = 0; };
-  issue_tile_begin();
+  const int total_tiles = u_end - u_begin;
 #pragma unroll
-  for (int u = 0; u < PIECES; ++u) issue(0, u);
-  issue_end();
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < total_tiles) {
+      issue_tile_begin();
+#pragma unroll
+      for (int u = 0; u < PIECES; ++u) issue(i, u);
+      issue_end();
+    }
 
   // ---- the row block's operands ----
   i32x8_t af[KS];
@@ -187,6 +185,28 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
   };
 
   u32x4_t resid[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // E_RESID: the tile's residual rows, requested before its MFMAs
+  // the tile's per-column vectors, requested before its MFMAs too (three ring slots leave no room for them in LDS): TR tiles, register 4 g + e <-> column 8 g + 4 hi + e
+  f32x4_t sw4[4], bi4[4], ls4[4];
+  float sw1 = 0.f, bi1 = 0.f;   // V^T tiles: the lane's column
+  auto load_vectors = [&](int j, auto tr_tag) __attribute__((always_inline)) {
+    constexpr bool TR = decltype(tr_tag)::value;
+    const int n0 = j * BN;
+    if constexpr (TR) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        sw4[g] = *(const f32x4_t*)(p.sw + n0 + 8 * g + 4 * hi);
+        bi4[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bi4[g] = *(const f32x4_t*)(p.bias + n0 + 8 * g + 4 * hi);
+        if constexpr (EPI == E_RESID) {
+          ls4[g] = f32x4_t{1.f, 1.f, 1.f, 1.f};
+          if (p.ls) ls4[g] = *(const f32x4_t*)(p.ls + n0 + 8 * g + 4 * hi);
+        }
+      }
+    } else {
+      sw1 = p.sw[n0 + l31];
+      bi1 = p.bias ? p.bias[n0 + l31] : 0.f;
+    }
+  };
   f32x16_t acc[2];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
       // lane = row m (scale sa_l), register 4 g + e = column n0 + 8 g + 4 hi + e
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4_t s4 = *(const f32x4_t*)(sw_l + n0 + 8 * g + 4 * hi), b4 = *(const f32x4_t*)(bias_l + n0 + 8 * g + 4 * hi);
+        const f32x4_t s4 = sw4[g], b4 = bi4[g];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(v[4 * g + e], sa_l * s4[e], b4[e]);
       }
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4_t o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-          o *= *(const f32x4_t*)(ls_l + n0 + 8 * g + 4 * hi);
+          o *= ls4[g];
           const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((n0 + 8 * g) * 4));
           const u32x4_t r = resid[g];
           u32x4_t w;
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
       }
     } else {
       // V^T: lane = column n = n0 + l31 (scale sw, bias), register 4 g + e = row m0w + 8 g + 4 hi + e (scale sa_r)
-      const float sl = sw_l[n0 + l31], bl = bias_l[n0 + l31];
+      const float sl = sw1, bl = bi1;
       uint32_t h[8];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -325,10 +345,16 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
     wf[set] = i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)h4[0], (int)h4[1], (int)h4[2], (int)h4[3]};
   };
   int ti = 0;
+  long long t_bar = 0, t_mm = 0, t_epi = 0, t_wait = 0, t_pro = 0;
+  const long long t_start = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
   auto tile = [&](int j, auto tr_tag) __attribute__((always_inline)) {
     constexpr bool TR = decltype(tr_tag)::value;
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if constexpr (TIMING) c0 = (long long)__builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();
+    if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
     issue_tile_begin();
+    load_vectors(j, tr_tag);
     if constexpr (EPI == E_RESID) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) resid[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, roff, __builtin_amdgcn_readfirstlane((unsigned)((j * BN + 8 * g) * 4)), 0);
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s + 2 < KS) frag_read(ti % NS, s + 2, (s + 2) % 3);
-      if ((s & 1) == 0) issue(ti + 1, s >> 1);
+      if ((s & 1) == 0) issue(ti + NS - 1, s >> 1);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TR) acc[s & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[s % 3], af[s], acc[s & 1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       else acc[s & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[s], wf[s % 3], acc[s & 1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
@@ -347,21 +373,25 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
     }
     issue_end();
     ++ti;
+    if constexpr (TIMING) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); c2 = (long long)__builtin_amdgcn_s_memtime(); }
     epilogue(j, tr_tag);
     zero_acc();
-    // the next tile's pieces have landed: everything but this epilogue's own stores (the youngest NST operations of the queue: the previous tile's stores, this
-    // tile's residual rows -- consumed above -- and the DMA pieces are older)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    if constexpr (TIMING) c3 = (long long)__builtin_amdgcn_s_memtime();
+    // the NEXT tile's pieces (requested a tile ago) have landed: everything but the youngest PIECES + NST operations of the queue -- the pieces of the tile after it,
+    // requested between this tile's MFMAs, and this epilogue's own stores; the previous tile's stores and this tile's vectors / residual rows (consumed above) are older
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES + NST) : "memory");
+    if constexpr (TIMING) { t_bar += c1 - c0; t_mm += c2 - c1; t_epi += c3 - c2; t_wait += (long long)__builtin_amdgcn_s_memtime() - c3; }
   };
 
-  __syncthreads();
   for (int u = u_begin; u < u_end;) {
     const int rb = u / NT, j0 = u - rb * NT, j1 = min(NT, j0 + (u_end - u));
     m0w = rb * BM + wave * 32;
+    const long long l0 = TIMING ? (long long)__builtin_amdgcn_s_memtime() : 0;
     load_a();
     offsets();
     zero_acc();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the first barrier of a row block: this wave's pieces of the coming tile have landed)
+    if constexpr (TIMING) { asm volatile("" : "+v"(af[0]), "+v"(af[11])); t_pro += (long long)__builtin_amdgcn_s_memtime() - l0; }
     using T = std::true_type; using F = std::false_type;
     if (j0 < nqk) {
       const int je = min(j1, nqk);
@@ -375,6 +405,12 @@ __global__ __launch_bounds__(256, 2) void gemm_a768_fp8_kernel(A768Params p) {
     u += j1 - j0;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last tile's surplus request lands before the wave ends)
+  if constexpr (TIMING) {
+    if (lane == 0 && p.dbg) {
+      long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+      d[0] = t_bar; d[1] = t_mm; d[2] = t_epi; d[3] = t_wait; d[4] = t_pro; d[5] = (long long)__builtin_amdgcn_s_memtime() - t_start; d[6] = u_end - u_begin;
+    }
+  }
 }
 
 int num_cus() {
@@ -394,15 +430,32 @@ int launch(const A768Params& p, hipStream_t st) {
   static const int per_cu = [] { const char* e = getenv("WVN_A768_WG_PER_CU"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 2 ? v : 2; }();
   const long long cap = (long long)per_cu * num_cus();
   const int grid = (int)(units < cap ? units : cap);
-  const int lds = VEC_OFF + (EPI == E_RESID ? 3 : 2) * p.N * 4;
-  if (lds > 80 * 1024) return WVN_ERR_ARG;
+  const int lds = LDS_BYTES;
   static LdsOptIn lds_opt_in;
-  if (const int rc = lds_opt_in(80 * 1024, (const void*)gemm_a768_fp8_kernel<EPI>)) return rc;
+  if (const int rc = lds_opt_in(80 * 1024, (const void*)gemm_a768_fp8_kernel<EPI>, (const void*)gemm_a768_fp8_kernel<EPI, true>)) return rc;
   static const bool dbg = getenv("WVN_A768_DEBUG") != nullptr;
   if (dbg) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm_a768_fp8_kernel<EPI>, 256, lds);
     fprintf(stderr, "gemm_a768_fp8<%d>: M %d N %d grid %d lds %d -> %d workgroups per CU\n", EPI, p.M, p.N, grid, lds, nb);
+  }
+  static const bool timing = getenv("WVN_A768_TIMING") != nullptr;   // (experiment: in-kernel cycle counters of one launch, printed to stderr)
+  if (timing) {
+    A768Params q = p;
+    const size_t n = (size_t)grid * 4 * 8;
+    if (hipMalloc((void**)&q.dbg, n * 8) != hipSuccess) return WVN_ERR_ARG;
+    (void)hipMemsetAsync(q.dbg, 0, n * 8, st);
+    hipLaunchKernelGGL((gemm_a768_fp8_kernel<EPI, true>), dim3(grid), dim3(256), lds, st, q);
+    std::vector<long long> h(n);
+    (void)hipMemcpyAsync(h.data(), q.dbg, n * 8, hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(q.dbg);
+    double a[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n / 8; ++i) for (int k = 0; k < 7; ++k) a[k] += (double)h[i * 8 + k];
+    const double tiles = a[6];
+    fprintf(stderr, "gemm_a768_fp8<%d> N %d: per wave and tile: barrier %.0f, MFMA loop %.0f (768 of MFMAs), epilogue %.0f, end wait %.0f, prologue %.0f, total %.0f cycles (%.1f tiles per wave)\n",
+            EPI, p.N, a[0] / tiles, a[1] / tiles, a[2] / tiles, a[3] / tiles, a[4] / tiles, a[5] / tiles, tiles / (n / 8));
+    return WVN_OK;
   }
   hipLaunchKernelGGL((gemm_a768_fp8_kernel<EPI>), dim3(grid), dim3(256), lds, st, p);
   WVN_LAUNCH_CHECK();
