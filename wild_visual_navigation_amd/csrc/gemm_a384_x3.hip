@@ -70,7 +70,6 @@ struct X384Params {
   // LNA: A = LayerNorm(ln_x) formed while the row block is loaded: ln_x fp32 [M][ln_ldx], ln_stats[m] = {mean, rstd} (left by the kernel
   // that wrote the rows: gemm_n384_x3.hip), gamma / beta [384]
   const float* ln_x; int ln_ldx; const float* ln_stats; const float* ln_g; const float* ln_b;
-  int prio;                             // gemm_a384_mx2_kernel: raise the wave's issue priority inside its MFMA periods (the CU's other workgroup is in its epilogue or prologue half the time)
 };
 
 __device__ inline void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -1023,7 +1022,6 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
     __builtin_amdgcn_s_barrier();
     if constexpr (TIMING) c1 = (long long)__builtin_amdgcn_s_memtime();
     issue_begin();
-    if (p.prio) __builtin_amdgcn_s_setprio(2);
     frag_read(i % S2_NS, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1035,7 +1033,6 @@ __global__ __launch_bounds__(256, 2) void gemm_a384_mx2_kernel(X384Params p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     issue_end();
-    if (p.prio) __builtin_amdgcn_s_setprio(0);
     if constexpr (TIMING) c2 = (long long)__builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S2_PIECES) : "memory");
     if constexpr (TIMING) { t_bar += c1 - c0 + (long long)__builtin_amdgcn_s_memtime() - c2; t_loop += c2 - c1; }
@@ -1132,8 +1129,6 @@ template <int EPI>
 int launch_mx2(X384Params p, hipStream_t st) {
   if (!p.ln_x || !p.ln_stats || !p.ln_g || !p.ln_b || (p.ln_ldx % 4) || ((uintptr_t)p.ln_x & 15) || ((uintptr_t)p.ln_stats & 7)) return WVN_ERR_ARG;
   p.W = (const bf16_t*)((const unsigned char*)p.W + (size_t)p.N * KD * 4);
-  static const bool no_prio = getenv("WVN_A384_MX2_NO_PRIO") != nullptr;   // (A/B: 0.25 % of the step, 880 -> 882 frames/s in both pairs of one call)
-  p.prio = no_prio ? 0 : 1;
   const int lds = S2_RING + (EPI == X_QKV_F16 ? 4 * S2_STG : 0) + p.N * 4 + 2 * KD * 4;
   if (lds > 80 * 1024) return WVN_ERR_ARG;
   static LdsOptIn lds_opt_in;
