@@ -577,7 +577,7 @@ def timed_leg(args, dev, world, rank, steps, warmup, precision, stego_reading, p
         lin_tf = lin_flops / (lin_ms * 1e-3) / 1e12
         peak = PEAK_FP8_TFLOPS if precision == "fp8" else PEAK_BF16_TFLOPS
         lin = {"kernels": "QKV + projection + fc1 + fc2 of all blocks (" + {"mixed": "gemm_a384_mx2 (two workgroups per CU) / gemm_n384_mx_pair", "mixed_x3": "gemm_a384_x3 / gemm_n384_x3_frag_pair",
-                                                                              "exact": "gemm_a384_x3 / gemm_n384_x3", "fp8": "gemm_a768_fp8 (QKV, projection, fc1: A-stationary) + gemm_fp8 (fc2: 128 x 128 tiles, MX block-scaled A) + row quantisers",
+                                                                              "exact": "gemm_a384_x3 / gemm_n384_x3", "fp8": "gemm_a768_fp8 (QKV, projection, fc1: A-stationary) + gemm_fp8_dma (fc2: DMA-fed 128 x 128 tiles, MX block-scaled A) + row quantisers",
                                                                               "fp32": "gemm_f32"}.get(mxkey, "qkv_fused + mlp_fused") + ")",
                "ms_per_step": round(lin_ms / steps, 3), "launches_per_step": round(lin_launches / steps, 1), "achieved": round(lin_tf, 1), "peak": peak, "unit": "TFLOP/s",
                "frac": round(lin_tf / peak, 4), "algorithmic_flops_per_step": lin_flops / steps}
@@ -752,7 +752,7 @@ def main():
                 o["workload"] = ("BASELINE configs[1]: DINO ViT-S/8 448x448 batch=32, feature extraction only (fp16 operands, fp32 accumulate)"
                                  if name == "backbone_b32" else
                                  "BASELINE configs[4], one GPU's share: DINOv2 ViT-B/14 518x518 batch=16 (1370 tokens, LayerScale) + STEGO head -> "
-                                 "90-d code, one backbone pass per frame (no flip TTA); block linears in fp8-e4m3: QKV / projection / fc1 on the A-stationary K = 768 kernel, fc2 (K = 3072) on the generic 128 x 128 tiles with its A operand (the hidden activation) as e4m3 + MX block scales straight from fc1's epilogue")
+                                 "90-d code, one backbone pass per frame (no flip TTA); block linears in fp8-e4m3: QKV / projection / fc1 on the A-stationary K = 768 kernel, fc2 (K = 3072) on DMA-fed 128 x 128 tiles at three workgroups per CU with its A operand (the hidden activation) as e4m3 + MX block scales straight from fc1's epilogue")
                 if not args.no_cpu_baseline:   # its own bounded oracle sample (2 frames): other weights / another architecture
                     la.cpu_frames = 2
                     _, orc_l = cpu_oracle_sample(la, leg["fe"])

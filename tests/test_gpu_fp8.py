@@ -35,7 +35,7 @@ def test_quantize_rows(dev, dtype, R, C):
     assert (q.cpu().float()[3] == 0).all() and float(sc[3]) == 1.0
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 2304, 768), (515, 768, 3072), (130, 200, 128)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 384), (300, 2304, 768), (515, 768, 3072), (130, 200, 128), (777, 256, 1536)])   # (the last and the K = 3072 one: the DMA-fed kernel)
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "f32", "resid"])
 def test_gemm_fp8_against_fp64_on_the_quantised_operands(dev, M, N, K, epi):
     a = torch.randn(M, K, generator=g(2)) * torch.logspace(-1, 1, M)[:, None]
@@ -237,7 +237,7 @@ def test_a768_gelu_epilogue_writes_mx_blocks(dev, M, N):
     assert (out[M:] == 0x11).all() and (scales[M:] == 0x22).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(515, 768, 3072), (130, 256, 128), (4133, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(515, 768, 3072), (130, 256, 128), (4133, 768, 768), (1000, 384, 1024)])   # (K >= 1024, K % 512 == 0, N % 128 == 0: csrc/gemm_fp8_dma.hip)
 @pytest.mark.parametrize("epi", ["f32", "resid"])
 def test_gemm_fp8_mx_block_scales_against_fp64(dev, M, N, K, epi):
     """A as e4m3 with one E8M0 scale per (row, 32 k) -- random exponents per block -- against fp64 math on the same operands: pins which 32 elements of the
@@ -254,9 +254,10 @@ def test_gemm_fp8_mx_block_scales_against_fp64(dev, M, N, K, epi):
     mag = av.abs() @ wv.abs().T + 1.0
     c0 = torch.randn(M, N, generator=g(35)).to(dev)
     out = c0.clone()
-    _lib.check(lib.wvn_gemm_fp8_mx(a8.data_ptr(), K, a_sc.data_ptr(), wq.data_ptr(), K, sw.data_ptr(), bias.data_ptr(), 0, out.data_ptr(), N, M, N, K,
-                                   _lib.EPI_F32 if epi == "f32" else _lib.EPI_RESID_F32, _lib.stream()), "gemm_fp8_mx")
-    want = ref if epi == "f32" else ref + c0.double()
+    ls = (0.5 + torch.rand(N, generator=g(36))).to(dev) if epi == "resid" else None        # LayerScale rides in the residual epilogue (DINOv2)
+    _lib.check(lib.wvn_gemm_fp8_mx(a8.data_ptr(), K, a_sc.data_ptr(), wq.data_ptr(), K, sw.data_ptr(), bias.data_ptr(), ls.data_ptr() if ls is not None else 0,
+                                   out.data_ptr(), N, M, N, K, _lib.EPI_F32 if epi == "f32" else _lib.EPI_RESID_F32, _lib.stream()), "gemm_fp8_mx")
+    want = ref if epi == "f32" else ref * ls.double() + c0.double()
     # (the instruction's internal accumulation of its 64 products is narrower than fp32: 1.3e-5 of the magnitude sum with unit scales on these operands, 3.5 - 4.5e-5
     #  with fourteen octaves between neighbouring blocks -- scripts/dev/dbg_fp8_mx.py; a wrong block <-> byte mapping is wrong by factors of two)
     assert ((out.double() - want).abs() / mag).max().item() < 1e-4

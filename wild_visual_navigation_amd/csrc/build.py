@@ -18,7 +18,7 @@ PKG = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(PKG, "lib", "libwvn_hip.so")
 SOURCES = [
-    "api.hip", "gemm_bf16.hip", "gemm_a384.hip", "gemm_n384.hip", "mlp_fused.hip", "qkv_fused.hip", "gemm_proj.hip", "gemm_x3.hip", "gemm_a384_x3.hip", "gemm_n384_x3.hip", "gemm_fp8.hip", "gemm_a768_fp8.hip", "fp8.hip", "gemm_f32.hip", "elementwise.hip", "attention_bf16.hip",
+    "api.hip", "gemm_bf16.hip", "gemm_a384.hip", "gemm_n384.hip", "mlp_fused.hip", "qkv_fused.hip", "gemm_proj.hip", "gemm_x3.hip", "gemm_a384_x3.hip", "gemm_n384_x3.hip", "gemm_fp8.hip", "gemm_fp8_dma.hip", "gemm_a768_fp8.hip", "fp8.hip", "gemm_f32.hip", "elementwise.hip", "attention_bf16.hip",
     "attention_x3.hip", "attention_f32.hip",
     "segments.hip", "stego.hip", "stego_linear.hip", "mlp.hip", "mlp_train.hip", "pixel_mlp.hip", "supervision.hip", "slic.hip", "wire.hip",
 ]

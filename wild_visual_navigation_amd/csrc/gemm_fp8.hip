@@ -323,6 +323,10 @@ int launch_epi(const GemmFp8Params& p, hipStream_t st) {
 }  // namespace
 
 int wvn_gemm_fp8_launch(const GemmFp8Params& p, int epi, hipStream_t st) {
+  if ((epi == EPI_F32 || epi == EPI_RESID_F32) && p.K >= 1024) {   // long K: the DMA-fed kernel at three workgroups per CU where the shape is its
+    const int rc = wvn_gemm_fp8_dma_launch(p, epi, st);
+    if (rc != WVN_ERR_ARG) return rc;
+  }
   if (p.a_scales) {   // MX block scales on the A operand (what gemm_a768_fp8.hip's GELU epilogue writes): the residual epilogue of fc2
     if (!p.A || !p.W || !p.sw || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K % BK) != 0 || (p.lda % 16) != 0 || (p.ldw % 16) != 0) return WVN_ERR_ARG;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.a_scales & 3)) return WVN_ERR_ARG;

@@ -114,6 +114,8 @@ struct GemmFp8Params {
   unsigned char* c_scales;           // gemm_a768_fp8.hip, EPI_GELU_MX8: the block scales of the e4m3 output C [M][ldc], [M][N / 32]
 };
 int wvn_gemm_fp8_launch(const GemmFp8Params& p, int epi, hipStream_t st);
+// the DMA-fed form for long K (gemm_fp8_dma.hip: K % 512 == 0, N % 128 == 0, EPI_F32 / EPI_RESID_F32, per-row or MX block scales on A): wvn_gemm_fp8_launch tries it first
+int wvn_gemm_fp8_dma_launch(const GemmFp8Params& p, int epi, hipStream_t st);
 // the A-stationary form for K == 768 (gemm_a768_fp8.hip): Wp = backbone.pack_a768_fp8 of the e4m3 weight; EPI_BF16 / EPI_GELU_BF16 / EPI_RESID_F32 / EPI_QKV;
 // WVN_ERR_ARG where the shape is not its (the caller falls back to wvn_gemm_fp8_launch)
 int wvn_gemm_a768_fp8_launch(const GemmFp8Params& p, const void* Wp, int epi, hipStream_t st);
