@@ -179,7 +179,7 @@ def test_attention_bf16(dev, ntok, prescaled):
 
 
 # ---------------------------------------------------------------------------- patchify / up-sampling
-@pytest.mark.parametrize("S,P", [(64, 8), (224, 8), (64, 16)])
+@pytest.mark.parametrize("S,P", [(64, 8), (224, 8), (64, 16), (70, 14), (518, 14), (448, 16)])   # (16-bit output of the even patch sizes other than the P = 8 row kernels: the strip kernel)
 def test_patchify(dev, S, P):
     img = torch.rand(2, 3, S, S, generator=g(1))
     G = S // P
